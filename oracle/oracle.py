@@ -1,0 +1,203 @@
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+
+CPU restatement of the GraphPOPE hot path, used only by ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg.  ``graphpope_amd`` never imports it.
+
+Parity status
+-------------
+* geodesic (hops, f32 embedding, concat): **pinned** -- checked bit-for-bit against
+  ``tests/golden/geodesic_*.npz``, which are outputs of the reference's own ``utils.py`` run in the
+  build container by ``tests/golden/make_goldens.py`` (the reference has no tests or fixtures of
+  its own).
+* node2vec pairwise + min-max: **pinned to the container's scikit-learn 1.7.2** through
+  ``tests/golden/node2vec_*.npz`` (same script).  The reference pins scikit-learn 0.24.2
+  (requirements.txt:4), which is not installable offline, so float parity against *that* version
+  is unpinned; tolerance 1e-5 abs.
+* SAGEConv: **parity unpinned** -- PyG/torch_sparse are absent, the torch fp32 restatement below
+  is the only checker (op-level, self-referential; SURVEY.md §8c last row).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build() -> str:
+    """Compile oracle/pope_oracle.c with gcc (building the checker is not using it)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    return os.path.join(_HERE, "libpope_oracle.so")
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libpope_oracle.so")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(
+                os.path.join(_HERE, "pope_oracle.c")):
+            build()
+        lib = ctypes.CDLL(path)
+        lib.oracle_geodesic_hops.restype = ctypes.c_int
+        lib.oracle_geodesic_hops.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        lib.oracle_hops_to_embedding.restype = None
+        lib.oracle_hops_to_embedding.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        lib.oracle_concat.restype = None
+        lib.oracle_concat.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                      ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        _LIB = lib
+    return _LIB
+
+
+# --------------------------------------------------------------------------------------------
+# geodesic  (/root/reference/utils.py:64-135)
+# --------------------------------------------------------------------------------------------
+def geodesic_hops(edge_index: np.ndarray, num_nodes: int, anchors) -> np.ndarray:
+    """int32 [N, K]; hops[v, j] = edges on a shortest path v -> anchors[j], -1 if unreachable.
+
+    Follows utils.py:64-81 (value definition) and :92-107 (row i = node i).  One BFS per anchor over
+    reversed edges instead of one bidirectional BFS per pair -- same integers.
+    """
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+    assert ei.ndim == 2 and ei.shape[0] == 2
+    anc = np.ascontiguousarray(np.asarray(anchors), dtype=np.int64)
+    hops = np.empty((num_nodes, anc.size), dtype=np.int32)
+    rc = _lib().oracle_geodesic_hops(ei.ctypes.data, ei.shape[1], num_nodes, anc.ctypes.data,
+                                     anc.size, hops.ctypes.data)
+    if rc == -2:
+        raise IndexError("edge_index / anchor id outside [0, num_nodes)")
+    if rc:
+        raise MemoryError("oracle_geodesic_hops")
+    return hops
+
+
+def hops_to_embedding(hops: np.ndarray) -> np.ndarray:
+    """float32, 1/(hops+1), unreachable -> 0  (utils.py:73,75-76,125)."""
+    h = np.ascontiguousarray(hops, dtype=np.int32)
+    emb = np.empty(h.shape, dtype=np.float32)
+    _lib().oracle_hops_to_embedding(h.ctypes.data, h.size, emb.ctypes.data)
+    return emb
+
+
+def concat_into_features(x: np.ndarray, emb: np.ndarray) -> np.ndarray:
+    """utils.py:129-135."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    emb = np.ascontiguousarray(emb, dtype=np.float32)
+    out = np.empty((x.shape[0], x.shape[1] + emb.shape[1]), dtype=np.float32)
+    _lib().oracle_concat(x.ctypes.data, x.shape[0], x.shape[1], emb.ctypes.data, emb.shape[1],
+                         out.ctypes.data)
+    return out
+
+
+def geodesic_features(x, edge_index, num_nodes, anchors) -> np.ndarray:
+    """utils.py:137-147 given the anchors: [N, F+K] float32."""
+    return concat_into_features(x, hops_to_embedding(geodesic_hops(edge_index, num_nodes, anchors)))
+
+
+def sample_anchor_nodes_stochastic(num_nodes: int, num_anchor_nodes: int) -> np.ndarray:
+    """utils.py:22-24 -- draws from the GLOBAL legacy NumPy RNG, with replacement."""
+    return np.random.choice(np.arange(num_nodes), num_anchor_nodes)
+
+
+def geodesic_pairs_networkx(edge_index: np.ndarray, num_nodes: int, anchors, nodes) -> np.ndarray:
+    """The reference's actual CPU algorithm, statement for statement (utils.py:64-81, 116-121):
+    a NetworkX DiGraph and one ``nx.shortest_path`` (bidirectional BFS) per (node, anchor) pair.
+    Used for small cross-checks and as bench.py's reference-equivalent CPU baseline.  float32 [len(nodes), K].
+    """
+    import networkx as nx
+    G = nx.DiGraph()
+    G.add_nodes_from(range(num_nodes))
+    G.add_edges_from(zip(edge_index[0].tolist(), edge_index[1].tolist()))
+    rows = []
+    for node in nodes:
+        row = []
+        for a in anchors:
+            try:
+                row.append(1 / len(nx.shortest_path(G, source=int(node), target=int(a))))
+            except nx.NetworkXNoPath:
+                row.append(0)
+        rows.append(row)
+    return np.asarray(rows, dtype=np.float32).reshape(len(rows), len(anchors))
+
+
+# --------------------------------------------------------------------------------------------
+# node2vec-space pairwise + min-max  (/root/reference/utils.py:149-180)
+# --------------------------------------------------------------------------------------------
+def _normalize_rows(a: np.ndarray) -> np.ndarray:
+    # sklearn.preprocessing.normalize (l2): x / ||x||, zero rows left as zero; dtype kept (f32).
+    norms = np.sqrt(np.einsum("ij,ij->i", a, a))
+    norms[norms == 0.0] = 1.0
+    return a / norms[:, None]
+
+
+def pairwise(x: np.ndarray, anchors_emb: np.ndarray, distance_function: str) -> np.ndarray:
+    """utils.py:158-174 restated after scikit-learn's algorithms.
+
+    'similarity' -> cosine_similarity  (pairwise.py:1683-1738: normalise rows, f32 GEMM)
+    'distance'   -> cosine_distances   (pairwise.py:1129-1175: 1 - S clipped to [0, 2])
+    'euclidean'  -> euclidean_distances (pairwise.py:391-442, 582-653: f32 inputs are upcast to f64,
+                    d2 = xx + yy - 2 x.y in f64, cast to f32, clamp at 0, sqrt in f32)
+    """
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    a = np.ascontiguousarray(anchors_emb, dtype=np.float32)
+    if distance_function in ("similarity", "distance"):
+        s = _normalize_rows(x) @ _normalize_rows(a).T
+        if distance_function == "similarity":
+            return s.astype(np.float32)
+        return np.clip(np.float32(1.0) - s, 0.0, 2.0).astype(np.float32)
+    if distance_function == "euclidean":
+        x64, a64 = x.astype(np.float64), a.astype(np.float64)
+        d2 = -2.0 * (x64 @ a64.T)
+        d2 += np.einsum("ij,ij->i", x64, x64)[:, None]
+        d2 += np.einsum("ij,ij->i", a64, a64)[None, :]
+        d = d2.astype(np.float32)
+        np.maximum(d, 0, out=d)
+        return np.sqrt(d, out=d)
+    raise KeyError(distance_function)           # utils.py:164: dist_map[distance_function]
+
+
+def minmax_scale_columns(e: np.ndarray) -> np.ndarray:
+    """MinMaxScaler().fit(E).transform(E)  (utils.py:175-176; sklearn _data.py:92-124, 456-567).
+
+    Per COLUMN over all rows; scale_ = 1/range with range < 10*eps treated as 1; X*scale_ + min_.
+    """
+    e = np.asarray(e, dtype=np.float32)
+    dmin = e.min(axis=0)
+    dmax = e.max(axis=0)
+    rng = dmax - dmin
+    rng = np.where(rng < 10 * np.finfo(np.float32).eps, np.float32(1.0), rng).astype(np.float32)
+    scale = (np.float32(1.0) / rng).astype(np.float32)
+    mn = (np.float32(0.0) - dmin * scale).astype(np.float32)
+    return (e * scale + mn).astype(np.float32)
+
+
+def node2vec_features(x, node2vec_emb, anchors, distance_function) -> np.ndarray:
+    """utils.py:149-180, stochastic branch, given the anchors: [N, F+K] float32."""
+    emb = np.asarray(node2vec_emb, dtype=np.float32)
+    a = emb[np.asarray(anchors, dtype=np.int64)]
+    return concat_into_features(x, minmax_scale_columns(pairwise(emb, a, distance_function)))
+
+
+# --------------------------------------------------------------------------------------------
+# SAGEConv  (/root/reference/main.py:204-211 + PyG 1.7.0 SAGEConv, absent here: believed semantics)
+# --------------------------------------------------------------------------------------------
+def sage_conv_torch(x_src, rowptr, col, w_l, b_l, w_r):
+    """out[i] = lin_l(mean_{j in N(i)} x_src[j]) + lin_r(x_src[i]),  i < n_dst = len(rowptr)-1.
+
+    Plain torch fp32, differentiable.  Rows with no neighbours aggregate to zero (torch_sparse
+    ``matmul(adj_t, x, reduce='mean')`` semantics).  lin_l has a bias, lin_r has none.
+    """
+    import torch
+    n_dst = rowptr.numel() - 1
+    deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    seg = torch.repeat_interleave(torch.arange(n_dst, device=x_src.device), deg)
+    agg = torch.zeros(n_dst, x_src.shape[1], dtype=x_src.dtype, device=x_src.device)
+    agg.index_add_(0, seg, x_src.index_select(0, col.to(torch.int64)))
+    agg = agg / deg.clamp(min=1).to(x_src.dtype)[:, None]
+    out = torch.nn.functional.linear(agg, w_l, b_l)
+    return out + torch.nn.functional.linear(x_src[:n_dst], w_r)

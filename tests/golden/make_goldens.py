@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by RUNNING THE REFERENCE (build container only).
+
+    python tests/golden/make_goldens.py            # needs /root/reference, networkx, scikit-learn
+
+The reference (/root/reference/utils.py) is imported from where it lies; none of its text enters
+this repository.  Its single missing import, ``torch_geometric.utils.to_networkx`` (utils.py:12,
+used at utils.py:121), is supplied in memory with PyG 1.7.0's semantics for a ``Data`` object that
+has ``num_nodes`` and ``edge_index``: a ``networkx.DiGraph`` with nodes 0..N-1 and one directed
+edge per edge_index column.  Everything else -- anchor sampling, the multiprocessing pool, the
+per-pair ``nx.shortest_path`` loop, ``1/len(path)``, tensor conversion, concat, sklearn pairwise and
+MinMaxScaler -- is the reference's own code executing unmodified.
+
+The node2vec branch reads ``<reference dir>/data/{dataset}_node2vec.pt`` (utils.py:155), which
+does not exist (the reference tree is read-only and ships no data); ``torch.load`` is patched for
+that one call to return a seeded ``torch.randn(N, 128)`` -- the same distribution the reference's
+generator script saves (an untrained ``nn.Embedding`` table).
+
+Outputs (``tests/golden/*.npz``) are data only: inputs + the reference's returned tensor.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import networkx as nx  # noqa: E402
+import torch  # noqa: E402
+
+from graphpope_amd import synth  # noqa: E402
+
+
+def _install_to_networkx_standin():
+    tg = types.ModuleType("torch_geometric")
+    tgu = types.ModuleType("torch_geometric.utils")
+
+    def to_networkx(data):
+        g = nx.DiGraph()
+        g.add_nodes_from(range(data.num_nodes))
+        ei = data.edge_index.numpy()
+        for u, v in zip(ei[0].tolist(), ei[1].tolist()):
+            g.add_edge(u, v)
+        return g
+
+    tgu.to_networkx = to_networkx
+    tg.utils = tgu
+    sys.modules["torch_geometric"] = tg
+    sys.modules["torch_geometric.utils"] = tgu
+
+
+_install_to_networkx_standin()
+sys.path.insert(0, "/root/reference")
+import utils as ref  # noqa: E402  (the reference, imported in place)
+
+
+class Data:
+    """Duck-typed stand-in for torch_geometric.data.Data: the attributes utils.py touches."""
+
+    def __init__(self, x, edge_index, num_nodes):
+        self.x = torch.as_tensor(x, dtype=torch.float32)
+        self.edge_index = torch.as_tensor(edge_index, dtype=torch.int64)
+        self.num_nodes = int(num_nodes)
+
+
+def _reset_cache():
+    # utils.py:195-208 memoises in a module global; drop it so each fixture is computed afresh.
+    if hasattr(ref, "cached_pope_embedding"):
+        del ref.cached_pope_embedding
+
+
+def _features(n, f, seed):
+    return np.random.RandomState(seed).rand(n, f).astype(np.float32)
+
+
+def run_geodesic_with_anchors(edge_index, n, anchors, f=3, workers=2):
+    """utils.py:116-135 with data.anchor_nodes preset (what attach_distance_embedding does after sampling)."""
+    data = Data(_features(n, f, 7), edge_index, n)
+    data.anchor_nodes = np.asarray(anchors, dtype=np.int64)
+    emb = ref.get_geodesic_distance_vector(data=data, num_workers=workers)
+    out = ref.concat_into_features(embedding_matrix=emb, data=data)
+    return data.x.numpy(), out.numpy()
+
+
+def run_graphpope_seeded(edge_index, n, k, seed, f=3, workers=2):
+    """The public entry (utils.py:182-210) with the global legacy NumPy RNG seeded as main.py:260 does."""
+    _reset_cache()
+    data = Data(_features(n, f, 7), edge_index, n)
+    np.random.seed(seed)
+    out = ref.Graphpope(data, "flickr", "geodesic", "stochastic", k, None, workers)
+    _reset_cache()
+    return data.x.numpy(), out.numpy(), np.asarray(data.anchor_nodes, dtype=np.int64)
+
+
+def save_geodesic(name, edge_index, n, anchors, x, out):
+    f = x.shape[1]
+    emb = out[:, f:]
+    assert out.dtype == np.float32 and np.array_equal(out[:, :f], x)
+    # integer hop matrix implied by the reference's floats: emb = f32(1/(h+1)), 0 = unreachable
+    with np.errstate(divide="ignore"):
+        hops = np.where(emb > 0, np.rint(1.0 / emb.astype(np.float64)) - 1, -1).astype(np.int32)
+        back = np.where(hops >= 0, (1.0 / (hops.astype(np.float64) + 1)).astype(np.float32), np.float32(0))
+    assert np.array_equal(back, emb), name
+    np.savez_compressed(os.path.join(HERE, f"geodesic_{name}.npz"),
+                        edge_index=np.asarray(edge_index, dtype=np.int32), num_nodes=np.int64(n),
+                        anchors=np.asarray(anchors, dtype=np.int64), x=x, emb=emb, hops=hops)
+    reach = hops >= 0
+    print(f"geodesic_{name}: N={n} E={np.asarray(edge_index).shape[1]} K={len(anchors)} "
+          f"max_hop={hops.max()} unreachable={(~reach).sum()}")
+
+
+def both_ways(pairs):
+    p = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+    return np.concatenate([p, p[:, ::-1]]).T.copy()
+
+
+def geodesic_fixtures():
+    rs = np.random.RandomState(123)
+
+    # 1 tiny digraph: direction matters, unreachable pairs, node 4 isolated
+    ei = np.array([[0, 1, 2, 3], [1, 2, 0, 0]])
+    x, out = run_geodesic_with_anchors(ei, 5, [4, 0, 3])
+    save_geodesic("digraph5", ei, 5, [4, 0, 3], x, out)
+
+    # 2 undirected path, diameter 299 (> 255: hop counts need more than 8 bits)
+    n = 300
+    ei = both_ways([(i, i + 1) for i in range(n - 1)])
+    anc = [0, 299, 150, 7]
+    x, out = run_geodesic_with_anchors(ei, n, anc)
+    save_geodesic("path300", ei, n, anc, x, out)
+
+    # 3 one-way path: i -> i+1 only
+    n = 40
+    ei = np.array([[i for i in range(n - 1)], [i + 1 for i in range(n - 1)]])
+    anc = [0, 39, 20]
+    x, out = run_geodesic_with_anchors(ei, n, anc)
+    save_geodesic("oneway40", ei, n, anc, x, out)
+
+    # 4 star: hub 0 with 700 leaves (one very long adjacency row), anchors = hub, leaves
+    n = 701
+    ei = both_ways([(0, i) for i in range(1, n)])
+    anc = [0, 5, 700, 5]
+    x, out = run_geodesic_with_anchors(ei, n, anc)
+    save_geodesic("star701", ei, n, anc, x, out)
+
+    # 5 two components + isolated nodes; duplicate anchors and anchors in both components
+    n = 60
+    comp_a = [(i, (i + 1) % 25) for i in range(25)]
+    comp_b = [(25 + i, 25 + (i + 1) % 30) for i in range(30)] + [(25, 40), (30, 50)]
+    ei = both_ways(comp_a + comp_b)                      # nodes 55..59 isolated
+    anc = [3, 30, 57, 3, 59, 0]
+    x, out = run_geodesic_with_anchors(ei, n, anc)
+    save_geodesic("components60", ei, n, anc, x, out)
+
+    # 6 self-loops and repeated edges in edge_index (DiGraph collapses them)
+    n = 30
+    p = rs.randint(0, n, size=(80, 2))
+    ei = np.concatenate([p, p[:20], np.stack([np.arange(10), np.arange(10)], 1)]).T.copy()
+    anc = [1, 2, 3, 29, 29]
+    x, out = run_geodesic_with_anchors(ei, n, anc)
+    save_geodesic("multiloops30", ei, n, anc, x, out)
+
+    # 7 K not a multiple of 64 and spanning three 64-anchor words, with duplicates (drawn with replacement)
+    ei, n = synth.rmat(8, edge_factor=4, seed=3)
+    anc = np.random.RandomState(5).choice(np.arange(n), 130)
+    x, out = run_geodesic_with_anchors(ei, n, anc)
+    save_geodesic("rmat8_k130", ei, n, anc, x, out)
+
+    # 8 directed (not symmetrised) R-MAT: BFS must follow edge direction node -> anchor
+    ei, n = synth.rmat(9, edge_factor=4, seed=4, symmetric=False)
+    anc = np.random.RandomState(6).choice(np.arange(n), 24)
+    x, out = run_geodesic_with_anchors(ei, n, anc)
+    save_geodesic("rmat9_directed", ei, n, anc, x, out)
+
+    # 9 symmetric R-MAT scale 11, through the PUBLIC entry with seeded stochastic sampling
+    ei, n = synth.rmat(11, edge_factor=8, seed=1)
+    x, out, anc = run_graphpope_seeded(ei, n, 16, seed=42)
+    save_geodesic("rmat11_seed42", ei, n, anc, x, out)
+
+    # 10 Flickr-shaped power-law graph, 4 000 nodes, hubs with > 512 neighbours, public entry
+    ei = synth.powerlaw_graph(4000, 20000, seed=2, alpha=0.9, shift=0.6)
+    x, out, anc = run_graphpope_seeded(ei, 4000, 32, seed=42, workers=4)
+    save_geodesic("powerlaw4k_seed42", ei, 4000, anc, x, out)
+
+    # 11 PubMed-shaped sparse graph (mean degree ~4.5), 1 500 nodes, many small components
+    ei = synth.powerlaw_graph(1500, 2200, seed=5, alpha=0.6, shift=10.0)
+    x, out, anc = run_graphpope_seeded(ei, 1500, 64, seed=7, workers=3)
+    save_geodesic("sparse1500_seed7", ei, 1500, anc, x, out)
+
+    # 12 no edges at all: only an anchor's own entry is non-zero
+    ei = np.zeros((2, 0), dtype=np.int64)
+    anc = [2, 0, 2]
+    x, out = run_geodesic_with_anchors(ei, 6, anc)
+    save_geodesic("noedges6", ei, 6, anc, x, out)
+
+
+def anchor_fixtures():
+    """utils.py:22-24 under main.py:260's seed_everything(seed) -> np.random.seed(seed)."""
+    out = {}
+
+    class _D:
+        pass
+
+    for n, k, seed in [(19717, 32, 42), (89250, 256, 42), (89250, 1024, 42), (4194304, 512, 42), (10, 25, 0)]:
+        d = _D()
+        d.num_nodes = n
+        np.random.seed(seed)
+        out[f"n{n}_k{k}_s{seed}"] = np.asarray(ref.sample_anchor_nodes(d, k, "stochastic"), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "anchors_stochastic.npz"), **out)
+    print("anchors_stochastic:", {k: v[:4].tolist() for k, v in out.items()})
+
+
+def node2vec_fixtures():
+    n, d, k, f = 2048, 128, 64, 5
+    table = torch.randn(n, d, generator=torch.Generator().manual_seed(0))
+    real_load = ref.torch.load
+
+    def run(tab, n_nodes, kk, fn, seed):
+        _reset_cache()
+        data = Data(_features(n_nodes, f, 11), np.zeros((2, 0), dtype=np.int64), n_nodes)
+        ref.torch.load = lambda *a, **kw: tab.clone().requires_grad_(True)
+        try:
+            np.random.seed(seed)
+            # recover the anchors the call draws (same stream position: first draw after seeding)
+            anchors = np.random.RandomState(seed).choice(np.arange(n_nodes), kk)
+            out = ref.Graphpope(data, "flickr", "node2vec", "stochastic", kk, fn, 2)
+        finally:
+            ref.torch.load = real_load
+            _reset_cache()
+        return data.x.numpy(), out.numpy().astype(np.float32), anchors
+
+    def family(tag, tab, n_nodes, kk, seed):
+        pack = {}
+        for fn in ("distance", "similarity", "euclidean"):
+            x, out, anchors = run(tab, n_nodes, kk, fn, seed)
+            assert np.array_equal(out[:, :f], x)
+            pack.update(x=x, anchors=anchors, **{f"scaled_{fn}": out[:, f:]})
+            print(f"node2vec_{tag}/{fn}: {out.shape} min {out[:, f:].min():.3g} max {out[:, f:].max():.3g}")
+        np.savez_compressed(os.path.join(HERE, f"node2vec_{tag}.npz"), emb=tab.numpy(), **pack)
+
+    family("randn2048", table, n, k, 42)
+
+    # near-duplicate / shifted rows: small true distances (cancellation), and a zero row
+    tab2 = torch.randn(96, 16, generator=torch.Generator().manual_seed(1))
+    tab2[10] = tab2[3] * (1 + 1e-4)
+    tab2[11] = tab2[3] + 1e-3
+    tab2[12] = 0.0                                   # zero row: cosine of a zero vector
+    family("small96", tab2, 96, 12, 3)
+
+    # identical rows: every column is constant (range < 10 eps -> scale 1)
+    family("const40", torch.ones(40, 8), 40, 4, 1)
+
+
+if __name__ == "__main__":
+    geodesic_fixtures()
+    anchor_fixtures()
+    node2vec_fixtures()

@@ -1,0 +1,81 @@
+"""The CPU oracle against the golden vectors the reference produced (tests/golden/make_goldens.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_geodesic_files, load_golden
+
+
+@pytest.mark.parametrize("path", golden_geodesic_files(), ids=lambda p: os.path.basename(p)[9:-4])
+def test_geodesic_oracle_matches_reference_bit_exact(oracle, path):
+    g = load_golden(path)
+    n = int(g["num_nodes"])
+    hops = oracle.geodesic_hops(g["edge_index"].astype(np.int64), n, g["anchors"])
+    assert hops.dtype == np.int32 and hops.shape == g["hops"].shape
+    assert np.array_equal(hops, g["hops"])
+    emb = oracle.hops_to_embedding(hops)
+    assert emb.dtype == np.float32
+    assert np.array_equal(emb.view(np.uint32), g["emb"].view(np.uint32))          # bit-exact f32
+    out = oracle.concat_into_features(g["x"], emb)
+    assert out.shape == (n, g["x"].shape[1] + len(g["anchors"]))
+    assert np.array_equal(out[:, :g["x"].shape[1]], g["x"]) and np.array_equal(out[:, g["x"].shape[1]:], g["emb"])
+
+
+def test_goldens_cover_the_edge_cases():
+    names = {os.path.basename(p)[9:-4] for p in golden_geodesic_files()}
+    assert {"digraph5", "path300", "oneway40", "star701", "components60", "multiloops30", "rmat8_k130",
+            "rmat9_directed", "rmat11_seed42", "powerlaw4k_seed42", "sparse1500_seed7", "noedges6"} <= names
+    assert load_golden(os.path.join(GOLDEN, "geodesic_path300.npz"))["hops"].max() == 299      # > 8 bits
+    g = load_golden(os.path.join(GOLDEN, "geodesic_rmat8_k130.npz"))
+    assert len(g["anchors"]) == 130 and len(np.unique(g["anchors"])) < 130                       # duplicates kept
+
+
+def test_f32_division_equals_reference_double_rounding():
+    # utils.py:73 divides in float64 and torch.as_tensor rounds to float32; the device computes
+    # 1.0f / (float)(h + 1).  The two agree for every hop count a graph with < 2^24 nodes can produce.
+    h1 = np.arange(1, 1 << 24, dtype=np.int64)
+    via_f64 = (1.0 / h1.astype(np.float64)).astype(np.float32)
+    via_f32 = np.float32(1.0) / h1.astype(np.float32)
+    assert np.array_equal(via_f64.view(np.uint32), via_f32.view(np.uint32))
+
+
+def test_oracle_rejects_out_of_range_ids(oracle):
+    with pytest.raises(IndexError):
+        oracle.geodesic_hops(np.array([[0], [5]]), 3, [0])
+    with pytest.raises(IndexError):
+        oracle.geodesic_hops(np.array([[0], [1]]), 3, [3])
+
+
+def test_oracle_pairs_networkx_agrees(oracle):
+    g = load_golden(os.path.join(GOLDEN, "geodesic_rmat9_directed.npz"))
+    nodes = np.arange(0, 512, 37)
+    ref = oracle.geodesic_pairs_networkx(g["edge_index"].astype(np.int64), 512, g["anchors"][:6], nodes)
+    assert np.array_equal(ref, g["emb"][nodes][:, :6])
+
+
+def test_seeded_anchor_draw_matches_reference(oracle):
+    from graphpope_amd import synth
+    with np.load(os.path.join(GOLDEN, "anchors_stochastic.npz")) as z:
+        for key in z.files:
+            n, k, s = (int(t[1:]) for t in key.split("_"))
+            np.random.seed(s)
+            assert np.array_equal(oracle.sample_anchor_nodes_stochastic(n, k), z[key])
+            assert np.array_equal(synth.seeded_anchors(n, k, s), z[key])
+    assert synth.seeded_anchors(89250, 256, 42)[:8].tolist() == [15795, 860, 76820, 54886, 6265, 82386, 37194, 87498]
+
+
+@pytest.mark.parametrize("family", ["randn2048", "small96", "const40"])
+@pytest.mark.parametrize("fn", ["distance", "similarity", "euclidean"])
+def test_node2vec_oracle_matches_reference(oracle, family, fn):
+    g = load_golden(os.path.join(GOLDEN, f"node2vec_{family}.npz"))
+    out = oracle.node2vec_features(g["x"], g["emb"], g["anchors"], fn)
+    f = g["x"].shape[1]
+    assert out.dtype == np.float32 and np.array_equal(out[:, :f], g["x"])
+    # tolerance: SURVEY.md §8c, 1e-5 abs on the min-max scaled embedding
+    np.testing.assert_allclose(out[:, f:], g[f"scaled_{fn}"], rtol=0, atol=1e-5)
+
+
+def test_node2vec_unknown_distance_function_is_keyerror(oracle):
+    with pytest.raises(KeyError):
+        oracle.pairwise(np.zeros((2, 2), np.float32), np.zeros((1, 2), np.float32), "manhattan")

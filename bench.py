@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- GraphPOPE hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path over one synthetic Flickr-shaped input already resident in HBM:
+edge_index -> CSR -> multi-source BFS for all anchors -> hop planes -> [N, F+K] float32 features
+(BASELINE.json configs[1]: Flickr geodesic-stochastic, 256 anchors).  For N > 1 GPUs the run is WEAK
+scaled: every rank owns 256 anchors (K_total = 256 * N), planes are all-gathered (RCCL) and every rank
+materialises the full [N, F + K_total] matrix, as every DDP rank of the reference needs it.
+
+Rank 0 prints ONE JSON line.  At N = 1 it also times the CPU baselines on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from graphpope_amd import engine, synth  # noqa: E402
+from graphpope_amd import distributed as pdist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+F = 500                      # /root/reference/main.py:77-79
+K_PER_GPU = 256
+
+
+def _event():
+    return torch.cuda.Event(enable_timing=True)
+
+
+def pope_step(x, ei, n, anchors, world, timers=None):
+    """One full geodesic GraphPOPE pass on the device; returns the [N, F+K] tensor."""
+    k = len(anchors)
+    ev = [_event() for _ in range(4)] if timers is not None else None
+    if ev:
+        ev[0].record()
+    rowptr, col, _ = engine.build_csr(ei, n)
+    if ev:
+        ev[1].record()
+    if world == 1:
+        hp = engine.bfs(rowptr, col, n, anchors)
+        if ev:
+            ev[2].record()
+        out = torch.empty((n, F + k), dtype=torch.float32, device=x.device)
+        engine.finalize(hp.planes, hp.n_hop_bits, n, k, x, F, out, 0)
+        if ev:
+            ev[3].record()
+            torch.cuda.synchronize()
+            timers["csr"].append(ev[0].elapsed_time(ev[1]))
+            timers["bfs"].append(ev[1].elapsed_time(ev[2]))
+            timers["finalize"].append(ev[2].elapsed_time(ev[3]))
+            timers["max_hop"] = hp.max_hop
+            timers["n_hop_bits"] = hp.n_hop_bits
+        return out
+    return pdist.sharded_geodesic_features(x, n, anchors, None,
+                                           bfs_fn=lambda a: engine.bfs(rowptr, col, n, a),
+                                           finalize_fn=engine.finalize)
+
+
+def cpu_baselines(ei, n, anchors):
+    """Timed on this host's cores, bounded samples (rank 0, N = 1 only).  Uses the oracle as the measured CPU port."""
+    from oracle import oracle
+    res = {}
+    # (A) the reference's algorithm, statement for statement: nx.shortest_path per (node, anchor) pair
+    nodes = np.random.RandomState(0).choice(n, 96, replace=False)
+    try:
+        import networkx as nx  # noqa: F401
+        t0 = time.perf_counter()
+        g_nodes = oracle.geodesic_pairs_networkx  # builds the DiGraph as utils.py:121 does
+        t_build0 = time.perf_counter()
+        emb = g_nodes(ei, n, anchors, nodes)
+        t1 = time.perf_counter()
+        pairs = len(nodes) * len(anchors)
+        res["cpu_baseline"] = {
+            "value": pairs / (t1 - t0), "unit": "embeddings/s", "cores": 1, "kind": "port",
+            "sample": f"{len(nodes)} random nodes x {len(anchors)} anchors = {pairs} pairs of the same Flickr-shaped graph, "
+                      f"networkx per-pair bidirectional BFS as utils.py:64-81 (graph build included), {t1 - t0:.1f} s",
+        }
+        del emb, t_build0
+    except ImportError:
+        pass
+    # (B) honest CPU: the C oracle, one BFS per anchor, single core, all 256 anchors
+    t0 = time.perf_counter()
+    hops = oracle.geodesic_hops(ei, n, anchors)
+    oracle.hops_to_embedding(hops)
+    t1 = time.perf_counter()
+    res["cpu_baseline_bfs"] = {
+        "value": n * len(anchors) / (t1 - t0), "unit": "embeddings/s", "cores": 1, "kind": "port",
+        "sample": f"full N x K = {n} x {len(anchors)}, oracle/pope_oracle.c one BFS per anchor, {t1 - t0:.2f} s",
+    }
+    if "cpu_baseline" not in res:
+        res["cpu_baseline"] = res["cpu_baseline_bfs"]
+    return res, hops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = engine.require_gpu()
+
+    ei_np, n = synth.flickr_like(seed=1)
+    k_total = K_PER_GPU * world
+    anchors = synth.seeded_anchors(n, k_total, 42)
+    x = torch.rand((n, F), device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    ei = torch.as_tensor(ei_np, device=dev)
+    e = ei_np.shape[1]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = pope_step(x, ei, n, anchors, world)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pope_step(x, ei, n, anchors, world)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        result = {
+            "metric": "POPE embeddings/sec (nodes x anchors), Flickr 256 anchors",
+            "value": n * k_total / (elapsed / args.steps), "unit": "embeddings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 bitmaps -> f32",
+            "data": "synthetic",
+            "config": {"workload": "flickr-shaped geodesic-stochastic, N=89250 E=%d F=500, %d anchors per GPU (seed 42), "
+                                   "edge_index+x resident in HBM -> [N, F+K] f32 in HBM" % (e, K_PER_GPU),
+                       "anchors_total": k_total, "parallelism": f"anchor-shard x{world} + all-gather" if world > 1 else "single GPU"},
+        }
+    if world == 1:
+        # per-phase device time with HIP events on the launch stream, separate from the wall-clock loop above
+        timers = {"csr": [], "bfs": [], "finalize": []}
+        for _ in range(max(10, min(args.steps, 50))):
+            pope_step(x, ei, n, anchors, 1, timers)
+        med = {p: float(np.median(timers[p])) for p in ("csr", "bfs", "finalize")}
+        fin_bytes = 4.0 * n * F + 4.0 * n * (F + K_PER_GPU) + 8.0 * n * 4 * (1 + timers["n_hop_bits"])
+        fin_gbs = fin_bytes / (med["finalize"] * 1e-3) / 1e9
+        bfs_bytes = K_PER_GPU * (4.0 * e + 4.0 * (n + 1) + 4.0 * n)     # SURVEY.md §8d per-source model
+        result["phases_ms"] = med
+        result["max_hop"] = timers["max_hop"]
+        result["roofline"] = {"kernel": "k_finalize<true>", "bound": "hbm", "achieved": fin_gbs, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": fin_gbs / HBM_PEAK_GBS, "traffic": None,
+                              "algorithmic_bytes": fin_bytes}
+        geo_gbs = bfs_bytes / ((med["bfs"] + med["finalize"]) * 1e-3) / 1e9
+        result["roofline_geodesic_per_source_model"] = {
+            "kernels": "k_bfs_pull (all levels) + k_finalize", "bound": "hbm", "achieved": geo_gbs, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": geo_gbs / HBM_PEAK_GBS, "algorithmic_bytes": bfs_bytes,
+            "note": "SURVEY 8d per-source byte model (each anchor reads the CSR once); a 64-wide bit-parallel BFS shares "
+                    "each CSR read between 64 anchors, so frac > 1 is expected and is not an HBM measurement"}
+        if not args.no_cpu_baseline:
+            base, want_hops = cpu_baselines(ei_np, n, anchors)
+            result.update(base)
+            rowptr, col, _ = engine.build_csr(ei, n)
+            got = engine.hop_matrix(engine.bfs(rowptr, col, n, anchors)).cpu().numpy()
+            result["hops_bit_exact_vs_cpu"] = bool(np.array_equal(got, want_hops))
+            result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+    del out
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""ctypes binding of libgraphpope_hip.so (C ABI: include/graphpope_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgraphpope_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_HOP_OVERFLOW, ERR_WORKSPACE, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
+METRIC = {"distance": 0, "similarity": 1, "euclidean": 2}
+
+# name -> (restype, argtypes); exactly the symbols include/graphpope_hip.h declares
+SIGNATURES = {
+    "pope_last_error": (c_char_p, []),
+    "pope_version": (c_char_p, []),
+    "pope_csr_scratch_bytes": (c_size_t, [c_int64, c_int64]),
+    "pope_csr_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
+                               POINTER(c_int32), c_void_p]),
+    "pope_words": (c_int32, [c_int32]),
+    "pope_plane_bytes": (c_size_t, [c_int64, c_int32]),
+    "pope_bfs_scratch_bytes": (c_size_t, [c_int64, c_int32]),
+    "pope_geodesic_bfs": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int32,
+                                  c_void_p, c_size_t, POINTER(c_int32), POINTER(c_int32), c_void_p]),
+    "pope_geodesic_finalize": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int64,
+                                       c_int32, c_void_p]),
+    "pope_geodesic_hops": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
+    "pope_pairwise_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "pope_pairwise_minmax": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,
+                                     c_int32, c_void_p, c_size_t, c_void_p]),
+    "pope_concat": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
+    "sage_conv_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int32, c_int32]),
+    "sage_conv_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p,
+                                  c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "sage_conv_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int32,
+                                   c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_size_t, c_void_p]),
+}
+
+
+class PopeError(RuntimeError):
+    """A libgraphpope_hip call returned a negative code (shim raises RuntimeError)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libgraphpope_hip error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library; raise loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C graphpope_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). graphpope_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so is stale: also loud
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(code: int) -> None:
+    if code != OK:
+        raise PopeError(code, load().pope_last_error().decode())
+
+
+def ptr(t) -> c_void_p:
+    """Device (or host) address of a torch tensor / None as a void*."""
+    return c_void_p(0) if t is None else c_void_p(t.data_ptr())

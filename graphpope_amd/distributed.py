@@ -1,0 +1,89 @@
+"""Anchor sharding over the GPUs of one node + all-gather of the hop planes.
+
+The reference has no collective on this path: every Lightning DDP rank recomputes all K anchors
+(/root/reference/main.py:94-98 runs per process).  Here rank g runs the multi-source BFS for the
+contiguous anchor slice g and the bit-sliced hop planes -- (1 + hop bits) bits per (node, anchor)
+instead of a 32-bit float -- are exchanged with ONE ``all_gather`` (RCCL over xGMI when the backend
+is "nccl"); every rank then expands them into the same [N, F+K] matrix.
+
+This module is device-agnostic host logic (the BFS and the expansion are passed in), so the N > 1
+path is covered by world_size-2 ``gloo`` tests on CPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world_size(group=None) -> int:
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(group)
+
+
+def rank(group=None) -> int:
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    return dist.get_rank(group)
+
+
+def shard_size(k: int, world: int) -> int:
+    """Anchors per rank: ceil(K / world); shard g owns anchors [g*size, min((g+1)*size, K)) in draw order."""
+    return -(-k // world)
+
+
+def shard_anchors(anchors: np.ndarray, world: int, rnk: int):
+    """(padded anchors of length shard_size, number of real anchors) for one rank.
+
+    All shards must have the same shape for the all-gather, so a short (or empty) last shard is
+    padded by repeating an anchor; the padded columns fall beyond column K and are dropped.
+    """
+    anchors = np.asarray(anchors, dtype=np.int64)
+    size = shard_size(anchors.size, world)
+    lo = min(rnk * size, anchors.size)
+    hi = min(lo + size, anchors.size)
+    real = anchors[lo:hi]
+    pad_value = real[-1] if real.size else anchors[0]
+    padded = np.concatenate([real, np.full(size - real.size, pad_value, dtype=np.int64)])
+    return padded, int(real.size)
+
+
+def _all_gather(local: torch.Tensor, group) -> torch.Tensor:
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, local, group=group)       # one RCCL all-gather, no staging copies
+    else:
+        dist.all_gather(list(out.unbind(0)), local, group=group)
+    return out
+
+
+def sharded_geodesic_features(x: torch.Tensor, num_nodes: int, anchors: np.ndarray, group, bfs_fn, finalize_fn) -> torch.Tensor:
+    """Every rank returns the full [N, F+K] float32 matrix.
+
+    bfs_fn(anchors) -> object with .planes ([>= 1 + n_hop_bits, N, W] int64), .n_hop_bits
+    finalize_fn(planes, n_hop_bits, N, K_shard, x_or_None, F, out, c0) writes x and one shard's columns.
+    """
+    world, rnk = dist.get_world_size(group), dist.get_rank(group)
+    anchors = np.asarray(anchors, dtype=np.int64)
+    k, f = int(anchors.size), x.shape[1]
+    size = shard_size(k, world)
+    local_anchors, _ = shard_anchors(anchors, world, rnk)
+    hp = bfs_fn(local_anchors)
+
+    # Ranks may have found different depths: agree on the number of hop-bit planes to exchange.
+    bits_t = torch.tensor([hp.n_hop_bits], dtype=torch.int32, device=x.device)
+    dist.all_reduce(bits_t, op=dist.ReduceOp.MAX, group=group)
+    bits = int(bits_t.item())
+    local = torch.zeros((1 + bits,) + tuple(hp.planes.shape[1:]), dtype=hp.planes.dtype, device=hp.planes.device)
+    local[: 1 + hp.n_hop_bits] = hp.planes[: 1 + hp.n_hop_bits]
+    gathered = _all_gather(local, group)                            # [world, 1 + bits, N, W]
+
+    cols = f + world * size
+    out = torch.empty((num_nodes, cols), dtype=torch.float32, device=x.device)
+    for g in range(world):
+        finalize_fn(gathered[g], bits, num_nodes, size, x if g == 0 else None, f, out, g * size)
+    if cols != f + k:                                               # K not divisible by world: drop the padding
+        out = out[:, : f + k].contiguous()
+    return out

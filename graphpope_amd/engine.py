@@ -1,0 +1,161 @@
+"""Device-side engine: torch owns memory and streams, libgraphpope_hip.so does the work.
+
+Every function here takes/returns tensors that live on the MI355X; ``graphpope_amd.utils`` wraps
+them behind the reference's ``Graphpope`` call.  PyTorch is plumbing only (allocation, streams,
+``torch.distributed``): no torch op computes any part of the embedding.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+DEFAULT_PLANE_CAPACITY = 8          # hop counts < 256; grown on POPE_ERR_HOP_OVERFLOW
+
+
+def require_gpu(device=None) -> torch.device:
+    """The product path needs a GPU and the HIP library; it never computes on the CPU."""
+    _lib.load()
+    if not torch.cuda.is_available():
+        raise RuntimeError("graphpope_amd needs an MI355X (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(f"graphpope_amd computes on the GPU only, got device {dev}")
+    return dev
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _bytes(n: int, device) -> torch.Tensor:
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
+
+
+def build_csr(edge_index: torch.Tensor, num_nodes: int):
+    """int64 [2, E] on the device -> (rowptr int32 [N+1], col int32 [E], max_degree).  utils.py:121."""
+    lib = _lib.load()
+    assert edge_index.is_cuda and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.shape[0] == 2
+    ei = edge_index.contiguous()
+    e = ei.shape[1]
+    dev = ei.device
+    with torch.cuda.device(dev):
+        rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+        scratch = _bytes(lib.pope_csr_scratch_bytes(num_nodes, e), dev)
+        maxdeg = ctypes.c_int32(0)
+        check(lib.pope_csr_build(ptr(ei), e, num_nodes, ptr(rowptr), ptr(col), ptr(scratch), scratch.numel(),
+                                 ctypes.byref(maxdeg), _stream()))
+    return rowptr, col[:e], int(maxdeg.value)
+
+
+class HopPlanes:
+    """Bit-sliced hop counts of K anchors (include/graphpope_hip.h, "hop planes")."""
+
+    def __init__(self, planes: torch.Tensor, n_hop_bits: int, max_hop: int, num_nodes: int, k: int):
+        self.planes = planes            # int64 [capacity + 1, N, W]; planes[:1 + n_hop_bits] valid
+        self.n_hop_bits = n_hop_bits
+        self.max_hop = max_hop
+        self.num_nodes = num_nodes
+        self.k = k
+
+    def valid(self) -> torch.Tensor:
+        return self.planes[: 1 + self.n_hop_bits]
+
+
+def bfs(rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int, anchors, capacity: int = DEFAULT_PLANE_CAPACITY) -> HopPlanes:
+    """Multi-source BFS for all anchors at once (utils.py:64-114).  Retries with more hop bits on overflow."""
+    lib = _lib.load()
+    anc = np.ascontiguousarray(np.asarray(anchors), dtype=np.int64)
+    k = int(anc.size)
+    dev = rowptr.device
+    w = lib.pope_words(k)
+    with torch.cuda.device(dev):
+        scratch = _bytes(lib.pope_bfs_scratch_bytes(num_nodes, k), dev)
+        while True:
+            planes = torch.empty((capacity + 1, num_nodes, w), dtype=torch.int64, device=dev)
+            max_hop, bits = ctypes.c_int32(0), ctypes.c_int32(0)
+            rc = lib.pope_geodesic_bfs(ptr(rowptr), ptr(col), num_nodes, col.numel(), ctypes.c_void_p(anc.ctypes.data), k,
+                                       ptr(planes), capacity, ptr(scratch), scratch.numel(),
+                                       ctypes.byref(max_hop), ctypes.byref(bits), _stream())
+            if rc == _lib.ERR_HOP_OVERFLOW and capacity < 31:
+                capacity = min(31, capacity * 2)      # 8 -> 16 -> 31 hop bits
+                continue
+            check(rc)
+            return HopPlanes(planes, int(bits.value), int(max_hop.value), num_nodes, k)
+
+
+def finalize(planes: torch.Tensor, n_hop_bits: int, num_nodes: int, k: int, x, f: int, out: torch.Tensor, c0: int = 0):
+    """Write x and 1/(hops+1) for one shard's k anchors into out[:, :f] and out[:, f+c0 : f+c0+k]."""
+    lib = _lib.load()
+    assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == num_nodes
+    assert planes.is_contiguous() and planes.shape[0] >= 1 + n_hop_bits
+    with torch.cuda.device(out.device):
+        check(lib.pope_geodesic_finalize(ptr(planes), n_hop_bits, num_nodes, k, ptr(x), f, ptr(out), out.shape[1],
+                                         c0, _stream()))
+
+
+def hop_matrix(hp: HopPlanes) -> torch.Tensor:
+    """int32 [N, K], -1 = unreachable (the integers behind the reference's floats)."""
+    lib = _lib.load()
+    dev = hp.planes.device
+    with torch.cuda.device(dev):
+        hops = torch.empty((hp.num_nodes, hp.k), dtype=torch.int32, device=dev)
+        check(lib.pope_geodesic_hops(ptr(hp.planes), hp.n_hop_bits, hp.num_nodes, hp.k, ptr(hops), _stream()))
+    return hops
+
+
+def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int, anchors, group=None,
+                      shard: bool = True) -> torch.Tensor:
+    """[N, F+K] float32 on the device: features next to the geodesic POPE embedding (utils.py:137-147).
+
+    With an initialised ``torch.distributed`` group of more than one rank the anchors are sharded
+    over the ranks and the hop planes are all-gathered; every rank returns the full matrix.
+    ``shard=False`` computes all anchors locally even inside a process group.
+    """
+    from . import distributed as pdist
+    dev = require_gpu(x.device)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] == num_nodes
+    x = x.contiguous()
+    anc = np.asarray(anchors, dtype=np.int64)
+    k, f = int(anc.size), x.shape[1]
+    rowptr, col, _ = build_csr(edge_index.to(dev), num_nodes)
+    world = pdist.world_size(group) if shard else 1
+    if world == 1:
+        hp = bfs(rowptr, col, num_nodes, anc)
+        out = torch.empty((num_nodes, f + k), dtype=torch.float32, device=dev)
+        finalize(hp.planes, hp.n_hop_bits, num_nodes, k, x, f, out, 0)
+        return out
+    return pdist.sharded_geodesic_features(
+        x, num_nodes, anc, group,
+        bfs_fn=lambda a: bfs(rowptr, col, num_nodes, a),
+        finalize_fn=finalize)
+
+
+# ------------------------------------------------------------------------------------------------
+# node2vec-space embedding (utils.py:149-180)
+# ------------------------------------------------------------------------------------------------
+def pairwise_features(x: torch.Tensor, emb: torch.Tensor, anchors, distance_function: str) -> torch.Tensor:
+    """[N, F+K] float32 on the device: min-max scaled distance of every node2vec row to the anchor rows."""
+    lib = _lib.load()
+    dev = require_gpu(x.device)
+    metric = _lib.METRIC[distance_function]          # KeyError for unknown names, as utils.py:164
+    x = x.contiguous()
+    emb = emb.to(dev, torch.float32).contiguous()
+    n, f = x.shape
+    d = emb.shape[1]
+    idx = torch.as_tensor(np.asarray(anchors, dtype=np.int64), device=dev)
+    a = emb.index_select(0, idx).contiguous()        # the K anchor rows (utils.py:167)
+    k = a.shape[0]
+    with torch.cuda.device(dev):
+        out = torch.empty((n, f + k), dtype=torch.float32, device=dev)
+        scratch = _bytes(lib.pope_pairwise_scratch_bytes(n, k, d), dev)
+        check(lib.pope_concat(ptr(x), n, f, ptr(out), f + k, _stream()))
+        check(lib.pope_pairwise_minmax(ptr(emb), n, d, ptr(a), k, metric, ptr(out), f + k, f, ptr(scratch),
+                                       scratch.numel(), _stream()))
+    return out

@@ -1,0 +1,160 @@
+"""Drop-in for the reference's ``utils`` module: ``from graphpope_amd.utils import Graphpope``.
+
+Same names, argument meaning, return layout and error behaviour as /root/reference/utils.py for the
+hot path; the arithmetic runs on the MI355X through libgraphpope_hip.so:
+
+=============================  =============================================================
+reference (utils.py)           here
+=============================  =============================================================
+sample_anchor_nodes :18-62     host NumPy ('stochastic' draws from the same global legacy RNG)
+shortest_path_length :64-81    engine.bfs -- batched multi-source BFS kernel
+all_pairs_..._parallel :92     (the mp.Pool fan-out is gone; num_workers is accepted and ignored)
+get_geodesic_distance_vector   engine.build_csr + engine.bfs + engine.finalize
+concat_into_features :129      fused into the finalise kernel / pope_concat
+attach_distance_embedding      same prints, sets data.anchor_nodes
+attach_node2vec :149           pairwise MFMA tile + column min-max kernel
+Graphpope :182                 same signature, same process-lifetime cache
+=============================  =============================================================
+
+``data`` is duck-typed: ``.x`` float32 [N, F], ``.edge_index`` int64 [2, E], ``.num_nodes``.
+The returned tensor is a NEW CPU float32 [N, F+K] tensor, as in the reference.
+"""
+from __future__ import annotations
+
+import os
+import os.path as osp
+
+import numpy as np
+import torch
+
+from . import engine
+
+# where attach_node2vec looks for {dataset}_node2vec.pt (reference: <dir of utils.py>/data, utils.py:155)
+NODE2VEC_DIR = os.environ.get("GRAPHPOPE_DATA_DIR", osp.join(osp.dirname(osp.realpath(__file__)), "data"))
+
+_CENTRALITIES = ("pagerank", "betweenness_centrality", "eigenvector_centrality", "closeness_centrality",
+                 "clustering_coefficient")
+
+
+def _device():
+    dev = engine.require_gpu()
+    local_rank = os.environ.get("LOCAL_RANK")
+    if local_rank is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+        dev = torch.device("cuda", int(local_rank) % torch.cuda.device_count())
+        torch.cuda.set_device(dev)
+    return dev
+
+
+def _shard() -> bool:
+    """Shard anchors over the ranks of an initialised process group unless GRAPHPOPE_SHARD=0."""
+    return os.environ.get("GRAPHPOPE_SHARD", "1") != "0"
+
+
+def sample_anchor_nodes(data, num_anchor_nodes, sampling_method):
+    """utils.py:18-62.  'stochastic' is bit-identical (global legacy NumPy RNG, with replacement).
+
+    'degree_centrality' is reproduced on the host from edge_index (in + out degree of the DiGraph
+    to_networkx builds: repeated edges collapsed, ascending stable sort, last K kept: utils.py:38-42).
+    The other centralities are one-off CPU NetworkX calls outside the accelerated path
+     and raise NotImplementedError.
+    """
+    if sampling_method == "stochastic":
+        node_indices = np.arange(data.num_nodes)
+        return np.random.choice(node_indices, num_anchor_nodes)
+    if sampling_method == "degree_centrality":
+        ei = data.edge_index.detach().cpu().numpy().astype(np.int64)
+        n = int(data.num_nodes)
+        pairs = np.unique(ei[0] * n + ei[1])                       # DiGraph keeps one edge per (u, v)
+        deg = np.bincount(pairs // n, minlength=n) + np.bincount(pairs % n, minlength=n)
+        order = np.argsort(deg, kind="stable")                     # ascending, ties in node order
+        return order[-num_anchor_nodes:].tolist()
+    if sampling_method in _CENTRALITIES:
+        raise NotImplementedError(
+            f"sampling_method={sampling_method!r}: NetworkX centrality ranking is outside the accelerated hot path "
+            "(SURVEY.md §8f rank 3); use 'stochastic' or 'degree_centrality'")
+    # the reference falls through every `if` and hits `return sampled_anchor_nodes` unbound (utils.py:62)
+    raise UnboundLocalError("local variable 'sampled_anchor_nodes' referenced before assignment")
+
+
+def _geodesic_device(data, dev):
+    x = data.x.detach().to(dev, torch.float32)
+    ei = data.edge_index.detach().to(dev, torch.int64)
+    return engine.geodesic_features(x, ei, int(data.num_nodes), data.anchor_nodes, shard=_shard())
+
+
+def get_geodesic_distance_vector(data, num_workers):
+    """utils.py:116-126: float32 [N, K], entry (v, j) = 1 / (hops(v -> anchor_nodes[j]) + 1), 0 if no path.
+
+    ``num_workers`` (CPU processes in the reference) is accepted for signature parity and unused.
+    """
+    dev = _device()
+    n = int(data.num_nodes)
+    rowptr, col, _ = engine.build_csr(data.edge_index.detach().to(dev, torch.int64), n)
+    hp = engine.bfs(rowptr, col, n, data.anchor_nodes)
+    out = torch.empty((n, hp.k), dtype=torch.float32, device=dev)
+    engine.finalize(hp.planes, hp.n_hop_bits, n, hp.k, None, 0, out, 0)
+    return out.cpu()
+
+
+def concat_into_features(embedding_matrix, data):
+    """utils.py:129-135."""
+    embedding_tensor = torch.as_tensor(embedding_matrix)
+    return torch.cat((data.x, embedding_tensor), 1)
+
+
+def attach_distance_embedding(data, dataset, num_anchor_nodes, sampling_method, distance_function, num_workers):
+    """utils.py:137-147 (ignores dataset / distance_function, like the reference)."""
+    print('sampling anchor nodes...')
+    data.anchor_nodes = sample_anchor_nodes(data=data, num_anchor_nodes=num_anchor_nodes, sampling_method=sampling_method)
+    print('deriving shortest paths to anchor nodes...')
+    extended_features = _geodesic_device(data, _device()).cpu()
+    print('feature matrix is blessed by the POPE!')
+    return extended_features
+
+
+def attach_node2vec(data, dataset, num_anchor_nodes, sampling_method, distance_function, num_workers):
+    """utils.py:149-180.  KeyError for an unknown distance_function, FileNotFoundError for a missing table."""
+    print('sampling anchor nodes...')
+    loading_path = osp.join(NODE2VEC_DIR, f'{dataset}_node2vec.pt')
+    node2vec_embeddings = torch.load(loading_path, map_location="cpu").detach()
+    if distance_function not in ('distance', 'similarity', 'euclidean'):
+        raise KeyError(distance_function)
+    if sampling_method == 'stochastic':
+        anchor_nodes = sample_anchor_nodes(data, num_anchor_nodes, sampling_method='stochastic')
+    else:
+        raise NotImplementedError("K-means anchors (utils.py:168-170) are outside the accelerated hot path "
+                                  "(SURVEY.md §8f rank 3); use sampling_method='stochastic'")
+    dev = _device()
+    x = data.x.detach().to(dev, torch.float32)
+    extended_features = engine.pairwise_features(x, node2vec_embeddings.to(dev), anchor_nodes, distance_function).cpu()
+    print('feature matrix is blessed by the POPE')
+    return extended_features
+
+
+_cached_pope_embedding = None
+
+
+def clear_cache():
+    """Forget the memoised result (the reference can only do this by restarting the process)."""
+    global _cached_pope_embedding
+    _cached_pope_embedding = None
+
+
+def Graphpope(data, dataset: str, embedding_space: str, sampling_method: str, num_anchor_nodes: int,
+              distance_function=None, num_workers=4):
+    """utils.py:182-210: returns the feature matrix with the GraphPOPE embedding in its last K columns.
+
+    The first result is memoised for the life of the process and returned -- the same object,
+    whatever the arguments -- by every later call (utils.py:201-208: trainer.test() re-runs setup()).
+    Unknown embedding_space -> KeyError.
+    """
+    global _cached_pope_embedding
+    pope_map = {
+        'geodesic': attach_distance_embedding,
+        'node2vec': attach_node2vec,
+    }
+    if _cached_pope_embedding is None:
+        pope = pope_map[embedding_space]
+        _cached_pope_embedding = pope(data, dataset, num_anchor_nodes, sampling_method, distance_function,
+                                      num_workers=num_workers)
+    return _cached_pope_embedding

@@ -1,0 +1,165 @@
+/*
+ * graphpope_hip.h -- C ABI of libgraphpope_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for GraphPOPE's one hot path: what a binding of the
+ * reference (/root/reference, 100 % Python) would load with ctypes.  INTEGRATION.md shows that stub.
+ * Plain pointers and sizes only; every buffer is allocated by the caller.  Unless a parameter name ends in
+ * `_host`, pointers are DEVICE pointers valid on the device that is current on the calling thread
+ * (hipSetDevice / torch.cuda.set_device), and work is enqueued on `stream` (a hipStream_t passed as
+ * void*, NULL = the default stream).  The library keeps no global mutable state apart from the
+ * per-thread error string; the library owns no device memory.
+ *
+ * Every function returns 0 on success or a negative POPE_ERR_* code; pope_last_error() then holds
+ * a message for the calling thread.  One host thread per device at a time.
+ *
+ * Which reference interface each entry point replaces (file:line into /root/reference):
+ *
+ *   pope_csr_build           utils.py:121        G = to_networkx(data)           (graph build from edge_index)
+ *   pope_geodesic_bfs        utils.py:64-81,     the per-(node, anchor) nx.shortest_path loop and its
+ *                            utils.py:92-114     multiprocessing fan-out, as one batched multi-source BFS
+ *   pope_geodesic_finalize   utils.py:73,125,    1/len(path), tensor conversion and torch.cat((x, emb), 1)
+ *                            utils.py:129-135
+ *   pope_geodesic_hops       (no counterpart)    the integer hop matrix the floats are made of; parity tests
+ *   pope_pairwise_minmax     utils.py:158-176    sklearn cosine/euclidean pairwise + MinMaxScaler
+ *   pope_concat              utils.py:129-135    torch.cat for the node2vec branch
+ *   sage_conv_forward /      main.py:206 and     PyG SAGEConv((x_src, x_dst), adj_t): mean aggregation over the
+ *   sage_conv_backward       PyG SAGEConv [3p]   sampled CSR + lin_l + lin_r, and its gradients
+ */
+#ifndef GRAPHPOPE_HIP_H
+#define GRAPHPOPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POPE_OK                 0
+#define POPE_ERR_INVALID       -1   /* bad argument (null pointer, negative size, K <= 0, ...)            */
+#define POPE_ERR_HIP           -2   /* a HIP runtime call failed; message has hipGetErrorString           */
+#define POPE_ERR_INDEX         -3   /* edge_index or anchor id outside [0, N)                             */
+#define POPE_ERR_HOP_OVERFLOW  -4   /* a hop count does not fit the plane capacity / hop dtype given      */
+#define POPE_ERR_WORKSPACE     -5   /* caller workspace too small                                         */
+#define POPE_ERR_NO_DEVICE     -6   /* no gfx950 device visible                                           */
+
+/* Message for the last error on the calling thread ("" if none).  Never NULL; valid until the next call. */
+const char *pope_last_error(void);
+
+/* Library / build identification, e.g. "graphpope_hip 0.1 gfx950". */
+const char *pope_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph: forward CSR (row = source node, columns = targets) in int32, built on the device into
+ * caller-allocated arrays.  Distance is measured node -> anchor along edge direction (utils.py:73
+ * nx.shortest_path(G, source=node, target=anchor) on a DiGraph), so the bottom-up BFS pulls over a
+ * node's OUT-edges: this is the only adjacency the path needs.
+ * ------------------------------------------------------------------------------------------------ */
+size_t pope_csr_scratch_bytes(int64_t N, int64_t E);
+
+/*
+ * edge_index: int64 [2, E] row-major on the device, PyG convention: edge e is
+ * edge_index[e] -> edge_index[E + e].  Self-loops and repeated edges are allowed and kept.
+ * rowptr int32 [N + 1], col int32 [max(E, 1)] are written.  Column order inside a row is unspecified
+ * unless edge_index is already sorted by source (then it is preserved).
+ * Synchronises `stream` once (index validation + max degree come back to the host).
+ * Requires 0 <= N < 2^31 and 0 <= E < 2^31.  Returns POPE_ERR_INDEX if an id is outside [0, N).
+ */
+int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col,
+                   void *scratch, size_t scratch_bytes, int32_t *max_degree_host, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Geodesic embedding.
+ *
+ * Hop counts are kept BIT-SLICED ("hop planes"): anchors are packed 64 per uint64 word, W = pope_words(K)
+ * words per node, and a plane is a uint64 [N, W] array.  planes[0] is the reachability plane (bit j of
+ * node v set <=> a directed path v -> anchors[j] exists); planes[1 + b] holds bit b of the hop count.
+ * This is also the shard exchange format for multi-GPU runs: a rank that owns anchors
+ * [k0, k0 + K_local) produces planes for K_local and the shards are concatenated by an all-gather.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Words per node for K anchors: ceil(K / 64) rounded up to 1, 2 or a multiple of 4. */
+int32_t pope_words(int32_t K);
+
+/* Bytes of one plane, and of the scratch pope_geodesic_bfs needs (two frontier planes + small control block). */
+size_t pope_plane_bytes(int64_t N, int32_t K);
+size_t pope_bfs_scratch_bytes(int64_t N, int32_t K);
+
+/*
+ * Multi-source BFS from all K anchors at once over the CSR of pope_csr_build.
+ *   anchors_host   int64 [K] on the HOST (the reference samples them on the host: utils.py:22-24); duplicates kept.
+ *   planes         uint64 [plane_capacity + 1, N, W]; need not be initialised.  On return planes
+ *                  [0, 1 + *n_hop_bits) are valid, the rest untouched.
+ *   scratch        pope_bfs_scratch_bytes(N, K) bytes.
+ *   max_hop_host   (out, host) largest finite hop count found.
+ *   n_hop_bits_host(out, host) number of hop-bit planes written = bits needed for *max_hop.
+ * Returns POPE_ERR_HOP_OVERFLOW if a hop count would need more than plane_capacity bits.
+ * Synchronises `stream` (the level loop polls a device flag every few levels).
+ */
+int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, int64_t N, int64_t E,
+                      const int64_t *anchors_host, int32_t K, uint64_t *planes, int32_t plane_capacity, void *scratch, size_t scratch_bytes,
+                      int32_t *max_hop_host, int32_t *n_hop_bits_host, void *stream);
+
+/*
+ * out[v, 0:F] = x[v, :],  out[v, F + c0 + j] = 1.0f / (hops(v, anchor j) + 1), 0.0f if unreachable,
+ * for the K_shard anchors of one shard.  out is float32 [N, out_cols] row-major with out_cols >= F + c0 + K_shard;
+ * x may be NULL (then only the embedding columns are written: used for shards after the first).
+ * Asynchronous on `stream`.
+ */
+int pope_geodesic_finalize(const uint64_t *planes, int32_t n_hop_bits, int64_t N, int32_t K_shard,
+                           const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, void *stream);
+
+/* Integer hop matrix: hops int32 [N, K] node-major, -1 = unreachable.  Asynchronous on `stream`. */
+int pope_geodesic_hops(const uint64_t *planes, int32_t n_hop_bits, int64_t N, int32_t K,
+                       int32_t *hops, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * node2vec-space embedding: pairwise distance to the anchor rows + per-column min-max scaling.
+ * ------------------------------------------------------------------------------------------------ */
+#define POPE_METRIC_COSINE_DISTANCE   0   /* 'distance'   -> sklearn cosine_distances   */
+#define POPE_METRIC_COSINE_SIMILARITY 1   /* 'similarity' -> sklearn cosine_similarity  */
+#define POPE_METRIC_EUCLIDEAN         2   /* 'euclidean'  -> sklearn euclidean_distances */
+
+size_t pope_pairwise_scratch_bytes(int64_t N, int32_t K, int32_t D);
+
+/*
+ * X float32 [N, D]; A float32 [K, D] (the anchor rows); writes the min-max scaled [N, K] block into
+ * out[v, c0 + j] of a float32 [N, out_cols] matrix.  Scaling is per column over all N rows:
+ * y = e * (1 / range) + (0 - min * (1 / range)), range < 10 * FLT_EPSILON treated as 1.
+ * Asynchronous on `stream`.
+ */
+int pope_pairwise_minmax(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric,
+                         float *out, int64_t out_cols, int32_t c0, void *scratch, size_t scratch_bytes,
+                         void *stream);
+
+/* out[v, 0:F] = x[v, :] for a float32 [N, out_cols] matrix (the feature half of torch.cat). Asynchronous. */
+int pope_concat(const float *x, int64_t N, int32_t F, float *out, int64_t out_cols, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SAGEConv over a sampled bipartite block (CSR by destination; destinations are the first n_dst sources).
+ *   out = lin_l(mean_{j in N(i)} x_src[j]) + lin_r(x_src[i]),  lin_l with bias, lin_r without.
+ * ------------------------------------------------------------------------------------------------ */
+size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t nnz, int32_t c_in, int32_t c_out);
+
+/*
+ * rowptr int32 [n_dst + 1], col int32 [nnz] (indices into x_src), x_src f32 [n_src, c_in],
+ * w_l / w_r f32 [c_out, c_in], b_l f32 [c_out] or NULL, out f32 [n_dst, c_out].
+ * agg (f32 [n_dst, c_in]) receives the mean-aggregated features (kept for backward).  Asynchronous.
+ */
+int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
+                      const float *x_src, int32_t c_in, const float *w_l, const float *b_l, const float *w_r,
+                      int32_t c_out, float *agg, float *out, void *stream);
+
+/*
+ * Gradients.  grad_out f32 [n_dst, c_out].  grad_x f32 [n_src, c_in] (may be NULL), grad_w_l, grad_w_r
+ * f32 [c_out, c_in], grad_b_l f32 [c_out] (may be NULL) are OVERWRITTEN.  Asynchronous.
+ */
+int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
+                       const float *x_src, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
+                       int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l,
+                       float *grad_w_r, void *scratch, size_t scratch_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHPOPE_HIP_H */

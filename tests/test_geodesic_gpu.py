@@ -1,0 +1,146 @@
+"""Parity of the HIP geodesic path (through the C ABI) with the oracle and the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_geodesic_files, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from graphpope_amd import engine
+    return engine.require_gpu()
+
+
+def _run(edge_index, n, anchors, x, dev):
+    from graphpope_amd import engine
+    ei = torch.as_tensor(np.asarray(edge_index, dtype=np.int64), device=dev)
+    rowptr, col, maxdeg = engine.build_csr(ei, n)
+    hp = engine.bfs(rowptr, col, n, anchors)
+    hops = engine.hop_matrix(hp).cpu().numpy()
+    xd = torch.as_tensor(x, device=dev)
+    out = torch.empty((n, x.shape[1] + len(anchors)), dtype=torch.float32, device=dev)
+    engine.finalize(hp.planes, hp.n_hop_bits, n, len(anchors), xd, x.shape[1], out, 0)
+    torch.cuda.synchronize()
+    return hops, out.cpu().numpy(), hp, (rowptr.cpu().numpy(), col.cpu().numpy(), maxdeg)
+
+
+@pytest.mark.parametrize("path", golden_geodesic_files(), ids=lambda p: os.path.basename(p)[9:-4])
+def test_golden_bit_exact(path, dev):
+    g = load_golden(path)
+    n = int(g["num_nodes"])
+    hops, out, hp, _ = _run(g["edge_index"], n, g["anchors"], g["x"], dev)
+    assert np.array_equal(hops, g["hops"])
+    f = g["x"].shape[1]
+    assert np.array_equal(out[:, :f], g["x"])
+    assert np.array_equal(out[:, f:].view(np.uint32), g["emb"].view(np.uint32))       # bit-exact float32
+    assert hp.max_hop == max(int(g["hops"].max()), 0)
+
+
+def test_csr_matches_edge_index(dev):
+    g = load_golden(os.path.join(GOLDEN, "geodesic_multiloops30.npz"))           # unsorted, loops, repeats
+    ei = g["edge_index"].astype(np.int64)
+    _, _, _, (rowptr, col, maxdeg) = _run(ei, 30, g["anchors"], g["x"], dev)
+    deg = np.bincount(ei[0], minlength=30)
+    assert np.array_equal(np.diff(rowptr), deg) and rowptr[0] == 0 and maxdeg == deg.max()
+    for v in range(30):
+        assert sorted(col[rowptr[v]:rowptr[v + 1]].tolist()) == sorted(ei[1][ei[0] == v].tolist())
+
+
+@pytest.mark.parametrize("k", [1, 63, 64, 65, 200, 300])
+def test_word_tilings_against_oracle(k, dev, oracle):
+    from graphpope_amd import synth
+    ei, n = synth.rmat(12, edge_factor=6, seed=9)
+    anchors = np.random.RandomState(k).choice(np.arange(n), k)
+    x = np.random.RandomState(1).rand(n, 6).astype(np.float32)          # F = 6, K odd: scalar store path too
+    hops, out, _, _ = _run(ei, n, anchors, x, dev)
+    want = oracle.geodesic_hops(ei, n, anchors)
+    assert np.array_equal(hops, want)
+    assert np.array_equal(out.view(np.uint32), oracle.geodesic_features(x, ei, n, anchors).view(np.uint32))
+
+
+def test_hub_rows_and_unsorted_edges(dev, oracle):
+    """Rows far longer than the per-group limit go through the block sweep; shuffled edge order hits the atomic fill."""
+    from graphpope_amd import synth
+    ei = synth.powerlaw_graph(20000, 150000, seed=3, alpha=1.0, shift=0.3)
+    n = 20000
+    assert np.bincount(ei[0]).max() > 4000
+    perm = np.random.RandomState(0).permutation(ei.shape[1])
+    ei = ei[:, perm]
+    anchors = np.random.RandomState(2).choice(np.arange(n), 96)
+    x = np.zeros((n, 4), dtype=np.float32)
+    hops, _, _, _ = _run(ei, n, anchors, x, dev)
+    assert np.array_equal(hops, oracle.geodesic_hops(ei, n, anchors))
+
+
+def test_long_path_needs_more_than_8_hop_bits(dev, oracle):
+    n = 1500
+    a = np.arange(n - 1)
+    ei = np.stack([np.concatenate([a, a + 1]), np.concatenate([a + 1, a])])
+    anchors = [0, n - 1, 700]
+    hops, out, hp, _ = _run(ei, n, anchors, np.zeros((n, 4), np.float32), dev)
+    assert hp.max_hop == n - 1 and hp.n_hop_bits == 11
+    assert np.array_equal(hops, oracle.geodesic_hops(ei, n, anchors))
+    assert out[0, 4 + 1] == np.float32(1.0 / n)
+
+
+def test_errors_surface_as_exceptions(dev):
+    from graphpope_amd import engine, _lib
+    ei = torch.tensor([[0, 1], [1, 7]], device=dev)
+    with pytest.raises(_lib.PopeError) as e:
+        engine.build_csr(ei, 3)
+    assert e.value.code == _lib.ERR_INDEX
+    rowptr, col, _ = engine.build_csr(torch.tensor([[0, 1], [1, 2]], device=dev), 3)
+    with pytest.raises(_lib.PopeError) as e:
+        engine.bfs(rowptr, col, 3, [3])
+    assert e.value.code == _lib.ERR_INDEX
+
+
+def test_flickr_full_size_properties(dev, oracle):
+    """BASELINE config 2 at full size: bit-exact against the oracle + size-independent properties."""
+    from graphpope_amd import synth
+    ei, n = synth.flickr_like()
+    anchors = synth.seeded_anchors(n, 256, 42)
+    x = np.random.RandomState(0).rand(n, 500).astype(np.float32)
+    hops, out, hp, _ = _run(ei, n, anchors, x, dev)
+    # (1) an anchor is at distance 0 from itself; (2) duplicate anchors give identical columns
+    assert (hops[anchors, np.arange(256)] == 0).all()
+    # (3) triangle property along every edge of a symmetric graph: |h(u) - h(v)| <= 1 where both reachable
+    hu, hv = hops[ei[0]], hops[ei[1]]
+    both = (hu >= 0) & (hv >= 0)
+    assert (np.abs(hu - hv)[both] <= 1).all() and ((hu >= 0) == (hv >= 0)).all()
+    # (4) every node at hop h > 0 has a neighbour at hop h - 1
+    want = oracle.geodesic_hops(ei, n, anchors)
+    assert np.array_equal(hops, want)
+    assert np.array_equal(out[:, :500], x)
+    assert np.array_equal(out[:, 500:].view(np.uint32), oracle.hops_to_embedding(want).view(np.uint32))
+
+
+def test_graphpope_entry_point(dev, oracle):
+    """The public call: same signature, anchors from the global NumPy RNG, cache returns the same object."""
+    from graphpope_amd import utils as gp
+    g = load_golden(os.path.join(GOLDEN, "geodesic_rmat11_seed42.npz"))
+
+    class Data:
+        pass
+    d = Data()
+    d.x = torch.as_tensor(g["x"])
+    d.edge_index = torch.as_tensor(g["edge_index"].astype(np.int64))
+    d.num_nodes = int(g["num_nodes"])
+    gp.clear_cache()
+    np.random.seed(42)
+    out = gp.Graphpope(d, "flickr", "geodesic", "stochastic", 16, None, 2)
+    assert out.device.type == "cpu" and out.dtype == torch.float32 and out.is_contiguous()
+    assert np.array_equal(np.asarray(d.anchor_nodes), g["anchors"])
+    assert np.array_equal(out.numpy()[:, 3:].view(np.uint32), g["emb"].view(np.uint32))
+    assert gp.Graphpope(d, "pubmed", "node2vec", "kmeans", 3) is out          # memoised, args ignored
+    gp.clear_cache()
+    with pytest.raises(KeyError):
+        gp.Graphpope(d, "flickr", "hyperbolic", "stochastic", 4)
+    with pytest.raises(UnboundLocalError):
+        gp.Graphpope(d, "flickr", "geodesic", "no_such_method", 4)
+    gp.clear_cache()

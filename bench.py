@@ -44,11 +44,11 @@ def pope_step(x, ei, n, anchors, world, timers=None):
     ev = [_event() for _ in range(4)] if timers is not None else None
     if ev:
         ev[0].record()
-    rowptr, col, _ = engine.build_csr(ei, n)
+    csr = engine.build_csr(ei, n)
     if ev:
         ev[1].record()
     if world == 1:
-        hp = engine.bfs(rowptr, col, n, anchors)
+        hp = engine.bfs(csr, anchors)
         if ev:
             ev[2].record()
         out = torch.empty((n, F + k), dtype=torch.float32, device=x.device)
@@ -63,7 +63,7 @@ def pope_step(x, ei, n, anchors, world, timers=None):
             timers["n_hop_bits"] = hp.n_hop_bits
         return out
     return pdist.sharded_geodesic_features(x, n, anchors, None,
-                                           bfs_fn=lambda a: engine.bfs(rowptr, col, n, a),
+                                           bfs_fn=lambda a: engine.bfs(csr, a),
                                            finalize_fn=engine.finalize)
 
 
@@ -176,15 +176,14 @@ def main():
                               "algorithmic_bytes": fin_bytes}
         geo_gbs = bfs_bytes / ((med["bfs"] + med["finalize"]) * 1e-3) / 1e9
         result["roofline_geodesic_per_source_model"] = {
-            "kernels": "k_bfs_pull (all levels) + k_finalize", "bound": "hbm", "achieved": geo_gbs, "peak": HBM_PEAK_GBS,
+            "kernels": "k_bfs_expand + k_bfs_update (all levels) + k_finalize", "bound": "hbm", "achieved": geo_gbs, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": geo_gbs / HBM_PEAK_GBS, "algorithmic_bytes": bfs_bytes,
             "note": "SURVEY 8d per-source byte model (each anchor reads the CSR once); a 64-wide bit-parallel BFS shares "
                     "each CSR read between 64 anchors, so frac > 1 is expected and is not an HBM measurement"}
         if not args.no_cpu_baseline:
             base, want_hops = cpu_baselines(ei_np, n, anchors)
             result.update(base)
-            rowptr, col, _ = engine.build_csr(ei, n)
-            got = engine.hop_matrix(engine.bfs(rowptr, col, n, anchors)).cpu().numpy()
+            got = engine.hop_matrix(engine.bfs(engine.build_csr(ei, n), anchors)).cpu().numpy()
             result["hops_bit_exact_vs_cpu"] = bool(np.array_equal(got, want_hops))
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
     if rank == 0:

@@ -19,12 +19,12 @@ SIGNATURES = {
     "pope_last_error": (c_char_p, []),
     "pope_version": (c_char_p, []),
     "pope_csr_scratch_bytes": (c_size_t, [c_int64, c_int64]),
-    "pope_csr_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
-                               POINTER(c_int32), c_void_p]),
+    "pope_csr_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                               c_void_p]),
     "pope_words": (c_int32, [c_int32]),
     "pope_plane_bytes": (c_size_t, [c_int64, c_int32]),
-    "pope_bfs_scratch_bytes": (c_size_t, [c_int64, c_int32]),
-    "pope_geodesic_bfs": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int32,
+    "pope_bfs_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
+    "pope_geodesic_bfs": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int32,
                                   c_void_p, c_size_t, POINTER(c_int32), POINTER(c_int32), c_void_p]),
     "pope_geodesic_finalize": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int64,
                                        c_int32, c_void_p]),

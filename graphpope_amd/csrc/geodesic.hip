@@ -24,49 +24,58 @@ namespace pope {
 // ------------------------------------------------------------------------------------------------
 enum { CSR_FLAG_BAD_INDEX = 1, CSR_FLAG_UNSORTED = 2 };
 
-struct CsrCtl {        // device control block, first 16 bytes of the scratch
+struct CsrCtl {        // device control block, first bytes of the scratch
     int flags;
-    int max_degree;
-    int pad[2];
+    int pad[3];
 };
 
-__global__ __launch_bounds__(256) void k_csr_count(const long long *__restrict__ src,
-                                                   const long long *__restrict__ dst, int E, int N,
-                                                   int *__restrict__ cnt, CsrCtl *ctl) {
+// Fast path, speculative: PyG stores edge_index grouped by source (coalesced), so slot e of the CSR is edge e
+// and rowptr is where the source changes.  One streaming pass, no atomics, no scan.  If a pair is out of
+// order the flag is raised and the counting path below redoes the build.
+__global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict__ src,
+                                                    const long long *__restrict__ dst, int E, int N,
+                                                    int *__restrict__ rowptr, int *__restrict__ col,
+                                                    int *__restrict__ erow, CsrCtl *ctl) {
     int flags = 0;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
-        long long s = src[e], d = dst[e];
+        const long long s = src[e], d = dst[e];
         if (s < 0 || s >= N || d < 0 || d >= N) {
             flags |= CSR_FLAG_BAD_INDEX;
-        } else {
-            atomicAdd(&cnt[s], 1);
-            if (e > 0 && src[e - 1] > s) flags |= CSR_FLAG_UNSORTED;
+            continue;
         }
+        long long prev = e > 0 ? src[e - 1] : -1;
+        if (prev > s) {
+            flags |= CSR_FLAG_UNSORTED;
+        } else if (prev >= -1 && prev < s) {
+            for (long long r = prev + 1; r <= s; ++r) rowptr[r] = e;      // rows prev+1 .. s start here
+        }
+        if (e == E - 1)
+            for (long long r = s + 1; r <= N; ++r) rowptr[r] = E;
+        col[e] = (int)d;
+        erow[e] = (int)s;
     }
     if (flags) atomicOr(&ctl->flags, flags);
 }
 
-__global__ __launch_bounds__(256) void k_csr_maxdeg(const int *__restrict__ rowptr, int N, CsrCtl *ctl) {
-    int m = 0;
-    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x)
-        m = max(m, rowptr[v + 1] - rowptr[v]);
-    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&ctl->max_degree, m);
+__global__ __launch_bounds__(256) void k_fill_int(int *p, int n, int value) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = value;
 }
 
-// SORTED: edge_index is already grouped by source, position e is its CSR slot.
-template <bool SORTED>
-__global__ __launch_bounds__(256) void k_csr_fill(const long long *__restrict__ src,
-                                                  const long long *__restrict__ dst, int E,
-                                                  const int *__restrict__ rowptr, int *__restrict__ cursor,
-                                                  int *__restrict__ col) {
+// General path for edge lists in arbitrary order: histogram, scan, scatter.
+__global__ __launch_bounds__(256) void k_csr_count(const long long *__restrict__ src, int E, int *__restrict__ cnt) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x)
+        atomicAdd(&cnt[src[e]], 1);
+}
+
+__global__ __launch_bounds__(256) void k_csr_scatter(const long long *__restrict__ src,
+                                                     const long long *__restrict__ dst, int E,
+                                                     const int *__restrict__ rowptr, int *__restrict__ cursor,
+                                                     int *__restrict__ col, int *__restrict__ erow) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
-        if (SORTED) {
-            col[e] = (int)dst[e];
-        } else {
-            int s = (int)src[e];
-            col[rowptr[s] + atomicAdd(&cursor[s], 1)] = (int)dst[e];
-        }
+        const int s = (int)src[e];
+        const int pos = rowptr[s] + atomicAdd(&cursor[s], 1);
+        col[pos] = (int)dst[e];
+        erow[pos] = s;
     }
 }
 
@@ -98,128 +107,150 @@ __global__ void k_bfs_seed(const long long *__restrict__ anchors, int K, int Wp,
     atomicOr(&front[idx], bit);
 }
 
-// Commit the words a node gained at `level`: frontier for the next level, reachability, hop-bit planes.
-__device__ __forceinline__ void commit(u64 fresh, size_t idx, u64 *front_next, u64 *seen, u64 *hop_planes,
-                                       size_t plane_elems, int level) {
-    front_next[idx] = fresh;
-    if (fresh) {
-        seen[idx] |= fresh;
-        for (int b = 0, l = level; l; ++b, l >>= 1)
-            if (l & 1) hop_planes[(size_t)b * plane_elems + idx] |= fresh;
+template <int WT> struct Words { u64 w[WT]; };
+
+template <int WT>
+__device__ __forceinline__ Words<WT> load_words(const u64 *__restrict__ p) {
+    Words<WT> r;
+    if constexpr (WT == 1) {
+        r.w[0] = p[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < WT; i += 2) {                      // 16-byte loads (rows of 16 / 32 bytes, aligned)
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p + i);
+            r.w[i] = v.x;
+            r.w[i + 1] = v.y;
+        }
+    }
+    return r;
+}
+
+template <int WT>
+__device__ __forceinline__ void store_words(u64 *__restrict__ p, const Words<WT> &r) {
+    if constexpr (WT == 1) {
+        p[0] = r.w[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < WT; i += 2) *reinterpret_cast<ulonglong2 *>(p + i) = make_ulonglong2(r.w[i], r.w[i + 1]);
     }
 }
 
-// One BFS level, bottom-up.  WT = words per tile (1, 2 or 4); blockIdx.y selects the tile of a node's words.
-// A "group" of GROUP lanes owns one node: lane = slot * WT + word, S = GROUP / WT edge slots.
-// Rows longer than BIG_DEG are deferred and then swept by the whole 256-thread block.
-template <int WT, int GROUP>
-__global__ __launch_bounds__(256) void k_bfs_pull(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                  int N, int K, int Wp,
-                                                  const u64 *__restrict__ front_prev, u64 *__restrict__ front_next,
-                                                  u64 *__restrict__ seen, u64 *__restrict__ hop_planes,
-                                                  size_t plane_elems, int level, BfsCtl *ctl) {
-    constexpr int S = GROUP / WT;            // edge slots per group
-    constexpr int GROUPS = 256 / GROUP;      // groups per block
-    constexpr int NPB = 64;                  // nodes per block
-    constexpr int BIG_DEG = 32 * S;          // longer rows go to the block sweep
-    constexpr int BS = 256 / WT;             // edge slots in the block sweep
-    static_assert(NPB % GROUPS == 0 && GROUP <= 64 && GROUP % WT == 0, "shape");
-
+// One BFS level, phase 1 ("expand"), bottom-up and EDGE-parallel: lane = one CSR slot e = (v -> u).
+//   cand = front[u] & ~seen[v]           anchors that reach v through u and had not reached v before
+// Slots are sorted by v, so a row is a run of consecutive lanes: a segmented OR-scan over the wave
+// combines each run.  Work per wave is 64 edges whatever the degree distribution (no long rows, no
+// dependent pointer chase: erow/col are coalesced streams), and there are NO atomics:
+//   * the run that contains a row's FIRST slot is the row's "owner piece" and is stored to acc[v];
+//   * a run that continues a row begun in an earlier chunk is a "continuation piece": there is at most
+//     one per 64-slot chunk (its first run) and it is stored to cont[chunk]; k_bfs_update ORs the
+//     continuation pieces of the few rows that span chunks.
+// WT = words per tile (1, 2 or 4); blockIdx.y selects the tile of a node's W words.
+template <int WT>
+__global__ __launch_bounds__(256) void k_bfs_expand(const int *__restrict__ erow, const int *__restrict__ col,
+                                                    int E, int Wp, const u64 *__restrict__ front,
+                                                    const u64 *__restrict__ seen, u64 *__restrict__ acc,
+                                                    u64 *__restrict__ cont, int level, BfsCtl *ctl) {
     // The previous level reached nothing new: the BFS is over, every later launch is a no-op.
     if (__hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < level - 1) return;
-
-    __shared__ int big_rows[NPB];
-    __shared__ int n_big;
-    __shared__ u64 red[4 * WT];
-    if (threadIdx.x == 0) n_big = 0;
-    __syncthreads();
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int gl = tid % GROUP;              // lane inside the group
-    const int w = gl % WT;                   // word inside the tile
-    const int slot = gl / WT;
-    const int group = tid / GROUP;
-    const int word = blockIdx.y * WT + w;    // word inside the node
-    const u64 vmask = valid_mask(K, word);
-    const int gshift = lane / GROUP * GROUP; // first lane of this group inside the wave
-    const u64 gbits = (GROUP == 64) ? ~0ull : (((1ull << GROUP) - 1ull) << gshift);
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nchunks = (E + 63) >> 6;
+    const int woff = blockIdx.y * WT;
     bool found = false;
-
-    for (int i = 0; i < NPB / GROUPS; ++i) {
-        const int v = blockIdx.x * NPB + i * GROUPS + group;
-        const bool in_range = v < N;
-        int beg = 0, end = 0;
-        u64 unseen = 0;
-        size_t idx = 0;
-        if (in_range) {
-            idx = (size_t)v * Wp + word;
-            unseen = ~seen[idx] & vmask;
-            beg = rowptr[v];
-            end = rowptr[v + 1];
+    for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
+        const int e = chunk * 64 + lane;
+        const bool valid = e < E;
+        int v = -1, u = 0;
+        if (valid) {
+            v = erow[e];
+            u = col[e];
         }
-        // Nodes every anchor of this tile has already reached never look at their edges again.
-        const bool open = (__ballot(unseen != 0) & gbits) != 0;
-        const bool big = open && (end - beg) > BIG_DEG;
-        if (big && gl == 0) big_rows[atomicAdd(&n_big, 1)] = v;
-
-        u64 acc = 0;
-        if (open && !big) {
-            int e = beg + slot;
-            for (; e + 3 * S < end; e += 4 * S) {          // four independent gathers in flight
-                int u0 = col[e], u1 = col[e + S], u2 = col[e + 2 * S], u3 = col[e + 3 * S];
-                u64 f0 = front_prev[(size_t)u0 * Wp + word];
-                u64 f1 = front_prev[(size_t)u1 * Wp + word];
-                u64 f2 = front_prev[(size_t)u2 * Wp + word];
-                u64 f3 = front_prev[(size_t)u3 * Wp + word];
-                acc |= (f0 | f1) | (f2 | f3);
+        const int v0 = __shfl(v, 0);                                       // row of the chunk's first slot
+        const bool head_continues = chunk > 0 && erow[chunk * 64 - 1] == v0;
+        Words<WT> c;
+#pragma unroll
+        for (int i = 0; i < WT; ++i) c.w[i] = 0;
+        if (valid) {
+            const Words<WT> f = load_words<WT>(front + (size_t)u * Wp + woff);
+            const Words<WT> s = load_words<WT>(seen + (size_t)v * Wp + woff);
+#pragma unroll
+            for (int i = 0; i < WT; ++i) c.w[i] = f.w[i] & ~s.w[i];
+        }
+        u64 any = 0;
+#pragma unroll
+        for (int i = 0; i < WT; ++i) any |= c.w[i];
+        u64 *cont_c = cont + (size_t)chunk * Wp + woff;
+        Words<WT> zero;
+#pragma unroll
+        for (int i = 0; i < WT; ++i) zero.w[i] = 0;
+        if (!__any(any != 0)) {                                            // nothing new through these 64 edges
+            if (lane == 0) store_words<WT>(cont_c, zero);
+            continue;
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {                                 // segmented inclusive OR-scan keyed by v
+            const int pv = __shfl_up(v, d);
+            const bool take = lane >= d && pv == v;
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                const u64 pc = __shfl_up(c.w[i], d);
+                if (take) c.w[i] |= pc;
             }
-            for (; e < end; e += S) acc |= front_prev[(size_t)col[e] * Wp + word];
         }
+        const int nv = __shfl_down(v, 1);
+        const bool tail = valid && (lane == 63 || nv != v);                // last lane of its run
+        if (tail) {
+            u64 nz = 0;
 #pragma unroll
-        for (int off = WT; off < GROUP; off <<= 1) acc |= __shfl_xor(acc, off);
-        if (in_range && slot == 0 && !big) {
-            u64 fresh = acc & unseen;
-            commit(fresh, idx, front_next, seen, hop_planes, plane_elems, level);
-            found |= fresh != 0;
+            for (int i = 0; i < WT; ++i) nz |= c.w[i];
+            if (head_continues && v == v0) {
+                store_words<WT>(cont_c, c);                                // continuation piece of a row begun earlier
+            } else {
+                if (nz) store_words<WT>(acc + (size_t)v * Wp + woff, c);   // owner piece; acc was zero: plain store
+                if (v == v0) store_words<WT>(cont_c, zero);                // this chunk continues nothing
+            }
+            found |= nz != 0;
         }
     }
-    __syncthreads();
-
-    // Block sweep of the deferred long rows: 256 / WT edge slots, four gathers in flight per lane.
-    const int bw = tid % WT, bslot = tid / WT, bword = blockIdx.y * WT + bw;
-    const u64 bmask = valid_mask(K, bword);
-    const int nb = n_big;
-    for (int r = 0; r < nb; ++r) {
-        const int v = big_rows[r];
-        const size_t idx = (size_t)v * Wp + bword;
-        const u64 unseen = ~seen[idx] & bmask;
-        const int beg = rowptr[v], end = rowptr[v + 1];
-        u64 acc = 0;
-        int e = beg + bslot;
-        for (; e + 3 * BS < end; e += 4 * BS) {
-            int u0 = col[e], u1 = col[e + BS], u2 = col[e + 2 * BS], u3 = col[e + 3 * BS];
-            u64 f0 = front_prev[(size_t)u0 * Wp + bword];
-            u64 f1 = front_prev[(size_t)u1 * Wp + bword];
-            u64 f2 = front_prev[(size_t)u2 * Wp + bword];
-            u64 f3 = front_prev[(size_t)u3 * Wp + bword];
-            acc |= (f0 | f1) | (f2 | f3);
-        }
-        for (; e < end; e += BS) acc |= front_prev[(size_t)col[e] * Wp + bword];
-#pragma unroll
-        for (int off = WT; off < 64; off <<= 1) acc |= __shfl_xor(acc, off);
-        if (lane < WT) red[(tid >> 6) * WT + lane] = acc;
-        __syncthreads();
-        if (tid < WT) {
-            u64 fresh = (red[tid] | red[WT + tid] | red[2 * WT + tid] | red[3 * WT + tid]) & unseen;
-            commit(fresh, idx, front_next, seen, hop_planes, plane_elems, level);
-            found |= fresh != 0;
-        }
-        __syncthreads();
-    }
-
-    if (__any(found) && lane == 0)
+    // Raise the "this level reached something" flag.  Same-address device-scope stores serialise at the memory
+    // side (tens of ns each), so a wave stores only while the flag still shows an older level.
+    if (__any(found) && lane == 0 &&
+        __hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != level)
         __hip_atomic_store(&ctl->last_active, level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Phase 2 ("update"): one thread per (node, word).  acc holds the owner piece; rows that span several
+// 64-slot chunks add their continuation pieces.  The result is exactly the set of newly reached anchors
+// (expand masked with ~seen, which nobody modified meanwhile), i.e. the next frontier: commit it to the
+// reachability plane and the hop-bit planes, and clear the old frontier so it can be the next accumulator.
+__global__ __launch_bounds__(256) void k_bfs_update(const int *__restrict__ rowptr, int Wp, size_t plane_elems,
+                                                    u64 *__restrict__ fresh_front, u64 *__restrict__ old_front,
+                                                    const u64 *__restrict__ cont, u64 *__restrict__ seen,
+                                                    u64 *__restrict__ hop_planes, int level, BfsCtl *ctl) {
+    if (__hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < level) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane_elems; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i / Wp), w = (int)(i % Wp);
+        old_front[i] = 0;
+        u64 fresh = fresh_front[i];
+        const int p0 = rowptr[v], p1 = rowptr[v + 1];
+        if (p1 > p0) {
+            const int c0 = p0 >> 6, c1 = (p1 - 1) >> 6;
+            if (c1 > c0) {
+                u64 extra = 0;
+                for (int c = c0 + 1; c <= c1; ++c) extra |= cont[(size_t)c * Wp + w];
+                if (extra & ~fresh) {
+                    fresh |= extra;
+                    fresh_front[i] = fresh;
+                }
+            }
+        }
+        if (fresh) {
+            seen[i] |= fresh;
+            for (int b = 0, l = level; l; ++b, l >>= 1)
+                if (l & 1) hop_planes[(size_t)b * plane_elems + i] |= fresh;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -331,17 +362,17 @@ using namespace pope;
 extern "C" size_t pope_csr_scratch_bytes(int64_t N, int64_t E) {
     (void)E;
     if (N < 0) return 0;
-    // control block | cnt[N + 1] | rocPRIM scan temp
+    // control block | cnt[N + 1] | rocPRIM scan temp      (the last two only used for unsorted edge lists)
     return 256 + align_up((size_t)(N + 1) * sizeof(int), 256) + align_up(scan_temp_bytes((size_t)N + 1), 256);
 }
 
 extern "C" int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col,
-                              void *scratch, size_t scratch_bytes, int32_t *max_degree_host, void *stream_) {
+                              int32_t *erow, void *scratch, size_t scratch_bytes, void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(N >= 0 && N < INT32_MAX && E >= 0 && E < INT32_MAX, "pope_csr_build: need 0 <= N, E < 2^31 (N=%lld E=%lld)",
                  (long long)N, (long long)E);
-    POPE_REQUIRE(rowptr && col && scratch && (edge_index || E == 0), "pope_csr_build: null pointer");
+    POPE_REQUIRE(rowptr && scratch && ((edge_index && col && erow) || E == 0), "pope_csr_build: null pointer");
     if (scratch_bytes < pope_csr_scratch_bytes(N, E)) {
         set_error("pope_csr_build: scratch %zu < %zu bytes", scratch_bytes, pope_csr_scratch_bytes(N, E));
         return POPE_ERR_WORKSPACE;
@@ -350,15 +381,14 @@ extern "C" int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, i
     CsrCtl *ctl = (CsrCtl *)base;
     int *cnt = (int *)(base + 256);
     void *scan_tmp = base + 256 + align_up((size_t)(N + 1) * sizeof(int), 256);
-    size_t scan_bytes = scan_temp_bytes((size_t)N + 1);
-
-    POPE_HIP(hipMemsetAsync(base, 0, 256 + (size_t)(N + 1) * sizeof(int), stream));
     const long long *src = (const long long *)edge_index, *dst = src + E;
-    if (E > 0)
-        hipLaunchKernelGGL(k_csr_count, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, (int)N, cnt, ctl);
-    POPE_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, cnt, rowptr, 0, (size_t)N + 1, rocprim::plus<int>(), stream));
-    if (N > 0)
-        hipLaunchKernelGGL(k_csr_maxdeg, dim3(capped_grid(N, 256)), dim3(256), 0, stream, rowptr, (int)N, ctl);
+
+    if (E == 0) {
+        POPE_HIP(hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * sizeof(int), stream));
+        return POPE_OK;
+    }
+    POPE_HIP(hipMemsetAsync(ctl, 0, 256, stream));
+    hipLaunchKernelGGL(k_csr_sorted, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, ctl);
     CsrCtl h;
     POPE_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
     POPE_HIP(hipStreamSynchronize(stream));
@@ -366,16 +396,15 @@ extern "C" int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, i
         set_error("pope_csr_build: edge_index holds a node id outside [0, %lld)", (long long)N);
         return POPE_ERR_INDEX;
     }
-    if (E > 0) {
-        if (h.flags & CSR_FLAG_UNSORTED) {
-            POPE_HIP(hipMemsetAsync(cnt, 0, (size_t)(N + 1) * sizeof(int), stream));
-            hipLaunchKernelGGL(k_csr_fill<false>, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, rowptr, cnt, col);
-        } else {
-            hipLaunchKernelGGL(k_csr_fill<true>, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, rowptr, cnt, col);
-        }
+    if (h.flags & CSR_FLAG_UNSORTED) {
+        size_t scan_bytes = scan_temp_bytes((size_t)N + 1);
+        POPE_HIP(hipMemsetAsync(cnt, 0, (size_t)(N + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_csr_count, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, (int)E, cnt);
+        POPE_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, cnt, rowptr, 0, (size_t)N + 1, rocprim::plus<int>(), stream));
+        POPE_HIP(hipMemsetAsync(cnt, 0, (size_t)(N + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_csr_scatter, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, rowptr, cnt, col, erow);
     }
     POPE_HIP(hipGetLastError());
-    if (max_degree_host) *max_degree_host = h.max_degree;
     return POPE_OK;
 }
 
@@ -386,21 +415,22 @@ extern "C" size_t pope_plane_bytes(int64_t N, int32_t K) {
     return (size_t)N * words_for(K) * sizeof(u64);
 }
 
-extern "C" size_t pope_bfs_scratch_bytes(int64_t N, int32_t K) {
-    if (N < 0 || K <= 0) return 0;
-    // control block | anchors[K] | two frontier planes
-    return 256 + align_up((size_t)K * sizeof(long long), 256) + 2 * align_up(pope_plane_bytes(N, K), 256);
+static size_t cont_bytes(int64_t E, int32_t K) { return align_up((size_t)((E + 63) / 64 + 1) * words_for(K) * sizeof(u64), 256); }
+
+extern "C" size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K) {
+    if (N < 0 || E < 0 || K <= 0) return 0;
+    // control block | anchors[K] | two frontier planes | continuation pieces (one per 64 CSR slots)
+    return 256 + align_up((size_t)K * sizeof(long long), 256) + 2 * align_up(pope_plane_bytes(N, K), 256) + cont_bytes(E, K);
 }
 
-template <int WT, int GROUP>
-static void launch_pull(int N, int K, int Wp, const int *rowptr, const int *col, const u64 *fp, u64 *fn, u64 *seen,
-                        u64 *hop_planes, size_t plane_elems, int level, BfsCtl *ctl, hipStream_t stream) {
-    dim3 grid((N + 63) / 64, Wp / WT);
-    hipLaunchKernelGGL((k_bfs_pull<WT, GROUP>), grid, dim3(256), 0, stream, rowptr, col, N, K, Wp, fp, fn, seen,
-                       hop_planes, plane_elems, level, ctl);
+template <int WT>
+static void launch_expand(int E, int Wp, const int *erow, const int *col, const u64 *front, const u64 *seen, u64 *acc,
+                          u64 *cont, int level, BfsCtl *ctl, hipStream_t stream) {
+    dim3 grid(capped_grid((size_t)E, 256, 256u * 32u), Wp / WT);
+    hipLaunchKernelGGL((k_bfs_expand<WT>), grid, dim3(256), 0, stream, erow, col, E, Wp, front, seen, acc, cont, level, ctl);
 }
 
-extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, int64_t N, int64_t E,
+extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *erow, int64_t N, int64_t E,
                                  const int64_t *anchors_host, int32_t K, uint64_t *planes_, int32_t plane_capacity,
                                  void *scratch, size_t scratch_bytes, int32_t *max_hop_host, int32_t *n_hop_bits_host,
                                  void *stream_) {
@@ -408,9 +438,9 @@ extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, int6
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(N > 0 && N < INT32_MAX && E >= 0 && E < INT32_MAX, "pope_geodesic_bfs: need 0 < N < 2^31, 0 <= E < 2^31");
     POPE_REQUIRE(K > 0 && plane_capacity >= 1 && plane_capacity <= 31, "pope_geodesic_bfs: need K > 0 and 1 <= plane_capacity <= 31");
-    POPE_REQUIRE(rowptr && col && anchors_host && planes_ && scratch, "pope_geodesic_bfs: null pointer");
-    if (scratch_bytes < pope_bfs_scratch_bytes(N, K)) {
-        set_error("pope_geodesic_bfs: scratch %zu < %zu bytes", scratch_bytes, pope_bfs_scratch_bytes(N, K));
+    POPE_REQUIRE(rowptr && ((erow && col) || E == 0) && anchors_host && planes_ && scratch, "pope_geodesic_bfs: null pointer");
+    if (scratch_bytes < pope_bfs_scratch_bytes(N, E, K)) {
+        set_error("pope_geodesic_bfs: scratch %zu < %zu bytes", scratch_bytes, pope_bfs_scratch_bytes(N, E, K));
         return POPE_ERR_WORKSPACE;
     }
     for (int j = 0; j < K; ++j)
@@ -430,11 +460,12 @@ extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, int6
     u64 *front[2];
     front[0] = (u64 *)(base + 256 + align_up((size_t)K * sizeof(long long), 256));
     front[1] = (u64 *)((char *)front[0] + align_up(plane_bytes, 256));
+    u64 *cont = (u64 *)((char *)front[1] + align_up(plane_bytes, 256));
 
     POPE_HIP(hipMemsetAsync(ctl, 0, 256, stream));
     POPE_HIP(hipMemcpyAsync(anchors_dev, anchors_host, (size_t)K * sizeof(long long), hipMemcpyHostToDevice, stream));
     POPE_HIP(hipMemsetAsync(seen, 0, plane_bytes, stream));
-    POPE_HIP(hipMemsetAsync(front[0], 0, plane_bytes, stream));
+    POPE_HIP(hipMemsetAsync(front[0], 0, 2 * align_up(plane_bytes, 256), stream));      // both frontier buffers
     hipLaunchKernelGGL(k_bfs_seed, dim3((K + 255) / 256), dim3(256), 0, stream, anchors_dev, K, Wp, seen, front[0]);
 
     const long long level_limit = 1ll << plane_capacity;      // levels 1 .. limit-1 fit plane_capacity bits
@@ -442,21 +473,23 @@ extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, int6
     for (;;) {
         const int stop = level + batch;                         // enqueue levels [level, stop)
         for (; level < stop; ++level) {
-            if (level >= level_limit) break;
+            if (level >= level_limit || E == 0) break;
             if ((level & (level - 1)) == 0) {                    // first level with this hop bit: clear its plane
                 int b = 0;
                 while ((1 << b) < level) ++b;
                 POPE_HIP(hipMemsetAsync(hop_planes + (size_t)b * plane_elems, 0, plane_bytes, stream));
             }
-            const u64 *fp = front[(level - 1) & 1];
-            u64 *fn = front[level & 1];
-            if (Wp == 1)      launch_pull<1, 8>((int)N, K, Wp, rowptr, col, fp, fn, seen, hop_planes, plane_elems, level, ctl, stream);
-            else if (Wp == 2) launch_pull<2, 16>((int)N, K, Wp, rowptr, col, fp, fn, seen, hop_planes, plane_elems, level, ctl, stream);
-            else              launch_pull<4, 16>((int)N, K, Wp, rowptr, col, fp, fn, seen, hop_planes, plane_elems, level, ctl, stream);
+            u64 *prev = front[(level - 1) & 1];               // frontier of level - 1
+            u64 *next = front[level & 1];                        // all zero: accumulates, becomes the new frontier
+            if (Wp == 1)      launch_expand<1>((int)E, Wp, erow, col, prev, seen, next, cont, level, ctl, stream);
+            else if (Wp == 2) launch_expand<2>((int)E, Wp, erow, col, prev, seen, next, cont, level, ctl, stream);
+            else              launch_expand<4>((int)E, Wp, erow, col, prev, seen, next, cont, level, ctl, stream);
+            hipLaunchKernelGGL(k_bfs_update, dim3(capped_grid(plane_elems, 256)), dim3(256), 0, stream, rowptr, Wp,
+                               plane_elems, next, prev, cont, seen, hop_planes, level, ctl);
         }
         POPE_HIP(hipMemcpyAsync(&last_active, &ctl->last_active, sizeof(int), hipMemcpyDeviceToHost, stream));
         POPE_HIP(hipStreamSynchronize(stream));
-        if (last_active < level - 1) break;                      // some enqueued level found nothing: finished
+        if (last_active < level - 1 || E == 0) break;           // some enqueued level found nothing: finished
         if (level >= level_limit) {
             // the last representable level still discovered nodes: deeper levels may exist
             set_error("pope_geodesic_bfs: hop count needs more than %d bits", plane_capacity);

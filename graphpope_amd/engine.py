@@ -37,8 +37,16 @@ def _bytes(n: int, device) -> torch.Tensor:
     return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
 
 
-def build_csr(edge_index: torch.Tensor, num_nodes: int):
-    """int64 [2, E] on the device -> (rowptr int32 [N+1], col int32 [E], max_degree).  utils.py:121."""
+class Csr:
+    """Forward CSR on the device: slot p is the edge erow[p] -> col[p], slots sorted by erow."""
+
+    def __init__(self, rowptr, col, erow, num_nodes, num_edges):
+        self.rowptr, self.col, self.erow = rowptr, col, erow        # int32 [N+1], [E], [E]
+        self.num_nodes, self.num_edges = num_nodes, num_edges
+
+
+def build_csr(edge_index: torch.Tensor, num_nodes: int) -> Csr:
+    """int64 [2, E] on the device -> Csr.  Replaces utils.py:121 ``to_networkx(data)``."""
     lib = _lib.load()
     assert edge_index.is_cuda and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.shape[0] == 2
     ei = edge_index.contiguous()
@@ -47,11 +55,11 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int):
     with torch.cuda.device(dev):
         rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
         col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+        erow = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
         scratch = _bytes(lib.pope_csr_scratch_bytes(num_nodes, e), dev)
-        maxdeg = ctypes.c_int32(0)
-        check(lib.pope_csr_build(ptr(ei), e, num_nodes, ptr(rowptr), ptr(col), ptr(scratch), scratch.numel(),
-                                 ctypes.byref(maxdeg), _stream()))
-    return rowptr, col[:e], int(maxdeg.value)
+        check(lib.pope_csr_build(ptr(ei), e, num_nodes, ptr(rowptr), ptr(col), ptr(erow), ptr(scratch), scratch.numel(),
+                                 _stream()))
+    return Csr(rowptr, col, erow, num_nodes, e)
 
 
 class HopPlanes:
@@ -68,19 +76,20 @@ class HopPlanes:
         return self.planes[: 1 + self.n_hop_bits]
 
 
-def bfs(rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int, anchors, capacity: int = DEFAULT_PLANE_CAPACITY) -> HopPlanes:
+def bfs(csr: Csr, anchors, capacity: int = DEFAULT_PLANE_CAPACITY) -> HopPlanes:
     """Multi-source BFS for all anchors at once (utils.py:64-114).  Retries with more hop bits on overflow."""
     lib = _lib.load()
     anc = np.ascontiguousarray(np.asarray(anchors), dtype=np.int64)
     k = int(anc.size)
-    dev = rowptr.device
+    dev = csr.col.device
+    num_nodes = csr.num_nodes
     w = lib.pope_words(k)
     with torch.cuda.device(dev):
-        scratch = _bytes(lib.pope_bfs_scratch_bytes(num_nodes, k), dev)
+        scratch = _bytes(lib.pope_bfs_scratch_bytes(num_nodes, csr.num_edges, k), dev)
         while True:
             planes = torch.empty((capacity + 1, num_nodes, w), dtype=torch.int64, device=dev)
             max_hop, bits = ctypes.c_int32(0), ctypes.c_int32(0)
-            rc = lib.pope_geodesic_bfs(ptr(rowptr), ptr(col), num_nodes, col.numel(), ctypes.c_void_p(anc.ctypes.data), k,
+            rc = lib.pope_geodesic_bfs(ptr(csr.rowptr), ptr(csr.col), ptr(csr.erow), num_nodes, csr.num_edges, ctypes.c_void_p(anc.ctypes.data), k,
                                        ptr(planes), capacity, ptr(scratch), scratch.numel(),
                                        ctypes.byref(max_hop), ctypes.byref(bits), _stream())
             if rc == _lib.ERR_HOP_OVERFLOW and capacity < 31:
@@ -124,16 +133,16 @@ def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int,
     x = x.contiguous()
     anc = np.asarray(anchors, dtype=np.int64)
     k, f = int(anc.size), x.shape[1]
-    rowptr, col, _ = build_csr(edge_index.to(dev), num_nodes)
+    csr = build_csr(edge_index.to(dev), num_nodes)
     world = pdist.world_size(group) if shard else 1
     if world == 1:
-        hp = bfs(rowptr, col, num_nodes, anc)
+        hp = bfs(csr, anc)
         out = torch.empty((num_nodes, f + k), dtype=torch.float32, device=dev)
         finalize(hp.planes, hp.n_hop_bits, num_nodes, k, x, f, out, 0)
         return out
     return pdist.sharded_geodesic_features(
         x, num_nodes, anc, group,
-        bfs_fn=lambda a: bfs(rowptr, col, num_nodes, a),
+        bfs_fn=lambda a: bfs(csr, a),
         finalize_fn=finalize)
 
 

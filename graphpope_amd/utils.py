@@ -89,8 +89,8 @@ def get_geodesic_distance_vector(data, num_workers):
     """
     dev = _device()
     n = int(data.num_nodes)
-    rowptr, col, _ = engine.build_csr(data.edge_index.detach().to(dev, torch.int64), n)
-    hp = engine.bfs(rowptr, col, n, data.anchor_nodes)
+    csr = engine.build_csr(data.edge_index.detach().to(dev, torch.int64), n)
+    hp = engine.bfs(csr, data.anchor_nodes)
     out = torch.empty((n, hp.k), dtype=torch.float32, device=dev)
     engine.finalize(hp.planes, hp.n_hop_bits, n, hp.k, None, 0, out, 0)
     return out.cpu()

@@ -60,13 +60,15 @@ size_t pope_csr_scratch_bytes(int64_t N, int64_t E);
 /*
  * edge_index: int64 [2, E] row-major on the device, PyG convention: edge e is
  * edge_index[e] -> edge_index[E + e].  Self-loops and repeated edges are allowed and kept.
- * rowptr int32 [N + 1], col int32 [max(E, 1)] are written.  Column order inside a row is unspecified
- * unless edge_index is already sorted by source (then it is preserved).
- * Synchronises `stream` once (index validation + max degree come back to the host).
+ * rowptr int32 [N + 1], col int32 [max(E, 1)] and erow int32 [max(E, 1)] are written: CSR slot p holds the
+ * edge erow[p] -> col[p], slots sorted by erow (erow is the row id of every slot: the edge-parallel BFS kernel
+ * streams erow/col instead of chasing rowptr).  Column order inside a row is unspecified unless edge_index is
+ * already sorted by source (PyG's coalesced order; then it is preserved and no atomics are used).
+ * Synchronises `stream` once (index validation result comes back to the host).
  * Requires 0 <= N < 2^31 and 0 <= E < 2^31.  Returns POPE_ERR_INDEX if an id is outside [0, N).
  */
-int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col,
-                   void *scratch, size_t scratch_bytes, int32_t *max_degree_host, void *stream);
+int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col, int32_t *erow,
+                   void *scratch, size_t scratch_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Geodesic embedding.
@@ -81,22 +83,23 @@ int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *row
 /* Words per node for K anchors: ceil(K / 64) rounded up to 1, 2 or a multiple of 4. */
 int32_t pope_words(int32_t K);
 
-/* Bytes of one plane, and of the scratch pope_geodesic_bfs needs (two frontier planes + small control block). */
+/* Bytes of one plane, and of the scratch pope_geodesic_bfs needs (two frontier planes, one word set per 64 CSR
+ * slots, a small control block). */
 size_t pope_plane_bytes(int64_t N, int32_t K);
-size_t pope_bfs_scratch_bytes(int64_t N, int32_t K);
+size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K);
 
 /*
  * Multi-source BFS from all K anchors at once over the CSR of pope_csr_build.
  *   anchors_host   int64 [K] on the HOST (the reference samples them on the host: utils.py:22-24); duplicates kept.
  *   planes         uint64 [plane_capacity + 1, N, W]; need not be initialised.  On return planes
  *                  [0, 1 + *n_hop_bits) are valid, the rest untouched.
- *   scratch        pope_bfs_scratch_bytes(N, K) bytes.
+ *   scratch        pope_bfs_scratch_bytes(N, E, K) bytes.
  *   max_hop_host   (out, host) largest finite hop count found.
  *   n_hop_bits_host(out, host) number of hop-bit planes written = bits needed for *max_hop.
  * Returns POPE_ERR_HOP_OVERFLOW if a hop count would need more than plane_capacity bits.
  * Synchronises `stream` (the level loop polls a device flag every few levels).
  */
-int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, int64_t N, int64_t E,
+int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *erow, int64_t N, int64_t E,
                       const int64_t *anchors_host, int32_t K, uint64_t *planes, int32_t plane_capacity, void *scratch, size_t scratch_bytes,
                       int32_t *max_hop_host, int32_t *n_hop_bits_host, void *stream);
 

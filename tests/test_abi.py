@@ -30,7 +30,7 @@ def test_size_queries_need_no_gpu():
     assert lib.pope_version().startswith(b"graphpope_hip")
     assert [lib.pope_words(k) for k in (1, 64, 65, 128, 129, 130, 256, 257, 1024)] == [1, 1, 2, 2, 4, 4, 4, 8, 16]
     assert lib.pope_plane_bytes(89250, 256) == 89250 * 4 * 8
-    assert lib.pope_bfs_scratch_bytes(89250, 256) >= 2 * 89250 * 4 * 8
+    assert lib.pope_bfs_scratch_bytes(89250, 899756, 256) >= 2 * 89250 * 4 * 8
     assert lib.pope_csr_scratch_bytes(89250, 899756) >= (89250 + 1) * 4
     assert lib.pope_last_error() == b""
 

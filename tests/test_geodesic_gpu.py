@@ -19,14 +19,14 @@ def dev():
 def _run(edge_index, n, anchors, x, dev):
     from graphpope_amd import engine
     ei = torch.as_tensor(np.asarray(edge_index, dtype=np.int64), device=dev)
-    rowptr, col, maxdeg = engine.build_csr(ei, n)
-    hp = engine.bfs(rowptr, col, n, anchors)
+    csr = engine.build_csr(ei, n)
+    hp = engine.bfs(csr, anchors)
     hops = engine.hop_matrix(hp).cpu().numpy()
     xd = torch.as_tensor(x, device=dev)
     out = torch.empty((n, x.shape[1] + len(anchors)), dtype=torch.float32, device=dev)
     engine.finalize(hp.planes, hp.n_hop_bits, n, len(anchors), xd, x.shape[1], out, 0)
     torch.cuda.synchronize()
-    return hops, out.cpu().numpy(), hp, (rowptr.cpu().numpy(), col.cpu().numpy(), maxdeg)
+    return hops, out.cpu().numpy(), hp, (csr.rowptr.cpu().numpy(), csr.col.cpu().numpy(), csr.erow.cpu().numpy())
 
 
 @pytest.mark.parametrize("path", golden_geodesic_files(), ids=lambda p: os.path.basename(p)[9:-4])
@@ -44,11 +44,13 @@ def test_golden_bit_exact(path, dev):
 def test_csr_matches_edge_index(dev):
     g = load_golden(os.path.join(GOLDEN, "geodesic_multiloops30.npz"))           # unsorted, loops, repeats
     ei = g["edge_index"].astype(np.int64)
-    _, _, _, (rowptr, col, maxdeg) = _run(ei, 30, g["anchors"], g["x"], dev)
-    deg = np.bincount(ei[0], minlength=30)
-    assert np.array_equal(np.diff(rowptr), deg) and rowptr[0] == 0 and maxdeg == deg.max()
-    for v in range(30):
-        assert sorted(col[rowptr[v]:rowptr[v + 1]].tolist()) == sorted(ei[1][ei[0] == v].tolist())
+    for edges in (ei, ei[:, np.lexsort((ei[1], ei[0]))]):                       # atomic scatter path, sorted fast path
+        _, _, _, (rowptr, col, erow) = _run(edges, 30, g["anchors"], g["x"], dev)
+        deg = np.bincount(edges[0], minlength=30)
+        assert np.array_equal(np.diff(rowptr), deg) and rowptr[0] == 0
+        assert np.array_equal(erow, np.repeat(np.arange(30), deg))
+        for v in range(30):
+            assert sorted(col[rowptr[v]:rowptr[v + 1]].tolist()) == sorted(edges[1][edges[0] == v].tolist())
 
 
 @pytest.mark.parametrize("k", [1, 63, 64, 65, 200, 300])
@@ -94,9 +96,9 @@ def test_errors_surface_as_exceptions(dev):
     with pytest.raises(_lib.PopeError) as e:
         engine.build_csr(ei, 3)
     assert e.value.code == _lib.ERR_INDEX
-    rowptr, col, _ = engine.build_csr(torch.tensor([[0, 1], [1, 2]], device=dev), 3)
+    csr = engine.build_csr(torch.tensor([[0, 1], [1, 2]], device=dev), 3)
     with pytest.raises(_lib.PopeError) as e:
-        engine.bfs(rowptr, col, 3, [3])
+        engine.bfs(csr, [3])
     assert e.value.code == _lib.ERR_INDEX
 
 

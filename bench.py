@@ -38,33 +38,35 @@ def _event():
     return torch.cuda.Event(enable_timing=True)
 
 
-def pope_step(x, ei, n, anchors, world, timers=None):
+def pope_step(x, ei, n, anchors, world):
     """One full geodesic GraphPOPE pass on the device; returns the [N, F+K] tensor."""
-    k = len(anchors)
-    ev = [_event() for _ in range(4)] if timers is not None else None
-    if ev:
-        ev[0].record()
-    csr = engine.build_csr(ei, n)
-    if ev:
-        ev[1].record()
     if world == 1:
-        hp = engine.bfs(csr, anchors)
-        if ev:
-            ev[2].record()
-        out = torch.empty((n, F + k), dtype=torch.float32, device=x.device)
-        engine.finalize(hp.planes, hp.n_hop_bits, n, k, x, F, out, 0)
-        if ev:
-            ev[3].record()
-            torch.cuda.synchronize()
-            timers["csr"].append(ev[0].elapsed_time(ev[1]))
-            timers["bfs"].append(ev[1].elapsed_time(ev[2]))
-            timers["finalize"].append(ev[2].elapsed_time(ev[3]))
-            timers["max_hop"] = hp.max_hop
-            timers["n_hop_bits"] = hp.n_hop_bits
-        return out
+        return engine.geodesic_run(x, ei, n, anchors)[0]
+    csr = engine.build_csr(ei, n, defer_check=True)
     return pdist.sharded_geodesic_features(x, n, anchors, None,
                                            bfs_fn=lambda a: engine.bfs(csr, a),
                                            finalize_fn=engine.finalize)
+
+
+def pope_phases(x, ei, n, anchors, timers):
+    """The same pass through the separate entry points, bracketed by HIP events on the launch stream."""
+    k = len(anchors)
+    ev = [_event() for _ in range(4)]
+    ev[0].record()
+    csr = engine.build_csr(ei, n, defer_check=True)
+    ev[1].record()
+    hp = engine.bfs(csr, anchors)
+    ev[2].record()
+    out = torch.empty((n, F + k), dtype=torch.float32, device=x.device)
+    engine.finalize(hp.planes, hp.n_hop_bits, n, k, x, F, out, 0)
+    ev[3].record()
+    torch.cuda.synchronize()
+    timers["csr"].append(ev[0].elapsed_time(ev[1]))
+    timers["bfs"].append(ev[1].elapsed_time(ev[2]))
+    timers["finalize"].append(ev[2].elapsed_time(ev[3]))
+    timers["max_hop"] = hp.max_hop
+    timers["n_hop_bits"] = hp.n_hop_bits
+    return out
 
 
 def cpu_baselines(ei, n, anchors):
@@ -164,7 +166,7 @@ def main():
         # per-phase device time with HIP events on the launch stream, separate from the wall-clock loop above
         timers = {"csr": [], "bfs": [], "finalize": []}
         for _ in range(max(10, min(args.steps, 50))):
-            pope_step(x, ei, n, anchors, 1, timers)
+            pope_phases(x, ei, n, anchors, timers)
         med = {p: float(np.median(timers[p])) for p in ("csr", "bfs", "finalize")}
         fin_bytes = 4.0 * n * F + 4.0 * n * (F + K_PER_GPU) + 8.0 * n * 4 * (1 + timers["n_hop_bits"])
         fin_gbs = fin_bytes / (med["finalize"] * 1e-3) / 1e9

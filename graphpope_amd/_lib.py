@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTE
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphpope_hip.so")
 
-OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_HOP_OVERFLOW, ERR_WORKSPACE, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_HOP_OVERFLOW, ERR_WORKSPACE, ERR_NO_DEVICE, ERR_UNSORTED = 0, -1, -2, -3, -4, -5, -6, -7
 METRIC = {"distance": 0, "similarity": 1, "euclidean": 2}
 
 # name -> (restype, argtypes); exactly the symbols include/graphpope_hip.h declares
@@ -19,15 +19,20 @@ SIGNATURES = {
     "pope_last_error": (c_char_p, []),
     "pope_version": (c_char_p, []),
     "pope_csr_scratch_bytes": (c_size_t, [c_int64, c_int64]),
-    "pope_csr_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                               c_void_p]),
+    "pope_csr_aux_elems": (c_size_t, [c_int64]),
+    "pope_csr_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                               c_int32, c_void_p]),
     "pope_words": (c_int32, [c_int32]),
     "pope_plane_bytes": (c_size_t, [c_int64, c_int32]),
     "pope_bfs_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
-    "pope_geodesic_bfs": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int32,
+    "pope_geodesic_bfs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int32,
                                   c_void_p, c_size_t, POINTER(c_int32), POINTER(c_int32), c_void_p]),
     "pope_geodesic_finalize": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int64,
                                        c_int32, c_void_p]),
+    "pope_geodesic_run_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),
+    "pope_geodesic_run_planes": (c_void_p, [c_void_p, c_int64, c_int64, c_int32, c_int32]),
+    "pope_geodesic_run": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64,
+                                  c_int32, c_void_p, c_size_t, POINTER(c_int32), POINTER(c_int32), c_void_p]),
     "pope_geodesic_hops": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
     "pope_pairwise_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "pope_pairwise_minmax": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,

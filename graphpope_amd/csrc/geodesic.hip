@@ -23,19 +23,16 @@ namespace pope {
 // CSR build
 // ------------------------------------------------------------------------------------------------
 enum { CSR_FLAG_BAD_INDEX = 1, CSR_FLAG_UNSORTED = 2 };
-
-struct CsrCtl {        // device control block, first bytes of the scratch
-    int flags;
-    int pad[3];
-};
+enum { AUX_N_MROWS = 0, AUX_N_HUBS = 1, AUX_FLAGS = 2, AUX_HEADER = 16 };
+constexpr int SMALL_SPAN = 4;      // rows with <= 4 continuation chunks are fixed up by one thread, longer ones by a wave
 
 // Fast path, speculative: PyG stores edge_index grouped by source (coalesced), so slot e of the CSR is edge e
 // and rowptr is where the source changes.  One streaming pass, no atomics, no scan.  If a pair is out of
-// order the flag is raised and the counting path below redoes the build.
+// order the flag is raised and the counting path redoes the build.
 __global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict__ src,
                                                     const long long *__restrict__ dst, int E, int N,
                                                     int *__restrict__ rowptr, int *__restrict__ col,
-                                                    int *__restrict__ erow, CsrCtl *ctl) {
+                                                    int *__restrict__ erow, int *aux) {
     int flags = 0;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
         const long long s = src[e], d = dst[e];
@@ -54,11 +51,7 @@ __global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict_
         col[e] = (int)d;
         erow[e] = (int)s;
     }
-    if (flags) atomicOr(&ctl->flags, flags);
-}
-
-__global__ __launch_bounds__(256) void k_fill_int(int *p, int n, int value) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = value;
+    if (flags) atomicOr(&aux[AUX_FLAGS], flags);
 }
 
 // General path for edge lists in arbitrary order: histogram, scan, scatter.
@@ -79,6 +72,38 @@ __global__ __launch_bounds__(256) void k_csr_scatter(const long long *__restrict
     }
 }
 
+// The BFS walks the CSR in chunks of 64 slots.  Rows that span several chunks need their pieces combined:
+// list them once per graph (a row is listed by its first continuation chunk).  aux = header | mrows | hubs.
+__global__ __launch_bounds__(256) void k_csr_lists(const int *__restrict__ rowptr, const int *__restrict__ erow,
+                                                   int E, int *aux, int cap) {
+    if (aux[AUX_FLAGS]) return;                                   // speculative CSR was rejected: arrays are garbage
+    const int nchunks = (E + 63) >> 6;
+    int *mrows = aux + AUX_HEADER, *hubs = aux + AUX_HEADER + cap;
+    const int lane = threadIdx.x & 63;
+    // wave-uniform trip count; appends are aggregated per wave (one same-address atomic costs tens of ns)
+    for (int base = blockIdx.x * blockDim.x + 1; base < nchunks; base += gridDim.x * blockDim.x) {
+        const int c = base + threadIdx.x;
+        int v = -1, span = 0;
+        if (c < nchunks) {
+            v = erow[c * 64];
+            if (erow[c * 64 - 1] == v && (rowptr[v] >> 6) == c - 1)
+                span = ((rowptr[v + 1] - 1) >> 6) - (c - 1);        // number of continuation chunks of row v
+        }
+        const bool small = span > 0 && span <= SMALL_SPAN, hub = span > SMALL_SPAN;
+        const u64 ms = __ballot(small), mh = __ballot(hub);
+        const u64 below = (1ull << lane) - 1ull;
+        int bs = 0, bh = 0;
+        if (lane == 0) {
+            if (ms) bs = atomicAdd(&aux[AUX_N_MROWS], __popcll(ms));
+            if (mh) bh = atomicAdd(&aux[AUX_N_HUBS], __popcll(mh));
+        }
+        bs = __shfl(bs, 0);
+        bh = __shfl(bh, 0);
+        if (small) mrows[bs + __popcll(ms & below)] = v;
+        if (hub) hubs[bh + __popcll(mh & below)] = v;
+    }
+}
+
 static size_t scan_temp_bytes(size_t n) {
     size_t bytes = 0;
     (void)rocprim::exclusive_scan(nullptr, bytes, (int *)nullptr, (int *)nullptr, 0, n, rocprim::plus<int>());
@@ -93,9 +118,27 @@ struct BfsCtl {          // device control block at the start of the BFS scratch
     int pad[3];
 };
 
-__device__ __forceinline__ u64 valid_mask(int K, int word) {
-    int bits = K - 64 * word;
-    return bits >= 64 ? ~0ull : (bits <= 0 ? 0ull : ((1ull << bits) - 1ull));
+__device__ __forceinline__ bool bfs_over(const BfsCtl *ctl, const int *aux, int level) {
+    // the previous level reached nothing new (every later launch is a no-op), or the CSR is not usable
+    return __hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < level - 1 ||
+           aux[AUX_FLAGS] != 0;
+}
+
+// Same-address device-scope stores serialise at the memory side (tens of ns each): a wave stores only while
+// the flag still shows an older level.
+__device__ __forceinline__ void raise_level(BfsCtl *ctl, int level) {
+    if (__hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != level)
+        __hip_atomic_store(&ctl->last_active, level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Zero `n16` 16-byte units at each of up to 3 regions + the control block, then nothing else: one launch
+// instead of a string of hipMemsetAsync calls (each is its own ~4 us fill kernel).
+__global__ __launch_bounds__(256) void k_zero(uint4 *a, size_t na, uint4 *b, size_t nb, uint4 *c, size_t nc) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = z;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = z;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += stride) c[i] = z;
 }
 
 __global__ void k_bfs_seed(const long long *__restrict__ anchors, int K, int Wp, u64 *seen, u64 *front) {
@@ -135,23 +178,52 @@ __device__ __forceinline__ void store_words(u64 *__restrict__ p, const Words<WT>
     }
 }
 
+template <int WT>
+__device__ __forceinline__ u64 any_bits(const Words<WT> &r) {
+    u64 a = 0;
+#pragma unroll
+    for (int i = 0; i < WT; ++i) a |= r.w[i];
+    return a;
+}
+
+// Newly reached anchors of node slot idx at `level`: reachability plane and hop-bit planes (bit-sliced count).
+template <int WT>
+__device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words<WT> &seen_old, size_t idx,
+                                             u64 *__restrict__ seen, u64 *__restrict__ hop_planes,
+                                             size_t plane_elems, int level) {
+    Words<WT> s;
+#pragma unroll
+    for (int i = 0; i < WT; ++i) s.w[i] = seen_old.w[i] | fresh.w[i];
+    store_words<WT>(seen + idx, s);
+    for (int b = 0, l = level; l; ++b, l >>= 1)
+        if (l & 1) {
+            u64 *p = hop_planes + (size_t)b * plane_elems + idx;
+            Words<WT> h = load_words<WT>(p);
+#pragma unroll
+            for (int i = 0; i < WT; ++i) h.w[i] |= fresh.w[i];
+            store_words<WT>(p, h);
+        }
+}
+
 // One BFS level, phase 1 ("expand"), bottom-up and EDGE-parallel: lane = one CSR slot e = (v -> u).
 //   cand = front[u] & ~seen[v]           anchors that reach v through u and had not reached v before
 // Slots are sorted by v, so a row is a run of consecutive lanes: a segmented OR-scan over the wave
 // combines each run.  Work per wave is 64 edges whatever the degree distribution (no long rows, no
 // dependent pointer chase: erow/col are coalesced streams), and there are NO atomics:
-//   * the run that contains a row's FIRST slot is the row's "owner piece" and is stored to acc[v];
-//   * a run that continues a row begun in an earlier chunk is a "continuation piece": there is at most
-//     one per 64-slot chunk (its first run) and it is stored to cont[chunk]; k_bfs_update ORs the
-//     continuation pieces of the few rows that span chunks.
+//   * a row that lies inside this chunk is complete: its words are stored to acc[v] (the next frontier)
+//     and committed (seen, hop planes) right here -- only this wave ever touches row v's state;
+//   * a row that runs on into the next chunk stores its "owner piece" to acc[v] and commits nothing;
+//   * a run that continues a row begun in an earlier chunk is a "continuation piece" (at most one per
+//     chunk: its first run), stored to cont[chunk]; k_bfs_fixup combines the pieces of those rows.
+// acc[v] is stored for every row with edges (zeros included), so it needs no clearing between levels.
 // WT = words per tile (1, 2 or 4); blockIdx.y selects the tile of a node's W words.
 template <int WT>
 __global__ __launch_bounds__(256) void k_bfs_expand(const int *__restrict__ erow, const int *__restrict__ col,
                                                     int E, int Wp, const u64 *__restrict__ front,
-                                                    const u64 *__restrict__ seen, u64 *__restrict__ acc,
-                                                    u64 *__restrict__ cont, int level, BfsCtl *ctl) {
-    // The previous level reached nothing new: the BFS is over, every later launch is a no-op.
-    if (__hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < level - 1) return;
+                                                    u64 *__restrict__ seen, u64 *__restrict__ acc,
+                                                    u64 *__restrict__ cont, u64 *__restrict__ hop_planes,
+                                                    size_t plane_elems, int level, BfsCtl *ctl, const int *aux) {
+    if (bfs_over(ctl, aux, level)) return;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -168,89 +240,120 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const int *__restrict__ erow
         }
         const int v0 = __shfl(v, 0);                                       // row of the chunk's first slot
         const bool head_continues = chunk > 0 && erow[chunk * 64 - 1] == v0;
-        Words<WT> c;
+        const int next_v0 = (chunk + 1) * 64 < E ? erow[(chunk + 1) * 64] : -2;   // row of the next chunk's first slot
+        Words<WT> c, s;
 #pragma unroll
-        for (int i = 0; i < WT; ++i) c.w[i] = 0;
+        for (int i = 0; i < WT; ++i) c.w[i] = s.w[i] = 0;
         if (valid) {
             const Words<WT> f = load_words<WT>(front + (size_t)u * Wp + woff);
-            const Words<WT> s = load_words<WT>(seen + (size_t)v * Wp + woff);
+            s = load_words<WT>(seen + (size_t)v * Wp + woff);
 #pragma unroll
             for (int i = 0; i < WT; ++i) c.w[i] = f.w[i] & ~s.w[i];
         }
-        u64 any = 0;
+        if (__any(any_bits<WT>(c) != 0)) {                                // else: nothing new through these 64 edges
 #pragma unroll
-        for (int i = 0; i < WT; ++i) any |= c.w[i];
-        u64 *cont_c = cont + (size_t)chunk * Wp + woff;
-        Words<WT> zero;
+            for (int d = 1; d < 64; d <<= 1) {                             // segmented inclusive OR-scan keyed by v
+                const int pv = __shfl_up(v, d);
+                const bool take = lane >= d && pv == v;
 #pragma unroll
-        for (int i = 0; i < WT; ++i) zero.w[i] = 0;
-        if (!__any(any != 0)) {                                            // nothing new through these 64 edges
-            if (lane == 0) store_words<WT>(cont_c, zero);
-            continue;
-        }
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {                                 // segmented inclusive OR-scan keyed by v
-            const int pv = __shfl_up(v, d);
-            const bool take = lane >= d && pv == v;
-#pragma unroll
-            for (int i = 0; i < WT; ++i) {
-                const u64 pc = __shfl_up(c.w[i], d);
-                if (take) c.w[i] |= pc;
-            }
-        }
-        const int nv = __shfl_down(v, 1);
-        const bool tail = valid && (lane == 63 || nv != v);                // last lane of its run
-        if (tail) {
-            u64 nz = 0;
-#pragma unroll
-            for (int i = 0; i < WT; ++i) nz |= c.w[i];
-            if (head_continues && v == v0) {
-                store_words<WT>(cont_c, c);                                // continuation piece of a row begun earlier
-            } else {
-                if (nz) store_words<WT>(acc + (size_t)v * Wp + woff, c);   // owner piece; acc was zero: plain store
-                if (v == v0) store_words<WT>(cont_c, zero);                // this chunk continues nothing
-            }
-            found |= nz != 0;
-        }
-    }
-    // Raise the "this level reached something" flag.  Same-address device-scope stores serialise at the memory
-    // side (tens of ns each), so a wave stores only while the flag still shows an older level.
-    if (__any(found) && lane == 0 &&
-        __hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != level)
-        __hip_atomic_store(&ctl->last_active, level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Phase 2 ("update"): one thread per (node, word).  acc holds the owner piece; rows that span several
-// 64-slot chunks add their continuation pieces.  The result is exactly the set of newly reached anchors
-// (expand masked with ~seen, which nobody modified meanwhile), i.e. the next frontier: commit it to the
-// reachability plane and the hop-bit planes, and clear the old frontier so it can be the next accumulator.
-__global__ __launch_bounds__(256) void k_bfs_update(const int *__restrict__ rowptr, int Wp, size_t plane_elems,
-                                                    u64 *__restrict__ fresh_front, u64 *__restrict__ old_front,
-                                                    const u64 *__restrict__ cont, u64 *__restrict__ seen,
-                                                    u64 *__restrict__ hop_planes, int level, BfsCtl *ctl) {
-    if (__hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < level) return;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane_elems; i += (size_t)gridDim.x * blockDim.x) {
-        const int v = (int)(i / Wp), w = (int)(i % Wp);
-        old_front[i] = 0;
-        u64 fresh = fresh_front[i];
-        const int p0 = rowptr[v], p1 = rowptr[v + 1];
-        if (p1 > p0) {
-            const int c0 = p0 >> 6, c1 = (p1 - 1) >> 6;
-            if (c1 > c0) {
-                u64 extra = 0;
-                for (int c = c0 + 1; c <= c1; ++c) extra |= cont[(size_t)c * Wp + w];
-                if (extra & ~fresh) {
-                    fresh |= extra;
-                    fresh_front[i] = fresh;
+                for (int i = 0; i < WT; ++i) {
+                    const u64 pc = __shfl_up(c.w[i], d);
+                    if (take) c.w[i] |= pc;
                 }
             }
         }
-        if (fresh) {
-            seen[i] |= fresh;
-            for (int b = 0, l = level; l; ++b, l >>= 1)
-                if (l & 1) hop_planes[(size_t)b * plane_elems + i] |= fresh;
+        const int nv = __shfl_down(v, 1);
+        if (valid && (lane == 63 || nv != v)) {                            // last lane of its run: holds the run's OR
+            const size_t idx = (size_t)v * Wp + woff;
+            if (head_continues && v == v0) {
+                store_words<WT>(cont + (size_t)chunk * Wp + woff, c);      // continuation piece of a row begun earlier
+            } else {
+                store_words<WT>(acc + idx, c);
+                const bool runs_on = lane == 63 && next_v0 == v;           // the row continues in the next chunk
+                if (!runs_on && any_bits<WT>(c)) {
+                    commit_words<WT>(c, s, idx, seen, hop_planes, plane_elems, level);
+                    found = true;
+                }
+            }
         }
     }
+    if (__any(found) && lane == 0) raise_level(ctl, level);
+}
+
+// Phase 2 ("fixup"): rows that span several 64-slot chunks.  fresh = owner piece | continuation pieces; it
+// replaces the owner piece in the frontier and is committed.  Blocks [0, small_blocks) take the short rows,
+// one thread per (row, tile); the remaining blocks take the hubs, one wave per (row, tile).
+template <int WT>
+__global__ __launch_bounds__(256) void k_bfs_fixup(const int *__restrict__ rowptr, int Wp, u64 *__restrict__ acc,
+                                                   const u64 *__restrict__ cont, u64 *__restrict__ seen,
+                                                   u64 *__restrict__ hop_planes, size_t plane_elems, int level,
+                                                   BfsCtl *ctl, const int *__restrict__ aux, int cap, int small_blocks) {
+    if (bfs_over(ctl, aux, level)) return;
+    const int lane = threadIdx.x & 63;
+    const int woff = blockIdx.y * WT;
+    bool found = false;
+    if ((int)blockIdx.x < small_blocks) {
+        const int n = aux[AUX_N_MROWS];
+        const int *mrows = aux + AUX_HEADER;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += small_blocks * blockDim.x) {
+            const int v = mrows[i];
+            const size_t idx = (size_t)v * Wp + woff;
+            const int c0 = rowptr[v] >> 6, c1 = (rowptr[v + 1] - 1) >> 6;
+            Words<WT> own = load_words<WT>(acc + idx), fresh = own;
+#pragma unroll
+            for (int k = 1; k <= SMALL_SPAN; ++k)
+                if (c0 + k <= c1) {
+                    const Words<WT> p = load_words<WT>(cont + (size_t)(c0 + k) * Wp + woff);
+#pragma unroll
+                    for (int j = 0; j < WT; ++j) fresh.w[j] |= p.w[j];
+                }
+            if (any_bits<WT>(fresh)) {
+                bool grew = false;
+#pragma unroll
+                for (int j = 0; j < WT; ++j) grew |= fresh.w[j] != own.w[j];
+                if (grew) store_words<WT>(acc + idx, fresh);
+                commit_words<WT>(fresh, load_words<WT>(seen + idx), idx, seen, hop_planes, plane_elems, level);
+                found = true;
+            }
+        }
+    } else {
+        const int n = aux[AUX_N_HUBS];
+        const int *hubs = aux + AUX_HEADER + cap;
+        const int wave = (((int)blockIdx.x - small_blocks) * blockDim.x + threadIdx.x) >> 6;
+        const int nwaves = ((gridDim.x - small_blocks) * blockDim.x) >> 6;
+        for (int i = wave; i < n; i += nwaves) {
+            const int v = hubs[i];
+            const size_t idx = (size_t)v * Wp + woff;
+            const int c0 = rowptr[v] >> 6, c1 = (rowptr[v + 1] - 1) >> 6;
+            Words<WT> fresh;
+#pragma unroll
+            for (int j = 0; j < WT; ++j) fresh.w[j] = 0;
+            for (int c = c0 + 1 + lane; c <= c1; c += 64) {
+                const Words<WT> p = load_words<WT>(cont + (size_t)c * Wp + woff);
+#pragma unroll
+                for (int j = 0; j < WT; ++j) fresh.w[j] |= p.w[j];
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int j = 0; j < WT; ++j) fresh.w[j] |= __shfl_xor(fresh.w[j], off);
+            if (lane == 0) {
+                const Words<WT> own = load_words<WT>(acc + idx);
+                bool grew = false;
+#pragma unroll
+                for (int j = 0; j < WT; ++j) {
+                    grew |= (fresh.w[j] & ~own.w[j]) != 0;
+                    fresh.w[j] |= own.w[j];
+                }
+                if (any_bits<WT>(fresh)) {
+                    if (grew) store_words<WT>(acc + idx, fresh);
+                    commit_words<WT>(fresh, load_words<WT>(seen + idx), idx, seen, hop_planes, plane_elems, level);
+                    found = true;
+                }
+            }
+        }
+    }
+    if (__any(found) && lane == 0) raise_level(ctl, level);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -268,9 +371,13 @@ __device__ __forceinline__ float hop_value(const u64 *__restrict__ planes, size_
 // One wave per row at a time.  VEC: 16-byte accesses (F, K, c0, out_cols multiples of 4, bases aligned).
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_finalize(const u64 *__restrict__ planes, size_t plane_elems,
-                                                  int n_hop_bits, int N, int K, int Wp,
-                                                  const float *__restrict__ x, int F, float *__restrict__ out,
-                                                  long long out_cols, int c0) {
+                                                  int n_hop_bits, const int *__restrict__ max_hop_dev, int N, int K,
+                                                  int Wp, const float *__restrict__ x, int F,
+                                                  float *__restrict__ out, long long out_cols, int c0) {
+    if (max_hop_dev) {                        // enqueued before the host knew the depth: read it from the BFS control block
+        const int m = *max_hop_dev;
+        n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -359,52 +466,63 @@ using namespace pope;
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+static int aux_cap(int64_t E) { return (int)((E + 63) / 64) + 1; }
+
+extern "C" size_t pope_csr_aux_elems(int64_t E) { return E < 0 ? 0 : (size_t)AUX_HEADER + 2 * (size_t)aux_cap(E); }
+
 extern "C" size_t pope_csr_scratch_bytes(int64_t N, int64_t E) {
     (void)E;
     if (N < 0) return 0;
-    // control block | cnt[N + 1] | rocPRIM scan temp      (the last two only used for unsorted edge lists)
-    return 256 + align_up((size_t)(N + 1) * sizeof(int), 256) + align_up(scan_temp_bytes((size_t)N + 1), 256);
+    // cnt[N + 1] | rocPRIM scan temp      (only used for edge lists that are not sorted by source)
+    return align_up((size_t)(N + 1) * sizeof(int), 256) + align_up(scan_temp_bytes((size_t)N + 1), 256);
+}
+
+static int csr_fallback(const long long *src, const long long *dst, int E, int N, int *rowptr, int *col, int *erow,
+                        int *aux, void *scratch, hipStream_t stream) {
+    int *cnt = (int *)scratch;
+    void *scan_tmp = (char *)scratch + align_up((size_t)(N + 1) * sizeof(int), 256);
+    size_t scan_bytes = scan_temp_bytes((size_t)N + 1);
+    POPE_HIP(hipMemsetAsync(cnt, 0, (size_t)(N + 1) * sizeof(int), stream));
+    hipLaunchKernelGGL(k_csr_count, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, E, cnt);
+    POPE_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, cnt, rowptr, 0, (size_t)N + 1, rocprim::plus<int>(), stream));
+    POPE_HIP(hipMemsetAsync(cnt, 0, (size_t)(N + 1) * sizeof(int), stream));
+    hipLaunchKernelGGL(k_csr_scatter, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, E, rowptr, cnt, col, erow);
+    POPE_HIP(hipMemsetAsync(aux, 0, AUX_HEADER * sizeof(int), stream));
+    hipLaunchKernelGGL(k_csr_lists, dim3(capped_grid((size_t)aux_cap(E), 256)), dim3(256), 0, stream, rowptr, erow, E, aux, aux_cap(E));
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
 }
 
 extern "C" int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col,
-                              int32_t *erow, void *scratch, size_t scratch_bytes, void *stream_) {
+                              int32_t *erow, int32_t *aux, void *scratch, size_t scratch_bytes, int32_t defer_check,
+                              void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(N >= 0 && N < INT32_MAX && E >= 0 && E < INT32_MAX, "pope_csr_build: need 0 <= N, E < 2^31 (N=%lld E=%lld)",
                  (long long)N, (long long)E);
-    POPE_REQUIRE(rowptr && scratch && ((edge_index && col && erow) || E == 0), "pope_csr_build: null pointer");
+    POPE_REQUIRE(rowptr && aux && scratch && ((edge_index && col && erow) || E == 0), "pope_csr_build: null pointer");
     if (scratch_bytes < pope_csr_scratch_bytes(N, E)) {
         set_error("pope_csr_build: scratch %zu < %zu bytes", scratch_bytes, pope_csr_scratch_bytes(N, E));
         return POPE_ERR_WORKSPACE;
     }
-    char *base = (char *)scratch;
-    CsrCtl *ctl = (CsrCtl *)base;
-    int *cnt = (int *)(base + 256);
-    void *scan_tmp = base + 256 + align_up((size_t)(N + 1) * sizeof(int), 256);
     const long long *src = (const long long *)edge_index, *dst = src + E;
-
+    POPE_HIP(hipMemsetAsync(aux, 0, AUX_HEADER * sizeof(int), stream));
     if (E == 0) {
         POPE_HIP(hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * sizeof(int), stream));
         return POPE_OK;
     }
-    POPE_HIP(hipMemsetAsync(ctl, 0, 256, stream));
-    hipLaunchKernelGGL(k_csr_sorted, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, ctl);
-    CsrCtl h;
-    POPE_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(k_csr_sorted, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, aux);
+    hipLaunchKernelGGL(k_csr_lists, dim3(capped_grid((size_t)aux_cap(E), 256)), dim3(256), 0, stream, rowptr, erow, (int)E, aux, aux_cap(E));
+    POPE_HIP(hipGetLastError());
+    if (defer_check) return POPE_OK;                 // pope_geodesic_bfs reports what the speculative pass found
+    int flags = 0;
+    POPE_HIP(hipMemcpyAsync(&flags, aux + AUX_FLAGS, sizeof(int), hipMemcpyDeviceToHost, stream));
     POPE_HIP(hipStreamSynchronize(stream));
-    if (h.flags & CSR_FLAG_BAD_INDEX) {
+    if (flags & CSR_FLAG_BAD_INDEX) {
         set_error("pope_csr_build: edge_index holds a node id outside [0, %lld)", (long long)N);
         return POPE_ERR_INDEX;
     }
-    if (h.flags & CSR_FLAG_UNSORTED) {
-        size_t scan_bytes = scan_temp_bytes((size_t)N + 1);
-        POPE_HIP(hipMemsetAsync(cnt, 0, (size_t)(N + 1) * sizeof(int), stream));
-        hipLaunchKernelGGL(k_csr_count, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, (int)E, cnt);
-        POPE_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, cnt, rowptr, 0, (size_t)N + 1, rocprim::plus<int>(), stream));
-        POPE_HIP(hipMemsetAsync(cnt, 0, (size_t)(N + 1) * sizeof(int), stream));
-        hipLaunchKernelGGL(k_csr_scatter, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, rowptr, cnt, col, erow);
-    }
-    POPE_HIP(hipGetLastError());
+    if (flags & CSR_FLAG_UNSORTED) return csr_fallback(src, dst, (int)E, (int)N, rowptr, col, erow, aux, scratch, stream);
     return POPE_OK;
 }
 
@@ -415,7 +533,7 @@ extern "C" size_t pope_plane_bytes(int64_t N, int32_t K) {
     return (size_t)N * words_for(K) * sizeof(u64);
 }
 
-static size_t cont_bytes(int64_t E, int32_t K) { return align_up((size_t)((E + 63) / 64 + 1) * words_for(K) * sizeof(u64), 256); }
+static size_t cont_bytes(int64_t E, int32_t K) { return align_up((size_t)aux_cap(E) * words_for(K) * sizeof(u64), 256); }
 
 extern "C" size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K) {
     if (N < 0 || E < 0 || K <= 0) return 0;
@@ -423,85 +541,159 @@ extern "C" size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K) {
     return 256 + align_up((size_t)K * sizeof(long long), 256) + 2 * align_up(pope_plane_bytes(N, K), 256) + cont_bytes(E, K);
 }
 
+constexpr int EAGER_PLANES = 4;      // hop-bit planes cleared up front (levels < 16); deeper ones when first needed
+
 template <int WT>
-static void launch_expand(int E, int Wp, const int *erow, const int *col, const u64 *front, const u64 *seen, u64 *acc,
-                          u64 *cont, int level, BfsCtl *ctl, hipStream_t stream) {
+static void launch_level(int E, int Wp, const int *rowptr, const int *col, const int *erow, const int *aux,
+                         const u64 *front, u64 *seen, u64 *acc, u64 *cont, u64 *hop_planes, size_t plane_elems,
+                         int level, BfsCtl *ctl, hipStream_t stream) {
+    const int cap = aux_cap(E);
     dim3 grid(capped_grid((size_t)E, 256, 256u * 32u), Wp / WT);
-    hipLaunchKernelGGL((k_bfs_expand<WT>), grid, dim3(256), 0, stream, erow, col, E, Wp, front, seen, acc, cont, level, ctl);
+    hipLaunchKernelGGL((k_bfs_expand<WT>), grid, dim3(256), 0, stream, erow, col, E, Wp, front, seen, acc, cont,
+                       hop_planes, plane_elems, level, ctl, aux);
+    int small_blocks = (cap + 255) / 256;
+    if (small_blocks > 256) small_blocks = 256;
+    hipLaunchKernelGGL((k_bfs_fixup<WT>), dim3(small_blocks + 64, Wp / WT), dim3(256), 0, stream, rowptr, Wp, acc, cont,
+                       seen, hop_planes, plane_elems, level, ctl, aux, cap, small_blocks);
 }
 
-extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *erow, int64_t N, int64_t E,
-                                 const int64_t *anchors_host, int32_t K, uint64_t *planes_, int32_t plane_capacity,
-                                 void *scratch, size_t scratch_bytes, int32_t *max_hop_host, int32_t *n_hop_bits_host,
-                                 void *stream_) {
-    clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    POPE_REQUIRE(N > 0 && N < INT32_MAX && E >= 0 && E < INT32_MAX, "pope_geodesic_bfs: need 0 < N < 2^31, 0 <= E < 2^31");
-    POPE_REQUIRE(K > 0 && plane_capacity >= 1 && plane_capacity <= 31, "pope_geodesic_bfs: need K > 0 and 1 <= plane_capacity <= 31");
-    POPE_REQUIRE(rowptr && ((erow && col) || E == 0) && anchors_host && planes_ && scratch, "pope_geodesic_bfs: null pointer");
+// Everything one BFS needs, carved out of the caller's buffers.
+struct Bfs {
+    const int *rowptr, *col, *erow, *aux;
+    int N, E, K, Wp, capacity;
+    size_t plane_elems, plane_bytes, front_off;
+    u64 *seen, *hop_planes, *front[2], *cont;
+    char *base;
+    BfsCtl *ctl;
+    long long *anchors_dev;
+    long long level_limit;       // levels 1 .. limit-1 fit `capacity` hop bits
+};
+
+constexpr int LEVEL_BATCH = 16;     // levels enqueued between two polls of the device flag (hop < 16 needs one poll)
+
+static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                     int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
+                     int32_t plane_capacity, void *scratch, size_t scratch_bytes) {
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && E >= 0 && E < INT32_MAX, "geodesic bfs: need 0 < N < 2^31, 0 <= E < 2^31");
+    POPE_REQUIRE(K > 0 && plane_capacity >= 1 && plane_capacity <= 31, "geodesic bfs: need K > 0 and 1 <= plane_capacity <= 31");
+    POPE_REQUIRE(rowptr && aux && ((erow && col) || E == 0) && anchors_host && planes && scratch, "geodesic bfs: null pointer");
     if (scratch_bytes < pope_bfs_scratch_bytes(N, E, K)) {
-        set_error("pope_geodesic_bfs: scratch %zu < %zu bytes", scratch_bytes, pope_bfs_scratch_bytes(N, E, K));
+        set_error("geodesic bfs: scratch %zu < %zu bytes", scratch_bytes, pope_bfs_scratch_bytes(N, E, K));
         return POPE_ERR_WORKSPACE;
     }
     for (int j = 0; j < K; ++j)
         if (anchors_host[j] < 0 || anchors_host[j] >= N) {
-            set_error("pope_geodesic_bfs: anchor %d = %lld outside [0, %lld)", j, (long long)anchors_host[j], (long long)N);
+            set_error("geodesic bfs: anchor %d = %lld outside [0, %lld)", j, (long long)anchors_host[j], (long long)N);
             return POPE_ERR_INDEX;
         }
+    b.rowptr = rowptr; b.col = col; b.erow = erow; b.aux = aux;
+    b.N = (int)N; b.E = (int)E; b.K = K; b.Wp = words_for(K); b.capacity = plane_capacity;
+    b.plane_elems = (size_t)N * b.Wp;
+    b.plane_bytes = b.plane_elems * sizeof(u64);
+    b.seen = (u64 *)planes;
+    b.hop_planes = b.seen + b.plane_elems;
+    b.base = (char *)scratch;
+    b.ctl = (BfsCtl *)b.base;
+    b.front_off = 256 + align_up((size_t)K * sizeof(long long), 256);
+    b.anchors_dev = (long long *)(b.base + 256);
+    b.front[0] = (u64 *)(b.base + b.front_off);
+    b.front[1] = (u64 *)((char *)b.front[0] + align_up(b.plane_bytes, 256));
+    b.cont = (u64 *)((char *)b.front[1] + align_up(b.plane_bytes, 256));
+    b.level_limit = 1ll << plane_capacity;
+    return POPE_OK;
+}
+
+static int bfs_enqueue_init(const Bfs &b, const int64_t *anchors_host, hipStream_t stream) {
+    // one launch clears the control block, both frontier buffers, the reachability plane and the first hop planes
+    const int eager = b.capacity < EAGER_PLANES ? b.capacity : EAGER_PLANES;
+    hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, stream, (uint4 *)b.base,
+                       (b.front_off + 2 * align_up(b.plane_bytes, 256)) / 16, (uint4 *)b.seen,
+                       (size_t)(1 + eager) * b.plane_bytes / 16, (uint4 *)nullptr, (size_t)0);
+    POPE_HIP(hipMemcpyAsync(b.anchors_dev, anchors_host, (size_t)b.K * sizeof(long long), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_bfs_seed, dim3((b.K + 255) / 256), dim3(256), 0, stream, b.anchors_dev, b.K, b.Wp, b.seen, b.front[0]);
+    return POPE_OK;
+}
+
+// Enqueue levels [level, stop) (clipped to what the hop-bit capacity can represent); returns the next level.
+static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t stream) {
+    for (; level < stop; ++level) {
+        if (level >= b.level_limit || b.E == 0) break;
+        if ((level & (level - 1)) == 0 && level >= (1 << EAGER_PLANES)) {   // first level with this hop bit
+            int bit = 0;
+            while ((1 << bit) < level) ++bit;
+            hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, stream, (uint4 *)(b.hop_planes + (size_t)bit * b.plane_elems),
+                               b.plane_bytes / 16, (uint4 *)nullptr, (size_t)0, (uint4 *)nullptr, (size_t)0);
+        }
+        const u64 *prev = b.front[(level - 1) & 1];           // frontier of level - 1
+        u64 *next = b.front[level & 1];                          // receives the frontier of this level
+        if (b.Wp == 1)      launch_level<1>(b.E, b.Wp, b.rowptr, b.col, b.erow, b.aux, prev, b.seen, next, b.cont, b.hop_planes, b.plane_elems, level, b.ctl, stream);
+        else if (b.Wp == 2) launch_level<2>(b.E, b.Wp, b.rowptr, b.col, b.erow, b.aux, prev, b.seen, next, b.cont, b.hop_planes, b.plane_elems, level, b.ctl, stream);
+        else                launch_level<4>(b.E, b.Wp, b.rowptr, b.col, b.erow, b.aux, prev, b.seen, next, b.cont, b.hop_planes, b.plane_elems, level, b.ctl, stream);
+    }
+    return level;
+}
+
+// Wait for the stream and read the verdicts.  Returns POPE_OK with *done set, or an error code.
+static int bfs_poll(const Bfs &b, int next_level, int *last_active, bool *done, hipStream_t stream) {
+    int flags = 0;
+    POPE_HIP(hipMemcpyAsync(last_active, &b.ctl->last_active, sizeof(int), hipMemcpyDeviceToHost, stream));
+    POPE_HIP(hipMemcpyAsync(&flags, b.aux + AUX_FLAGS, sizeof(int), hipMemcpyDeviceToHost, stream));
+    POPE_HIP(hipStreamSynchronize(stream));
+    POPE_HIP(hipGetLastError());
+    if (flags & CSR_FLAG_BAD_INDEX) {
+        set_error("geodesic bfs: edge_index holds a node id outside [0, %d)", b.N);
+        return POPE_ERR_INDEX;
+    }
+    if (flags & CSR_FLAG_UNSORTED) {
+        set_error("geodesic bfs: edge_index is not sorted by source; rebuild the CSR with defer_check = 0");
+        return POPE_ERR_UNSORTED;
+    }
+    *done = *last_active < next_level - 1 || b.E == 0;          // some enqueued level found nothing
+    if (!*done && next_level >= b.level_limit) {
+        // the last representable level still discovered nodes: deeper levels may exist
+        set_error("geodesic bfs: hop count needs more than %d bits", b.capacity);
+        return POPE_ERR_HOP_OVERFLOW;
+    }
+    return POPE_OK;
+}
+
+static int hop_bits(int max_hop) {
+    int bits = 0;
+    while ((1 << bits) <= max_hop) ++bits;
+    return bits;
+}
+
+extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                                 int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
+                                 int32_t plane_capacity, void *scratch, size_t scratch_bytes, int32_t *max_hop_host,
+                                 int32_t *n_hop_bits_host, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    Bfs b;
+    int rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes);
+    if (rc) return rc;
+    if ((rc = bfs_enqueue_init(b, anchors_host, stream))) return rc;
+    int level = 1, last_active = 0;
+    for (bool done = false; !done;) {
+        level = bfs_enqueue_levels(b, level, level + LEVEL_BATCH, stream);
+        if ((rc = bfs_poll(b, level, &last_active, &done, stream))) return rc;
+    }
+    if (max_hop_host) *max_hop_host = last_active;
+    if (n_hop_bits_host) *n_hop_bits_host = hop_bits(last_active);
+    return POPE_OK;
+}
+
+static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_hop_dev, int64_t N, int32_t K,
+                            const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, hipStream_t stream) {
     const int Wp = words_for(K);
     const size_t plane_elems = (size_t)N * Wp;
-    const size_t plane_bytes = plane_elems * sizeof(u64);
-    u64 *planes = (u64 *)planes_;
-    u64 *seen = planes;
-    u64 *hop_planes = planes + plane_elems;
-    char *base = (char *)scratch;
-    BfsCtl *ctl = (BfsCtl *)base;
-    long long *anchors_dev = (long long *)(base + 256);
-    u64 *front[2];
-    front[0] = (u64 *)(base + 256 + align_up((size_t)K * sizeof(long long), 256));
-    front[1] = (u64 *)((char *)front[0] + align_up(plane_bytes, 256));
-    u64 *cont = (u64 *)((char *)front[1] + align_up(plane_bytes, 256));
-
-    POPE_HIP(hipMemsetAsync(ctl, 0, 256, stream));
-    POPE_HIP(hipMemcpyAsync(anchors_dev, anchors_host, (size_t)K * sizeof(long long), hipMemcpyHostToDevice, stream));
-    POPE_HIP(hipMemsetAsync(seen, 0, plane_bytes, stream));
-    POPE_HIP(hipMemsetAsync(front[0], 0, 2 * align_up(plane_bytes, 256), stream));      // both frontier buffers
-    hipLaunchKernelGGL(k_bfs_seed, dim3((K + 255) / 256), dim3(256), 0, stream, anchors_dev, K, Wp, seen, front[0]);
-
-    const long long level_limit = 1ll << plane_capacity;      // levels 1 .. limit-1 fit plane_capacity bits
-    int level = 1, batch = 8, last_active = 0;
-    for (;;) {
-        const int stop = level + batch;                         // enqueue levels [level, stop)
-        for (; level < stop; ++level) {
-            if (level >= level_limit || E == 0) break;
-            if ((level & (level - 1)) == 0) {                    // first level with this hop bit: clear its plane
-                int b = 0;
-                while ((1 << b) < level) ++b;
-                POPE_HIP(hipMemsetAsync(hop_planes + (size_t)b * plane_elems, 0, plane_bytes, stream));
-            }
-            u64 *prev = front[(level - 1) & 1];               // frontier of level - 1
-            u64 *next = front[level & 1];                        // all zero: accumulates, becomes the new frontier
-            if (Wp == 1)      launch_expand<1>((int)E, Wp, erow, col, prev, seen, next, cont, level, ctl, stream);
-            else if (Wp == 2) launch_expand<2>((int)E, Wp, erow, col, prev, seen, next, cont, level, ctl, stream);
-            else              launch_expand<4>((int)E, Wp, erow, col, prev, seen, next, cont, level, ctl, stream);
-            hipLaunchKernelGGL(k_bfs_update, dim3(capped_grid(plane_elems, 256)), dim3(256), 0, stream, rowptr, Wp,
-                               plane_elems, next, prev, cont, seen, hop_planes, level, ctl);
-        }
-        POPE_HIP(hipMemcpyAsync(&last_active, &ctl->last_active, sizeof(int), hipMemcpyDeviceToHost, stream));
-        POPE_HIP(hipStreamSynchronize(stream));
-        if (last_active < level - 1 || E == 0) break;           // some enqueued level found nothing: finished
-        if (level >= level_limit) {
-            // the last representable level still discovered nodes: deeper levels may exist
-            set_error("pope_geodesic_bfs: hop count needs more than %d bits", plane_capacity);
-            return POPE_ERR_HOP_OVERFLOW;
-        }
-        if (batch < 1024) batch *= 2;
-    }
+    const bool vec = F % 4 == 0 && K % 4 == 0 && c0 % 4 == 0 && out_cols % 4 == 0 && aligned16(out) && (!x || aligned16(x));
+    dim3 grid(capped_grid((size_t)N * 64, 256)), block(256);
+    if (vec)
+        hipLaunchKernelGGL(k_finalize<true>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0);
+    else
+        hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0);
     POPE_HIP(hipGetLastError());
-    int bits = 0;
-    while ((1 << bits) <= last_active) ++bits;
-    if (max_hop_host) *max_hop_host = last_active;
-    if (n_hop_bits_host) *n_hop_bits_host = bits;
     return POPE_OK;
 }
 
@@ -509,21 +701,95 @@ extern "C" int pope_geodesic_finalize(const uint64_t *planes, int32_t n_hop_bits
                                       const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0,
                                       void *stream_) {
     clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(planes && out, "pope_geodesic_finalize: null pointer");
     POPE_REQUIRE(N > 0 && N < INT32_MAX && K > 0 && F >= 0 && c0 >= 0 && n_hop_bits >= 0 && n_hop_bits <= 31,
                  "pope_geodesic_finalize: bad size");
     POPE_REQUIRE(out_cols >= (int64_t)F + c0 + K, "pope_geodesic_finalize: out_cols %lld < F + c0 + K = %lld",
                  (long long)out_cols, (long long)F + c0 + K);
-    const int Wp = words_for(K);
-    const size_t plane_elems = (size_t)N * Wp;
-    const bool vec = F % 4 == 0 && K % 4 == 0 && c0 % 4 == 0 && out_cols % 4 == 0 && aligned16(out) && (!x || aligned16(x));
-    dim3 grid(capped_grid((size_t)N * 64, 256)), block(256);
-    if (vec)
-        hipLaunchKernelGGL(k_finalize<true>, grid, block, 0, stream, (const u64 *)planes, plane_elems, n_hop_bits, (int)N, K, Wp, x, F, out, (long long)out_cols, c0);
-    else
-        hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, stream, (const u64 *)planes, plane_elems, n_hop_bits, (int)N, K, Wp, x, F, out, (long long)out_cols, c0);
-    POPE_HIP(hipGetLastError());
+    return finalize_enqueue((const u64 *)planes, n_hop_bits, nullptr, N, K, x, F, out, out_cols, c0, (hipStream_t)stream_);
+}
+
+// ---- the whole geodesic hot path in one call: edge_index -> [N, out_cols] features, one host synchronisation ----
+struct RunLayout {
+    size_t rowptr, col, erow, aux, csr_scratch, planes, bfs_scratch, total;
+};
+
+static RunLayout run_layout(int64_t N, int64_t E, int32_t K, int32_t capacity) {
+    RunLayout L;
+    size_t o = 0;
+    L.rowptr = o;      o += align_up((size_t)(N + 1) * sizeof(int), 256);
+    L.col = o;         o += align_up((size_t)(E > 0 ? E : 1) * sizeof(int), 256);
+    L.erow = o;        o += align_up((size_t)(E > 0 ? E : 1) * sizeof(int), 256);
+    L.aux = o;         o += align_up(pope_csr_aux_elems(E) * sizeof(int), 256);
+    L.csr_scratch = o; o += align_up(pope_csr_scratch_bytes(N, E), 256);
+    L.planes = o;      o += align_up((size_t)(capacity + 1) * pope_plane_bytes(N, K), 256);
+    L.bfs_scratch = o; o += align_up(pope_bfs_scratch_bytes(N, E, K), 256);
+    L.total = o;
+    return L;
+}
+
+extern "C" size_t pope_geodesic_run_workspace_bytes(int64_t N, int64_t E, int32_t K, int32_t plane_capacity) {
+    if (N < 0 || E < 0 || K <= 0 || plane_capacity < 1 || plane_capacity > 31) return 0;
+    return run_layout(N, E, K, plane_capacity).total;
+}
+
+extern "C" uint64_t *pope_geodesic_run_planes(void *workspace, int64_t N, int64_t E, int32_t K, int32_t plane_capacity) {
+    if (!workspace || N < 0 || E < 0 || K <= 0 || plane_capacity < 1 || plane_capacity > 31) return nullptr;
+    return (uint64_t *)((char *)workspace + run_layout(N, E, K, plane_capacity).planes);
+}
+
+extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N, const int64_t *anchors_host, int32_t K,
+                                 const float *x, int32_t F, float *out, int64_t out_cols, int32_t plane_capacity,
+                                 void *workspace, size_t workspace_bytes, int32_t *max_hop_host,
+                                 int32_t *n_hop_bits_host, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && E >= 0 && E < INT32_MAX && K > 0 && F >= 0, "pope_geodesic_run: bad size");
+    POPE_REQUIRE(plane_capacity >= 1 && plane_capacity <= 31, "pope_geodesic_run: need 1 <= plane_capacity <= 31");
+    POPE_REQUIRE(workspace && (edge_index || E == 0) && anchors_host && (out || K == 0), "pope_geodesic_run: null pointer");
+    POPE_REQUIRE(!out || out_cols >= (int64_t)F + K, "pope_geodesic_run: out_cols %lld < F + K", (long long)out_cols);
+    const RunLayout L = run_layout(N, E, K, plane_capacity);
+    if (workspace_bytes < L.total) {
+        set_error("pope_geodesic_run: workspace %zu < %zu bytes", workspace_bytes, L.total);
+        return POPE_ERR_WORKSPACE;
+    }
+    char *ws = (char *)workspace;
+    int *rowptr = (int *)(ws + L.rowptr), *col = (int *)(ws + L.col), *erow = (int *)(ws + L.erow), *aux = (int *)(ws + L.aux);
+    u64 *planes = (u64 *)(ws + L.planes);
+    // speculative: sorted-CSR fast path, the first LEVEL_BATCH levels and the finalise kernel are all enqueued
+    // before the host looks at anything; the finalise kernel reads the depth from the BFS control block.
+    int rc = pope_csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 1, stream_);
+    if (rc) return rc;
+    Bfs b;
+    if ((rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, (uint64_t *)planes, plane_capacity,
+                        ws + L.bfs_scratch, L.total - L.bfs_scratch))) return rc;
+    if ((rc = bfs_enqueue_init(b, anchors_host, stream))) return rc;
+    int level = bfs_enqueue_levels(b, 1, 1 + LEVEL_BATCH, stream);
+    if (out && (rc = finalize_enqueue(planes, 0, &b.ctl->last_active, N, K, x, F, out, out_cols, 0, stream))) return rc;
+    int last_active = 0;
+    bool done = false;
+    rc = bfs_poll(b, level, &last_active, &done, stream);
+    if (rc == POPE_ERR_UNSORTED) {                        // general path: counting sort, then start over
+        clear_error();
+        if ((rc = csr_fallback((const long long *)edge_index, (const long long *)edge_index + E, (int)E, (int)N, rowptr, col,
+                               erow, aux, ws + L.csr_scratch, stream))) return rc;
+        if ((rc = bfs_enqueue_init(b, anchors_host, stream))) return rc;
+        level = 1;
+        done = false;
+    } else if (rc) {
+        return rc;
+    } else if (done) {
+        if (max_hop_host) *max_hop_host = last_active;
+        if (n_hop_bits_host) *n_hop_bits_host = hop_bits(last_active);
+        return POPE_OK;
+    }
+    while (!done) {                                        // deep or re-sorted graph: keep going, then finalise again
+        level = bfs_enqueue_levels(b, level, level + LEVEL_BATCH, stream);
+        if ((rc = bfs_poll(b, level, &last_active, &done, stream))) return rc;
+    }
+    if (out && (rc = finalize_enqueue(planes, hop_bits(last_active), nullptr, N, K, x, F, out, out_cols, 0, stream))) return rc;
+    if (max_hop_host) *max_hop_host = last_active;
+    if (n_hop_bits_host) *n_hop_bits_host = hop_bits(last_active);
     return POPE_OK;
 }
 

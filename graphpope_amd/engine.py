@@ -40,13 +40,19 @@ def _bytes(n: int, device) -> torch.Tensor:
 class Csr:
     """Forward CSR on the device: slot p is the edge erow[p] -> col[p], slots sorted by erow."""
 
-    def __init__(self, rowptr, col, erow, num_nodes, num_edges):
-        self.rowptr, self.col, self.erow = rowptr, col, erow        # int32 [N+1], [E], [E]
+    def __init__(self, rowptr, col, erow, aux, num_nodes, num_edges, edge_index, checked):
+        self.rowptr, self.col, self.erow, self.aux = rowptr, col, erow, aux     # int32 [N+1], [E], [E], [aux]
         self.num_nodes, self.num_edges = num_nodes, num_edges
+        self.edge_index = edge_index        # kept so an unsorted edge list can be rebuilt on demand
+        self.checked = checked              # False: built with defer_check, verdict still on the device
 
 
-def build_csr(edge_index: torch.Tensor, num_nodes: int) -> Csr:
-    """int64 [2, E] on the device -> Csr.  Replaces utils.py:121 ``to_networkx(data)``."""
+def build_csr(edge_index: torch.Tensor, num_nodes: int, defer_check: bool = False) -> Csr:
+    """int64 [2, E] on the device -> Csr.  Replaces utils.py:121 ``to_networkx(data)``.
+
+    ``defer_check=True`` skips the host synchronisation: index validation and the sortedness verdict are
+    picked up by :func:`bfs`, which rebuilds through the general path if the edge list was not sorted.
+    """
     lib = _lib.load()
     assert edge_index.is_cuda and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.shape[0] == 2
     ei = edge_index.contiguous()
@@ -56,10 +62,11 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int) -> Csr:
         rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
         col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
         erow = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+        aux = torch.empty(lib.pope_csr_aux_elems(e), dtype=torch.int32, device=dev)
         scratch = _bytes(lib.pope_csr_scratch_bytes(num_nodes, e), dev)
-        check(lib.pope_csr_build(ptr(ei), e, num_nodes, ptr(rowptr), ptr(col), ptr(erow), ptr(scratch), scratch.numel(),
-                                 _stream()))
-    return Csr(rowptr, col, erow, num_nodes, e)
+        check(lib.pope_csr_build(ptr(ei), e, num_nodes, ptr(rowptr), ptr(col), ptr(erow), ptr(aux), ptr(scratch),
+                                 scratch.numel(), 1 if defer_check else 0, _stream()))
+    return Csr(rowptr, col, erow, aux, num_nodes, e, ei, not defer_check)
 
 
 class HopPlanes:
@@ -89,9 +96,13 @@ def bfs(csr: Csr, anchors, capacity: int = DEFAULT_PLANE_CAPACITY) -> HopPlanes:
         while True:
             planes = torch.empty((capacity + 1, num_nodes, w), dtype=torch.int64, device=dev)
             max_hop, bits = ctypes.c_int32(0), ctypes.c_int32(0)
-            rc = lib.pope_geodesic_bfs(ptr(csr.rowptr), ptr(csr.col), ptr(csr.erow), num_nodes, csr.num_edges, ctypes.c_void_p(anc.ctypes.data), k,
-                                       ptr(planes), capacity, ptr(scratch), scratch.numel(),
-                                       ctypes.byref(max_hop), ctypes.byref(bits), _stream())
+            rc = lib.pope_geodesic_bfs(ptr(csr.rowptr), ptr(csr.col), ptr(csr.erow), ptr(csr.aux), num_nodes, csr.num_edges,
+                                       ctypes.c_void_p(anc.ctypes.data), k, ptr(planes), capacity, ptr(scratch),
+                                       scratch.numel(), ctypes.byref(max_hop), ctypes.byref(bits), _stream())
+            if rc == _lib.ERR_UNSORTED and not csr.checked:
+                fixed = build_csr(csr.edge_index, num_nodes)          # general path (counting sort), synchronous
+                csr.rowptr, csr.col, csr.erow, csr.aux, csr.checked = fixed.rowptr, fixed.col, fixed.erow, fixed.aux, True
+                continue
             if rc == _lib.ERR_HOP_OVERFLOW and capacity < 31:
                 capacity = min(31, capacity * 2)      # 8 -> 16 -> 31 hop bits
                 continue
@@ -119,6 +130,38 @@ def hop_matrix(hp: HopPlanes) -> torch.Tensor:
     return hops
 
 
+def geodesic_run(x, edge_index: torch.Tensor, num_nodes: int, anchors, capacity: int = DEFAULT_PLANE_CAPACITY,
+                 want_out: bool = True):
+    """The whole geodesic hot path in one library call (one host synchronisation): (out, HopPlanes).
+
+    ``x`` float32 [N, F] on the device (or None with ``want_out=False`` for a BFS-only run).
+    """
+    lib = _lib.load()
+    ei = edge_index.contiguous()
+    dev = ei.device
+    assert ei.is_cuda and ei.dtype == torch.int64 and ei.dim() == 2 and ei.shape[0] == 2
+    anc = np.ascontiguousarray(np.asarray(anchors), dtype=np.int64)
+    k, e = int(anc.size), ei.shape[1]
+    f = 0 if x is None else x.shape[1]
+    w = lib.pope_words(k)
+    with torch.cuda.device(dev):
+        out = torch.empty((num_nodes, f + k), dtype=torch.float32, device=dev) if want_out else None
+        while True:
+            ws = _bytes(lib.pope_geodesic_run_workspace_bytes(num_nodes, e, k, capacity), dev)
+            max_hop, bits = ctypes.c_int32(0), ctypes.c_int32(0)
+            rc = lib.pope_geodesic_run(ptr(ei), e, num_nodes, ctypes.c_void_p(anc.ctypes.data), k, ptr(x), f, ptr(out),
+                                       f + k, capacity, ptr(ws), ws.numel(), ctypes.byref(max_hop), ctypes.byref(bits),
+                                       _stream())
+            if rc == _lib.ERR_HOP_OVERFLOW and capacity < 31:
+                capacity = min(31, capacity * 2)
+                continue
+            check(rc)
+            off = lib.pope_geodesic_run_planes(ptr(ws), num_nodes, e, k, capacity) - ws.data_ptr()
+            nbytes = (capacity + 1) * num_nodes * w * 8
+            planes = ws[off: off + nbytes].view(torch.int64).view(capacity + 1, num_nodes, w)
+            return out, HopPlanes(planes, int(bits.value), int(max_hop.value), num_nodes, k)
+
+
 def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int, anchors, group=None,
                       shard: bool = True) -> torch.Tensor:
     """[N, F+K] float32 on the device: features next to the geodesic POPE embedding (utils.py:137-147).
@@ -132,14 +175,10 @@ def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int,
     assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] == num_nodes
     x = x.contiguous()
     anc = np.asarray(anchors, dtype=np.int64)
-    k, f = int(anc.size), x.shape[1]
-    csr = build_csr(edge_index.to(dev), num_nodes)
     world = pdist.world_size(group) if shard else 1
     if world == 1:
-        hp = bfs(csr, anc)
-        out = torch.empty((num_nodes, f + k), dtype=torch.float32, device=dev)
-        finalize(hp.planes, hp.n_hop_bits, num_nodes, k, x, f, out, 0)
-        return out
+        return geodesic_run(x, edge_index.to(dev), num_nodes, anc)[0]
+    csr = build_csr(edge_index.to(dev), num_nodes, defer_check=True)
     return pdist.sharded_geodesic_features(
         x, num_nodes, anc, group,
         bfs_fn=lambda a: bfs(csr, a),

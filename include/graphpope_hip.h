@@ -19,6 +19,7 @@
  *                            utils.py:92-114     multiprocessing fan-out, as one batched multi-source BFS
  *   pope_geodesic_finalize   utils.py:73,125,    1/len(path), tensor conversion and torch.cat((x, emb), 1)
  *                            utils.py:129-135
+ *   pope_geodesic_run        utils.py:144-145    get_geodesic_distance_vector + concat_into_features in one call
  *   pope_geodesic_hops       (no counterpart)    the integer hop matrix the floats are made of; parity tests
  *   pope_pairwise_minmax     utils.py:158-176    sklearn cosine/euclidean pairwise + MinMaxScaler
  *   pope_concat              utils.py:129-135    torch.cat for the node2vec branch
@@ -42,6 +43,7 @@ extern "C" {
 #define POPE_ERR_HOP_OVERFLOW  -4   /* a hop count does not fit the plane capacity / hop dtype given      */
 #define POPE_ERR_WORKSPACE     -5   /* caller workspace too small                                         */
 #define POPE_ERR_NO_DEVICE     -6   /* no gfx950 device visible                                           */
+#define POPE_ERR_UNSORTED      -7   /* CSR was built with defer_check and edge_index is not sorted by source */
 
 /* Message for the last error on the calling thread ("" if none).  Never NULL; valid until the next call. */
 const char *pope_last_error(void);
@@ -56,19 +58,25 @@ const char *pope_version(void);
  * node's OUT-edges: this is the only adjacency the path needs.
  * ------------------------------------------------------------------------------------------------ */
 size_t pope_csr_scratch_bytes(int64_t N, int64_t E);
+size_t pope_csr_aux_elems(int64_t E);          /* int32 elements of `aux` below */
 
 /*
  * edge_index: int64 [2, E] row-major on the device, PyG convention: edge e is
  * edge_index[e] -> edge_index[E + e].  Self-loops and repeated edges are allowed and kept.
- * rowptr int32 [N + 1], col int32 [max(E, 1)] and erow int32 [max(E, 1)] are written: CSR slot p holds the
- * edge erow[p] -> col[p], slots sorted by erow (erow is the row id of every slot: the edge-parallel BFS kernel
- * streams erow/col instead of chasing rowptr).  Column order inside a row is unspecified unless edge_index is
- * already sorted by source (PyG's coalesced order; then it is preserved and no atomics are used).
- * Synchronises `stream` once (index validation result comes back to the host).
- * Requires 0 <= N < 2^31 and 0 <= E < 2^31.  Returns POPE_ERR_INDEX if an id is outside [0, N).
+ * Written (all caller-allocated, int32):
+ *   rowptr [N + 1], col [max(E, 1)], erow [max(E, 1)]: CSR slot p holds the edge erow[p] -> col[p], slots sorted
+ *       by erow (erow is the row id of every slot: the edge-parallel BFS kernel streams erow/col instead of
+ *       chasing rowptr).  Column order inside a row is unspecified unless edge_index is already sorted by source
+ *       (PyG's coalesced order; then it is preserved and no atomics are used).
+ *   aux [pope_csr_aux_elems(E)]: header (counts, status flags) + the rows that span several 64-slot chunks.
+ * defer_check = 0: synchronises `stream` once; returns POPE_ERR_INDEX for an id outside [0, N) and falls back
+ *   to a counting sort when edge_index is not sorted by source.
+ * defer_check = 1: fully asynchronous; only the sorted fast path is attempted and its verdict stays in aux:
+ *   pope_geodesic_bfs then returns POPE_ERR_INDEX / POPE_ERR_UNSORTED (rebuild with defer_check = 0).
+ * Requires 0 <= N < 2^31 and 0 <= E < 2^31.
  */
 int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col, int32_t *erow,
-                   void *scratch, size_t scratch_bytes, void *stream);
+                   int32_t *aux, void *scratch, size_t scratch_bytes, int32_t defer_check, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Geodesic embedding.
@@ -99,7 +107,8 @@ size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K);
  * Returns POPE_ERR_HOP_OVERFLOW if a hop count would need more than plane_capacity bits.
  * Synchronises `stream` (the level loop polls a device flag every few levels).
  */
-int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *erow, int64_t N, int64_t E,
+int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                      int64_t N, int64_t E,
                       const int64_t *anchors_host, int32_t K, uint64_t *planes, int32_t plane_capacity, void *scratch, size_t scratch_bytes,
                       int32_t *max_hop_host, int32_t *n_hop_bits_host, void *stream);
 
@@ -111,6 +120,23 @@ int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *
  */
 int pope_geodesic_finalize(const uint64_t *planes, int32_t n_hop_bits, int64_t N, int32_t K_shard,
                            const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, void *stream);
+
+/*
+ * The whole geodesic hot path in ONE call (what utils.py:137-147 does after sampling the anchors):
+ * edge_index -> CSR -> multi-source BFS -> out[v, 0:F] = x[v, :], out[v, F + j] = 1 / (hops(v, anchor j) + 1).
+ * Everything is enqueued speculatively (sorted-CSR fast path, 16 BFS levels, the finalise kernel reading the
+ * depth from device memory) and the host synchronises `stream` ONCE to read the verdicts; unsorted edge lists
+ * and graphs deeper than 15 hops transparently take the general path (more synchronisations).
+ * workspace: pope_geodesic_run_workspace_bytes(N, E, K, plane_capacity) bytes, device memory, no initialisation
+ * needed; afterwards pope_geodesic_run_planes() locates the hop planes inside it (planes [0, 1 + *n_hop_bits) valid).
+ * out may be NULL (BFS only).  Returns POPE_ERR_HOP_OVERFLOW if plane_capacity bits cannot hold the depth.
+ */
+size_t pope_geodesic_run_workspace_bytes(int64_t N, int64_t E, int32_t K, int32_t plane_capacity);
+uint64_t *pope_geodesic_run_planes(void *workspace, int64_t N, int64_t E, int32_t K, int32_t plane_capacity);
+int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N, const int64_t *anchors_host, int32_t K,
+                      const float *x, int32_t F, float *out, int64_t out_cols, int32_t plane_capacity,
+                      void *workspace, size_t workspace_bytes, int32_t *max_hop_host, int32_t *n_hop_bits_host,
+                      void *stream);
 
 /* Integer hop matrix: hops int32 [N, K] node-major, -1 = unreachable.  Asynchronous on `stream`. */
 int pope_geodesic_hops(const uint64_t *planes, int32_t n_hop_bits, int64_t N, int32_t K,

@@ -79,6 +79,38 @@ def test_hub_rows_and_unsorted_edges(dev, oracle):
     assert np.array_equal(hops, oracle.geodesic_hops(ei, n, anchors))
 
 
+def test_deferred_check_rebuilds_unsorted_edge_lists(dev, oracle):
+    """defer_check: the sorted fast path is speculative; bfs() picks up the verdict and rebuilds through the counting sort."""
+    from graphpope_amd import engine, synth, _lib
+    ei, n = synth.rmat(10, edge_factor=8, seed=5)
+    ei = ei[:, np.random.RandomState(1).permutation(ei.shape[1])]
+    anchors = np.arange(0, 70)
+    csr = engine.build_csr(torch.as_tensor(ei, device=dev), n, defer_check=True)
+    assert not csr.checked
+    hp = engine.bfs(csr, anchors)
+    assert csr.checked
+    assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), oracle.geodesic_hops(ei, n, anchors))
+    bad = engine.build_csr(torch.tensor([[0, 1], [1, 9]], device=dev), 3, defer_check=True)
+    with pytest.raises(_lib.PopeError) as e:
+        engine.bfs(bad, [0])
+    assert e.value.code == _lib.ERR_INDEX
+
+
+@pytest.mark.parametrize("name", ["rmat11_seed42", "powerlaw4k_seed42", "path300", "multiloops30", "noedges6", "star701"])
+def test_single_call_run_matches_golden(name, dev):
+    """pope_geodesic_run: speculative one-sync path (sorted), deep graph (path300: > 16 levels), unsorted input, E = 0."""
+    from graphpope_amd import engine
+    g = load_golden(os.path.join(GOLDEN, f"geodesic_{name}.npz"))
+    n = int(g["num_nodes"])
+    ei = torch.as_tensor(g["edge_index"].astype(np.int64), device=dev)
+    out, hp = engine.geodesic_run(torch.as_tensor(g["x"], device=dev), ei, n, g["anchors"])
+    torch.cuda.synchronize()
+    f = g["x"].shape[1]
+    assert np.array_equal(out.cpu().numpy()[:, f:].view(np.uint32), g["emb"].view(np.uint32))
+    assert np.array_equal(out.cpu().numpy()[:, :f], g["x"])
+    assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), g["hops"])
+
+
 def test_long_path_needs_more_than_8_hop_bits(dev, oracle):
     n = 1500
     a = np.arange(n - 1)

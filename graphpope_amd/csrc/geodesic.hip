@@ -119,9 +119,10 @@ struct BfsCtl {          // device control block at the start of the BFS scratch
 };
 
 __device__ __forceinline__ bool bfs_over(const BfsCtl *ctl, const int *aux, int level) {
-    // the previous level reached nothing new (every later launch is a no-op), or the CSR is not usable
-    return __hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < level - 1 ||
-           aux[AUX_FLAGS] != 0;
+    // The previous level reached nothing new (every later launch is a no-op), or the CSR is not usable.
+    // Plain loads: both words were last written by EARLIER launches (a wave of this launch may be raising
+    // last_active to `level` meanwhile, which does not change the verdict).
+    return *(const volatile int *)&ctl->last_active < level - 1 || aux[AUX_FLAGS] != 0;
 }
 
 // Same-address device-scope stores serialise at the memory side (tens of ns each): a wave stores only while
@@ -548,7 +549,7 @@ static void launch_level(int E, int Wp, const int *rowptr, const int *col, const
                          const u64 *front, u64 *seen, u64 *acc, u64 *cont, u64 *hop_planes, size_t plane_elems,
                          int level, BfsCtl *ctl, hipStream_t stream) {
     const int cap = aux_cap(E);
-    dim3 grid(capped_grid((size_t)E, 256, 256u * 32u), Wp / WT);
+    dim3 grid(capped_grid((size_t)E, 256, 256u * 8u), Wp / WT);      // <= 8 blocks per CU, waves loop over chunks
     hipLaunchKernelGGL((k_bfs_expand<WT>), grid, dim3(256), 0, stream, erow, col, E, Wp, front, seen, acc, cont,
                        hop_planes, plane_elems, level, ctl, aux);
     int small_blocks = (cap + 255) / 256;
@@ -569,7 +570,7 @@ struct Bfs {
     long long level_limit;       // levels 1 .. limit-1 fit `capacity` hop bits
 };
 
-constexpr int LEVEL_BATCH = 16;     // levels enqueued between two polls of the device flag (hop < 16 needs one poll)
+constexpr int LEVEL_BATCH = 12;     // levels enqueued between two polls of the device flag (hops <= 10: one poll)
 
 static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
                      int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,

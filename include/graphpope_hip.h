@@ -124,9 +124,9 @@ int pope_geodesic_finalize(const uint64_t *planes, int32_t n_hop_bits, int64_t N
 /*
  * The whole geodesic hot path in ONE call (what utils.py:137-147 does after sampling the anchors):
  * edge_index -> CSR -> multi-source BFS -> out[v, 0:F] = x[v, :], out[v, F + j] = 1 / (hops(v, anchor j) + 1).
- * Everything is enqueued speculatively (sorted-CSR fast path, 16 BFS levels, the finalise kernel reading the
+ * Everything is enqueued speculatively (sorted-CSR fast path, 12 BFS levels, the finalise kernel reading the
  * depth from device memory) and the host synchronises `stream` ONCE to read the verdicts; unsorted edge lists
- * and graphs deeper than 15 hops transparently take the general path (more synchronisations).
+ * and graphs deeper than 10 hops transparently take the general path (more synchronisations).
  * workspace: pope_geodesic_run_workspace_bytes(N, E, K, plane_capacity) bytes, device memory, no initialisation
  * needed; afterwards pope_geodesic_run_planes() locates the hop planes inside it (planes [0, 1 + *n_hop_bits) valid).
  * out may be NULL (BFS only).  Returns POPE_ERR_HOP_OVERFLOW if plane_capacity bits cannot hold the depth.

@@ -1,0 +1,95 @@
+"""node2vec-space embedding on the GPU (MFMA pairwise + column min-max) against the reference goldens and the oracle.
+
+Tolerance: 1e-5 absolute on the min-max scaled values (float parity is pinned to the
+container's scikit-learn through tests/golden/node2vec_*.npz).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from graphpope_amd import engine
+    return engine.require_gpu()
+
+
+@pytest.mark.parametrize("family", ["randn2048", "small96", "const40"])
+@pytest.mark.parametrize("fn", ["distance", "similarity", "euclidean"])
+def test_golden(family, fn, dev):
+    from graphpope_amd import engine
+    g = load_golden(os.path.join(GOLDEN, f"node2vec_{family}.npz"))
+    out = engine.pairwise_features(torch.as_tensor(g["x"], device=dev), torch.as_tensor(g["emb"], device=dev),
+                                   g["anchors"], fn).cpu().numpy()
+    f = g["x"].shape[1]
+    assert out.dtype == np.float32 and np.array_equal(out[:, :f], g["x"])
+    np.testing.assert_allclose(out[:, f:], g[f"scaled_{fn}"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("n,d,k", [(1000, 128, 256), (777, 100, 300), (130, 7, 5), (4096, 64, 33)])
+@pytest.mark.parametrize("fn", ["distance", "similarity", "euclidean"])
+def test_shapes_against_oracle(n, d, k, fn, dev, oracle):
+    from graphpope_amd import engine
+    rs = np.random.RandomState(n + k)
+    emb = rs.randn(n, d).astype(np.float32)
+    emb[5] = emb[9]                                   # coincident rows: exact zero distance
+    anchors = rs.choice(n, k)
+    x = rs.rand(n, 3).astype(np.float32)
+    out = engine.pairwise_features(torch.as_tensor(x, device=dev), torch.as_tensor(emb, device=dev), anchors, fn).cpu().numpy()
+    want = oracle.node2vec_features(x, emb, anchors, fn)
+    assert out.shape == want.shape
+    np.testing.assert_allclose(out, want, rtol=0, atol=ATOL)
+    assert out[:, 3:].min() >= -1e-6 and out[:, 3:].max() <= 1.0 + 1e-6
+
+
+def test_flickr_size_euclidean_properties(dev, oracle):
+    """BASELINE config 3 at full size: every column spans [0, 1]; an anchor's own row is the column minimum."""
+    from graphpope_amd import engine, synth
+    n, d, k = synth.FLICKR_N, 128, 256
+    emb = torch.randn(n, d, generator=torch.Generator().manual_seed(0))
+    anchors = synth.seeded_anchors(n, k, 42)
+    x = torch.zeros(n, 4)
+    out = engine.pairwise_features(x.to(dev), emb.to(dev), anchors, "euclidean").cpu().numpy()[:, 4:]
+    assert np.allclose(out.min(axis=0), 0.0, atol=1e-6) and np.allclose(out.max(axis=0), 1.0, atol=1e-6)
+    assert (out[anchors, np.arange(k)] <= 1e-6).all()
+    rows = np.random.RandomState(0).choice(n, 4000, replace=False)       # oracle on a row sample (needs the global min/max)
+    raw = oracle.pairwise(emb.numpy(), emb.numpy()[anchors], "euclidean")
+    want = oracle.minmax_scale_columns(raw)
+    np.testing.assert_allclose(out[rows], want[rows], rtol=0, atol=ATOL)
+
+
+def test_unknown_metric_is_keyerror(dev):
+    from graphpope_amd import engine
+    with pytest.raises(KeyError):
+        engine.pairwise_features(torch.zeros(4, 2, device=dev), torch.zeros(4, 3, device=dev), [0, 1], "manhattan")
+
+
+def test_graphpope_node2vec_entry(dev, tmp_path, monkeypatch):
+    from graphpope_amd import utils as gp
+    g = load_golden(os.path.join(GOLDEN, "node2vec_randn2048.npz"))
+    torch.save(torch.nn.Parameter(torch.as_tensor(g["emb"])), tmp_path / "flickr_node2vec.pt")
+    monkeypatch.setattr(gp, "NODE2VEC_DIR", str(tmp_path))
+
+    class Data:
+        pass
+    d = Data()
+    d.x, d.edge_index, d.num_nodes = torch.as_tensor(g["x"]), torch.zeros(2, 0, dtype=torch.int64), 2048
+    gp.clear_cache()
+    np.random.seed(42)
+    out = gp.Graphpope(d, "flickr", "node2vec", "stochastic", 64, "euclidean", 2)
+    assert not hasattr(d, "anchor_nodes")                      # utils.py:165: the node2vec branch does not set it
+    np.testing.assert_allclose(out.numpy()[:, 5:], g["scaled_euclidean"], rtol=0, atol=ATOL)
+    gp.clear_cache()
+    with pytest.raises(FileNotFoundError):
+        gp.Graphpope(d, "pubmed", "node2vec", "stochastic", 4, "euclidean")
+    gp.clear_cache()
+    with pytest.raises(KeyError):
+        gp.Graphpope(d, "flickr", "node2vec", "stochastic", 4, "chebyshev")
+    gp.clear_cache()

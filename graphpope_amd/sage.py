@@ -1,0 +1,176 @@
+"""GraphSAGE on the HIP SAGEConv kernels: the consumer of the ``features (+) POPE`` tensor.
+
+Mirrors /root/reference/main.py:182-211 (class SAGE: ModuleList of SAGEConv + BatchNorm1d, forward
+over the sampled ``adjs``) with the PyG ``SAGEConv`` replaced by :class:`SAGEConv` below, whose
+neighbour gather + mean and both projections run in libgraphpope_hip.so (fp32, exact-f32 MFMA).
+Parameter names follow PyG 1.7.0 (``lin_l.weight``, ``lin_l.bias``, ``lin_r.weight``) so the
+reference's Lightning checkpoints stay loadable.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class SampledAdj:
+    """One bipartite block of a sampled mini-batch: CSR by destination, destinations = first n_dst sources.
+
+    Stands in for the ``torch_sparse.SparseTensor`` ``adj_t`` PyG's NeighborSampler yields
+    (main.py:59-63, 118-123): ``size(0)`` = n_dst, ``size(1)`` = n_src, values dropped.
+    """
+
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, n_src: int):
+        self.rowptr = rowptr.to(torch.int32).contiguous()
+        self.col = col.to(torch.int32).contiguous()
+        self.n_dst = int(rowptr.numel() - 1)
+        self.n_src = int(n_src)
+
+    def size(self, dim: int) -> int:
+        return (self.n_dst, self.n_src)[dim]
+
+    def to(self, device):
+        return SampledAdj(self.rowptr.to(device), self.col.to(device), self.n_src)
+
+
+class _SageConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_src, w_l, b_l, w_r, rowptr, col, n_dst):
+        lib = _lib.load()
+        if not x_src.is_cuda:
+            raise RuntimeError("SAGEConv runs on the GPU only (no CPU fallback)")
+        x_src, w_l, w_r = x_src.contiguous(), w_l.contiguous(), w_r.contiguous()
+        n_src, c_in = x_src.shape
+        c_out = w_l.shape[0]
+        agg = torch.empty((n_dst, c_in), dtype=torch.float32, device=x_src.device)
+        out = torch.empty((n_dst, c_out), dtype=torch.float32, device=x_src.device)
+        with torch.cuda.device(x_src.device):
+            check(lib.sage_conv_forward(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), c_in, ptr(w_l),
+                                        ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(out), _stream()))
+        ctx.save_for_backward(x_src, agg, w_l, w_r, rowptr, col)
+        ctx.has_bias = b_l is not None
+        ctx.n_dst = n_dst
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        x_src, agg, w_l, w_r, rowptr, col = ctx.saved_tensors
+        n_src, c_in = x_src.shape
+        c_out, n_dst = w_l.shape[0], ctx.n_dst
+        grad_out = grad_out.contiguous()
+        dev = x_src.device
+        need_x = ctx.needs_input_grad[0]
+        grad_x = torch.empty_like(x_src) if need_x else None
+        grad_w_l = torch.empty_like(w_l)
+        grad_w_r = torch.empty_like(w_r)
+        grad_b = torch.empty(c_out, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        with torch.cuda.device(dev):
+            scratch = torch.empty(max(lib.sage_conv_scratch_bytes(n_src, n_dst, col.numel(), c_in, c_out), 16),
+                                  dtype=torch.uint8, device=dev)
+            check(lib.sage_conv_backward(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), ptr(agg), c_in,
+                                         ptr(w_l), ptr(w_r), c_out, ptr(grad_out), ptr(grad_x), ptr(grad_w_l), ptr(grad_b),
+                                         ptr(grad_w_r), ptr(scratch), scratch.numel(), _stream()))
+        return grad_x, grad_w_l, grad_b, grad_w_r, None, None, None
+
+
+class _Linear(nn.Module):
+    """Weight (+ bias) holder named like torch.nn.Linear so state dicts line up with PyG's lin_l / lin_r."""
+
+    def __init__(self, c_in, c_out, bias):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c_out, c_in))
+        self.bias = nn.Parameter(torch.empty(c_out)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))       # torch.nn.Linear's default
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.weight.shape[1])
+            nn.init.uniform_(self.bias, -bound, bound)
+
+
+class SAGEConv(nn.Module):
+    """``conv((x_src, x_dst), adj_t)`` with mean aggregation (PyG 1.7.0 SAGEConv defaults: root_weight, bias, no normalize)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin_l = _Linear(in_channels, out_channels, bias=True)
+        self.lin_r = _Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x, adj_t: SampledAdj):
+        x_src = x[0] if isinstance(x, (tuple, list)) else x       # x_dst = x_src[:n_dst] by construction (main.py:206)
+        return _SageConvFn.apply(x_src, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, adj_t.rowptr, adj_t.col,
+                                 adj_t.size(0))
+
+
+class SAGE(nn.Module):
+    """main.py:182-211 without the Lightning plumbing.  Keeps the reference's depth quirk: ``forward`` iterates over
+    the sampled adjs (two of them, sizes=[25, 10]), so with num_layers=3 the last conv / bn are never executed and
+    the logits are hidden_channels wide (SURVEY.md §7 trap 7)."""
+
+    def __init__(self, in_channels: int, out_channels: int, hidden_channels: int, num_layers: int, dropout: float = 0.5):
+        super().__init__()
+        self.dropout = dropout
+        self.convs = nn.ModuleList()
+        self.convs.append(SAGEConv(in_channels, hidden_channels))
+        for _ in range(num_layers - 2):
+            self.convs.append(SAGEConv(hidden_channels, hidden_channels))
+        self.convs.append(SAGEConv(hidden_channels, out_channels))
+        self.bns = nn.ModuleList()
+        for _ in range(num_layers - 1):
+            self.bns.append(nn.BatchNorm1d(hidden_channels))
+
+    def forward(self, x, adjs):
+        for i, adj_t in enumerate(adjs):
+            x = self.convs[i]((x, x[:adj_t.size(0)]), adj_t)
+            if i < len(adjs) - 1:
+                x = self.bns[i](x)
+                x = x.relu_()
+                x = F.dropout(x, p=self.dropout, training=self.training)
+        return x
+
+
+# ------------------------------------------------------------------------------------------------
+# Host-side fan-out sampler for synthetic batches (stands in for PyG NeighborSampler, main.py:100-116).
+# Not accelerated; only used to produce Flickr-shaped pre-sampled batches.
+# ------------------------------------------------------------------------------------------------
+def sample_batch(rowptr: np.ndarray, col: np.ndarray, seeds: np.ndarray, sizes=(25, 10), rng=None):
+    """Returns (n_id, adjs) like NeighborSampler: adjs outer -> inner, each a SampledAdj over local ids, and the
+    destinations of every block are the first n_dst entries of its sources."""
+    rng = rng or np.random.default_rng(0)
+    n_id = np.asarray(seeds, dtype=np.int64)
+    adjs = []
+    for size in sizes:
+        local = {int(g): i for i, g in enumerate(n_id)}
+        ids = list(n_id)
+        rp = [0]
+        cols = []
+        for g in n_id:
+            nbr = col[rowptr[g]:rowptr[g + 1]]
+            if nbr.size > size:
+                nbr = rng.choice(nbr, size, replace=False)
+            for u in nbr:
+                u = int(u)
+                j = local.get(u)
+                if j is None:
+                    j = len(ids)
+                    local[u] = j
+                    ids.append(u)
+                cols.append(j)
+            rp.append(len(cols))
+        adjs.append(SampledAdj(torch.tensor(rp, dtype=torch.int32), torch.tensor(cols, dtype=torch.int32), len(ids)))
+        n_id = np.asarray(ids, dtype=np.int64)
+    return n_id, adjs[::-1]

@@ -1,0 +1,103 @@
+"""HIP SAGEConv forward/backward against the torch fp32 restatement (oracle.sage_conv_torch).
+
+PyG / torch_sparse are absent, so this parity is op-level and self-referential:
+tolerances fwd 1e-4, grads 1e-3 relative to the largest magnitude (fp32 reduction-order noise).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from graphpope_amd import engine
+    return engine.require_gpu()
+
+
+def _random_block(n_dst, n_src, max_deg, seed, empty_rows=True):
+    rs = np.random.RandomState(seed)
+    deg = rs.randint(0 if empty_rows else 1, max_deg + 1, size=n_dst)
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = rs.randint(0, n_src, size=int(rowptr[-1])).astype(np.int32)
+    return torch.tensor(rowptr), torch.tensor(col)
+
+
+def _close(got, want, rel):
+    scale = max(float(want.abs().max()), 1e-6)
+    err = float((got - want).abs().max())
+    assert err <= rel * scale, (err, scale)
+
+
+@pytest.mark.parametrize("n_dst,n_src,c_in,c_out,max_deg", [
+    (5, 9, 7, 3, 3), (130, 400, 64, 32, 10), (1000, 3000, 532, 256, 25), (1550, 10136, 256, 256, 25), (300, 301, 130, 257, 4)])
+def test_forward_backward_match_torch(n_dst, n_src, c_in, c_out, max_deg, dev, oracle):
+    from graphpope_amd.sage import SAGEConv, SampledAdj
+    rowptr, col = _random_block(n_dst, n_src, max_deg, seed=n_dst + c_in)
+    torch.manual_seed(0)
+    conv = SAGEConv(c_in, c_out).to(dev)
+    x = torch.randn(n_src, c_in)
+    g = torch.randn(n_dst, c_out)
+
+    xd = x.to(dev).requires_grad_(True)
+    out = conv((xd, xd[:n_dst]), SampledAdj(rowptr, col, n_src).to(dev))
+    out.backward(g.to(dev))
+
+    xr = x.clone().requires_grad_(True)
+    wl, bl, wr = (p.detach().cpu().clone().requires_grad_(True) for p in (conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight))
+    ref = oracle.sage_conv_torch(xr, rowptr, col, wl, bl, wr)
+    ref.backward(g)
+
+    _close(out.detach().cpu(), ref.detach(), 1e-4)
+    _close(xd.grad.cpu(), xr.grad, 1e-3)
+    _close(conv.lin_l.weight.grad.cpu(), wl.grad, 1e-3)
+    _close(conv.lin_l.bias.grad.cpu(), bl.grad, 1e-3)
+    _close(conv.lin_r.weight.grad.cpu(), wr.grad, 1e-3)
+
+
+def test_no_input_grad_skips_grad_x(dev):
+    from graphpope_amd.sage import SAGEConv, SampledAdj
+    rowptr, col = _random_block(64, 200, 10, seed=1)
+    conv = SAGEConv(36, 16).to(dev)
+    x = torch.randn(200, 36, device=dev)                     # layer 0: features need no gradient
+    out = conv((x, x[:64]), SampledAdj(rowptr, col, 200).to(dev))
+    out.sum().backward()
+    assert x.grad is None and conv.lin_l.weight.grad is not None
+
+
+def test_state_dict_names_follow_pyg(dev):
+    from graphpope_amd.sage import SAGE
+    m = SAGE(756, 7, 256, 3)
+    keys = set(m.state_dict())
+    assert {"convs.0.lin_l.weight", "convs.0.lin_l.bias", "convs.0.lin_r.weight", "convs.2.lin_l.weight",
+            "bns.0.weight", "bns.1.running_mean"} <= keys
+    assert "convs.0.lin_r.bias" not in keys
+    assert m.convs[0].lin_l.weight.shape == (256, 756) and m.convs[2].lin_l.weight.shape == (7, 256)
+
+
+def test_model_depth_quirk_and_training_step(dev):
+    """main.py:204-211 iterates over the 2 sampled adjs: with num_layers=3 the logits are hidden-wide (256)."""
+    from graphpope_amd import synth
+    from graphpope_amd.sage import SAGE, sample_batch
+    ei, n = synth.pubmed_like()
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei[0], minlength=n))])
+    n_id, adjs = sample_batch(rowptr, ei[1], np.arange(0, 512), sizes=(25, 10))
+    assert adjs[1].size(0) == 512 and adjs[0].size(0) == adjs[1].size(1) and adjs[0].size(1) == len(n_id)
+    torch.manual_seed(0)
+    model = SAGE(40, 3, 64, 3).to(dev)
+    x = torch.randn(len(n_id), 40, device=dev)
+    y = torch.randint(0, 3, (512,), device=dev)
+    adjs = [a.to(dev) for a in adjs]
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        out = model(x, adjs)
+        assert out.shape == (512, 64)                        # hidden width, not num_classes
+        loss = torch.nn.functional.cross_entropy(out, y)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.7 * losses[0]
+    assert model.convs[2].lin_l.weight.grad is None          # never executed

@@ -3,17 +3,24 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is one pass of the hot path over one synthetic Flickr-shaped input already resident in HBM:
-edge_index -> CSR -> multi-source BFS for all anchors -> hop planes -> [N, F+K] float32 features
-(BASELINE.json configs[1]: Flickr geodesic-stochastic, 256 anchors).  For N > 1 GPUs the run is WEAK
-scaled: every rank owns 256 anchors (K_total = 256 * N), planes are all-gathered (RCCL) and every rank
-materialises the full [N, F + K_total] matrix, as every DDP rank of the reference needs it.
+A "step" is one pass of the hot path over one synthetic Flickr-shaped input already resident in HBM
+(BASELINE.json configs[1]: Flickr geodesic-stochastic, 256 anchors, 3-layer GraphSAGE on 1 MI355X):
 
-Rank 0 prints ONE JSON line.  At N = 1 it also times the CPU baselines on this host.
+    edge_index -> CSR -> multi-source BFS for all anchors -> hop planes -> [N, F+K] float32 features
+
+`value` is POPE embeddings/s = N * K / step time (the first half of BASELINE.json's metric); the second half,
+SAGE nodes/s (seed nodes through fwd + bwd + Adam on pre-sampled [25, 10] fan-out batches over those features),
+is reported in the same line under "sage".  For N > 1 GPUs the POPE pass is WEAK scaled: every rank owns 256
+anchors (K_total = 256 * N), planes are all-gathered (RCCL) and every rank materialises the full
+[N, F + K_total] matrix, as every DDP rank of the reference needs it.
+
+Rank 0 prints ONE JSON line.  At N = 1 it also carries the roofline of the dominant kernel (durations measured
+live with HIP events on the launch stream) and the CPU baselines timed on this host's cores.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -26,12 +33,14 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from graphpope_amd import engine, synth  # noqa: E402
+from graphpope_amd import _lib, engine, synth  # noqa: E402
 from graphpope_amd import distributed as pdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 F = 500                      # /root/reference/main.py:77-79
 K_PER_GPU = 256
+BATCH = 1550                 # main.py:44
+HIDDEN = 256
 
 
 def _event():
@@ -69,40 +78,153 @@ def pope_phases(x, ei, n, anchors, timers):
     return out
 
 
+def level_kernel_times(ei, n, anchors, reps):
+    """Per-launch durations of the BFS level kernels (HIP events recorded by the library on the launch stream)."""
+    lib = _lib.load()
+    csr = engine.build_csr(ei, n)
+    engine.bfs(csr, anchors)
+    torch.cuda.synchronize()
+    lib.pope_profile_levels(1)
+    for _ in range(reps):
+        hp = engine.bfs(csr, anchors)
+    torch.cuda.synchronize()
+    cap = 4096
+    lv = (ctypes.c_int32 * cap)()
+    ex = (ctypes.c_float * cap)()
+    fx = (ctypes.c_float * cap)()
+    cnt = lib.pope_profile_read(lv, ex, fx, cap)
+    lib.pope_profile_levels(0)
+    active = hp.max_hop + 1                     # levels 1 .. max_hop reach something, level max_hop + 1 proves the end
+    exp = [ex[i] for i in range(cnt) if lv[i] <= active]
+    fix = [fx[i] for i in range(cnt) if lv[i] <= active]
+    return float(np.mean(exp)), float(np.mean(fix)), active, hp
+
+
 def cpu_baselines(ei, n, anchors):
-    """Timed on this host's cores, bounded samples (rank 0, N = 1 only).  Uses the oracle as the measured CPU port."""
+    """Timed on this host's cores, bounded samples (rank 0, N = 1 only).  The oracle is the measured CPU port."""
     from oracle import oracle
     res = {}
-    # (A) the reference's algorithm, statement for statement: nx.shortest_path per (node, anchor) pair
-    nodes = np.random.RandomState(0).choice(n, 96, replace=False)
+    # (A) the reference's algorithm, statement for statement: nx.shortest_path per (node, anchor) pair (utils.py:64-81)
+    nodes = np.random.RandomState(0).choice(n, 400, replace=False)
     try:
-        import networkx as nx  # noqa: F401
+        import networkx  # noqa: F401
         t0 = time.perf_counter()
-        g_nodes = oracle.geodesic_pairs_networkx  # builds the DiGraph as utils.py:121 does
-        t_build0 = time.perf_counter()
-        emb = g_nodes(ei, n, anchors, nodes)
-        t1 = time.perf_counter()
+        oracle.geodesic_pairs_networkx(ei, n, anchors, nodes)
+        dt = time.perf_counter() - t0
         pairs = len(nodes) * len(anchors)
         res["cpu_baseline"] = {
-            "value": pairs / (t1 - t0), "unit": "embeddings/s", "cores": 1, "kind": "port",
-            "sample": f"{len(nodes)} random nodes x {len(anchors)} anchors = {pairs} pairs of the same Flickr-shaped graph, "
-                      f"networkx per-pair bidirectional BFS as utils.py:64-81 (graph build included), {t1 - t0:.1f} s",
+            "value": pairs / dt, "unit": "embeddings/s", "cores": 1, "kind": "port",
+            "sample": f"{len(nodes)} random nodes x {len(anchors)} anchors = {pairs} pairs of the same Flickr-shaped graph: "
+                      f"networkx DiGraph build + nx.shortest_path per pair as utils.py:64-81,121 on 1 core, {dt:.1f} s "
+                      "(the reference spreads this loop over --num_workers processes, default 6)",
         }
-        del emb, t_build0
     except ImportError:
         pass
-    # (B) honest CPU: the C oracle, one BFS per anchor, single core, all 256 anchors
+    # (B) honest CPU: the C oracle, one BFS per anchor, single core, all anchors
     t0 = time.perf_counter()
     hops = oracle.geodesic_hops(ei, n, anchors)
     oracle.hops_to_embedding(hops)
-    t1 = time.perf_counter()
+    dt = time.perf_counter() - t0
     res["cpu_baseline_bfs"] = {
-        "value": n * len(anchors) / (t1 - t0), "unit": "embeddings/s", "cores": 1, "kind": "port",
-        "sample": f"full N x K = {n} x {len(anchors)}, oracle/pope_oracle.c one BFS per anchor, {t1 - t0:.2f} s",
+        "value": n * len(anchors) / dt, "unit": "embeddings/s", "cores": 1, "kind": "port",
+        "sample": f"full N x K = {n} x {len(anchors)}, oracle/pope_oracle.c one BFS per anchor over the reversed CSR, {dt:.2f} s",
     }
-    if "cpu_baseline" not in res:
-        res["cpu_baseline"] = res["cpu_baseline_bfs"]
+    res.setdefault("cpu_baseline", res["cpu_baseline_bfs"])
     return res, hops
+
+
+def sage_leg(feats, ei_np, n, dev, steps, warmup):
+    """SAGE nodes/s: fwd + bwd + Adam on pre-sampled Flickr-shaped batches over the features + POPE matrix."""
+    from graphpope_amd.sage import SAGE, sample_batch
+    from oracle import oracle
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei_np[0], minlength=n))])
+    col = ei_np[1]                                               # synthetic edge list is sorted by source
+    rng = np.random.default_rng(0)
+    batches = []
+    for b in range(8):
+        seeds = rng.choice(n, BATCH, replace=False)
+        n_id, adjs = sample_batch(rowptr, col, seeds, sizes=(25, 10), rng=rng)
+        batches.append((torch.as_tensor(n_id, device=dev), [a.to(dev) for a in adjs],
+                        torch.randint(0, 7, (BATCH,), device=dev, generator=torch.Generator(device=dev).manual_seed(b))))
+    c_in = feats.shape[1]
+    torch.manual_seed(0)
+    model = SAGE(c_in, 7, HIDDEN, 3).to(dev)                     # --num_layers 3: two convs execute, logits 256 wide
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+    def step(i):
+        n_id, adjs, y = batches[i % len(batches)]
+        x = feats.index_select(0, n_id)                          # main.py:118-123 convert_batch, on the device
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(model(x, adjs), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    shapes = [(a.n_dst, a.n_src, int(a.col.numel())) for a in batches[0][1]]
+
+    # per-kernel view of layer 0 forward: gather (HBM/L2 bound) and projection (f32 MFMA bound)
+    n_id, adjs, _ = batches[0]
+    x = feats.index_select(0, n_id)
+    conv = model.convs[0]
+    ev = [_event() for _ in range(2)]
+    with torch.no_grad():
+        for _ in range(3):
+            conv((x, x[:adjs[0].n_dst]), adjs[0])
+        ev[0].record()
+        for _ in range(10):
+            conv((x, x[:adjs[0].n_dst]), adjs[0])
+        ev[1].record()
+    torch.cuda.synchronize()
+    l0_ms = ev[0].elapsed_time(ev[1]) / 10
+    n_dst, _, nnz = shapes[0]
+    l0_flops = 2.0 * 2 * n_dst * c_in * HIDDEN
+    l0_bytes = 4.0 * (nnz * c_in + 2 * n_dst * c_in + n_dst * HIDDEN) + 4.0 * nnz + 4.0 * (n_dst + 1)
+
+    # CPU baseline: the torch restatement, one fwd + bwd of the same model shape on the host cores
+    try:
+        xc = x.cpu()
+        adj_cpu = [(a.rowptr.cpu(), a.col.cpu()) for a in adjs]
+        w = [(c.lin_l.weight.detach().cpu().requires_grad_(True), c.lin_l.bias.detach().cpu().requires_grad_(True),
+              c.lin_r.weight.detach().cpu().requires_grad_(True)) for c in model.convs[:2]]
+        t0 = time.perf_counter()
+        h = xc
+        for li, (rp, cl) in enumerate(adj_cpu):
+            h = oracle.sage_conv_torch(h, rp, cl, *w[li])
+            if li == 0:
+                h = torch.relu(h)
+        h.sum().backward()
+        cdt = time.perf_counter() - t0
+        cpu = {"value": BATCH / cdt, "unit": "seed nodes/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"1 batch fwd + bwd, torch CPU restatement (oracle.sage_conv_torch), {cdt:.2f} s"}
+    except Exception as exc:                                    # the CPU leg must never take the bench down
+        cpu = {"error": repr(exc)}
+    return {
+        "nodes_per_s": BATCH / dt, "ms_per_step": dt * 1e3, "steps": steps, "batch_seed_nodes": BATCH,
+        "model": f"SAGE {c_in}->{HIDDEN}->{HIDDEN} (num_layers 3, 2 executed), fan-out [25, 10], fp32, Adam",
+        "block_shapes_n_dst_n_src_nnz": shapes,
+        "layer0_forward_ms": l0_ms,
+        "layer0_forward_tflops": l0_flops / (l0_ms * 1e-3) / 1e12,
+        "layer0_forward_gbs": l0_bytes / (l0_ms * 1e-3) / 1e9,
+        "cpu_baseline": cpu,
+    }
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernels from the committed rocprofv3 --pmc summary, if any."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -111,6 +233,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sage", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,17 +273,18 @@ def main():
         elapsed = float(t.item())
 
     result = None
+    ms = elapsed / args.steps * 1e3
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
         result = {
-            "metric": "POPE embeddings/sec (nodes x anchors), Flickr 256 anchors",
+            "metric": "POPE embeddings/sec (nodes x anchors) + SAGE nodes/sec, Flickr 256 anchors",
             "value": n * k_total / (elapsed / args.steps), "unit": "embeddings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 bitmaps -> f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "flickr-shaped geodesic-stochastic, N=89250 E=%d F=500, %d anchors per GPU (seed 42), "
-                                   "edge_index+x resident in HBM -> [N, F+K] f32 in HBM" % (e, K_PER_GPU),
-                       "anchors_total": k_total, "parallelism": f"anchor-shard x{world} + all-gather" if world > 1 else "single GPU"},
+            "config": {"workload": "configs[1]: flickr-shaped geodesic-stochastic, N=89250 E=%d F=500, %d anchors per GPU "
+                                   "(np.random seed 42), edge_index + x resident in HBM -> [N, F+K] f32 in HBM" % (e, K_PER_GPU),
+                       "anchors_total": k_total,
+                       "parallelism": f"anchor-shard x{world} + RCCL all-gather of hop planes" if world > 1 else "single GPU"},
         }
     if world == 1:
         # per-phase device time with HIP events on the launch stream, separate from the wall-clock loop above
@@ -168,24 +292,42 @@ def main():
         for _ in range(max(10, min(args.steps, 50))):
             pope_phases(x, ei, n, anchors, timers)
         med = {p: float(np.median(timers[p])) for p in ("csr", "bfs", "finalize")}
-        fin_bytes = 4.0 * n * F + 4.0 * n * (F + K_PER_GPU) + 8.0 * n * 4 * (1 + timers["n_hop_bits"])
-        fin_gbs = fin_bytes / (med["finalize"] * 1e-3) / 1e9
-        bfs_bytes = K_PER_GPU * (4.0 * e + 4.0 * (n + 1) + 4.0 * n)     # SURVEY.md §8d per-source model
+        exp_ms, fix_ms, active_levels, hp = level_kernel_times(ei, n, anchors, reps=10)
+        wp = hp.planes.shape[2]
         result["phases_ms"] = med
         result["max_hop"] = timers["max_hop"]
-        result["roofline"] = {"kernel": "k_finalize<true>", "bound": "hbm", "achieved": fin_gbs, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": fin_gbs / HBM_PEAK_GBS, "traffic": None,
-                              "algorithmic_bytes": fin_bytes}
-        geo_gbs = bfs_bytes / ((med["bfs"] + med["finalize"]) * 1e-3) / 1e9
-        result["roofline_geodesic_per_source_model"] = {
-            "kernels": "k_bfs_expand + k_bfs_update (all levels) + k_finalize", "bound": "hbm", "achieved": geo_gbs, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": geo_gbs / HBM_PEAK_GBS, "algorithmic_bytes": bfs_bytes,
-            "note": "SURVEY 8d per-source byte model (each anchor reads the CSR once); a 64-wide bit-parallel BFS shares "
-                    "each CSR read between 64 anchors, so frac > 1 is expected and is not an HBM measurement"}
+        # dominant kernel by total time: k_bfs_expand (one launch per level).  Algorithmic bytes of ONE launch
+        # (DESIGN.md §5): per CSR slot erow + col (8 B) + the neighbour's frontier words (8W B); per node seen (read)
+        # + frontier (write) (16W B).  W = 4 words for 256 anchors.
+        exp_bytes = e * (8.0 + 8.0 * wp) + n * 16.0 * wp
+        exp_gbs = exp_bytes / (exp_ms * 1e-3) / 1e9
+        pmc = pmc_traffic() or {}
+        result["roofline"] = {
+            "kernel": "k_bfs_expand<4>", "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": exp_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_expand_hbm_bytes_per_launch"),
+            "algorithmic_bytes_per_launch": exp_bytes, "avg_launch_ms": exp_ms, "launches_per_step": active_levels,
+            "note": "working set (CSR 7.2 MB + 3 planes of 2.9 MB) is L2 / Infinity-Cache resident; the kernel is bounded by "
+                    "32-byte gathers and wave-instruction issue, not by HBM (DESIGN.md §5)"}
+        fin_bytes = 4.0 * n * F + 4.0 * n * (F + K_PER_GPU) + 8.0 * n * wp * (1 + timers["n_hop_bits"])
+        fin_gbs = fin_bytes / (med["finalize"] * 1e-3) / 1e9
+        result["roofline_finalize"] = {
+            "kernel": "k_finalize<true>", "bound": "hbm", "achieved": fin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": fin_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_finalize_hbm_bytes_per_launch"),
+            "algorithmic_bytes_per_launch": fin_bytes, "avg_launch_ms": med["finalize"]}
+        src_bytes = K_PER_GPU * (4.0 * e + 4.0 * (n + 1) + 4.0 * n)      # SURVEY.md §8d per-source model
+        geo_gbs = src_bytes / (ms * 1e-3) / 1e9
+        result["roofline_per_source_model"] = {
+            "scope": "whole step (CSR + BFS + finalise)", "bound": "hbm", "achieved": geo_gbs, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": geo_gbs / HBM_PEAK_GBS, "algorithmic_bytes": src_bytes,
+            "note": "SURVEY 8d per-source byte model (every anchor reads the CSR once and writes one f32 column); the "
+                    "bit-parallel BFS shares each CSR pass between 64 anchors per word, so this is a model, not traffic"}
+        result["level_kernels_ms"] = {"expand_avg": exp_ms, "fixup_avg": fix_ms, "active_levels": active_levels}
+        if not args.no_sage:
+            result["sage"] = sage_leg(out, ei_np, n, dev, steps=max(10, min(args.steps, 50)), warmup=3)
         if not args.no_cpu_baseline:
             base, want_hops = cpu_baselines(ei_np, n, anchors)
             result.update(base)
-            got = engine.hop_matrix(engine.bfs(engine.build_csr(ei, n), anchors)).cpu().numpy()
+            got = engine.hop_matrix(engine.geodesic_run(None, ei, n, anchors, want_out=False)[1]).cpu().numpy()
             result["hops_bit_exact_vs_cpu"] = bool(np.array_equal(got, want_hops))
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
     if rank == 0:

@@ -12,6 +12,7 @@
 //    a few N*W*8-byte planes that live in L2 / Infinity Cache; the 4*N*K-byte float matrix is written once,
 //    coalesced, by the finalise kernel straight into the [N, F+K] output (no transpose, no torch.cat).
 #include <cstring>
+#include <vector>
 
 #include <rocprim/device/device_scan.hpp>
 
@@ -544,18 +545,38 @@ extern "C" size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K) {
 
 constexpr int EAGER_PLANES = 4;      // hop-bit planes cleared up front (levels < 16); deeper ones when first needed
 
+// Optional per-launch timing of the level kernels with HIP events on the launch stream (bench.py's roofline leg).
+struct LevelProfile {
+    bool enabled = false;
+    std::vector<hipEvent_t> ev;          // 3 per level: before expand, after expand, after fixup
+    std::vector<int> level;
+};
+static LevelProfile g_profile;
+
+static void profile_mark(hipStream_t stream, int level, int which) {
+    if (!g_profile.enabled) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, stream);
+    g_profile.ev.push_back(e);
+    if (which == 0) g_profile.level.push_back(level);
+}
+
 template <int WT>
 static void launch_level(int E, int Wp, const int *rowptr, const int *col, const int *erow, const int *aux,
                          const u64 *front, u64 *seen, u64 *acc, u64 *cont, u64 *hop_planes, size_t plane_elems,
                          int level, BfsCtl *ctl, hipStream_t stream) {
     const int cap = aux_cap(E);
     dim3 grid(capped_grid((size_t)E, 256, 256u * 8u), Wp / WT);      // <= 8 blocks per CU, waves loop over chunks
+    profile_mark(stream, level, 0);
     hipLaunchKernelGGL((k_bfs_expand<WT>), grid, dim3(256), 0, stream, erow, col, E, Wp, front, seen, acc, cont,
                        hop_planes, plane_elems, level, ctl, aux);
+    profile_mark(stream, level, 1);
     int small_blocks = (cap + 255) / 256;
     if (small_blocks > 256) small_blocks = 256;
     hipLaunchKernelGGL((k_bfs_fixup<WT>), dim3(small_blocks + 64, Wp / WT), dim3(256), 0, stream, rowptr, Wp, acc, cont,
                        seen, hop_planes, plane_elems, level, ctl, aux, cap, small_blocks);
+    profile_mark(stream, level, 2);
 }
 
 // Everything one BFS needs, carved out of the caller's buffers.
@@ -662,6 +683,30 @@ static int hop_bits(int max_hop) {
     int bits = 0;
     while ((1 << bits) <= max_hop) ++bits;
     return bits;
+}
+
+extern "C" void pope_profile_levels(int32_t enable) {
+    for (hipEvent_t e : g_profile.ev) (void)hipEventDestroy(e);
+    g_profile.ev.clear();
+    g_profile.level.clear();
+    g_profile.enabled = enable != 0;
+}
+
+extern "C" int32_t pope_profile_read(int32_t *levels, float *expand_ms, float *fixup_ms, int32_t capacity) {
+    const int n = (int)g_profile.level.size();
+    int written = 0;
+    for (int i = 0; i < n && written < capacity; ++i) {
+        if ((size_t)(3 * i + 2) >= g_profile.ev.size()) break;
+        float a = 0.f, b = 0.f;
+        if (hipEventSynchronize(g_profile.ev[3 * i + 2]) != hipSuccess) break;
+        (void)hipEventElapsedTime(&a, g_profile.ev[3 * i], g_profile.ev[3 * i + 1]);
+        (void)hipEventElapsedTime(&b, g_profile.ev[3 * i + 1], g_profile.ev[3 * i + 2]);
+        levels[written] = g_profile.level[i];
+        expand_ms[written] = a;
+        fixup_ms[written] = b;
+        ++written;
+    }
+    return written;
 }
 
 extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,

@@ -792,7 +792,7 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(N > 0 && N < INT32_MAX && E >= 0 && E < INT32_MAX && K > 0 && F >= 0, "pope_geodesic_run: bad size");
     POPE_REQUIRE(plane_capacity >= 1 && plane_capacity <= 31, "pope_geodesic_run: need 1 <= plane_capacity <= 31");
-    POPE_REQUIRE(workspace && (edge_index || E == 0) && anchors_host && (out || K == 0), "pope_geodesic_run: null pointer");
+    POPE_REQUIRE(workspace && (edge_index || E == 0) && anchors_host, "pope_geodesic_run: null pointer");
     POPE_REQUIRE(!out || out_cols >= (int64_t)F + K, "pope_geodesic_run: out_cols %lld < F + K", (long long)out_cols);
     const RunLayout L = run_layout(N, E, K, plane_capacity);
     if (workspace_bytes < L.total) {

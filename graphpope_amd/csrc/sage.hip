@@ -6,20 +6,20 @@
 //
 //   k_gather_mean    neighbour gather + mean over the CSR block: one wave per destination row, 16-byte lane
 //                    accesses along the feature dimension, several neighbour rows in flight.  HBM / L2 bound.
-//   k_gemm           exact-f32 MFMA (v_mfma_f32_32x32x2_f32) tile, 128 x 256 per block, operands staged through
+//   k_gemm           exact-f32 MFMA (v_mfma_f32_32x32x2_f32) tile, 128 x 256 or 64 x 128 per block, operands staged through
 //                    LDS; C = sum_p A_p * B_p (+ bias) with p <= 2, so lin_l(agg) + lin_r(x_dst) is ONE pass
 //                    that never materialises either product.  Arbitrary strides cover NT / NN / TN shapes;
 //                    split-K (grid.z) with partial slabs + k_slab_reduce for the weight gradients
 //                    (reduction over ~40 000 rows), deterministic: no float atomics there.
 //   k_scatter_mean   grad_x[col[p]] += grad_agg[i] / deg(i) (float atomics, whole 16-byte-aligned row segments)
-//   k_colsum         grad_bias
+//   k_colsum_*       grad_bias, two deterministic stages
 #include "common.h"
 
 namespace pope {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GM = 128, GN = 256, GK = 64, GLD = GK + 1, GNT = GN / 32;
+constexpr int GK = 64, GLD = GK + 1;          // depth per LDS stage, padded leading dimension
 
 // ------------------------------------------------------------------------------------------------
 // neighbour gather + mean
@@ -85,17 +85,29 @@ __global__ __launch_bounds__(256) void k_scatter_mean(const int *__restrict__ ro
     }
 }
 
-// out[c] = sum_i g[i, c]: block per 64 columns, rows strided over 4 waves... simple two-level form.
-__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ g, int rows, int C, float *__restrict__ out) {
+// Column sums in two deterministic stages: part[s][c] = sum over row slice s, then out[c] = sum_s part[s][c].
+constexpr int COLSUM_SPLITS = 64;
+
+__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ g, int rows, int C, float *__restrict__ part) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
+    const int per = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     float s = 0.f;
     if (c < C)
-        for (int i = wave; i < rows; i += 4) s += g[(size_t)i * C + c];
+        for (int i = r0 + wave; i < r1; i += 4) s += g[(size_t)i * C + c];
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && c < C) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ part, int splits, int C, float *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += part[(size_t)z * C + c];
+    out[c] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -149,21 +161,26 @@ __device__ __forceinline__ void stage(float *__restrict__ lds, const Operand &op
     }
 }
 
-// C[M, N] = sum_{p < NP} A_p[M, K_p] * B_p[N, K_p]^T (+ bias[n]).  grid = (ceil(M/GM), ceil(N/GN), splits).
+// C[M, N] = sum_{p < 2} A_p[M, K_p] * B_p[N, K_p]^T (+ bias[n]).  grid = (ceil(M/TM), ceil(N/TN), splits).
+// 4 waves as WM x WN; a wave owns 32 rows x (TN / WN) columns = NT accumulator tiles of 32 x 32.
 // splits > 1: every z handles a slice of the depth of every product and writes its partial tile to
 // slab[z][M][N]; k_slab_reduce adds them (fixed order: deterministic).
+template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Operand A1, Operand B1, int K1, int M, int N,
                                               const float *__restrict__ bias, float *__restrict__ C, long long ldc,
                                               float *__restrict__ slab) {
+    static_assert(WM * WN == 4 && TM == WM * 32 && TN % (WN * 32) == 0, "tile shape");
+    constexpr int NT = TN / WN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *As = reinterpret_cast<float *>(smem);                   // [GM][GLD]
-    float *Bs = As + GM * GLD;                                     // [GN][GLD]
+    float *As = reinterpret_cast<float *>(smem);                   // [TM][GLD]
+    float *Bs = As + TM * GLD;                                     // [TN][GLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
+    const int wm = wave % WM, wn = wave / WM;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
     const int splits = gridDim.z, z = blockIdx.z;
-    f32x16 acc[GNT];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < GNT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
@@ -175,16 +192,16 @@ __global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Op
         const int per = ((K + splits - 1) / splits + GK - 1) / GK * GK;       // depth per split, whole LDS stages
         const int kb = z * per, ke = min(K, kb + per);
         for (int k0 = kb; k0 < ke; k0 += GK) {
-            stage<GM>(As, A, m0, M, k0, ke, tid);
-            stage<GN>(Bs, B, n0, N, k0, ke, tid);
+            stage<TM>(As, A, m0, M, k0, ke, tid);
+            stage<TN>(Bs, B, n0, N, k0, ke, tid);
             __syncthreads();
-            const float *xa = As + (wave * 32 + (lane & 31)) * GLD + (lane >> 5);
-            const float *xb = Bs + (lane & 31) * GLD + (lane >> 5);
+            const float *xa = As + (wm * 32 + (lane & 31)) * GLD + (lane >> 5);
+            const float *xb = Bs + (wn * (TN / WN) + (lane & 31)) * GLD + (lane >> 5);
 #pragma unroll 4
             for (int kk = 0; kk < GK; kk += 2) {
                 const float a = xa[kk];
 #pragma unroll
-                for (int t = 0; t < GNT; ++t)
+                for (int t = 0; t < NT; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[t * 32 * GLD + kk], acc[t], 0, 0, 0);
             }
             __syncthreads();
@@ -194,13 +211,13 @@ __global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Op
     float *dst = splits > 1 ? slab + (size_t)z * M * N : C;
     const long long ld = splits > 1 ? (long long)N : ldc;
 #pragma unroll
-    for (int t = 0; t < GNT; ++t) {
-        const int n = n0 + t * 32 + (lane & 31);
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + wn * (TN / WN) + t * 32 + (lane & 31);
         if (n >= N) continue;
         const float b = (bias && splits == 1) ? bias[n] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m < M) dst[(size_t)m * ld + n] = acc[t][r] + b;
         }
     }
@@ -215,17 +232,31 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float *__restrict__ s
     }
 }
 
-static size_t gemm_lds_bytes() { return (size_t)(GM + GN) * GLD * sizeof(float); }
-
-static int gemm(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1, int M, int N,
-                const float *bias, float *C, long long ldc, int splits, float *slab, hipStream_t stream) {
+template <int TM, int TN, int WM, int WN>
+static int launch_gemm(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1, int M,
+                       int N, const float *bias, float *C, long long ldc, int splits, float *slab, hipStream_t stream) {
+    const size_t lds = (size_t)(TM + TN) * GLD * sizeof(float);
     static bool opt_in = false;
     if (!opt_in) {
-        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes()));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm<TM, TN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         opt_in = true;
     }
-    dim3 grid((M + GM - 1) / GM, (N + GN - 1) / GN, splits);
-    hipLaunchKernelGGL(k_gemm, grid, dim3(256), gemm_lds_bytes(), stream, A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, slab);
+    dim3 grid((M + TM - 1) / TM, (N + TN - 1) / TN, splits);
+    hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN>), grid, dim3(256), lds, stream, A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, slab);
+    return POPE_OK;
+}
+
+static long long big_tile_blocks(int M, int N) { return (long long)((M + 127) / 128) * ((N + 255) / 256); }
+
+// Tile choice: 128 x 256 per block when that already gives every CU a block, else 64 x 128 (4x the blocks, 3 per CU).
+static int gemm(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1, int M, int N,
+                const float *bias, float *C, long long ldc, int splits, float *slab, hipStream_t stream) {
+    int rc;
+    if (big_tile_blocks(M, N) * splits >= 256)
+        rc = launch_gemm<128, 256, 4, 1>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, stream);
+    else
+        rc = launch_gemm<64, 128, 2, 2>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, stream);
+    if (rc) return rc;
     if (splits > 1)
         hipLaunchKernelGGL(k_slab_reduce, dim3(capped_grid((size_t)M * N, 256)), dim3(256), 0, stream, slab, splits,
                            (size_t)M * N, N, C, ldc);
@@ -233,11 +264,11 @@ static int gemm(const Operand &A0, const Operand &B0, int K0, const Operand &A1,
     return POPE_OK;
 }
 
-// split the reduction over rows so that the grid has a few hundred blocks
+// Weight gradients reduce over the n_dst rows: split that depth so the 64 x 128 tiles give ~400 blocks.
 static int weight_grad_splits(int64_t n_dst, int c_in, int c_out) {
-    const int tiles = ((c_out + GM - 1) / GM) * ((c_in + GN - 1) / GN);
-    int s = (512 + tiles - 1) / tiles;
-    const int max_s = (int)((n_dst + GK - 1) / GK);
+    const int tiles = ((c_out + 63) / 64) * ((c_in + 127) / 128);
+    int s = (400 + tiles - 1) / tiles;
+    const int max_s = (int)((n_dst + 4 * GK - 1) / (4 * GK));       // at least four LDS stages of depth per block
     if (s > max_s) s = max_s;
     return s < 1 ? 1 : s;
 }
@@ -253,7 +284,9 @@ extern "C" size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t 
     if (n_dst <= 0 || c_in <= 0 || c_out <= 0) return 0;
     // backward: grad_agg [n_dst, c_in] | split-K slabs for one weight gradient at a time
     const size_t gagg = align_up((size_t)n_dst * c_in * sizeof(float), 256);
-    const size_t slabs = align_up((size_t)weight_grad_splits(n_dst, c_in, c_out) * c_out * c_in * sizeof(float), 256);
+    size_t slabs = (size_t)weight_grad_splits(n_dst, c_in, c_out) * c_out * c_in * sizeof(float);
+    if (slabs < (size_t)COLSUM_SPLITS * c_out * sizeof(float)) slabs = (size_t)COLSUM_SPLITS * c_out * sizeof(float);
+    slabs = align_up(slabs, 256);
     return gagg + slabs;
 }
 
@@ -298,8 +331,10 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
     const Operand AggT{agg, 1, c_in}, XdT{x_src, 1, c_in};      // (outer c, depth i)
     if ((rc = gemm(Gt, AggT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_l, c_in, splits, slab, stream))) return rc;
     if ((rc = gemm(Gt, XdT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_r, c_in, splits, slab, stream))) return rc;
-    if (grad_b_l)
-        hipLaunchKernelGGL(k_colsum, dim3((c_out + 63) / 64), dim3(256), 0, stream, grad_out, (int)n_dst, c_out, grad_b_l);
+    if (grad_b_l) {                                             // the slab region is free again: stream order
+        hipLaunchKernelGGL(k_colsum_partial, dim3((c_out + 63) / 64, COLSUM_SPLITS), dim3(256), 0, stream, grad_out, (int)n_dst, c_out, slab);
+        hipLaunchKernelGGL(k_colsum_final, dim3((c_out + 255) / 256), dim3(256), 0, stream, slab, COLSUM_SPLITS, c_out, grad_b_l);
+    }
     if (grad_x) {
         // grad_x[:n_dst] = grad_out * w_r ; rows >= n_dst start at zero; then scatter grad_agg = grad_out * w_l
         POPE_HIP(hipMemsetAsync(grad_x + (size_t)n_dst * c_in, 0, (size_t)(n_src - n_dst) * c_in * sizeof(float), stream));

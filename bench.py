@@ -105,7 +105,7 @@ def cpu_baselines(ei, n, anchors):
     from oracle import oracle
     res = {}
     # (A) the reference's algorithm, statement for statement: nx.shortest_path per (node, anchor) pair (utils.py:64-81)
-    nodes = np.random.RandomState(0).choice(n, 400, replace=False)
+    nodes = np.random.RandomState(0).choice(n, 1200, replace=False)
     try:
         import networkx  # noqa: F401
         t0 = time.perf_counter()

@@ -25,6 +25,8 @@ namespace pope {
 // ------------------------------------------------------------------------------------------------
 enum { CSR_FLAG_BAD_INDEX = 1, CSR_FLAG_UNSORTED = 2 };
 enum { AUX_N_MROWS = 0, AUX_N_HUBS = 1, AUX_FLAGS = 2, AUX_HEADER = 16 };
+constexpr int SLOTS = 4;                      // CSR slots per lane in the BFS expand kernel
+constexpr int CHUNK_SHIFT = 8, CHUNK = 1 << CHUNK_SHIFT;   // slots per wave pass = 64 lanes x SLOTS
 constexpr int SMALL_SPAN = 4;      // rows with <= 4 continuation chunks are fixed up by one thread, longer ones by a wave
 
 // Fast path, speculative: PyG stores edge_index grouped by source (coalesced), so slot e of the CSR is edge e
@@ -73,12 +75,12 @@ __global__ __launch_bounds__(256) void k_csr_scatter(const long long *__restrict
     }
 }
 
-// The BFS walks the CSR in chunks of 64 slots.  Rows that span several chunks need their pieces combined:
+// The BFS walks the CSR in chunks of CHUNK = 256 slots.  Rows that span several chunks need their pieces combined:
 // list them once per graph (a row is listed by its first continuation chunk).  aux = header | mrows | hubs.
 __global__ __launch_bounds__(256) void k_csr_lists(const int *__restrict__ rowptr, const int *__restrict__ erow,
                                                    int E, int *aux, int cap) {
     if (aux[AUX_FLAGS]) return;                                   // speculative CSR was rejected: arrays are garbage
-    const int nchunks = (E + 63) >> 6;
+    const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
     int *mrows = aux + AUX_HEADER, *hubs = aux + AUX_HEADER + cap;
     const int lane = threadIdx.x & 63;
     // wave-uniform trip count; appends are aggregated per wave (one same-address atomic costs tens of ns)
@@ -86,9 +88,9 @@ __global__ __launch_bounds__(256) void k_csr_lists(const int *__restrict__ rowpt
         const int c = base + threadIdx.x;
         int v = -1, span = 0;
         if (c < nchunks) {
-            v = erow[c * 64];
-            if (erow[c * 64 - 1] == v && (rowptr[v] >> 6) == c - 1)
-                span = ((rowptr[v + 1] - 1) >> 6) - (c - 1);        // number of continuation chunks of row v
+            v = erow[c * CHUNK];
+            if (erow[c * CHUNK - 1] == v && (rowptr[v] >> CHUNK_SHIFT) == c - 1)
+                span = ((rowptr[v + 1] - 1) >> CHUNK_SHIFT) - (c - 1);        // number of continuation chunks of row v
         }
         const bool small = span > 0 && span <= SMALL_SPAN, hub = span > SMALL_SPAN;
         const u64 ms = __ballot(small), mh = __ballot(hub);
@@ -152,6 +154,20 @@ __global__ void k_bfs_seed(const long long *__restrict__ anchors, int K, int Wp,
     atomicOr(&front[idx], bit);
 }
 
+#ifdef POPE_STAMP
+// Diagnostic build only (make stamp): per-wave phase timestamps of k_bfs_expand in 100 MHz real-time ticks.
+__device__ unsigned long long g_stamps[16384 * 8];
+__device__ int g_stamp_level;
+#define STAMP(slot)                                                                         \
+    do {                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if (lane == 0 && wave < 16384 && level == g_stamp_level) g_stamps[wave * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 template <int WT> struct Words { u64 w[WT]; };
 
 template <int WT>
@@ -189,6 +205,8 @@ __device__ __forceinline__ u64 any_bits(const Words<WT> &r) {
 }
 
 // Newly reached anchors of node slot idx at `level`: reachability plane and hop-bit planes (bit-sliced count).
+// All plane loads are issued before the first store, so the read-modify-writes cost ONE memory round trip
+// instead of one per set bit of the level.
 template <int WT>
 __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words<WT> &seen_old, size_t idx,
                                              u64 *__restrict__ seen, u64 *__restrict__ hop_planes,
@@ -197,21 +215,37 @@ __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words
 #pragma unroll
     for (int i = 0; i < WT; ++i) s.w[i] = seen_old.w[i] | fresh.w[i];
     store_words<WT>(seen + idx, s);
-    for (int b = 0, l = level; l; ++b, l >>= 1)
+    Words<WT> h[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        h[b] = fresh;
+        if ((level >> b) & 1) h[b] = load_words<WT>(hop_planes + (size_t)b * plane_elems + idx);
+    }
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+        if ((level >> b) & 1) {
+#pragma unroll
+            for (int i = 0; i < WT; ++i) h[b].w[i] |= fresh.w[i];
+            store_words<WT>(hop_planes + (size_t)b * plane_elems + idx, h[b]);
+        }
+    for (int b = 5, l = level >> 5; l; ++b, l >>= 1)              // levels >= 32: rare, one at a time
         if (l & 1) {
             u64 *p = hop_planes + (size_t)b * plane_elems + idx;
-            Words<WT> h = load_words<WT>(p);
+            Words<WT> g = load_words<WT>(p);
 #pragma unroll
-            for (int i = 0; i < WT; ++i) h.w[i] |= fresh.w[i];
-            store_words<WT>(p, h);
+            for (int i = 0; i < WT; ++i) g.w[i] |= fresh.w[i];
+            store_words<WT>(p, g);
         }
 }
 
-// One BFS level, phase 1 ("expand"), bottom-up and EDGE-parallel: lane = one CSR slot e = (v -> u).
+// One BFS level, phase 1 ("expand"), bottom-up and EDGE-parallel: a lane owns SLOTS = 4 consecutive CSR slots
+// e = (v -> u), a wave pass covers a chunk of 256 slots.
 //   cand = front[u] & ~seen[v]           anchors that reach v through u and had not reached v before
-// Slots are sorted by v, so a row is a run of consecutive lanes: a segmented OR-scan over the wave
-// combines each run.  Work per wave is 64 edges whatever the degree distribution (no long rows, no
-// dependent pointer chase: erow/col are coalesced streams), and there are NO atomics:
+// Slots are sorted by v, so a row is a run of consecutive slots.  Runs are combined in two steps: serially
+// inside the lane, then ONE 6-step segmented OR-scan across the 64 lanes on each lane's last run (a lane whose
+// four slots share one row is "transparent" and passes the carry on).  Work per wave is 256 edges whatever the
+// degree distribution (no long rows, no dependent pointer chase: erow/col are coalesced 16-byte streams), and
+// there are NO atomics:
 //   * a row that lies inside this chunk is complete: its words are stored to acc[v] (the next frontier)
 //     and committed (seen, hop planes) right here -- only this wave ever touches row v's state;
 //   * a row that runs on into the next chunk stores its "owner piece" to acc[v] and commits nothing;
@@ -229,56 +263,143 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const int *__restrict__ erow
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int nchunks = (E + 63) >> 6;
+    const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
     const int woff = blockIdx.y * WT;
     bool found = false;
+    STAMP(0);
     for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
-        const int e = chunk * 64 + lane;
-        const bool valid = e < E;
-        int v = -1, u = 0;
-        if (valid) {
-            v = erow[e];
-            u = col[e];
+        const int base = chunk * CHUNK + lane * SLOTS;
+        int v0 = -1, v1 = -1, v2 = -1, v3 = -1, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+        if (base < E) {                       // arrays are padded to a multiple of 4 entries: the 16-byte load is in bounds
+            const int4 vr = *reinterpret_cast<const int4 *>(erow + base);
+            const int4 ur = *reinterpret_cast<const int4 *>(col + base);
+            v0 = vr.x; u0 = ur.x;
+            if (base + 1 < E) { v1 = vr.y; u1 = ur.y; }
+            if (base + 2 < E) { v2 = vr.z; u2 = ur.z; }
+            if (base + 3 < E) { v3 = vr.w; u3 = ur.w; }
         }
-        const int v0 = __shfl(v, 0);                                       // row of the chunk's first slot
-        const bool head_continues = chunk > 0 && erow[chunk * 64 - 1] == v0;
-        const int next_v0 = (chunk + 1) * 64 < E ? erow[(chunk + 1) * 64] : -2;   // row of the next chunk's first slot
-        Words<WT> c, s;
+        const int vc = __shfl(v0, 0);                                                  // row of the chunk's first slot
+        STAMP(1);
+        const bool head_continues = chunk > 0 && erow[chunk * CHUNK - 1] == vc;
+        const int next_vc = (chunk + 1) * CHUNK < E ? erow[(chunk + 1) * CHUNK] : -2;  // row of the next chunk's first slot
+
+        Words<WT> c0, c1, c2, c3, s0, s1, s2, s3;
 #pragma unroll
-        for (int i = 0; i < WT; ++i) c.w[i] = s.w[i] = 0;
-        if (valid) {
-            const Words<WT> f = load_words<WT>(front + (size_t)u * Wp + woff);
-            s = load_words<WT>(seen + (size_t)v * Wp + woff);
-#pragma unroll
-            for (int i = 0; i < WT; ++i) c.w[i] = f.w[i] & ~s.w[i];
+        for (int i = 0; i < WT; ++i) c0.w[i] = c1.w[i] = c2.w[i] = c3.w[i] = s0.w[i] = s1.w[i] = s2.w[i] = s3.w[i] = 0;
+        if (v0 >= 0) {
+            c0 = load_words<WT>(front + (size_t)u0 * Wp + woff);
+            s0 = load_words<WT>(seen + (size_t)v0 * Wp + woff);
         }
-        if (__any(any_bits<WT>(c) != 0)) {                                // else: nothing new through these 64 edges
+        if (v1 >= 0) c1 = load_words<WT>(front + (size_t)u1 * Wp + woff);
+        if (v2 >= 0) c2 = load_words<WT>(front + (size_t)u2 * Wp + woff);
+        if (v3 >= 0) {
+            c3 = load_words<WT>(front + (size_t)u3 * Wp + woff);
+            s3 = v3 == v0 ? s0 : load_words<WT>(seen + (size_t)v3 * Wp + woff);
+        }
+        if (v1 >= 0) s1 = v1 == v0 ? s0 : (v1 == v3 ? s3 : load_words<WT>(seen + (size_t)v1 * Wp + woff));
+        if (v2 >= 0) s2 = v2 == v1 ? s1 : (v2 == v3 ? s3 : load_words<WT>(seen + (size_t)v2 * Wp + woff));
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {                             // segmented inclusive OR-scan keyed by v
-                const int pv = __shfl_up(v, d);
-                const bool take = lane >= d && pv == v;
+        for (int i = 0; i < WT; ++i) {
+            c0.w[i] &= ~s0.w[i];
+            c1.w[i] &= ~s1.w[i];
+            c2.w[i] &= ~s2.w[i];
+            c3.w[i] &= ~s3.w[i];
+        }
+        const u64 any = any_bits<WT>(c0) | any_bits<WT>(c1) | any_bits<WT>(c2) | any_bits<WT>(c3);
+        STAMP(2);
+        if (__any(any != 0)) {                                         // else: nothing new through these 256 edges
+            // inclusive OR along the lane's own slots, restarting where the row changes
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                if (v1 == v0) c1.w[i] |= c0.w[i];
+                if (v2 == v1) c2.w[i] |= c1.w[i];
+                if (v3 == v2) c3.w[i] |= c2.w[i];
+            }
+            // across lanes: segmented scan over each lane's LAST run (row v3); a lane starts a new segment unless all
+            // its slots share one row and that row is also the previous lane's last row
+            const int pv3 = __shfl_up(v3, 1);
+            const bool connects = lane > 0 && pv3 == v0 && v0 >= 0;
+            Words<WT> t = c3;
+            bool head = !(connects && v0 == v3);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const bool ph = __shfl_up((int)head, d) != 0;
+                const bool take = lane >= d && !head;
 #pragma unroll
                 for (int i = 0; i < WT; ++i) {
-                    const u64 pc = __shfl_up(c.w[i], d);
-                    if (take) c.w[i] |= pc;
+                    const u64 pt = __shfl_up(t.w[i], d);
+                    if (take) t.w[i] |= pt;
                 }
+                if (take) head = ph;
+            }
+            // carry into this lane's first run = accumulated value of the previous lane's last run
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                u64 ci = __shfl_up(t.w[i], 1);
+                if (!connects) ci = 0;
+                c0.w[i] |= ci;
+                if (v1 == v0) c1.w[i] |= ci;
+                if (v2 == v0) c2.w[i] |= ci;
+                if (v3 == v0) c3.w[i] |= ci;
             }
         }
-        const int nv = __shfl_down(v, 1);
-        if (valid && (lane == 63 || nv != v)) {                            // last lane of its run: holds the run's OR
-            const size_t idx = (size_t)v * Wp + woff;
-            if (head_continues && v == v0) {
-                store_words<WT>(cont + (size_t)chunk * Wp + woff, c);      // continuation piece of a row begun earlier
-            } else {
-                store_words<WT>(acc + idx, c);
-                const bool runs_on = lane == 63 && next_v0 == v;           // the row continues in the next chunk
-                if (!runs_on && any_bits<WT>(c)) {
-                    commit_words<WT>(c, s, idx, seen, hop_planes, plane_elems, level);
-                    found = true;
+        STAMP(3);
+        // Emit every run that ends in this lane (the slot after it belongs to another row).  Phase A stores the
+        // frontier words (no dependencies); phase B commits complete rows, all four slots side by side per hop
+        // bit so that their plane read-modify-writes overlap instead of forming a chain of round trips.
+        const int nv0 = __shfl_down(v0, 1);
+        const int after3 = lane == 63 ? -3 : nv0;                       // the run of lane 63's last slot ends this chunk's pass
+        const bool runs_on = lane == 63 && next_vc == v3;               // ... but its row continues in the next chunk
+        const size_t i0 = (size_t)v0 * Wp + woff, i1 = (size_t)v1 * Wp + woff, i2 = (size_t)v2 * Wp + woff,
+                     i3 = (size_t)v3 * Wp + woff;
+        u64 *cont_c = cont + (size_t)chunk * Wp + woff;
+        const bool e0 = v0 >= 0 && v0 != v1, e1 = v1 >= 0 && v1 != v2, e2 = v2 >= 0 && v2 != v3, e3 = v3 >= 0 && v3 != after3;
+        const bool k0 = head_continues && v0 == vc, k1 = head_continues && v1 == vc, k2 = head_continues && v2 == vc,
+                   k3 = head_continues && v3 == vc;                     // continuation piece of a row begun earlier
+        if (e0) store_words<WT>(k0 ? cont_c : acc + i0, c0);
+        if (e1) store_words<WT>(k1 ? cont_c : acc + i1, c1);
+        if (e2) store_words<WT>(k2 ? cont_c : acc + i2, c2);
+        if (e3) store_words<WT>(k3 ? cont_c : acc + i3, c3);
+        STAMP(4);
+        const bool m0 = e0 && !k0 && any_bits<WT>(c0) != 0, m1 = e1 && !k1 && any_bits<WT>(c1) != 0,
+                   m2 = e2 && !k2 && any_bits<WT>(c2) != 0, m3 = e3 && !k3 && !runs_on && any_bits<WT>(c3) != 0;
+        if (__any(m0 || m1 || m2 || m3)) {
+            found |= m0 || m1 || m2 || m3;
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                s0.w[i] |= c0.w[i];
+                s1.w[i] |= c1.w[i];
+                s2.w[i] |= c2.w[i];
+                s3.w[i] |= c3.w[i];
+            }
+            if (m0) store_words<WT>(seen + i0, s0);
+            if (m1) store_words<WT>(seen + i1, s1);
+            if (m2) store_words<WT>(seen + i2, s2);
+            if (m3) store_words<WT>(seen + i3, s3);
+            for (int b = 0, l = level; l; ++b, l >>= 1) {
+                if (!(l & 1)) continue;
+                u64 *p = hop_planes + (size_t)b * plane_elems;
+                Words<WT> h0 = c0, h1 = c1, h2 = c2, h3 = c3;
+                if (m0) h0 = load_words<WT>(p + i0);
+                if (m1) h1 = load_words<WT>(p + i1);
+                if (m2) h2 = load_words<WT>(p + i2);
+                if (m3) h3 = load_words<WT>(p + i3);
+#pragma unroll
+                for (int i = 0; i < WT; ++i) {
+                    h0.w[i] |= c0.w[i];
+                    h1.w[i] |= c1.w[i];
+                    h2.w[i] |= c2.w[i];
+                    h3.w[i] |= c3.w[i];
                 }
+                if (m0) store_words<WT>(p + i0, h0);
+                if (m1) store_words<WT>(p + i1, h1);
+                if (m2) store_words<WT>(p + i2, h2);
+                if (m3) store_words<WT>(p + i3, h3);
             }
         }
+        STAMP(5);
     }
+    STAMP(6);
     if (__any(found) && lane == 0) raise_level(ctl, level);
 }
 
@@ -300,7 +421,7 @@ __global__ __launch_bounds__(256) void k_bfs_fixup(const int *__restrict__ rowpt
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += small_blocks * blockDim.x) {
             const int v = mrows[i];
             const size_t idx = (size_t)v * Wp + woff;
-            const int c0 = rowptr[v] >> 6, c1 = (rowptr[v + 1] - 1) >> 6;
+            const int c0 = rowptr[v] >> CHUNK_SHIFT, c1 = (rowptr[v + 1] - 1) >> CHUNK_SHIFT;
             Words<WT> own = load_words<WT>(acc + idx), fresh = own;
 #pragma unroll
             for (int k = 1; k <= SMALL_SPAN; ++k)
@@ -326,7 +447,7 @@ __global__ __launch_bounds__(256) void k_bfs_fixup(const int *__restrict__ rowpt
         for (int i = wave; i < n; i += nwaves) {
             const int v = hubs[i];
             const size_t idx = (size_t)v * Wp + woff;
-            const int c0 = rowptr[v] >> 6, c1 = (rowptr[v + 1] - 1) >> 6;
+            const int c0 = rowptr[v] >> CHUNK_SHIFT, c1 = (rowptr[v + 1] - 1) >> CHUNK_SHIFT;
             Words<WT> fresh;
 #pragma unroll
             for (int j = 0; j < WT; ++j) fresh.w[j] = 0;
@@ -468,7 +589,7 @@ using namespace pope;
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-static int aux_cap(int64_t E) { return (int)((E + 63) / 64) + 1; }
+static int aux_cap(int64_t E) { return (int)((E + CHUNK - 1) / CHUNK) + 1; }
 
 extern "C" size_t pope_csr_aux_elems(int64_t E) { return E < 0 ? 0 : (size_t)AUX_HEADER + 2 * (size_t)aux_cap(E); }
 
@@ -684,6 +805,15 @@ static int hop_bits(int max_hop) {
     while ((1 << bits) <= max_hop) ++bits;
     return bits;
 }
+
+#ifdef POPE_STAMP
+extern "C" int pope_debug_set_stamp_level(int level) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_level), &level, sizeof(int));
+}
+extern "C" int pope_debug_read_stamps(unsigned long long *host, int count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)count * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" void pope_profile_levels(int32_t enable) {
     for (hipEvent_t e : g_profile.ev) (void)hipEventDestroy(e);

@@ -60,8 +60,9 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int, defer_check: bool = Fals
     dev = ei.device
     with torch.cuda.device(dev):
         rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
-        col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
-        erow = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+        padded = (max(e, 1) + 63) // 64 * 64                      # the BFS kernel reads col / erow 16 bytes at a time
+        col = torch.empty(padded, dtype=torch.int32, device=dev)
+        erow = torch.empty(padded, dtype=torch.int32, device=dev)
         aux = torch.empty(lib.pope_csr_aux_elems(e), dtype=torch.int32, device=dev)
         scratch = _bytes(lib.pope_csr_scratch_bytes(num_nodes, e), dev)
         check(lib.pope_csr_build(ptr(ei), e, num_nodes, ptr(rowptr), ptr(col), ptr(erow), ptr(aux), ptr(scratch),

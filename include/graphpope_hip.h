@@ -64,11 +64,11 @@ size_t pope_csr_aux_elems(int64_t E);          /* int32 elements of `aux` below 
  * edge_index: int64 [2, E] row-major on the device, PyG convention: edge e is
  * edge_index[e] -> edge_index[E + e].  Self-loops and repeated edges are allowed and kept.
  * Written (all caller-allocated, int32):
- *   rowptr [N + 1], col [max(E, 1)], erow [max(E, 1)]: CSR slot p holds the edge erow[p] -> col[p], slots sorted
+ *   rowptr [N + 1], col [E rounded up to a multiple of 4, >= 4], erow [same]: CSR slot p holds the edge erow[p] -> col[p], slots sorted
  *       by erow (erow is the row id of every slot: the edge-parallel BFS kernel streams erow/col instead of
  *       chasing rowptr).  Column order inside a row is unspecified unless edge_index is already sorted by source
  *       (PyG's coalesced order; then it is preserved and no atomics are used).
- *   aux [pope_csr_aux_elems(E)]: header (counts, status flags) + the rows that span several 64-slot chunks.
+ *   aux [pope_csr_aux_elems(E)]: header (counts, status flags) + the rows that span several 256-slot chunks.
  * defer_check = 0: synchronises `stream` once; returns POPE_ERR_INDEX for an id outside [0, N) and falls back
  *   to a counting sort when edge_index is not sorted by source.
  * defer_check = 1: fully asynchronous; only the sorted fast path is attempted and its verdict stays in aux:

@@ -91,13 +91,11 @@ def level_kernel_times(ei, n, anchors, reps):
     cap = 4096
     lv = (ctypes.c_int32 * cap)()
     ex = (ctypes.c_float * cap)()
-    fx = (ctypes.c_float * cap)()
-    cnt = lib.pope_profile_read(lv, ex, fx, cap)
+    cnt = lib.pope_profile_read(lv, ex, cap)
     lib.pope_profile_levels(0)
     active = hp.max_hop + 1                     # levels 1 .. max_hop reach something, level max_hop + 1 proves the end
     exp = [ex[i] for i in range(cnt) if lv[i] <= active]
-    fix = [fx[i] for i in range(cnt) if lv[i] <= active]
-    return float(np.mean(exp)), float(np.mean(fix)), active, hp
+    return float(np.mean(exp)), active, hp
 
 
 def cpu_baselines(ei, n, anchors):
@@ -292,19 +290,19 @@ def main():
         for _ in range(max(10, min(args.steps, 50))):
             pope_phases(x, ei, n, anchors, timers)
         med = {p: float(np.median(timers[p])) for p in ("csr", "bfs", "finalize")}
-        exp_ms, fix_ms, active_levels, hp = level_kernel_times(ei, n, anchors, reps=10)
+        exp_ms, active_levels, hp = level_kernel_times(ei, n, anchors, reps=10)
         wp = hp.planes.shape[2]
         result["phases_ms"] = med
         result["max_hop"] = timers["max_hop"]
-        # dominant kernel by total time: k_bfs_expand (one launch per level).  Algorithmic bytes of ONE launch
+        # dominant kernel by total time: k_bfs_level (one launch per level).  Algorithmic bytes of ONE launch
         # (DESIGN.md §5): per CSR slot erow + col (8 B) + the neighbour's frontier words (8W B); per node seen (read)
         # + frontier (write) (16W B).  W = 4 words for 256 anchors.
         exp_bytes = e * (8.0 + 8.0 * wp) + n * 16.0 * wp
         exp_gbs = exp_bytes / (exp_ms * 1e-3) / 1e9
         pmc = pmc_traffic() or {}
         result["roofline"] = {
-            "kernel": "k_bfs_expand<4>", "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": exp_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_expand_hbm_bytes_per_launch"),
+            "kernel": "k_bfs_level<4>", "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": exp_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch"),
             "algorithmic_bytes_per_launch": exp_bytes, "avg_launch_ms": exp_ms, "launches_per_step": active_levels,
             "note": "working set (CSR 7.2 MB + 3 planes of 2.9 MB) is L2 / Infinity-Cache resident; the kernel is bounded by "
                     "32-byte gathers and wave-instruction issue, not by HBM (DESIGN.md §5)"}
@@ -321,7 +319,7 @@ def main():
             "unit": "GB/s", "frac": geo_gbs / HBM_PEAK_GBS, "algorithmic_bytes": src_bytes,
             "note": "SURVEY 8d per-source byte model (every anchor reads the CSR once and writes one f32 column); the "
                     "bit-parallel BFS shares each CSR pass between 64 anchors per word, so this is a model, not traffic"}
-        result["level_kernels_ms"] = {"expand_avg": exp_ms, "fixup_avg": fix_ms, "active_levels": active_levels}
+        result["level_kernel_ms"] = {"avg": exp_ms, "active_levels": active_levels}
         if not args.no_sage:
             result["sage"] = sage_leg(out, ei_np, n, dev, steps=max(10, min(args.steps, 50)), warmup=3)
         if not args.no_cpu_baseline:

@@ -24,10 +24,9 @@ namespace pope {
 // CSR build
 // ------------------------------------------------------------------------------------------------
 enum { CSR_FLAG_BAD_INDEX = 1, CSR_FLAG_UNSORTED = 2 };
-enum { AUX_N_MROWS = 0, AUX_N_HUBS = 1, AUX_FLAGS = 2, AUX_HEADER = 16 };
+enum { AUX_N_MROWS = 0, AUX_FLAGS = 2, AUX_HEADER = 16 };
 constexpr int SLOTS = 4;                      // CSR slots per lane in the BFS expand kernel
 constexpr int CHUNK_SHIFT = 8, CHUNK = 1 << CHUNK_SHIFT;   // slots per wave pass = 64 lanes x SLOTS
-constexpr int SMALL_SPAN = 4;      // rows with <= 4 continuation chunks are fixed up by one thread, longer ones by a wave
 
 // Fast path, speculative: PyG stores edge_index grouped by source (coalesced), so slot e of the CSR is edge e
 // and rowptr is where the source changes.  One streaming pass, no atomics, no scan.  If a pair is out of
@@ -75,35 +74,30 @@ __global__ __launch_bounds__(256) void k_csr_scatter(const long long *__restrict
     }
 }
 
-// The BFS walks the CSR in chunks of CHUNK = 256 slots.  Rows that span several chunks need their pieces combined:
-// list them once per graph (a row is listed by its first continuation chunk).  aux = header | mrows | hubs.
+// The BFS walks the CSR in chunks of CHUNK = 256 slots.  Rows that span several chunks are accumulated with
+// atomics and committed one level late (k_bfs_level): list them once per graph (a row is listed by its first
+// continuation chunk).  aux = header | mrows.
 __global__ __launch_bounds__(256) void k_csr_lists(const int *__restrict__ rowptr, const int *__restrict__ erow,
                                                    int E, int *aux, int cap) {
     if (aux[AUX_FLAGS]) return;                                   // speculative CSR was rejected: arrays are garbage
+    (void)cap;
     const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
-    int *mrows = aux + AUX_HEADER, *hubs = aux + AUX_HEADER + cap;
+    int *mrows = aux + AUX_HEADER;
     const int lane = threadIdx.x & 63;
     // wave-uniform trip count; appends are aggregated per wave (one same-address atomic costs tens of ns)
     for (int base = blockIdx.x * blockDim.x + 1; base < nchunks; base += gridDim.x * blockDim.x) {
         const int c = base + threadIdx.x;
-        int v = -1, span = 0;
+        int v = -1;
+        bool first_continuation = false;
         if (c < nchunks) {
             v = erow[c * CHUNK];
-            if (erow[c * CHUNK - 1] == v && (rowptr[v] >> CHUNK_SHIFT) == c - 1)
-                span = ((rowptr[v + 1] - 1) >> CHUNK_SHIFT) - (c - 1);        // number of continuation chunks of row v
+            first_continuation = erow[c * CHUNK - 1] == v && (rowptr[v] >> CHUNK_SHIFT) == c - 1;
         }
-        const bool small = span > 0 && span <= SMALL_SPAN, hub = span > SMALL_SPAN;
-        const u64 ms = __ballot(small), mh = __ballot(hub);
-        const u64 below = (1ull << lane) - 1ull;
-        int bs = 0, bh = 0;
-        if (lane == 0) {
-            if (ms) bs = atomicAdd(&aux[AUX_N_MROWS], __popcll(ms));
-            if (mh) bh = atomicAdd(&aux[AUX_N_HUBS], __popcll(mh));
-        }
-        bs = __shfl(bs, 0);
-        bh = __shfl(bh, 0);
-        if (small) mrows[bs + __popcll(ms & below)] = v;
-        if (hub) hubs[bh + __popcll(mh & below)] = v;
+        const u64 m = __ballot(first_continuation);
+        int pos = 0;
+        if (lane == 0 && m) pos = atomicAdd(&aux[AUX_N_MROWS], __popcll(m));
+        pos = __shfl(pos, 0);
+        if (first_continuation) mrows[pos + __popcll(m & ((1ull << lane) - 1ull))] = v;
     }
 }
 
@@ -155,7 +149,7 @@ __global__ void k_bfs_seed(const long long *__restrict__ anchors, int K, int Wp,
 }
 
 #ifdef POPE_STAMP
-// Diagnostic build only (make stamp): per-wave phase timestamps of k_bfs_expand in 100 MHz real-time ticks.
+// Diagnostic build only (make stamp): per-wave phase timestamps of k_bfs_level in 100 MHz real-time ticks.
 __device__ unsigned long long g_stamps[16384 * 8];
 __device__ int g_stamp_level;
 #define STAMP(slot)                                                                         \
@@ -238,33 +232,57 @@ __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words
         }
 }
 
-// One BFS level, phase 1 ("expand"), bottom-up and EDGE-parallel: a lane owns SLOTS = 4 consecutive CSR slots
-// e = (v -> u), a wave pass covers a chunk of 256 slots.
+// One BFS level, bottom-up and EDGE-parallel: a lane owns SLOTS = 4 consecutive CSR slots e = (v -> u), a wave
+// pass covers a chunk of 256 slots.
 //   cand = front[u] & ~seen[v]           anchors that reach v through u and had not reached v before
 // Slots are sorted by v, so a row is a run of consecutive slots.  Runs are combined in two steps: serially
 // inside the lane, then ONE 6-step segmented OR-scan across the 64 lanes on each lane's last run (a lane whose
 // four slots share one row is "transparent" and passes the carry on).  Work per wave is 256 edges whatever the
-// degree distribution (no long rows, no dependent pointer chase: erow/col are coalesced 16-byte streams), and
-// there are NO atomics:
-//   * a row that lies inside this chunk is complete: its words are stored to acc[v] (the next frontier)
-//     and committed (seen, hop planes) right here -- only this wave ever touches row v's state;
-//   * a row that runs on into the next chunk stores its "owner piece" to acc[v] and commits nothing;
-//   * a run that continues a row begun in an earlier chunk is a "continuation piece" (at most one per
-//     chunk: its first run), stored to cont[chunk]; k_bfs_fixup combines the pieces of those rows.
-// acc[v] is stored for every row with edges (zeros included), so it needs no clearing between levels.
+// degree distribution (no long rows, no dependent pointer chase: erow/col are coalesced 16-byte streams).
+//   * A row that lies inside this chunk is complete: its words are stored to acc[v] (the next frontier, zeros
+//     included, so acc needs no clearing) and committed (seen, hop planes) right here -- only this wave ever
+//     touches row v's state.
+//   * A row that spans chunks ("multi-chunk": every hub) receives one piece per chunk, OR-ed into acc[v] with a
+//     device-scope atomic (a few thousand per level, distinct addresses).  Its commit is DEFERRED to the next
+//     level's launch: the housekeeping blocks of launch l commit level l-1 for the listed rows and clear their
+//     words in the idle third buffer, which launch l+1 will accumulate into.  Until then the row masks its
+//     candidates with seen[v] | front[v] -- front[v] is exactly what level l-1 added -- so a commit that has or
+//     has not landed yet gives the same result.  One launch per level, no second pass, no inter-block hand-off
+//     inside a launch.
+// Three frontier buffers rotate: front = level l-1 (read), acc = level l (written), idle = level l+1 (cleared).
 // WT = words per tile (1, 2 or 4); blockIdx.y selects the tile of a node's W words.
 template <int WT>
-__global__ __launch_bounds__(256) void k_bfs_expand(const int *__restrict__ erow, const int *__restrict__ col,
-                                                    int E, int Wp, const u64 *__restrict__ front,
-                                                    u64 *__restrict__ seen, u64 *__restrict__ acc,
-                                                    u64 *__restrict__ cont, u64 *__restrict__ hop_planes,
-                                                    size_t plane_elems, int level, BfsCtl *ctl, const int *aux) {
+__global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
+                                                   int E, int Wp, const u64 *__restrict__ front,
+                                                   u64 *__restrict__ seen, u64 *__restrict__ acc,
+                                                   u64 *__restrict__ idle, u64 *__restrict__ hop_planes,
+                                                   size_t plane_elems, int level, BfsCtl *ctl, const int *aux,
+                                                   int expand_blocks) {
     if (bfs_over(ctl, aux, level)) return;
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
     const int woff = blockIdx.y * WT;
+    if ((int)blockIdx.x >= expand_blocks) {
+        // housekeeping for the rows that span chunks: one thread per (row, tile)
+        const int n = aux[AUX_N_MROWS];
+        const int *mrows = aux + AUX_HEADER;
+        const int hb = gridDim.x - expand_blocks;
+        Words<WT> zero;
+#pragma unroll
+        for (int i = 0; i < WT; ++i) zero.w[i] = 0;
+        for (int i = ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x; i < n; i += hb * blockDim.x) {
+            const size_t idx = (size_t)mrows[i] * Wp + woff;
+            store_words<WT>(idle + idx, zero);
+            if (level > 1) {
+                const Words<WT> fresh = load_words<WT>(front + idx);       // complete: every piece landed last launch
+                if (any_bits<WT>(fresh))
+                    commit_words<WT>(fresh, load_words<WT>(seen + idx), idx, seen, hop_planes, plane_elems, level - 1);
+            }
+        }
+        return;
+    }
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (expand_blocks * blockDim.x) >> 6;
+    const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
     bool found = false;
     STAMP(0);
     for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
@@ -279,9 +297,13 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const int *__restrict__ erow
             if (base + 3 < E) { v3 = vr.w; u3 = ur.w; }
         }
         const int vc = __shfl(v0, 0);                                                  // row of the chunk's first slot
+        const int vl = __shfl(v3, 63);                                                 // row of its last slot (-1: short chunk)
         STAMP(1);
-        const bool head_continues = chunk > 0 && erow[chunk * CHUNK - 1] == vc;
-        const int next_vc = (chunk + 1) * CHUNK < E ? erow[(chunk + 1) * CHUNK] : -2;  // row of the next chunk's first slot
+        const bool head_multi = chunk > 0 && erow[chunk * CHUNK - 1] == vc;             // first row began in an earlier chunk
+        const bool tail_multi = vl >= 0 && (chunk + 1) * CHUNK < E && erow[(chunk + 1) * CHUNK] == vl;   // last row runs on
+        // slots of a row that spans chunks (only the chunk's first and last row can)
+        const bool x0 = (head_multi && v0 == vc) || (tail_multi && v0 == vl);
+        const bool x3 = (head_multi && v3 == vc) || (tail_multi && v3 == vl);
 
         Words<WT> c0, c1, c2, c3, s0, s1, s2, s3;
 #pragma unroll
@@ -289,13 +311,28 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const int *__restrict__ erow
         if (v0 >= 0) {
             c0 = load_words<WT>(front + (size_t)u0 * Wp + woff);
             s0 = load_words<WT>(seen + (size_t)v0 * Wp + woff);
+            if (x0) {                                                    // deferred commit: level l-1 may not be in seen yet
+                const Words<WT> f = load_words<WT>(front + (size_t)v0 * Wp + woff);
+#pragma unroll
+                for (int i = 0; i < WT; ++i) s0.w[i] |= f.w[i];
+            }
         }
         if (v1 >= 0) c1 = load_words<WT>(front + (size_t)u1 * Wp + woff);
         if (v2 >= 0) c2 = load_words<WT>(front + (size_t)u2 * Wp + woff);
         if (v3 >= 0) {
             c3 = load_words<WT>(front + (size_t)u3 * Wp + woff);
-            s3 = v3 == v0 ? s0 : load_words<WT>(seen + (size_t)v3 * Wp + woff);
+            if (v3 == v0) {
+                s3 = s0;
+            } else {
+                s3 = load_words<WT>(seen + (size_t)v3 * Wp + woff);
+                if (x3) {
+                    const Words<WT> f = load_words<WT>(front + (size_t)v3 * Wp + woff);
+#pragma unroll
+                    for (int i = 0; i < WT; ++i) s3.w[i] |= f.w[i];
+                }
+            }
         }
+        // an interior row (neither the lane's first nor last row) lies inside the chunk: plain seen is its mask
         if (v1 >= 0) s1 = v1 == v0 ? s0 : (v1 == v3 ? s3 : load_words<WT>(seen + (size_t)v1 * Wp + woff));
         if (v2 >= 0) s2 = v2 == v1 ? s1 : (v2 == v3 ? s3 : load_words<WT>(seen + (size_t)v2 * Wp + woff));
 #pragma unroll
@@ -344,27 +381,30 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const int *__restrict__ erow
             }
         }
         STAMP(3);
-        // Emit every run that ends in this lane (the slot after it belongs to another row).  Phase A stores the
-        // frontier words (no dependencies); phase B commits complete rows, all four slots side by side per hop
-        // bit so that their plane read-modify-writes overlap instead of forming a chain of round trips.
+        // Emit every run that ends in this lane (the slot after it belongs to another row, or the chunk ends).
         const int nv0 = __shfl_down(v0, 1);
-        const int after3 = lane == 63 ? -3 : nv0;                       // the run of lane 63's last slot ends this chunk's pass
-        const bool runs_on = lane == 63 && next_vc == v3;               // ... but its row continues in the next chunk
+        const int after3 = lane == 63 ? -3 : nv0;
         const size_t i0 = (size_t)v0 * Wp + woff, i1 = (size_t)v1 * Wp + woff, i2 = (size_t)v2 * Wp + woff,
                      i3 = (size_t)v3 * Wp + woff;
-        u64 *cont_c = cont + (size_t)chunk * Wp + woff;
         const bool e0 = v0 >= 0 && v0 != v1, e1 = v1 >= 0 && v1 != v2, e2 = v2 >= 0 && v2 != v3, e3 = v3 >= 0 && v3 != after3;
-        const bool k0 = head_continues && v0 == vc, k1 = head_continues && v1 == vc, k2 = head_continues && v2 == vc,
-                   k3 = head_continues && v3 == vc;                     // continuation piece of a row begun earlier
-        if (e0) store_words<WT>(k0 ? cont_c : acc + i0, c0);
-        if (e1) store_words<WT>(k1 ? cont_c : acc + i1, c1);
-        if (e2) store_words<WT>(k2 ? cont_c : acc + i2, c2);
-        if (e3) store_words<WT>(k3 ? cont_c : acc + i3, c3);
+        const bool x1 = (head_multi && v1 == vc) || (tail_multi && v1 == vl);
+        const bool x2 = (head_multi && v2 == vc) || (tail_multi && v2 == vl);
+        // piece of a row that spans chunks: OR it in (its words were cleared two launches ago), commit later
+        auto piece = [&](size_t idx, const Words<WT> &c) {
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+                if (c.w[i]) atomicOr(&acc[idx + i], c.w[i]);
+        };
+        if (e0) { if (x0) piece(i0, c0); else store_words<WT>(acc + i0, c0); }
+        if (e1) { if (x1) piece(i1, c1); else store_words<WT>(acc + i1, c1); }
+        if (e2) { if (x2) piece(i2, c2); else store_words<WT>(acc + i2, c2); }
+        if (e3) { if (x3) piece(i3, c3); else store_words<WT>(acc + i3, c3); }
         STAMP(4);
-        const bool m0 = e0 && !k0 && any_bits<WT>(c0) != 0, m1 = e1 && !k1 && any_bits<WT>(c1) != 0,
-                   m2 = e2 && !k2 && any_bits<WT>(c2) != 0, m3 = e3 && !k3 && !runs_on && any_bits<WT>(c3) != 0;
+        const bool n0 = e0 && any_bits<WT>(c0) != 0, n1 = e1 && any_bits<WT>(c1) != 0, n2 = e2 && any_bits<WT>(c2) != 0,
+                   n3 = e3 && any_bits<WT>(c3) != 0;
+        found |= n0 || n1 || n2 || n3;
+        const bool m0 = n0 && !x0, m1 = n1 && !x1, m2 = n2 && !x2, m3 = n3 && !x3;     // complete rows: commit now
         if (__any(m0 || m1 || m2 || m3)) {
-            found |= m0 || m1 || m2 || m3;
 #pragma unroll
             for (int i = 0; i < WT; ++i) {
                 s0.w[i] |= c0.w[i];
@@ -376,7 +416,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const int *__restrict__ erow
             if (m1) store_words<WT>(seen + i1, s1);
             if (m2) store_words<WT>(seen + i2, s2);
             if (m3) store_words<WT>(seen + i3, s3);
-            for (int b = 0, l = level; l; ++b, l >>= 1) {
+            for (int b = 0, l = level; l; ++b, l >>= 1) {               // all four slots side by side per hop bit
                 if (!(l & 1)) continue;
                 u64 *p = hop_planes + (size_t)b * plane_elems;
                 Words<WT> h0 = c0, h1 = c1, h2 = c2, h3 = c3;
@@ -400,82 +440,6 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const int *__restrict__ erow
         STAMP(5);
     }
     STAMP(6);
-    if (__any(found) && lane == 0) raise_level(ctl, level);
-}
-
-// Phase 2 ("fixup"): rows that span several 64-slot chunks.  fresh = owner piece | continuation pieces; it
-// replaces the owner piece in the frontier and is committed.  Blocks [0, small_blocks) take the short rows,
-// one thread per (row, tile); the remaining blocks take the hubs, one wave per (row, tile).
-template <int WT>
-__global__ __launch_bounds__(256) void k_bfs_fixup(const int *__restrict__ rowptr, int Wp, u64 *__restrict__ acc,
-                                                   const u64 *__restrict__ cont, u64 *__restrict__ seen,
-                                                   u64 *__restrict__ hop_planes, size_t plane_elems, int level,
-                                                   BfsCtl *ctl, const int *__restrict__ aux, int cap, int small_blocks) {
-    if (bfs_over(ctl, aux, level)) return;
-    const int lane = threadIdx.x & 63;
-    const int woff = blockIdx.y * WT;
-    bool found = false;
-    if ((int)blockIdx.x < small_blocks) {
-        const int n = aux[AUX_N_MROWS];
-        const int *mrows = aux + AUX_HEADER;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += small_blocks * blockDim.x) {
-            const int v = mrows[i];
-            const size_t idx = (size_t)v * Wp + woff;
-            const int c0 = rowptr[v] >> CHUNK_SHIFT, c1 = (rowptr[v + 1] - 1) >> CHUNK_SHIFT;
-            Words<WT> own = load_words<WT>(acc + idx), fresh = own;
-#pragma unroll
-            for (int k = 1; k <= SMALL_SPAN; ++k)
-                if (c0 + k <= c1) {
-                    const Words<WT> p = load_words<WT>(cont + (size_t)(c0 + k) * Wp + woff);
-#pragma unroll
-                    for (int j = 0; j < WT; ++j) fresh.w[j] |= p.w[j];
-                }
-            if (any_bits<WT>(fresh)) {
-                bool grew = false;
-#pragma unroll
-                for (int j = 0; j < WT; ++j) grew |= fresh.w[j] != own.w[j];
-                if (grew) store_words<WT>(acc + idx, fresh);
-                commit_words<WT>(fresh, load_words<WT>(seen + idx), idx, seen, hop_planes, plane_elems, level);
-                found = true;
-            }
-        }
-    } else {
-        const int n = aux[AUX_N_HUBS];
-        const int *hubs = aux + AUX_HEADER + cap;
-        const int wave = (((int)blockIdx.x - small_blocks) * blockDim.x + threadIdx.x) >> 6;
-        const int nwaves = ((gridDim.x - small_blocks) * blockDim.x) >> 6;
-        for (int i = wave; i < n; i += nwaves) {
-            const int v = hubs[i];
-            const size_t idx = (size_t)v * Wp + woff;
-            const int c0 = rowptr[v] >> CHUNK_SHIFT, c1 = (rowptr[v + 1] - 1) >> CHUNK_SHIFT;
-            Words<WT> fresh;
-#pragma unroll
-            for (int j = 0; j < WT; ++j) fresh.w[j] = 0;
-            for (int c = c0 + 1 + lane; c <= c1; c += 64) {
-                const Words<WT> p = load_words<WT>(cont + (size_t)c * Wp + woff);
-#pragma unroll
-                for (int j = 0; j < WT; ++j) fresh.w[j] |= p.w[j];
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-                for (int j = 0; j < WT; ++j) fresh.w[j] |= __shfl_xor(fresh.w[j], off);
-            if (lane == 0) {
-                const Words<WT> own = load_words<WT>(acc + idx);
-                bool grew = false;
-#pragma unroll
-                for (int j = 0; j < WT; ++j) {
-                    grew |= (fresh.w[j] & ~own.w[j]) != 0;
-                    fresh.w[j] |= own.w[j];
-                }
-                if (any_bits<WT>(fresh)) {
-                    if (grew) store_words<WT>(acc + idx, fresh);
-                    commit_words<WT>(fresh, load_words<WT>(seen + idx), idx, seen, hop_planes, plane_elems, level);
-                    found = true;
-                }
-            }
-        }
-    }
     if (__any(found) && lane == 0) raise_level(ctl, level);
 }
 
@@ -591,7 +555,7 @@ using namespace pope;
 // ------------------------------------------------------------------------------------------------
 static int aux_cap(int64_t E) { return (int)((E + CHUNK - 1) / CHUNK) + 1; }
 
-extern "C" size_t pope_csr_aux_elems(int64_t E) { return E < 0 ? 0 : (size_t)AUX_HEADER + 2 * (size_t)aux_cap(E); }
+extern "C" size_t pope_csr_aux_elems(int64_t E) { return E < 0 ? 0 : (size_t)AUX_HEADER + (size_t)aux_cap(E); }
 
 extern "C" size_t pope_csr_scratch_bytes(int64_t N, int64_t E) {
     (void)E;
@@ -656,12 +620,11 @@ extern "C" size_t pope_plane_bytes(int64_t N, int32_t K) {
     return (size_t)N * words_for(K) * sizeof(u64);
 }
 
-static size_t cont_bytes(int64_t E, int32_t K) { return align_up((size_t)aux_cap(E) * words_for(K) * sizeof(u64), 256); }
-
 extern "C" size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K) {
     if (N < 0 || E < 0 || K <= 0) return 0;
-    // control block | anchors[K] | two frontier planes | continuation pieces (one per 64 CSR slots)
-    return 256 + align_up((size_t)K * sizeof(long long), 256) + 2 * align_up(pope_plane_bytes(N, K), 256) + cont_bytes(E, K);
+    (void)E;
+    // control block | anchors[K] | three rotating frontier planes
+    return 256 + align_up((size_t)K * sizeof(long long), 256) + 3 * align_up(pope_plane_bytes(N, K), 256);
 }
 
 constexpr int EAGER_PLANES = 4;      // hop-bit planes cleared up front (levels < 16); deeper ones when first needed
@@ -669,7 +632,7 @@ constexpr int EAGER_PLANES = 4;      // hop-bit planes cleared up front (levels 
 // Optional per-launch timing of the level kernels with HIP events on the launch stream (bench.py's roofline leg).
 struct LevelProfile {
     bool enabled = false;
-    std::vector<hipEvent_t> ev;          // 3 per level: before expand, after expand, after fixup
+    std::vector<hipEvent_t> ev;          // 2 per level: before and after the level kernel
     std::vector<int> level;
 };
 static LevelProfile g_profile;
@@ -684,20 +647,18 @@ static void profile_mark(hipStream_t stream, int level, int which) {
 }
 
 template <int WT>
-static void launch_level(int E, int Wp, const int *rowptr, const int *col, const int *erow, const int *aux,
-                         const u64 *front, u64 *seen, u64 *acc, u64 *cont, u64 *hop_planes, size_t plane_elems,
-                         int level, BfsCtl *ctl, hipStream_t stream) {
-    const int cap = aux_cap(E);
-    dim3 grid(capped_grid((size_t)E, 256, 256u * 8u), Wp / WT);      // <= 8 blocks per CU, waves loop over chunks
+static void launch_level(int E, int Wp, const int *col, const int *erow, const int *aux, const u64 *front, u64 *seen,
+                         u64 *acc, u64 *idle, u64 *hop_planes, size_t plane_elems, int level, BfsCtl *ctl,
+                         hipStream_t stream) {
+    const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
+    int expand_blocks = (nchunks + 3) / 4;                           // one wave per chunk ...
+    if (expand_blocks > 256 * 8) expand_blocks = 256 * 8;            // ... up to 8 blocks per CU, then waves loop
+    int house_blocks = (nchunks + 255) / 256;                        // rows that span chunks: at most one per chunk
+    if (house_blocks > 64) house_blocks = 64;
     profile_mark(stream, level, 0);
-    hipLaunchKernelGGL((k_bfs_expand<WT>), grid, dim3(256), 0, stream, erow, col, E, Wp, front, seen, acc, cont,
-                       hop_planes, plane_elems, level, ctl, aux);
+    hipLaunchKernelGGL((k_bfs_level<WT>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow, col, E,
+                       Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks);
     profile_mark(stream, level, 1);
-    int small_blocks = (cap + 255) / 256;
-    if (small_blocks > 256) small_blocks = 256;
-    hipLaunchKernelGGL((k_bfs_fixup<WT>), dim3(small_blocks + 64, Wp / WT), dim3(256), 0, stream, rowptr, Wp, acc, cont,
-                       seen, hop_planes, plane_elems, level, ctl, aux, cap, small_blocks);
-    profile_mark(stream, level, 2);
 }
 
 // Everything one BFS needs, carved out of the caller's buffers.
@@ -705,7 +666,7 @@ struct Bfs {
     const int *rowptr, *col, *erow, *aux;
     int N, E, K, Wp, capacity;
     size_t plane_elems, plane_bytes, front_off;
-    u64 *seen, *hop_planes, *front[2], *cont;
+    u64 *seen, *hop_planes, *front[3];
     char *base;
     BfsCtl *ctl;
     long long *anchors_dev;
@@ -741,16 +702,16 @@ static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const in
     b.anchors_dev = (long long *)(b.base + 256);
     b.front[0] = (u64 *)(b.base + b.front_off);
     b.front[1] = (u64 *)((char *)b.front[0] + align_up(b.plane_bytes, 256));
-    b.cont = (u64 *)((char *)b.front[1] + align_up(b.plane_bytes, 256));
+    b.front[2] = (u64 *)((char *)b.front[1] + align_up(b.plane_bytes, 256));
     b.level_limit = 1ll << plane_capacity;
     return POPE_OK;
 }
 
 static int bfs_enqueue_init(const Bfs &b, const int64_t *anchors_host, hipStream_t stream) {
-    // one launch clears the control block, both frontier buffers, the reachability plane and the first hop planes
+    // one launch clears the control block, the three frontier buffers, the reachability plane and the first hop planes
     const int eager = b.capacity < EAGER_PLANES ? b.capacity : EAGER_PLANES;
     hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, stream, (uint4 *)b.base,
-                       (b.front_off + 2 * align_up(b.plane_bytes, 256)) / 16, (uint4 *)b.seen,
+                       (b.front_off + 3 * align_up(b.plane_bytes, 256)) / 16, (uint4 *)b.seen,
                        (size_t)(1 + eager) * b.plane_bytes / 16, (uint4 *)nullptr, (size_t)0);
     POPE_HIP(hipMemcpyAsync(b.anchors_dev, anchors_host, (size_t)b.K * sizeof(long long), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_bfs_seed, dim3((b.K + 255) / 256), dim3(256), 0, stream, b.anchors_dev, b.K, b.Wp, b.seen, b.front[0]);
@@ -767,11 +728,12 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
             hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, stream, (uint4 *)(b.hop_planes + (size_t)bit * b.plane_elems),
                                b.plane_bytes / 16, (uint4 *)nullptr, (size_t)0, (uint4 *)nullptr, (size_t)0);
         }
-        const u64 *prev = b.front[(level - 1) & 1];           // frontier of level - 1
-        u64 *next = b.front[level & 1];                          // receives the frontier of this level
-        if (b.Wp == 1)      launch_level<1>(b.E, b.Wp, b.rowptr, b.col, b.erow, b.aux, prev, b.seen, next, b.cont, b.hop_planes, b.plane_elems, level, b.ctl, stream);
-        else if (b.Wp == 2) launch_level<2>(b.E, b.Wp, b.rowptr, b.col, b.erow, b.aux, prev, b.seen, next, b.cont, b.hop_planes, b.plane_elems, level, b.ctl, stream);
-        else                launch_level<4>(b.E, b.Wp, b.rowptr, b.col, b.erow, b.aux, prev, b.seen, next, b.cont, b.hop_planes, b.plane_elems, level, b.ctl, stream);
+        const u64 *prev = b.front[(level - 1) % 3];           // frontier of level - 1
+        u64 *next = b.front[level % 3];                          // receives the frontier of this level
+        u64 *idle = b.front[(level + 1) % 3];                    // next level's accumulator: rows spanning chunks cleared now
+        if (b.Wp == 1)      launch_level<1>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, stream);
+        else if (b.Wp == 2) launch_level<2>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, stream);
+        else                launch_level<4>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, stream);
     }
     return level;
 }
@@ -822,18 +784,16 @@ extern "C" void pope_profile_levels(int32_t enable) {
     g_profile.enabled = enable != 0;
 }
 
-extern "C" int32_t pope_profile_read(int32_t *levels, float *expand_ms, float *fixup_ms, int32_t capacity) {
+extern "C" int32_t pope_profile_read(int32_t *levels, float *level_ms, int32_t capacity) {
     const int n = (int)g_profile.level.size();
     int written = 0;
     for (int i = 0; i < n && written < capacity; ++i) {
-        if ((size_t)(3 * i + 2) >= g_profile.ev.size()) break;
-        float a = 0.f, b = 0.f;
-        if (hipEventSynchronize(g_profile.ev[3 * i + 2]) != hipSuccess) break;
-        (void)hipEventElapsedTime(&a, g_profile.ev[3 * i], g_profile.ev[3 * i + 1]);
-        (void)hipEventElapsedTime(&b, g_profile.ev[3 * i + 1], g_profile.ev[3 * i + 2]);
+        if ((size_t)(2 * i + 1) >= g_profile.ev.size()) break;
+        float a = 0.f;
+        if (hipEventSynchronize(g_profile.ev[2 * i + 1]) != hipSuccess) break;
+        (void)hipEventElapsedTime(&a, g_profile.ev[2 * i], g_profile.ev[2 * i + 1]);
         levels[written] = g_profile.level[i];
-        expand_ms[written] = a;
-        fixup_ms[written] = b;
+        level_ms[written] = a;
         ++written;
     }
     return written;

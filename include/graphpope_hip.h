@@ -141,10 +141,10 @@ int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N, const int
 /*
  * Measurement hook (bench.py): while enabled, every BFS level launch is bracketed by HIP events on the launch
  * stream.  pope_profile_read returns, per level launched since enabling, the level number and the elapsed
- * milliseconds of its expand and fixup kernels (waits for the events).  Not thread-safe; off by default.
+ * milliseconds of its kernel (waits for the events).  Not thread-safe; off by default.
  */
 void pope_profile_levels(int32_t enable);
-int32_t pope_profile_read(int32_t *levels_host, float *expand_ms_host, float *fixup_ms_host, int32_t capacity);
+int32_t pope_profile_read(int32_t *levels_host, float *level_ms_host, int32_t capacity);
 
 /* Integer hop matrix: hops int32 [N, K] node-major, -1 = unreachable.  Asynchronous on `stream`. */
 int pope_geodesic_hops(const uint64_t *planes, int32_t n_hop_bits, int64_t N, int32_t K,

@@ -54,7 +54,7 @@ def main(tag, rnd):
         out["kernels"][short] = {"fetch_kib_raw": f_mean, "write_kib_raw": w_mean, "active_launches": f_act, "launches": f_all,
                                  "hbm_bytes_per_launch": f_mean * 1024 * 2 + w_mean * 1024}
     k = out["kernels"]
-    out["k_bfs_expand_hbm_bytes_per_launch"] = next(v["hbm_bytes_per_launch"] for n, v in k.items() if n.startswith("k_bfs_expand"))
+    out["k_bfs_level_hbm_bytes_per_launch"] = next(v["hbm_bytes_per_launch"] for n, v in k.items() if n.startswith("k_bfs_level"))
     out["k_finalize_hbm_bytes_per_launch"] = next(v["hbm_bytes_per_launch"] for n, v in k.items() if n.startswith("k_finalize"))
     with open(os.path.join(dst, f"{rnd}_pmc_summary.json"), "w") as fh:
         json.dump(out, fh, indent=1)

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""A/B of the finalise kernel variants in one process, interleaved rounds (GPU box)."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from graphpope_amd import _lib, engine, synth
+lib = _lib.load()
+dev = engine.require_gpu()
+ei_np, n = synth.flickr_like()
+anchors = synth.seeded_anchors(n, 256, 42)
+x = torch.rand((n, 500), device=dev)
+csr = engine.build_csr(torch.as_tensor(ei_np, device=dev), n)
+hp = engine.bfs(csr, anchors)
+out = torch.empty((n, 756), device=dev)
+ref = None
+res = {0: [], 1: [], 2: []}
+for rnd in range(12):
+    for var in (0, 1, 2):
+        lib.pope_debug_finalize_variant(var)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            engine.finalize(hp.planes, hp.n_hop_bits, n, 256, x, 500, out, 0)
+        e1.record(); torch.cuda.synchronize()
+        res[var].append(e0.elapsed_time(e1) / 5 * 1e3)
+        if ref is None: ref = out.clone()
+        assert torch.equal(out, ref), var
+byt = 4.0 * n * 500 + 4.0 * n * 756 + 8.0 * n * 4 * (1 + hp.n_hop_bits)
+for var in res:
+    med = float(np.median(res[var][2:]))
+    print(f"variant {var}: median {med:.1f} us  min {min(res[var]):.1f} us  -> {byt / med / 1e3:.0f} GB/s")

@@ -50,7 +50,7 @@ def _event():
 def pope_step(x, ei, n, anchors, world):
     """One full geodesic GraphPOPE pass on the device; returns the [N, F+K] tensor."""
     if world == 1:
-        return engine.geodesic_run(x, ei, n, anchors)[0]
+        return engine.geodesic_run(x, ei, n, anchors, reuse_workspace=True)[0]
     csr = engine.build_csr(ei, n, defer_check=True)
     return pdist.sharded_geodesic_features(x, n, anchors, None,
                                            bfs_fn=lambda a: engine.bfs(csr, a),

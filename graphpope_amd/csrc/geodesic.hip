@@ -443,6 +443,8 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
     if (__any(found) && lane == 0) raise_level(ctl, level);
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: what the non-temporal builtins accept
+
 // ------------------------------------------------------------------------------------------------
 // Finalise: hop planes -> 1/(h+1) float32 written next to the features (utils.py:73,125,129-135)
 // ------------------------------------------------------------------------------------------------
@@ -517,8 +519,6 @@ __global__ __launch_bounds__(256) void k_finalize(const u64 *__restrict__ planes
 //  * the four hop counts of a lane are pulled out of the packed plane nibbles with one multiply each;
 //  * x is read with non-temporal loads (read once); stores are plain -- non-temporal stores measured 23 % slower.
 // MODE: 0 plain stores (default), 1 non-temporal stores (kept for A/B, tools/ab_finalize.py).
-typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: what the non-temporal builtins accept
-
 template <int MODE>
 __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ planes, size_t plane_elems,
                                                        int n_hop_bits, const int *__restrict__ max_hop_dev, int N, int K,
@@ -590,17 +590,21 @@ __global__ __launch_bounds__(256) void k_hops(const u64 *__restrict__ planes, si
     }
 }
 
+// out[v, 0:F] = x[v, :].  Every wave owns a contiguous block of rows (see k_finalize_fast).
 __global__ __launch_bounds__(256) void k_concat(const float *__restrict__ x, int N, int F, float *__restrict__ out,
                                                 long long out_cols, bool vec) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int v = wave; v < N; v += nwaves) {
+    const int per = (N + nwaves - 1) / nwaves;
+    const int v_begin = wave * per, v_end = min(N, v_begin + per);
+    for (int v = v_begin; v < v_end; ++v) {
         const float *xrow = x + (size_t)v * F;
         float *orow = out + (size_t)v * out_cols;
         if (vec) {
-            for (int q = lane; q < F / 4; q += 64)
-                reinterpret_cast<float4 *>(orow)[q] = reinterpret_cast<const float4 *>(xrow)[q];
+            const f32x4 *xs = reinterpret_cast<const f32x4 *>(xrow);
+            f32x4 *os = reinterpret_cast<f32x4 *>(orow);
+            for (int q = lane; q < F / 4; q += 64) os[q] = __builtin_nontemporal_load(xs + q);
         } else {
             for (int c = lane; c < F; c += 64) orow[c] = xrow[c];
         }
@@ -724,6 +728,45 @@ static void launch_level(int E, int Wp, const int *col, const int *erow, const i
     profile_mark(stream, level, 1);
 }
 
+// Per-device host-side context, created on first use (the only objects the library ever keeps): small pinned,
+// device-mapped host buffers.  Anchors are staged through one (a pageable hipMemcpyAsync is a synchronous staging
+// copy) and the poll kernel writes the BFS verdict straight into the other (no copy kernels, one stream sync).
+// (Measured and rejected: running the feature copy out[:, :F] = x on a side stream underneath the BFS levels.  The
+// streaming copy saturates the memory queues and the latency-bound level kernels run 2-4x slower beside it; the
+// serial order is faster.)
+struct DeviceCtx {
+    int *report = nullptr;               // pinned host: [0] last_active, [1] csr flags
+    int *report_dev = nullptr;           // the same memory as seen from the device
+    long long *anchors = nullptr;        // pinned host staging for the anchor ids
+    size_t anchors_cap = 0;
+};
+static DeviceCtx g_ctx[64];
+
+static int device_ctx(DeviceCtx **out, size_t n_anchors) {
+    int dev = 0;
+    POPE_HIP(hipGetDevice(&dev));
+    POPE_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    DeviceCtx &c = g_ctx[dev];
+    if (!c.report) {
+        POPE_HIP(hipHostMalloc((void **)&c.report, 256, hipHostMallocMapped));
+        POPE_HIP(hipHostGetDevicePointer((void **)&c.report_dev, c.report, 0));
+    }
+    if (n_anchors > c.anchors_cap) {
+        if (c.anchors) POPE_HIP(hipHostFree(c.anchors));
+        c.anchors_cap = n_anchors < 1024 ? 1024 : n_anchors;
+        POPE_HIP(hipHostMalloc((void **)&c.anchors, c.anchors_cap * sizeof(long long), hipHostMallocDefault));
+    }
+    *out = &c;
+    return POPE_OK;
+}
+
+// The BFS verdict (deepest active level, CSR status flags) written straight into pinned host memory.
+__global__ void k_bfs_report(const BfsCtl *ctl, const int *aux, int *report) {
+    report[0] = ctl->last_active;
+    report[1] = aux[AUX_FLAGS];
+    __threadfence_system();
+}
+
 // Everything one BFS needs, carved out of the caller's buffers.
 struct Bfs {
     const int *rowptr, *col, *erow, *aux;
@@ -734,6 +777,7 @@ struct Bfs {
     BfsCtl *ctl;
     long long *anchors_dev;
     long long level_limit;       // levels 1 .. limit-1 fit `capacity` hop bits
+    DeviceCtx *dev;
 };
 
 constexpr int LEVEL_BATCH = 12;     // levels enqueued between two polls of the device flag (hops <= 10: one poll)
@@ -767,7 +811,7 @@ static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const in
     b.front[1] = (u64 *)((char *)b.front[0] + align_up(b.plane_bytes, 256));
     b.front[2] = (u64 *)((char *)b.front[1] + align_up(b.plane_bytes, 256));
     b.level_limit = 1ll << plane_capacity;
-    return POPE_OK;
+    return device_ctx(&b.dev, (size_t)K);
 }
 
 static int bfs_enqueue_init(const Bfs &b, const int64_t *anchors_host, hipStream_t stream) {
@@ -776,7 +820,8 @@ static int bfs_enqueue_init(const Bfs &b, const int64_t *anchors_host, hipStream
     hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, stream, (uint4 *)b.base,
                        (b.front_off + 3 * align_up(b.plane_bytes, 256)) / 16, (uint4 *)b.seen,
                        (size_t)(1 + eager) * b.plane_bytes / 16, (uint4 *)nullptr, (size_t)0);
-    POPE_HIP(hipMemcpyAsync(b.anchors_dev, anchors_host, (size_t)b.K * sizeof(long long), hipMemcpyHostToDevice, stream));
+    memcpy(b.dev->anchors, anchors_host, (size_t)b.K * sizeof(long long));        // pinned staging: the copy below is truly async
+    POPE_HIP(hipMemcpyAsync(b.anchors_dev, b.dev->anchors, (size_t)b.K * sizeof(long long), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_bfs_seed, dim3((b.K + 255) / 256), dim3(256), 0, stream, b.anchors_dev, b.K, b.Wp, b.seen, b.front[0]);
     return POPE_OK;
 }
@@ -803,11 +848,11 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
 
 // Wait for the stream and read the verdicts.  Returns POPE_OK with *done set, or an error code.
 static int bfs_poll(const Bfs &b, int next_level, int *last_active, bool *done, hipStream_t stream) {
-    int flags = 0;
-    POPE_HIP(hipMemcpyAsync(last_active, &b.ctl->last_active, sizeof(int), hipMemcpyDeviceToHost, stream));
-    POPE_HIP(hipMemcpyAsync(&flags, b.aux + AUX_FLAGS, sizeof(int), hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(k_bfs_report, dim3(1), dim3(1), 0, stream, b.ctl, b.aux, b.dev->report_dev);
     POPE_HIP(hipStreamSynchronize(stream));
     POPE_HIP(hipGetLastError());
+    *last_active = b.dev->report[0];
+    const int flags = b.dev->report[1];
     if (flags & CSR_FLAG_BAD_INDEX) {
         set_error("geodesic bfs: edge_index holds a node id outside [0, %d)", b.N);
         return POPE_ERR_INDEX;
@@ -972,7 +1017,8 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     u64 *planes = (u64 *)(ws + L.planes);
     // speculative: sorted-CSR fast path, the first LEVEL_BATCH levels and the finalise kernel are all enqueued
     // before the host looks at anything; the finalise kernel reads the depth from the BFS control block.
-    int rc = pope_csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 1, stream_);
+    int rc;
+    rc = pope_csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 1, stream_);
     if (rc) return rc;
     Bfs b;
     if ((rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, (uint64_t *)planes, plane_capacity,
@@ -1026,7 +1072,7 @@ extern "C" int pope_concat(const float *x, int64_t N, int32_t F, float *out, int
     POPE_REQUIRE(x && out, "pope_concat: null pointer");
     POPE_REQUIRE(N > 0 && N < INT32_MAX && F > 0 && out_cols >= F, "pope_concat: bad size");
     const bool vec = F % 4 == 0 && out_cols % 4 == 0 && aligned16(out) && aligned16(x);
-    hipLaunchKernelGGL(k_concat, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, x, (int)N, F, out,
+    hipLaunchKernelGGL(k_concat, dim3(256 * 8), dim3(256), 0, stream, x, (int)N, F, out,
                        (long long)out_cols, vec);
     POPE_HIP(hipGetLastError());
     return POPE_OK;

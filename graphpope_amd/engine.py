@@ -131,11 +131,16 @@ def hop_matrix(hp: HopPlanes) -> torch.Tensor:
     return hops
 
 
+_WORKSPACE = {}          # (device, bytes) -> uint8 tensor, reused by geodesic_run(reuse_workspace=True)
+
+
 def geodesic_run(x, edge_index: torch.Tensor, num_nodes: int, anchors, capacity: int = DEFAULT_PLANE_CAPACITY,
-                 want_out: bool = True):
+                 want_out: bool = True, reuse_workspace: bool = False):
     """The whole geodesic hot path in one library call (one host synchronisation): (out, HopPlanes).
 
     ``x`` float32 [N, F] on the device (or None with ``want_out=False`` for a BFS-only run).
+    ``reuse_workspace`` keeps the scratch allocation between calls; the returned HopPlanes then only stay valid
+    until the next such call.
     """
     lib = _lib.load()
     ei = edge_index.contiguous()
@@ -148,7 +153,14 @@ def geodesic_run(x, edge_index: torch.Tensor, num_nodes: int, anchors, capacity:
     with torch.cuda.device(dev):
         out = torch.empty((num_nodes, f + k), dtype=torch.float32, device=dev) if want_out else None
         while True:
-            ws = _bytes(lib.pope_geodesic_run_workspace_bytes(num_nodes, e, k, capacity), dev)
+            nbytes_ws = lib.pope_geodesic_run_workspace_bytes(num_nodes, e, k, capacity)
+            if reuse_workspace:
+                ws = _WORKSPACE.get((dev, nbytes_ws))
+                if ws is None:
+                    _WORKSPACE.clear()
+                    ws = _WORKSPACE.setdefault((dev, nbytes_ws), _bytes(nbytes_ws, dev))
+            else:
+                ws = _bytes(nbytes_ws, dev)
             max_hop, bits = ctypes.c_int32(0), ctypes.c_int32(0)
             rc = lib.pope_geodesic_run(ptr(ei), e, num_nodes, ctypes.c_void_p(anc.ctypes.data), k, ptr(x), f, ptr(out),
                                        f + k, capacity, ptr(ws), ws.numel(), ctypes.byref(max_hop), ctypes.byref(bits),
@@ -178,7 +190,7 @@ def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int,
     anc = np.asarray(anchors, dtype=np.int64)
     world = pdist.world_size(group) if shard else 1
     if world == 1:
-        return geodesic_run(x, edge_index.to(dev), num_nodes, anc)[0]
+        return geodesic_run(x, edge_index.to(dev), num_nodes, anc, reuse_workspace=True)[0]
     csr = build_csr(edge_index.to(dev), num_nodes, defer_check=True)
     return pdist.sharded_geodesic_features(
         x, num_nodes, anc, group,

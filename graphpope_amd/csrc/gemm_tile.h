@@ -1,0 +1,156 @@
+// Exact-f32 MFMA tile machinery shared by the SAGEConv projections (sage.hip) and the pairwise kernel (pairwise.hip).
+//
+// v_mfma_f32_32x32x2_f32: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; the accumulator tile
+// has col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  A block of 4 waves (WM x WN) owns a
+// TM x TN output tile; a wave owns 32 rows x (TN / WN) columns = NT accumulators.  The depth is walked in stages of
+// GK = 64: the next stage's global loads are issued before the current stage's MFMAs and written to LDS after them
+// (register double buffering, one LDS image); LDS fragments are read in batches ahead of the MFMAs that use them.
+#pragma once
+
+#include "common.h"
+
+namespace pope {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GK = 64, GLD = GK + 1;          // depth per LDS stage, padded leading dimension
+
+struct Operand {            // element (outer index i, depth k) lives at p[i * s_outer + k * s_k]
+    const float *p;
+    long long s_outer, s_k;
+};
+
+// A [ROWS x GK] slice of an operand (outer range [o0, o0 + ROWS), depth [k0, k0 + GK)) travels global -> registers ->
+// LDS in two steps so that the global loads of stage s+1 are in flight while the MFMAs of stage s run.
+// LDS image, chosen by which index is contiguous in memory:
+//   depth contiguous  (s_k == 1):      [row][GK + 1]    scalar stores, fragment reads conflict-free
+//   outer contiguous  (s_outer == 1):  [k][ROWS + 4]    one 16-byte store per load, fragment reads conflict-free
+template <int ROWS>
+struct Tile {
+    static constexpr int NL = ROWS * GK / 4 / 256;             // float4 loads per thread
+    static constexpr int LDK = ROWS + 4;                        // leading dimension of the k-major image
+    static constexpr int FLOATS = (ROWS * GLD > GK * LDK) ? ROWS * GLD : GK * LDK;
+
+    __device__ static __forceinline__ void load(float4 (&reg)[NL], const Operand &op, int o0, int o_end, int k0, int k_end,
+                                                int tid) {
+        const bool aligned = (reinterpret_cast<uintptr_t>(op.p) & 15) == 0;
+        if (op.s_k == 1) {                                      // 16 consecutive threads read 64 floats of one row
+            const bool vec = aligned && (op.s_outer & 3) == 0;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int idx = tid + 256 * i, r = idx / (GK / 4), kq = (idx % (GK / 4)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (o0 + r < o_end) {
+                    const float *p = op.p + (size_t)(o0 + r) * op.s_outer + k0 + kq;
+                    if (vec && k0 + kq + 3 < k_end) {
+                        v = *reinterpret_cast<const float4 *>(p);
+                    } else {
+                        if (k0 + kq < k_end) v.x = p[0];
+                        if (k0 + kq + 1 < k_end) v.y = p[1];
+                        if (k0 + kq + 2 < k_end) v.z = p[2];
+                        if (k0 + kq + 3 < k_end) v.w = p[3];
+                    }
+                }
+                reg[i] = v;
+            }
+        } else {                                                // read along the outer index
+            const bool vec = aligned && op.s_outer == 1 && (op.s_k & 3) == 0;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int idx = tid + 256 * i, k = idx / (ROWS / 4), rq = (idx % (ROWS / 4)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + k < k_end) {
+                    const float *p = op.p + (size_t)(k0 + k) * op.s_k + (size_t)(o0 + rq) * op.s_outer;
+                    if (vec && o0 + rq + 3 < o_end) {
+                        v = *reinterpret_cast<const float4 *>(p);
+                    } else {
+                        if (o0 + rq < o_end) v.x = p[0];
+                        if (o0 + rq + 1 < o_end) v.y = p[(size_t)op.s_outer];
+                        if (o0 + rq + 2 < o_end) v.z = p[(size_t)2 * op.s_outer];
+                        if (o0 + rq + 3 < o_end) v.w = p[(size_t)3 * op.s_outer];
+                    }
+                }
+                reg[i] = v;
+            }
+        }
+    }
+
+    __device__ static __forceinline__ void store(float *__restrict__ lds, const float4 (&reg)[NL], bool k_contig, int tid) {
+        if (k_contig) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int idx = tid + 256 * i, r = idx / (GK / 4), kq = (idx % (GK / 4)) * 4;
+                float *d = lds + r * GLD + kq;
+                d[0] = reg[i].x; d[1] = reg[i].y; d[2] = reg[i].z; d[3] = reg[i].w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int idx = tid + 256 * i, k = idx / (ROWS / 4), rq = (idx % (ROWS / 4)) * 4;
+                *reinterpret_cast<float4 *>(lds + k * LDK + rq) = reg[i];
+            }
+        }
+    }
+};
+
+// acc[t] += sum over the depth slices [kb0, ke0) of product 0 and [kb1, ke1) of product 1 of A_p[m0.., :] * B_p[n0.., :]^T.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void mfma_accumulate(f32x16 (&acc)[TN / WN / 32], const Operand &A0, const Operand &B0, int kb0,
+                                                int ke0, const Operand &A1, const Operand &B1, int kb1, int ke1, int m0,
+                                                int n0, int M, int N, float *__restrict__ As, float *__restrict__ Bs) {
+    static_assert(WM * WN == 4 && TM == WM * 32 && TN % (WN * 32) == 0, "tile shape");
+    constexpr int NT = TN / WN / 32;
+    using TA = Tile<TM>;
+    using TB = Tile<TN>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int S0 = ke0 > kb0 ? (ke0 - kb0 + GK - 1) / GK : 0, S1 = ke1 > kb1 ? (ke1 - kb1 + GK - 1) / GK : 0;
+    const int S = S0 + S1;
+    float4 ra[TA::NL], rb[TB::NL];
+    auto fetch = [&](int s) {                                   // global -> registers for stage s
+        const bool second = s >= S0;
+        const Operand &A = second ? A1 : A0;
+        const Operand &B = second ? B1 : B0;
+        const int k0 = second ? kb1 + (s - S0) * GK : kb0 + s * GK, ke = second ? ke1 : ke0;
+        TA::load(ra, A, m0, M, k0, ke, tid);
+        TB::load(rb, B, n0, N, k0, ke, tid);
+    };
+    if (S > 0) fetch(0);
+    for (int s = 0; s < S; ++s) {
+        const bool second = s >= S0;
+        const bool a_kc = (second ? A1 : A0).s_k == 1, b_kc = (second ? B1 : B0).s_k == 1;
+        __syncthreads();                                        // previous stage's fragment reads are done
+        TA::store(As, ra, a_kc, tid);
+        TB::store(Bs, rb, b_kc, tid);
+        __syncthreads();
+        if (s + 1 < S) fetch(s + 1);                            // in flight while the MFMAs below run
+        const float *xa = a_kc ? As + (wm * 32 + (lane & 31)) * GLD + (lane >> 5)
+                               : As + (lane >> 5) * TA::LDK + wm * 32 + (lane & 31);
+        const float *xb = b_kc ? Bs + (wn * (TN / WN) + (lane & 31)) * GLD + (lane >> 5)
+                               : Bs + (lane >> 5) * TB::LDK + wn * (TN / WN) + (lane & 31);
+        const int ask = a_kc ? 1 : TA::LDK, bsk = b_kc ? 1 : TB::LDK, bst = b_kc ? 32 * GLD : 32;
+        // Fragments are read from LDS in batches of KB k-steps into registers BEFORE the MFMAs that use them: with one
+        // wave per SIMD nothing else hides the LDS latency, and a read-wait-MFMA sequence per step idles the matrix pipe.
+        constexpr int KB = NT <= 2 ? 16 : 4;
+#pragma unroll 1
+        for (int k0 = 0; k0 < GK / 2; k0 += KB) {
+            float fa[KB], fb[NT][KB];
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                fa[j] = xa[(k0 + j) * 2 * ask];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) fb[t][j] = xb[t * bst + (k0 + j) * 2 * bsk];
+            }
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[t][j], acc[t], 0, 0, 0);
+        }
+    }
+}
+
+template <int TM, int TN>
+constexpr size_t tile_lds_bytes() { return (size_t)(Tile<TM>::FLOATS + Tile<TN>::FLOATS) * sizeof(float); }
+
+}  // namespace pope

@@ -929,7 +929,9 @@ extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, cons
 
 static int g_finalize_variant = 1;     // 0: generic kernel, 1: fast path with plain stores (A/B: 86 us vs 98 / 106), 2: fast path, non-temporal stores
 
+static int g_finalize_blocks = 256 * 8;
 extern "C" void pope_debug_finalize_variant(int v) { g_finalize_variant = v; }
+extern "C" void pope_debug_finalize_blocks(int b) { g_finalize_blocks = b; }
 
 static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_hop_dev, int64_t N, int32_t K,
                             const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, hipStream_t stream) {
@@ -940,7 +942,7 @@ static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_ho
     // The device-side depth (max_hop_dev) is only used by pope_geodesic_run, whose speculative window stops at
     // LEVEL_BATCH = 12 levels: at most 4 hop bits.  With a host-side count the fast path needs n_hop_bits <= 4.
     if (vec && g_finalize_variant > 0 && (max_hop_dev || n_hop_bits <= 4)) {
-        dim3 fgrid(256 * 8);                                    // 8 blocks per CU, contiguous row blocks per wave
+        dim3 fgrid(g_finalize_blocks);                          // 8 blocks per CU, contiguous row blocks per wave
         if (g_finalize_variant == 2)
             hipLaunchKernelGGL(k_finalize_fast<1>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0);
         else

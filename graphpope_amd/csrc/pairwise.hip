@@ -4,24 +4,19 @@
 // Replaces /root/reference/utils.py:158-176 (sklearn cosine_similarity / cosine_distances / euclidean_distances
 // followed by MinMaxScaler().fit/transform).  Pipeline:
 //   k_sqnorm          ||x||^2 of every node2vec row and anchor row, accumulated in f64
-//   k_pairwise        dot(X, A^T) with v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate), metric
+//   k_pairwise        dot(X, A^T) with v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate; 64 x 128 tiles on the
+//                     machinery of gemm_tile.h: register double buffering, batched LDS fragment reads), metric
 //                     epilogue, raw values written straight into the [N, F+K] output, per-block column min/max
-//   k_minmax_reduce   column min/max over blocks -> scale_ = 1/range (range < 10 eps -> 1), min_ = 0 - min*scale_
+//   k_minmax_fold / k_minmax_reduce   column min/max over blocks (two stages) -> scale_ = 1/range (range < 10 eps -> 1), min_ = 0 - min*scale_
 //   k_minmax_apply    y = e * scale_ + min_ in place (two roundings, like NumPy's X *= scale_; X += min_)
 // Euclidean: sklearn upcasts f32 inputs to f64 (pairwise.py:582-653).  Here d2 = xx + aa - 2 dot is formed in f64
 // from the f32 MFMA dot; where d2 is small against the norms (cancellation) the entry is recomputed as a direct
 // sum of squared differences, so coincident rows give exactly 0 instead of ~1e-2.
-#include "common.h"
+#include "gemm_tile.h"
 
 namespace pope {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128;          // rows of X per block (4 waves x 32)
-constexpr int BN = 256;          // anchor columns per block (8 MFMA tiles of 32 per wave)
-constexpr int BK = 64;           // depth staged in LDS at a time
-constexpr int LDP = BK + 1;      // padded leading dimension: fragment reads and staging writes conflict-free
-constexpr int NT = BN / 32;
+constexpr int PM = 64, PN = 128;     // rows of X x anchor columns per block: 4 waves as 2 x 2, each 32 x 64 (two MFMA tiles)
 
 // One wave per row: sum of squares in f64 (sklearn row_norms on the upcast chunk).
 __global__ __launch_bounds__(256) void k_sqnorm(const float *__restrict__ m, long long rows, int D, double *__restrict__ out) {
@@ -48,83 +43,41 @@ __device__ __forceinline__ float direct_sqdist(const float *__restrict__ x, cons
     return acc;
 }
 
-// grid = (ceil(N / BM), ceil(K / BN)).  LDS: X tile [BM][LDP] + anchor tile [BN][LDP] + norms + reduction scratch.
+// grid = (ceil(N / PM), ceil(K / PN)).  dot(X, A^T) on the shared MFMA tile machinery (gemm_tile.h), then the metric
+// epilogue, the raw values into out[:, c0:], and this block's column min / max.
 __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, int N, int D, const float *__restrict__ A,
                                                   int K, int metric, const double *__restrict__ xx, const double *__restrict__ aa,
                                                   float *__restrict__ out, long long out_cols, int c0,
                                                   float *__restrict__ part_min, float *__restrict__ part_max, int Kpad) {
+    constexpr int NT = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *Xs = reinterpret_cast<float *>(smem);                   // [BM][LDP]
-    float *As = Xs + BM * LDP;                                     // [BN][LDP]
-    float *red_min = As + BN * LDP;                                // [4][BN]
-    float *red_max = red_min + 4 * BN;                             // [4][BN]
-
+    float *As = reinterpret_cast<float *>(smem);
+    float *Bs = As + Tile<PM>::FLOATS;
+    __shared__ float red_min[2][PN], red_max[2][PN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+    const int wm = wave % 2, wn = wave / 2;
+    const int row0 = blockIdx.x * PM, col0 = blockIdx.y * PN;
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-
-    for (int k0 = 0; k0 < D; k0 += BK) {
-        // stage: 16 consecutive threads read one row's 64 floats (256 contiguous bytes); zero beyond N / K / D
-        for (int idx = tid; idx < BM * (BK / 4); idx += 256) {
-            const int r = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (row0 + r < N) {
-                const float *p = X + (size_t)(row0 + r) * D + k0 + kq;
-                if (k0 + kq + 3 < D && (D & 3) == 0) {
-                    const float4 q = *reinterpret_cast<const float4 *>(p);
-                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-                } else {
-                    for (int i = 0; i < 4; ++i) if (k0 + kq + i < D) v[i] = p[i];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) Xs[r * LDP + kq + i] = v[i];
-        }
-        for (int idx = tid; idx < BN * (BK / 4); idx += 256) {
-            const int r = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (col0 + r < K) {
-                const float *p = A + (size_t)(col0 + r) * D + k0 + kq;
-                if (k0 + kq + 3 < D && (D & 3) == 0) {
-                    const float4 q = *reinterpret_cast<const float4 *>(p);
-                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-                } else {
-                    for (int i = 0; i < 4; ++i) if (k0 + kq + i < D) v[i] = p[i];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) As[r * LDP + kq + i] = v[i];
-        }
-        __syncthreads();
-        // v_mfma_f32_32x32x2_f32: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]
-        const float *xa = Xs + (wave * 32 + (lane & 31)) * LDP + (lane >> 5);
-        const float *ab = As + (lane & 31) * LDP + (lane >> 5);
-#pragma unroll 4
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a = xa[kk];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ab[t * 32 * LDP + kk], acc[t], 0, 0, 0);
-        }
-        __syncthreads();
-    }
+    const Operand Xo{X, D, 1}, Ao{A, D, 1}, none{nullptr, 0, 0};
+    mfma_accumulate<PM, PN, 2, 2>(acc, Xo, Ao, 0, D, none, none, 0, 0, row0, col0, N, K, As, Bs);
 
     // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const float inf = __builtin_huge_valf();
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int col = col0 + t * 32 + (lane & 31);
+        const int cl = wn * (PN / 2) + t * 32 + (lane & 31);              // column inside the block
+        const int col = col0 + cl;
         const bool col_ok = col < K;
         const double a2 = col_ok ? aa[col] : 0.0;
         const float na = col_ok ? (a2 == 0.0 ? 1.0f : (float)sqrt(a2)) : 1.0f;
         float cmin = inf, cmax = -inf;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < N && col_ok) {
                 const float dot = acc[t][r];
                 const double x2 = xx[row];
@@ -148,29 +101,55 @@ __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, i
         cmin = fminf(cmin, __shfl_xor(cmin, 32));
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
         if (lane < 32) {
-            red_min[wave * BN + t * 32 + lane] = cmin;
-            red_max[wave * BN + t * 32 + lane] = cmax;
+            red_min[wm][cl] = cmin;
+            red_max[wm][cl] = cmax;
         }
     }
     __syncthreads();
-    if (tid < BN && col0 + tid < K) {
-        const float mn = fminf(fminf(red_min[tid], red_min[BN + tid]), fminf(red_min[2 * BN + tid], red_min[3 * BN + tid]));
-        const float mx = fmaxf(fmaxf(red_max[tid], red_max[BN + tid]), fmaxf(red_max[2 * BN + tid], red_max[3 * BN + tid]));
-        part_min[(size_t)blockIdx.x * Kpad + col0 + tid] = mn;
-        part_max[(size_t)blockIdx.x * Kpad + col0 + tid] = mx;
+    if (tid < PN && col0 + tid < K) {
+        part_min[(size_t)blockIdx.x * Kpad + col0 + tid] = fminf(red_min[0][tid], red_min[1][tid]);
+        part_max[(size_t)blockIdx.x * Kpad + col0 + tid] = fmaxf(red_max[0][tid], red_max[1][tid]);
     }
 }
 
-// sklearn MinMaxScaler.fit (_data.py:456-567) with feature_range (0, 1), all in float32.
-__global__ __launch_bounds__(256) void k_minmax_reduce(const float *__restrict__ part_min, const float *__restrict__ part_max,
-                                                       int nblocks, int K, int Kpad, float *__restrict__ scale,
+// Column min / max over the per-block partials, two stages (a single pass over ~1 400 partial rows by one thread per
+// column is a 400 us chain of dependent loads): stage 1 folds the partial rows into RSPLIT rows, stage 2 finishes and
+// applies sklearn MinMaxScaler.fit (_data.py:456-567) with feature_range (0, 1), all in float32.
+constexpr int RSPLIT = 64;
+
+__global__ __launch_bounds__(256) void k_minmax_fold(const float *__restrict__ part_min, const float *__restrict__ part_max,
+                                                     int nblocks, int K, int Kpad, float *__restrict__ fold_min,
+                                                     float *__restrict__ fold_max) {
+    __shared__ float smin[4][64], smax[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int per = (nblocks + RSPLIT - 1) / RSPLIT;
+    const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+    float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
+    if (j < K)
+        for (int b = b0 + wave; b < b1; b += 4) {
+            mn = fminf(mn, part_min[(size_t)b * Kpad + j]);
+            mx = fmaxf(mx, part_max[(size_t)b * Kpad + j]);
+        }
+    smin[wave][lane] = mn;
+    smax[wave][lane] = mx;
+    __syncthreads();
+    if (wave == 0 && j < K) {
+        fold_min[(size_t)blockIdx.y * Kpad + j] = fminf(fminf(smin[0][lane], smin[1][lane]), fminf(smin[2][lane], smin[3][lane]));
+        fold_max[(size_t)blockIdx.y * Kpad + j] = fmaxf(fmaxf(smax[0][lane], smax[1][lane]), fmaxf(smax[2][lane], smax[3][lane]));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_minmax_reduce(const float *__restrict__ fold_min, const float *__restrict__ fold_max,
+                                                       int K, int Kpad, float *__restrict__ scale,
                                                        float *__restrict__ shift) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= K) return;
     float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
-    for (int b = 0; b < nblocks; ++b) {
-        mn = fminf(mn, part_min[(size_t)b * Kpad + j]);
-        mx = fmaxf(mx, part_max[(size_t)b * Kpad + j]);
+#pragma unroll 8
+    for (int b = 0; b < RSPLIT; ++b) {
+        mn = fminf(mn, fold_min[(size_t)b * Kpad + j]);
+        mx = fmaxf(mx, fold_max[(size_t)b * Kpad + j]);
     }
     float range = mx - mn;
     if (range < 10.0f * 1.1920929e-07f) range = 1.0f;             // _handle_zeros_in_scale: < 10 * eps -> 1
@@ -191,22 +170,24 @@ __global__ __launch_bounds__(256) void k_minmax_apply(float *__restrict__ out, i
     }
 }
 
-static size_t pw_lds_bytes() { return (size_t)(BM * LDP + BN * LDP + 8 * BN) * sizeof(float); }
+static size_t pw_lds_bytes() { return tile_lds_bytes<PM, PN>(); }
 
 struct PwLayout {
-    size_t xx, aa, pmin, pmax, scale, shift, total;
+    size_t xx, aa, pmin, pmax, fmin, fmax, scale, shift, total;
     int nblocks, Kpad;
 };
 
 static PwLayout pw_layout(int64_t N, int32_t K) {
     PwLayout L;
-    L.nblocks = (int)((N + BM - 1) / BM);
-    L.Kpad = (K + BN - 1) / BN * BN;
+    L.nblocks = (int)((N + PM - 1) / PM);
+    L.Kpad = (K + PN - 1) / PN * PN;
     size_t o = 0;
     L.xx = o;    o += align_up((size_t)N * sizeof(double), 256);
     L.aa = o;    o += align_up((size_t)K * sizeof(double), 256);
     L.pmin = o;  o += align_up((size_t)L.nblocks * L.Kpad * sizeof(float), 256);
     L.pmax = o;  o += align_up((size_t)L.nblocks * L.Kpad * sizeof(float), 256);
+    L.fmin = o;  o += align_up((size_t)RSPLIT * L.Kpad * sizeof(float), 256);
+    L.fmax = o;  o += align_up((size_t)RSPLIT * L.Kpad * sizeof(float), 256);
     L.scale = o; o += align_up((size_t)K * sizeof(float), 256);
     L.shift = o; o += align_up((size_t)K * sizeof(float), 256);
     L.total = o;
@@ -239,6 +220,7 @@ extern "C" int pope_pairwise_minmax(const float *X, int64_t N, int32_t D, const 
     char *base = (char *)scratch;
     double *xx = (double *)(base + L.xx), *aa = (double *)(base + L.aa);
     float *pmin = (float *)(base + L.pmin), *pmax = (float *)(base + L.pmax);
+    float *fmin = (float *)(base + L.fmin), *fmax = (float *)(base + L.fmax);
     float *scale = (float *)(base + L.scale), *shift = (float *)(base + L.shift);
 
     hipLaunchKernelGGL(k_sqnorm, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, X, (long long)N, D, xx);
@@ -248,9 +230,10 @@ extern "C" int pope_pairwise_minmax(const float *X, int64_t N, int32_t D, const 
         POPE_HIP(hipFuncSetAttribute((const void *)k_pairwise, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pw_lds_bytes()));
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL(k_pairwise, dim3(L.nblocks, L.Kpad / BN), dim3(256), pw_lds_bytes(), stream, X, (int)N, D, A, K, metric,
+    hipLaunchKernelGGL(k_pairwise, dim3(L.nblocks, L.Kpad / PN), dim3(256), pw_lds_bytes(), stream, X, (int)N, D, A, K, metric,
                        xx, aa, out, (long long)out_cols, c0, pmin, pmax, L.Kpad);
-    hipLaunchKernelGGL(k_minmax_reduce, dim3((K + 255) / 256), dim3(256), 0, stream, pmin, pmax, L.nblocks, K, L.Kpad, scale, shift);
+    hipLaunchKernelGGL(k_minmax_fold, dim3((K + 63) / 64, RSPLIT), dim3(256), 0, stream, pmin, pmax, L.nblocks, K, L.Kpad, fmin, fmax);
+    hipLaunchKernelGGL(k_minmax_reduce, dim3((K + 255) / 256), dim3(256), 0, stream, fmin, fmax, K, L.Kpad, scale, shift);
     hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K,
                        (long long)out_cols, c0, scale, shift);
     POPE_HIP(hipGetLastError());

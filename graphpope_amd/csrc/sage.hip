@@ -13,13 +13,9 @@
 //                    (reduction over ~40 000 rows), deterministic: no float atomics there.
 //   k_scatter_mean   grad_x[col[p]] += grad_agg[i] / deg(i) (float atomics, whole 16-byte-aligned row segments)
 //   k_colsum_*       grad_bias, two deterministic stages
-#include "common.h"
+#include "gemm_tile.h"
 
 namespace pope {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int GK = 64, GLD = GK + 1;          // depth per LDS stage, padded leading dimension
 
 // ------------------------------------------------------------------------------------------------
 // neighbour gather + mean
@@ -111,105 +107,20 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// f32 MFMA GEMM tile
+// f32 MFMA GEMM (tile machinery in gemm_tile.h)
 // ------------------------------------------------------------------------------------------------
-struct Operand {            // element (outer index i, depth k) lives at p[i * s_outer + k * s_k]
-    const float *p;
-    long long s_outer, s_k;
-};
-
-// A [ROWS x GK] slice of an operand (outer range [o0, o0 + ROWS), depth [k0, k0 + GK)) travels global -> registers ->
-// LDS in two steps so that the global loads of stage s+1 are in flight while the MFMAs of stage s run.
-// LDS image, chosen by which index is contiguous in memory:
-//   depth contiguous  (s_k == 1):      [row][GK + 1]    scalar stores, fragment reads conflict-free
-//   outer contiguous  (s_outer == 1):  [k][ROWS + 4]    one 16-byte store per load, fragment reads conflict-free
-template <int ROWS>
-struct Tile {
-    static constexpr int NL = ROWS * GK / 4 / 256;             // float4 loads per thread
-    static constexpr int LDK = ROWS + 4;                        // leading dimension of the k-major image
-    static constexpr int FLOATS = (ROWS * GLD > GK * LDK) ? ROWS * GLD : GK * LDK;
-
-    __device__ static __forceinline__ void load(float4 (&reg)[NL], const Operand &op, int o0, int o_end, int k0, int k_end,
-                                                int tid) {
-        const bool aligned = (reinterpret_cast<uintptr_t>(op.p) & 15) == 0;
-        if (op.s_k == 1) {                                      // 16 consecutive threads read 64 floats of one row
-            const bool vec = aligned && (op.s_outer & 3) == 0;
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int idx = tid + 256 * i, r = idx / (GK / 4), kq = (idx % (GK / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (o0 + r < o_end) {
-                    const float *p = op.p + (size_t)(o0 + r) * op.s_outer + k0 + kq;
-                    if (vec && k0 + kq + 3 < k_end) {
-                        v = *reinterpret_cast<const float4 *>(p);
-                    } else {
-                        if (k0 + kq < k_end) v.x = p[0];
-                        if (k0 + kq + 1 < k_end) v.y = p[1];
-                        if (k0 + kq + 2 < k_end) v.z = p[2];
-                        if (k0 + kq + 3 < k_end) v.w = p[3];
-                    }
-                }
-                reg[i] = v;
-            }
-        } else {                                                // read along the outer index
-            const bool vec = aligned && op.s_outer == 1 && (op.s_k & 3) == 0;
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int idx = tid + 256 * i, k = idx / (ROWS / 4), rq = (idx % (ROWS / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k0 + k < k_end) {
-                    const float *p = op.p + (size_t)(k0 + k) * op.s_k + (size_t)(o0 + rq) * op.s_outer;
-                    if (vec && o0 + rq + 3 < o_end) {
-                        v = *reinterpret_cast<const float4 *>(p);
-                    } else {
-                        if (o0 + rq < o_end) v.x = p[0];
-                        if (o0 + rq + 1 < o_end) v.y = p[(size_t)op.s_outer];
-                        if (o0 + rq + 2 < o_end) v.z = p[(size_t)2 * op.s_outer];
-                        if (o0 + rq + 3 < o_end) v.w = p[(size_t)3 * op.s_outer];
-                    }
-                }
-                reg[i] = v;
-            }
-        }
-    }
-
-    __device__ static __forceinline__ void store(float *__restrict__ lds, const float4 (&reg)[NL], bool k_contig, int tid) {
-        if (k_contig) {
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int idx = tid + 256 * i, r = idx / (GK / 4), kq = (idx % (GK / 4)) * 4;
-                float *d = lds + r * GLD + kq;
-                d[0] = reg[i].x; d[1] = reg[i].y; d[2] = reg[i].z; d[3] = reg[i].w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int idx = tid + 256 * i, k = idx / (ROWS / 4), rq = (idx % (ROWS / 4)) * 4;
-                *reinterpret_cast<float4 *>(lds + k * LDK + rq) = reg[i];
-            }
-        }
-    }
-};
-
 // C[M, N] = sum_{p < 2} A_p[M, K_p] * B_p[N, K_p]^T (+ bias[n]).  grid = (ceil(M/TM), ceil(N/TN), splits).
-// 4 waves as WM x WN; a wave owns 32 rows x (TN / WN) columns = NT accumulator tiles of 32 x 32
-// (v_mfma_f32_32x32x2_f32: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]).
-// The depth is walked in stages of GK = 64; the next stage's global loads are issued before the current stage's
-// MFMAs and written to LDS after them (register double buffering, one LDS image).
 // splits > 1: every z handles a slice of the depth of every product and writes its partial tile to
 // slab[z][M][N]; k_slab_reduce adds them (fixed order: deterministic).
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Operand A1, Operand B1, int K1, int M, int N,
                                               const float *__restrict__ bias, float *__restrict__ C, long long ldc,
                                               float *__restrict__ slab) {
-    static_assert(WM * WN == 4 && TM == WM * 32 && TN % (WN * 32) == 0, "tile shape");
     constexpr int NT = TN / WN / 32;
-    using TA = Tile<TM>;
-    using TB = Tile<TN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *As = reinterpret_cast<float *>(smem);
-    float *Bs = As + TA::FLOATS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *Bs = As + Tile<TM>::FLOATS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
     const int splits = gridDim.z, z = blockIdx.z;
@@ -218,56 +129,11 @@ __global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Op
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-
     // depth range of this split inside each product, in whole LDS stages
     const int per0 = K0 > 0 ? ((K0 + splits - 1) / splits + GK - 1) / GK * GK : 0;
     const int per1 = K1 > 0 ? ((K1 + splits - 1) / splits + GK - 1) / GK * GK : 0;
     const int kb0 = z * per0, ke0 = min(K0, kb0 + per0), kb1 = z * per1, ke1 = min(K1, kb1 + per1);
-    const int S0 = ke0 > kb0 ? (ke0 - kb0 + GK - 1) / GK : 0, S1 = ke1 > kb1 ? (ke1 - kb1 + GK - 1) / GK : 0;
-    const int S = S0 + S1;
-
-    float4 ra[TA::NL], rb[TB::NL];
-    auto fetch = [&](int s) {                                   // global -> registers for stage s
-        const bool second = s >= S0;
-        const Operand &A = second ? A1 : A0;
-        const Operand &B = second ? B1 : B0;
-        const int k0 = second ? kb1 + (s - S0) * GK : kb0 + s * GK, ke = second ? ke1 : ke0;
-        TA::load(ra, A, m0, M, k0, ke, tid);
-        TB::load(rb, B, n0, N, k0, ke, tid);
-    };
-    if (S > 0) fetch(0);
-    for (int s = 0; s < S; ++s) {
-        const bool second = s >= S0;
-        const bool a_kc = (second ? A1 : A0).s_k == 1, b_kc = (second ? B1 : B0).s_k == 1;
-        __syncthreads();                                        // previous stage's fragment reads are done
-        TA::store(As, ra, a_kc, tid);
-        TB::store(Bs, rb, b_kc, tid);
-        __syncthreads();
-        if (s + 1 < S) fetch(s + 1);                            // in flight while the MFMAs below run
-        const float *xa = a_kc ? As + (wm * 32 + (lane & 31)) * GLD + (lane >> 5)
-                               : As + (lane >> 5) * TA::LDK + wm * 32 + (lane & 31);
-        const float *xb = b_kc ? Bs + (wn * (TN / WN) + (lane & 31)) * GLD + (lane >> 5)
-                               : Bs + (lane >> 5) * TB::LDK + wn * (TN / WN) + (lane & 31);
-        const int ask = a_kc ? 1 : TA::LDK, bsk = b_kc ? 1 : TB::LDK, bst = b_kc ? 32 * GLD : 32;
-        // Fragments are read from LDS in batches of KB k-steps into registers BEFORE the MFMAs that use them: with one
-        // wave per SIMD nothing else hides the LDS latency, and a read-wait-MFMA sequence per step idles the matrix pipe.
-        constexpr int KB = NT <= 2 ? 16 : 4;
-#pragma unroll 1
-        for (int k0 = 0; k0 < GK / 2; k0 += KB) {
-            float fa[KB], fb[NT][KB];
-#pragma unroll
-            for (int j = 0; j < KB; ++j) {
-                fa[j] = xa[(k0 + j) * 2 * ask];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) fb[t][j] = xb[t * bst + (k0 + j) * 2 * bsk];
-            }
-#pragma unroll
-            for (int j = 0; j < KB; ++j)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[t][j], acc[t], 0, 0, 0);
-        }
-    }
+    mfma_accumulate<TM, TN, WM, WN>(acc, A0, B0, kb0, ke0, A1, B1, kb1, ke1, m0, n0, M, N, As, Bs);
     // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     float *dst = splits > 1 ? slab + (size_t)z * M * N : C;
     const long long ld = splits > 1 ? (long long)N : ldc;
@@ -296,7 +162,7 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float *__restrict__ s
 template <int TM, int TN, int WM, int WN>
 static int launch_gemm(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1, int M,
                        int N, const float *bias, float *C, long long ldc, int splits, float *slab, hipStream_t stream) {
-    const size_t lds = (size_t)(Tile<TM>::FLOATS + Tile<TN>::FLOATS) * sizeof(float);
+    const size_t lds = tile_lds_bytes<TM, TN>();
     static bool opt_in = false;
     if (!opt_in) {
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm<TM, TN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -45,6 +45,7 @@ __device__ __forceinline__ float direct_sqdist(const float *__restrict__ x, cons
 
 // grid = (ceil(N / PM), ceil(K / PN)).  dot(X, A^T) on the shared MFMA tile machinery (gemm_tile.h), then the metric
 // epilogue, the raw values into out[:, c0:], and this block's column min / max.
+template <int LAYOUT>
 __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, int N, int D, const float *__restrict__ A,
                                                   int K, int metric, const double *__restrict__ xx, const double *__restrict__ aa,
                                                   float *__restrict__ out, long long out_cols, int c0,
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const Operand Xo{X, D, 1}, Ao{A, D, 1}, none{nullptr, 0, 0};
-    mfma_accumulate<PM, PN, 2, 2>(acc, Xo, Ao, 0, D, none, none, 0, 0, row0, col0, N, K, As, Bs);
+    mfma_accumulate<PM, PN, 2, 2, LAYOUT, LAYOUT>(acc, Xo, Ao, 0, D, none, none, 0, 0, row0, col0, N, K, As, Bs);
 
     // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const float inf = __builtin_huge_valf();
@@ -225,13 +226,20 @@ extern "C" int pope_pairwise_minmax(const float *X, int64_t N, int32_t D, const 
 
     hipLaunchKernelGGL(k_sqnorm, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, X, (long long)N, D, xx);
     hipLaunchKernelGGL(k_sqnorm, dim3(capped_grid((size_t)K * 64, 256)), dim3(256), 0, stream, A, (long long)K, D, aa);
+    const Operand Xo{X, D, 1}, Ao{A, D, 1};
+    const bool vec = pick_layout(Xo, (int)N, D) == LAYOUT_KC_VEC && pick_layout(Ao, K, D) == LAYOUT_KC_VEC;
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        POPE_HIP(hipFuncSetAttribute((const void *)k_pairwise, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pw_lds_bytes()));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_pairwise<LAYOUT_KC_VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pw_lds_bytes()));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_pairwise<LAYOUT_GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pw_lds_bytes()));
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL(k_pairwise, dim3(L.nblocks, L.Kpad / PN), dim3(256), pw_lds_bytes(), stream, X, (int)N, D, A, K, metric,
-                       xx, aa, out, (long long)out_cols, c0, pmin, pmax, L.Kpad);
+    if (vec)
+        hipLaunchKernelGGL(k_pairwise<LAYOUT_KC_VEC>, dim3(L.nblocks, L.Kpad / PN), dim3(256), pw_lds_bytes(), stream, X, (int)N, D, A, K, metric,
+                           xx, aa, out, (long long)out_cols, c0, pmin, pmax, L.Kpad);
+    else
+        hipLaunchKernelGGL(k_pairwise<LAYOUT_GENERIC>, dim3(L.nblocks, L.Kpad / PN), dim3(256), pw_lds_bytes(), stream, X, (int)N, D, A, K, metric,
+                           xx, aa, out, (long long)out_cols, c0, pmin, pmax, L.Kpad);
     hipLaunchKernelGGL(k_minmax_fold, dim3((K + 63) / 64, RSPLIT), dim3(256), 0, stream, pmin, pmax, L.nblocks, K, L.Kpad, fmin, fmax);
     hipLaunchKernelGGL(k_minmax_reduce, dim3((K + 255) / 256), dim3(256), 0, stream, fmin, fmax, K, L.Kpad, scale, shift);
     hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K,

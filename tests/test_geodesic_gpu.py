@@ -206,3 +206,27 @@ def test_graphpope_entry_point(dev, oracle):
     with pytest.raises(UnboundLocalError):
         gp.Graphpope(d, "flickr", "geodesic", "no_such_method", 4)
     gp.clear_cache()
+
+
+def test_random_graphs_property_sweep(dev, oracle):
+    """60 small random graphs (directed and symmetric, sorted and shuffled edge lists, isolated nodes, every word tiling):
+    hop matrix bit-exact against the oracle.  Sizes straddle the 256-slot chunk and 4-slot lane boundaries."""
+    from graphpope_amd import engine
+    rs = np.random.RandomState(2024)
+    for trial in range(60):
+        n = int(rs.choice([2, 3, 5, 17, 64, 65, 200, 257, 1000]))
+        e = int(rs.choice([0, 1, 3, 4, 5, 255, 256, 257, 511, 1024, 1030, 4099]))
+        ei = rs.randint(0, n, size=(2, e)).astype(np.int64)
+        if trial % 3 == 0 and e:
+            ei = np.concatenate([ei, ei[::-1]], axis=1)                    # symmetric
+        if trial % 2 == 0 and ei.shape[1]:
+            ei = ei[:, np.lexsort((ei[1], ei[0]))]                           # sorted by source: fast CSR path
+        if trial % 5 == 0 and ei.shape[1] > 300:
+            ei[0, :300] = ei[0, 0]                                          # one long row (hub spanning chunks)
+            ei = ei[:, np.lexsort((ei[1], ei[0]))]
+        k = int(rs.choice([1, 2, 63, 64, 65, 128, 129, 257]))
+        anchors = rs.randint(0, n, size=k)
+        _, hp = engine.geodesic_run(None, torch.as_tensor(ei, device=dev), n, anchors, want_out=False)
+        got = engine.hop_matrix(hp).cpu().numpy()
+        want = oracle.geodesic_hops(ei, n, anchors)
+        assert np.array_equal(got, want), (trial, n, ei.shape[1], k)

@@ -1,0 +1,242 @@
+// GPU fan-out neighbour sampling for the GraphSAGE mini-batches.
+//
+// Replaces the host side of /root/reference/main.py:100-116: PyG NeighborSampler(adj_t, sizes=[25, 10]) ->
+// torch_sparse.sample_adj in DataLoader worker processes, followed by the host gather data.x[n_id] (main.py:118-123).
+// One hop = for every target node keep all its neighbours if it has at most `fanout`, else `fanout` DISTINCT ones,
+// then relabel: the new node list is the targets (same order) followed by the newly met nodes in order of first
+// appearance, and the block's CSR uses those local ids -- the layout sage_conv_forward consumes.
+//
+// Sampling without replacement needs no per-row state here: slot j of a row with d > fanout neighbours takes
+// neighbour perm(j), where perm is a keyed pseudo-random PERMUTATION of [0, d) (4-round Feistel network on the next
+// even power of two, cycle-walked into range); the first `fanout` outputs of a permutation are distinct by
+// construction.  The key mixes the caller's seed, the hop and the node id, so the sample is a pure function of its
+// arguments: the CPU checker used by the tests restates it and the comparison is bit for bit.  (The reference's own random stream --
+// torch_sparse's C++ RNG inside DataLoader workers -- is not reproducible outside that stack: SURVEY.md §7 trap 9.)
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include "common.h"
+
+namespace pope {
+
+__host__ __device__ __forceinline__ unsigned mix32(unsigned h) {
+    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    h ^= h >> 12; h *= 0x297A2D39u;
+    h ^= h >> 15;
+    return h;
+}
+
+__host__ __device__ __forceinline__ unsigned row_key(unsigned long long seed, int hop, int node) {
+    return mix32((unsigned)seed ^ mix32((unsigned)(seed >> 32) + 0x9E3779B1u * (unsigned)(hop + 1)) ^ mix32((unsigned)node * 0x85EBCA6Bu + 0x165667B1u));
+}
+
+// Keyed permutation of [0, d): Feistel on 2 * hb bits (the smallest even width covering d), cycle-walked.
+__host__ __device__ __forceinline__ int feistel_perm(int i, int d, unsigned key) {
+    int bits = 2;
+    while ((1 << bits) < d) ++bits;
+    const int hb = (bits + 1) >> 1;
+    const unsigned mask = (1u << hb) - 1u;
+    unsigned x = (unsigned)i;
+    do {
+        unsigned l = x >> hb, r = x & mask;
+#pragma unroll
+        for (int round = 0; round < 4; ++round) {
+            const unsigned f = mix32(r * 0x9E3779B1u + key + (unsigned)round * 0x85EBCA6Bu) & mask;
+            const unsigned nl = r;
+            r = l ^ f;
+            l = nl;
+        }
+        x = (l << hb) | r;
+    } while (x >= (unsigned)d);
+    return (int)x;
+}
+
+__global__ __launch_bounds__(256) void k_sample_count(const int *__restrict__ rowptr, const long long *__restrict__ targets,
+                                                      int T, int fanout, int *__restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > T) return;
+    int c = 0;
+    if (i < T) {
+        const long long g = targets[i];
+        const int d = rowptr[g + 1] - rowptr[g];
+        c = (fanout < 0 || d <= fanout) ? d : fanout;
+    }
+    cnt[i] = c;                                                    // cnt[T] = 0: the scan then yields rowptr_out[T] = nnz
+}
+
+// map[g] = smallest "position key" at which node g occurs: targets occupy keys [0, T), sampled slot p key T + p.
+__global__ __launch_bounds__(256) void k_sample_targets(const long long *__restrict__ targets, int T, int *__restrict__ map) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T) map[targets[i]] = i;                               // target lists hold distinct nodes
+}
+
+__global__ __launch_bounds__(256) void k_sample_pick(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                     const long long *__restrict__ targets, int T, int fanout,
+                                                     unsigned long long seed, int hop, const int *__restrict__ out_rowptr,
+                                                     int *__restrict__ picked, int *__restrict__ map) {
+    const int stride = fanout < 0 ? 1 : fanout;
+    const long long total = (long long)T * stride;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(q / stride), j = (int)(q % stride);
+        const int beg_out = out_rowptr[i], c = out_rowptr[i + 1] - beg_out;
+        if (j >= c) continue;
+        const int g = (int)targets[i];
+        const int beg = rowptr[g], d = rowptr[g + 1] - beg;
+        const int pick = d <= c ? j : feistel_perm(j, d, row_key(seed, hop, g));
+        const int u = col[beg + pick];
+        const int p = beg_out + j;
+        picked[p] = u;
+        atomicMin(&map[u], T + p);
+    }
+}
+
+// fanout < 0 ("all neighbours"): rows are copied whole, one thread per output slot.
+__global__ __launch_bounds__(256) void k_sample_all(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                    const long long *__restrict__ targets, int T,
+                                                    const int *__restrict__ out_rowptr, int *__restrict__ picked,
+                                                    int *__restrict__ map) {
+    const int i = blockIdx.x;                                      // one block per target row
+    if (i >= T) return;
+    const int g = (int)targets[i];
+    const int beg = rowptr[g], beg_out = out_rowptr[i], c = out_rowptr[i + 1] - beg_out;
+    for (int j = threadIdx.x; j < c; j += blockDim.x) {
+        const int u = col[beg + j];
+        picked[beg_out + j] = u;
+        atomicMin(&map[u], T + beg_out + j);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sample_flag(const int *__restrict__ picked, int nnz, int T, const int *__restrict__ map,
+                                                     int *__restrict__ first) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > nnz) return;
+    first[p] = (p < nnz && map[picked[p]] == T + p) ? 1 : 0;      // first[nnz] = 0: the scan yields the number of new nodes
+}
+
+__global__ __launch_bounds__(256) void k_sample_assign(const int *__restrict__ picked, int nnz, int T, const int *__restrict__ first,
+                                                       const int *__restrict__ rank, long long *__restrict__ n_id,
+                                                       int *__restrict__ newid) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz || !first[p]) return;
+    const int u = picked[p];
+    n_id[T + rank[p]] = u;
+    newid[u] = T + rank[p];                                        // separate array: map still holds keys other threads compare
+}
+
+__global__ __launch_bounds__(256) void k_sample_relabel(const int *__restrict__ picked, int nnz, int T, const int *__restrict__ map,
+                                                        const int *__restrict__ newid, int *__restrict__ out_col) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    const int u = picked[p], k = map[u];
+    out_col[p] = k < T ? k : newid[u];
+}
+
+__global__ void k_sample_nnz(const int *__restrict__ out_rowptr, int T, long long *__restrict__ report) { report[0] = out_rowptr[T]; }
+
+__global__ void k_sample_report(const int *__restrict__ out_rowptr, const int *__restrict__ rank, int T,
+                                long long *__restrict__ report) {
+    const int nnz = out_rowptr[T];
+    report[0] = nnz;
+    report[1] = T + rank[nnz];                                     // n_src: targets + distinct new nodes
+}
+
+static size_t scan_bytes(size_t n) {
+    size_t bytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, bytes, (int *)nullptr, (int *)nullptr, 0, n, rocprim::plus<int>());
+    return bytes;
+}
+
+struct SampleLayout {
+    size_t cnt, picked, first, rank, map, newid, report, scan, total;
+    int cap;
+};
+
+static SampleLayout sample_layout(int64_t N, int64_t T, int64_t cap) {
+    SampleLayout L;
+    L.cap = (int)cap;
+    size_t o = 0;
+    L.cnt = o;    o += align_up((size_t)(T + 1) * 4, 256);
+    L.picked = o; o += align_up((size_t)(cap + 1) * 4, 256);
+    L.first = o;  o += align_up((size_t)(cap + 1) * 4, 256);
+    L.rank = o;   o += align_up((size_t)(cap + 1) * 4, 256);
+    L.map = o;    o += align_up((size_t)N * 4, 256);
+    L.newid = o;  o += align_up((size_t)N * 4, 256);
+    L.report = o; o += 256;
+    L.scan = o;   o += align_up(scan_bytes((size_t)(cap > T ? cap : T) + 1), 256);
+    L.total = o;
+    return L;
+}
+
+}  // namespace pope
+
+using namespace pope;
+
+extern "C" size_t sage_sample_scratch_bytes(int64_t N, int64_t n_targets, int64_t nnz_capacity) {
+    if (N <= 0 || n_targets <= 0 || nnz_capacity < 0) return 0;
+    return sample_layout(N, n_targets, nnz_capacity).total;
+}
+
+extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *targets, int64_t n_targets,
+                               int32_t fanout, uint64_t seed, int32_t hop, int32_t *out_rowptr, int32_t *out_col,
+                               int64_t nnz_capacity, int64_t *out_n_id, int64_t *nnz_host, int64_t *n_src_host, void *scratch,
+                               size_t scratch_bytes, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(rowptr && col && targets && out_rowptr && out_col && out_n_id && scratch && nnz_host && n_src_host,
+                 "sage_sample_hop: null pointer");
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && n_targets > 0 && n_targets < INT32_MAX && nnz_capacity >= 0 && nnz_capacity < INT32_MAX,
+                 "sage_sample_hop: bad size");
+    POPE_REQUIRE(fanout != 0, "sage_sample_hop: fanout must be > 0, or < 0 for all neighbours");
+    POPE_REQUIRE(fanout < 0 || nnz_capacity >= n_targets * (int64_t)fanout, "sage_sample_hop: nnz_capacity %lld < n_targets * fanout",
+                 (long long)nnz_capacity);
+    const SampleLayout L = sample_layout(N, n_targets, nnz_capacity);
+    if (scratch_bytes < L.total) {
+        set_error("sage_sample_hop: scratch %zu < %zu bytes", scratch_bytes, L.total);
+        return POPE_ERR_WORKSPACE;
+    }
+    char *base = (char *)scratch;
+    int *cnt = (int *)(base + L.cnt), *picked = (int *)(base + L.picked), *first = (int *)(base + L.first);
+    int *rank = (int *)(base + L.rank), *map = (int *)(base + L.map), *newid = (int *)(base + L.newid);
+    long long *report = (long long *)(base + L.report);
+    void *scan_tmp = base + L.scan;
+    size_t sb = L.total - L.scan;
+    const int T = (int)n_targets;
+
+    hipLaunchKernelGGL(k_sample_count, dim3((T + 256) / 256), dim3(256), 0, stream, rowptr, (const long long *)targets, T, fanout, cnt);
+    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, cnt, out_rowptr, 0, (size_t)T + 1, rocprim::plus<int>(), stream));
+    POPE_HIP(hipMemsetAsync(map, 0x7F, (size_t)N * 4, stream));                       // 0x7F7F7F7F: larger than any key
+    hipLaunchKernelGGL(k_sample_targets, dim3((T + 255) / 256), dim3(256), 0, stream, (const long long *)targets, T, map);
+    POPE_HIP(hipMemcpyAsync(out_n_id, targets, (size_t)T * sizeof(long long), hipMemcpyDeviceToDevice, stream));
+    if (fanout < 0) {
+        // all neighbours: the total is only known on the device; the caller sized nnz_capacity for it
+        hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, picked, map);
+    } else {
+        hipLaunchKernelGGL(k_sample_pick, dim3(capped_grid((size_t)T * fanout, 256)), dim3(256), 0, stream, rowptr, col,
+                           (const long long *)targets, T, fanout, (unsigned long long)seed, hop, out_rowptr, picked, map);
+    }
+    // the edge count is known on the device only when rows are copied whole: one small readback either way
+    long long rep[2] = {0, 0};
+    hipLaunchKernelGGL(k_sample_nnz, dim3(1), dim3(1), 0, stream, out_rowptr, T, report);
+    POPE_HIP(hipMemcpyAsync(rep, report, sizeof(long long), hipMemcpyDeviceToHost, stream));
+    POPE_HIP(hipStreamSynchronize(stream));
+    const int nnz = (int)rep[0];
+    if (nnz > nnz_capacity) {
+        set_error("sage_sample_hop: %d sampled edges exceed nnz_capacity %lld", nnz, (long long)nnz_capacity);
+        return POPE_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(k_sample_flag, dim3((nnz + 256) / 256), dim3(256), 0, stream, picked, nnz, T, map, first);
+    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, first, rank, 0, (size_t)nnz + 1, rocprim::plus<int>(), stream));
+    if (nnz > 0) {
+        hipLaunchKernelGGL(k_sample_assign, dim3((nnz + 255) / 256), dim3(256), 0, stream, picked, nnz, T, first, rank,
+                           (long long *)out_n_id, newid);
+        hipLaunchKernelGGL(k_sample_relabel, dim3((nnz + 255) / 256), dim3(256), 0, stream, picked, nnz, T, map, newid, out_col);
+    }
+    hipLaunchKernelGGL(k_sample_report, dim3(1), dim3(1), 0, stream, out_rowptr, rank, T, report);
+    POPE_HIP(hipMemcpyAsync(rep, report, 2 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+    POPE_HIP(hipStreamSynchronize(stream));
+    POPE_HIP(hipGetLastError());
+    *nnz_host = rep[0];
+    *n_src_host = rep[1];
+    return POPE_OK;
+}

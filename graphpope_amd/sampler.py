@@ -1,0 +1,62 @@
+"""Device-side mini-batch sampling: the GPU stand-in for PyG ``NeighborSampler`` (main.py:100-116) and
+``convert_batch`` (main.py:118-123).  SURVEY.md §8f rank 1.
+
+    sampler = NeighborSampler(rowptr, col, num_nodes, sizes=[25, 10])       # CSR on the device (engine.build_csr)
+    n_id, adjs = sampler.sample(seeds, seed=epoch_seed)                      # adjs: outer -> inner, like the reference
+    x = data_x_device.index_select(0, n_id)                                  # features stay resident in HBM
+
+``sizes`` has PyG's meaning: the first entry is the fan-out around the seed nodes, and the returned list is reversed
+(outermost block first), so ``model(x, adjs)`` consumes it exactly like the reference's ``Batch.adjs_t``.
+The draw is a pure function of (seed, hop, node): reproducible, and checked bit for bit against a CPU restatement.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+from .sage import SampledAdj
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class NeighborSampler:
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int, sizes=(25, 10)):
+        assert rowptr.is_cuda and rowptr.dtype == torch.int32 and col.dtype == torch.int32
+        self.rowptr, self.col, self.num_nodes, self.sizes = rowptr, col, int(num_nodes), list(sizes)
+        self._scratch = None
+
+    def _hop(self, targets: torch.Tensor, fanout: int, seed: int, hop: int):
+        lib = _lib.load()
+        dev = targets.device
+        t = targets.numel()
+        if fanout < 0:                                     # keep every neighbour: the edge count is the sum of the degrees
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).index_select(0, targets)
+            cap = int(deg.sum().item())
+        else:
+            cap = t * fanout
+        need = lib.sage_sample_scratch_bytes(self.num_nodes, t, cap)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+        out_rowptr = torch.empty(t + 1, dtype=torch.int32, device=dev)
+        out_col = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        n_id = torch.empty(t + cap, dtype=torch.int64, device=dev)
+        nnz, n_src = ctypes.c_int64(0), ctypes.c_int64(0)
+        with torch.cuda.device(dev):
+            check(lib.sage_sample_hop(ptr(self.rowptr), ptr(self.col), self.num_nodes, ptr(targets), t, fanout, seed, hop,
+                                      ptr(out_rowptr), ptr(out_col), cap, ptr(n_id), ctypes.byref(nnz), ctypes.byref(n_src),
+                                      ptr(self._scratch), self._scratch.numel(), _stream()))
+        return n_id[: n_src.value], SampledAdj(out_rowptr, out_col[: nnz.value], n_src.value)
+
+    def sample(self, seeds: torch.Tensor, seed: int = 0):
+        """(n_id int64 on the device, [SampledAdj outer ... inner])."""
+        n_id = seeds.to(self.rowptr.device, torch.int64).contiguous()
+        adjs = []
+        for hop, size in enumerate(self.sizes):
+            n_id, adj = self._hop(n_id, int(size), int(seed) & 0xFFFFFFFFFFFFFFFF, hop)
+            adjs.append(adj)
+        return n_id, adjs[::-1]

@@ -25,6 +25,7 @@
  *   pope_concat              utils.py:129-135    torch.cat for the node2vec branch
  *   sage_conv_forward /      main.py:206 and     PyG SAGEConv((x_src, x_dst), adj_t): mean aggregation over the
  *   sage_conv_backward       PyG SAGEConv [3p]   sampled CSR + lin_l + lin_r, and its gradients
+ *   sage_sample_hop          main.py:100-116     NeighborSampler -> torch_sparse.sample_adj (one hop), relabelled block
  */
 #ifndef GRAPHPOPE_HIP_H
 #define GRAPHPOPE_HIP_H
@@ -195,6 +196,26 @@ int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src,
                        const float *x_src, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
                        int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l,
                        float *grad_w_r, void *scratch, size_t scratch_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fan-out neighbour sampling on the device (one hop of PyG NeighborSampler / torch_sparse.sample_adj, main.py:100-116).
+ *   rowptr / col    int32 CSR of the whole graph by TARGET node (row v lists the nodes whose features v aggregates;
+ *                   adj_t in the reference).  For the symmetric Flickr / PubMed graphs this is pope_csr_build's CSR.
+ *   targets         int64 [n_targets] distinct node ids on the device.
+ *   fanout          > 0: rows with more neighbours keep `fanout` distinct ones, chosen by a keyed pseudo-random
+ *                   permutation that is a pure function of (seed, hop, node); < 0: keep all neighbours.
+ *   out_rowptr      int32 [n_targets + 1], out_col int32 [nnz_capacity]: the sampled block, LOCAL ids.
+ *   out_n_id        int64 [n_targets + nnz_capacity]: targets (same order) followed by the newly met nodes in order
+ *                   of first appearance; out_col indexes into it.
+ *   nnz_host / n_src_host   (out, host) edges kept and length of out_n_id.
+ * nnz_capacity >= n_targets * fanout (fanout > 0) or the sum of the targets' degrees (fanout < 0).
+ * Synchronises `stream` twice (the two counts come back to the host).
+ * ------------------------------------------------------------------------------------------------ */
+size_t sage_sample_scratch_bytes(int64_t N, int64_t n_targets, int64_t nnz_capacity);
+int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *targets, int64_t n_targets,
+                    int32_t fanout, uint64_t seed, int32_t hop, int32_t *out_rowptr, int32_t *out_col, int64_t nnz_capacity,
+                    int64_t *out_n_id, int64_t *nnz_host, int64_t *n_src_host, void *scratch, size_t scratch_bytes,
+                    void *stream);
 
 #ifdef __cplusplus
 }

@@ -201,3 +201,62 @@ def sage_conv_torch(x_src, rowptr, col, w_l, b_l, w_r):
     agg = agg / deg.clamp(min=1).to(x_src.dtype)[:, None]
     out = torch.nn.functional.linear(agg, w_l, b_l)
     return out + torch.nn.functional.linear(x_src[:n_dst], w_r)
+
+
+# --------------------------------------------------------------------------------------------
+# Fan-out sampling (stands in for PyG NeighborSampler, main.py:100-116): CPU restatement of
+# graphpope_amd/csrc/sampler.hip -- same keyed Feistel permutation, same first-appearance relabelling.
+# --------------------------------------------------------------------------------------------
+_M32 = 0xFFFFFFFF
+
+
+def _mix32(h):
+    h &= _M32
+    h ^= h >> 15
+    h = (h * 0x2C1B3C6D) & _M32
+    h ^= h >> 12
+    h = (h * 0x297A2D39) & _M32
+    h ^= h >> 15
+    return h
+
+
+def _row_key(seed, hop, node):
+    lo, hi = seed & _M32, (seed >> 32) & _M32
+    return _mix32(lo ^ _mix32((hi + 0x9E3779B1 * (hop + 1)) & _M32) ^ _mix32((node * 0x85EBCA6B + 0x165667B1) & _M32))
+
+
+def feistel_perm(i, d, key):
+    bits = 2
+    while (1 << bits) < d:
+        bits += 1
+    hb = (bits + 1) >> 1
+    mask = (1 << hb) - 1
+    x = i
+    while True:
+        l, r = x >> hb, x & mask
+        for rnd in range(4):
+            f = _mix32((r * 0x9E3779B1 + key + rnd * 0x85EBCA6B) & _M32) & mask
+            l, r = r, l ^ f
+        x = (l << hb) | r
+        if x < d:
+            return x
+
+
+def sample_hop(rowptr, col, targets, fanout, seed, hop):
+    """One hop: (out_rowptr, out_col local ids, n_id) exactly as sage_sample_hop produces them."""
+    targets = [int(t) for t in targets]
+    local = {g: i for i, g in enumerate(targets)}
+    n_id = list(targets)
+    out_rowptr, out_col = [0], []
+    for g in targets:
+        beg, d = int(rowptr[g]), int(rowptr[g + 1] - rowptr[g])
+        c = d if (fanout < 0 or d <= fanout) else fanout
+        key = _row_key(seed, hop, g)
+        for j in range(c):
+            u = int(col[beg + (j if d <= c else feistel_perm(j, d, key))])
+            if u not in local:
+                local[u] = len(n_id)
+                n_id.append(u)
+            out_col.append(local[u])
+        out_rowptr.append(len(out_col))
+    return np.asarray(out_rowptr, np.int32), np.asarray(out_col, np.int32), np.asarray(n_id, np.int64)

@@ -11,7 +11,7 @@ from conftest import ROOT
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "graphpope_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:pope|sage_conv)_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:pope|sage)_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():

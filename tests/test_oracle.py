@@ -79,3 +79,22 @@ def test_node2vec_oracle_matches_reference(oracle, family, fn):
 def test_node2vec_unknown_distance_function_is_keyerror(oracle):
     with pytest.raises(KeyError):
         oracle.pairwise(np.zeros((2, 2), np.float32), np.zeros((1, 2), np.float32), "manhattan")
+
+
+def test_sampler_restatement_properties(oracle):
+    """The CPU restatement of the fan-out sampler: distinct true neighbours, whole rows below the fan-out, targets first."""
+    from graphpope_amd import synth
+    ei = synth.powerlaw_graph(800, 4000, seed=3, alpha=0.9, shift=0.8)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei[0], minlength=800))])
+    col = ei[1]
+    seeds = np.arange(0, 200)
+    rp, cl, n_id = oracle.sample_hop(rowptr, col, seeds, 5, seed=42, hop=0)
+    assert np.array_equal(n_id[:200], seeds) and len(np.unique(n_id)) == len(n_id) and cl.max() < len(n_id)
+    for i, g in enumerate(seeds):
+        true = col[rowptr[g]:rowptr[g + 1]]
+        got = n_id[cl[rp[i]:rp[i + 1]]]
+        assert len(got) == min(len(true), 5) and len(set(got.tolist())) == len(got) and set(got.tolist()) <= set(true.tolist())
+    for d in (1, 2, 3, 17, 64, 65, 1000):                     # the keyed Feistel map is a permutation of [0, d)
+        assert sorted(oracle.feistel_perm(i, d, 0xC0FFEE) for i in range(d)) == list(range(d))
+    assert oracle.sample_hop(rowptr, col, seeds, 5, 42, 0)[1].tolist() == cl.tolist()            # pure function of its arguments
+    assert oracle.sample_hop(rowptr, col, seeds, 5, 43, 0)[1].tolist() != cl.tolist()

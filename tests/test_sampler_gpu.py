@@ -1,0 +1,87 @@
+"""GPU fan-out sampler against its CPU restatement (bit for bit) and against the properties NeighborSampler guarantees."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def graph():
+    from graphpope_amd import engine, synth
+    dev = engine.require_gpu()
+    ei = synth.powerlaw_graph(6000, 40000, seed=7, alpha=0.9, shift=0.8)
+    csr = engine.build_csr(torch.as_tensor(ei, device=dev), 6000)
+    return dev, ei, csr
+
+
+def _host_csr(csr):
+    return csr.rowptr.cpu().numpy(), csr.col.cpu().numpy()[: csr.num_edges]
+
+
+@pytest.mark.parametrize("sizes,seed", [((25, 10), 1), ((3,), 99), ((-1, 2), 5), ((1, 1, 1), 2**40 + 7)])
+def test_matches_cpu_restatement_bit_for_bit(graph, oracle, sizes, seed):
+    from graphpope_amd.sampler import NeighborSampler
+    dev, _, csr = graph
+    rowptr, col = _host_csr(csr)
+    seeds = np.random.RandomState(3).choice(6000, 257, replace=False)
+    n_id, adjs = NeighborSampler(csr.rowptr, csr.col, 6000, sizes).sample(torch.as_tensor(seeds, device=dev), seed=seed)
+    want_n_id, want = np.asarray(seeds, np.int64), []
+    for hop, size in enumerate(sizes):
+        rp, cl, want_n_id = oracle.sample_hop(rowptr, col, want_n_id, size, seed, hop)
+        want.append((rp, cl, len(want_n_id)))
+    assert np.array_equal(n_id.cpu().numpy(), want_n_id)
+    for adj, (rp, cl, n_src) in zip(adjs, want[::-1]):
+        assert adj.n_src == n_src and np.array_equal(adj.rowptr.cpu().numpy(), rp) and np.array_equal(adj.col.cpu().numpy(), cl)
+
+
+def test_neighbor_sampler_properties(graph):
+    """What the reference relies on: targets first, destinations = first n_dst sources, samples are distinct true
+    neighbours, rows with <= fan-out neighbours keep all of them, and the draw is roughly uniform."""
+    from graphpope_amd.sampler import NeighborSampler
+    dev, ei, csr = graph
+    rowptr, col = _host_csr(csr)
+    seeds = torch.arange(0, 1550, device=dev)
+    sampler = NeighborSampler(csr.rowptr, csr.col, 6000, (25, 10))
+    n_id, adjs = sampler.sample(seeds, seed=11)
+    n_id = n_id.cpu().numpy()
+    assert np.array_equal(n_id[:1550], np.arange(1550)) and len(np.unique(n_id)) == len(n_id)
+    assert adjs[1].size(0) == 1550 and adjs[0].size(0) == adjs[1].size(1) and adjs[0].size(1) == len(n_id)
+    for adj, fan in zip(adjs[::-1], (25, 10)):
+        rp, cl = adj.rowptr.cpu().numpy(), adj.col.cpu().numpy()
+        for i in range(0, adj.n_dst, 37):
+            g = n_id[i]
+            true = set(col[rowptr[g]:rowptr[g + 1]].tolist())
+            got = n_id[cl[rp[i]:rp[i + 1]]]
+            assert len(set(got.tolist())) == len(got) and set(got.tolist()) <= true
+            assert len(got) == min(len(true), fan)
+    # uniformity on the biggest hub: 400 draws of 10 out of d neighbours, every neighbour's frequency near 10/d
+    hub = int(np.argmax(np.diff(rowptr)))
+    d = int(rowptr[hub + 1] - rowptr[hub])
+    counts = np.zeros(6000)
+    for s in range(400):
+        nid, (adj,) = NeighborSampler(csr.rowptr, csr.col, 6000, (10,)).sample(torch.tensor([hub], device=dev), seed=s)
+        counts[nid.cpu().numpy()[1:]] += 1
+    freq = counts[col[rowptr[hub]:rowptr[hub + 1]]] / 400
+    assert abs(freq.mean() - 10 / d) < 1e-9 and freq.max() < 4 * 10 / d + 0.02
+
+
+def test_sampled_batch_trains(graph):
+    from graphpope_amd.sage import SAGE
+    from graphpope_amd.sampler import NeighborSampler
+    dev, _, csr = graph
+    torch.manual_seed(0)
+    feats = torch.randn(6000, 32, device=dev)
+    labels = torch.randint(0, 4, (6000,), device=dev)
+    model = SAGE(32, 4, 48, 2).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    sampler = NeighborSampler(csr.rowptr, csr.col, 6000, (25, 10))
+    seeds = torch.arange(512, device=dev)
+    first = last = None
+    for step in range(25):
+        n_id, adjs = sampler.sample(seeds, seed=step)
+        loss = torch.nn.functional.cross_entropy(model(feats.index_select(0, n_id), adjs), labels[:512])
+        opt.zero_grad(); loss.backward(); opt.step()
+        first = loss.item() if first is None else first
+        last = loss.item()
+    assert last < 0.8 * first

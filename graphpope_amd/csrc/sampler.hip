@@ -94,45 +94,47 @@ __global__ __launch_bounds__(256) void k_sample_pick(const int *__restrict__ row
 // fanout < 0 ("all neighbours"): rows are copied whole, one thread per output slot.
 __global__ __launch_bounds__(256) void k_sample_all(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                     const long long *__restrict__ targets, int T,
-                                                    const int *__restrict__ out_rowptr, int *__restrict__ picked,
+                                                    const int *__restrict__ out_rowptr, int cap, int *__restrict__ picked,
                                                     int *__restrict__ map) {
     const int i = blockIdx.x;                                      // one block per target row
     if (i >= T) return;
     const int g = (int)targets[i];
     const int beg = rowptr[g], beg_out = out_rowptr[i], c = out_rowptr[i + 1] - beg_out;
-    for (int j = threadIdx.x; j < c; j += blockDim.x) {
+    for (int j = threadIdx.x; j < c && beg_out + j < cap; j += blockDim.x) {     // cap too small: reported by the host below
         const int u = col[beg + j];
         picked[beg_out + j] = u;
         atomicMin(&map[u], T + beg_out + j);
     }
 }
 
-__global__ __launch_bounds__(256) void k_sample_flag(const int *__restrict__ picked, int nnz, int T, const int *__restrict__ map,
-                                                     int *__restrict__ first) {
+// The passes after the pick run over the CAPACITY (known on the host) and read the true edge count from out_rowptr[T],
+// so the host needs no readback until the very end.
+__global__ __launch_bounds__(256) void k_sample_flag(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int cap,
+                                                     int T, const int *__restrict__ map, int *__restrict__ first) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > nnz) return;
-    first[p] = (p < nnz && map[picked[p]] == T + p) ? 1 : 0;      // first[nnz] = 0: the scan yields the number of new nodes
+    if (p > cap) return;
+    const int nnz = out_rowptr[T];
+    first[p] = (p < nnz && map[picked[p]] == T + p) ? 1 : 0;      // zeros from nnz on: rank[nnz] = number of new nodes
 }
 
-__global__ __launch_bounds__(256) void k_sample_assign(const int *__restrict__ picked, int nnz, int T, const int *__restrict__ first,
-                                                       const int *__restrict__ rank, long long *__restrict__ n_id,
-                                                       int *__restrict__ newid) {
+__global__ __launch_bounds__(256) void k_sample_assign(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int T,
+                                                       const int *__restrict__ first, const int *__restrict__ rank,
+                                                       long long *__restrict__ n_id, int *__restrict__ newid) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nnz || !first[p]) return;
+    if (p >= out_rowptr[T] || !first[p]) return;
     const int u = picked[p];
     n_id[T + rank[p]] = u;
     newid[u] = T + rank[p];                                        // separate array: map still holds keys other threads compare
 }
 
-__global__ __launch_bounds__(256) void k_sample_relabel(const int *__restrict__ picked, int nnz, int T, const int *__restrict__ map,
-                                                        const int *__restrict__ newid, int *__restrict__ out_col) {
+__global__ __launch_bounds__(256) void k_sample_relabel(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int T,
+                                                        const int *__restrict__ map, const int *__restrict__ newid,
+                                                        int *__restrict__ out_col) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nnz) return;
+    if (p >= out_rowptr[T]) return;
     const int u = picked[p], k = map[u];
     out_col[p] = k < T ? k : newid[u];
 }
-
-__global__ void k_sample_nnz(const int *__restrict__ out_rowptr, int T, long long *__restrict__ report) { report[0] = out_rowptr[T]; }
 
 __global__ void k_sample_report(const int *__restrict__ out_rowptr, const int *__restrict__ rank, int T,
                                 long long *__restrict__ report) {
@@ -210,32 +212,28 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
     POPE_HIP(hipMemcpyAsync(out_n_id, targets, (size_t)T * sizeof(long long), hipMemcpyDeviceToDevice, stream));
     if (fanout < 0) {
         // all neighbours: the total is only known on the device; the caller sized nnz_capacity for it
-        hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, picked, map);
+        hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, (int)nnz_capacity, picked, map);
     } else {
         hipLaunchKernelGGL(k_sample_pick, dim3(capped_grid((size_t)T * fanout, 256)), dim3(256), 0, stream, rowptr, col,
                            (const long long *)targets, T, fanout, (unsigned long long)seed, hop, out_rowptr, picked, map);
     }
-    // the edge count is known on the device only when rows are copied whole: one small readback either way
+    const int cap = (int)nnz_capacity;
     long long rep[2] = {0, 0};
-    hipLaunchKernelGGL(k_sample_nnz, dim3(1), dim3(1), 0, stream, out_rowptr, T, report);
-    POPE_HIP(hipMemcpyAsync(rep, report, sizeof(long long), hipMemcpyDeviceToHost, stream));
-    POPE_HIP(hipStreamSynchronize(stream));
-    const int nnz = (int)rep[0];
-    if (nnz > nnz_capacity) {
-        set_error("sage_sample_hop: %d sampled edges exceed nnz_capacity %lld", nnz, (long long)nnz_capacity);
-        return POPE_ERR_WORKSPACE;
-    }
-    hipLaunchKernelGGL(k_sample_flag, dim3((nnz + 256) / 256), dim3(256), 0, stream, picked, nnz, T, map, first);
-    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, first, rank, 0, (size_t)nnz + 1, rocprim::plus<int>(), stream));
-    if (nnz > 0) {
-        hipLaunchKernelGGL(k_sample_assign, dim3((nnz + 255) / 256), dim3(256), 0, stream, picked, nnz, T, first, rank,
+    hipLaunchKernelGGL(k_sample_flag, dim3((cap + 256) / 256), dim3(256), 0, stream, picked, out_rowptr, cap, T, map, first);
+    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, first, rank, 0, (size_t)cap + 1, rocprim::plus<int>(), stream));
+    if (cap > 0) {
+        hipLaunchKernelGGL(k_sample_assign, dim3((cap + 255) / 256), dim3(256), 0, stream, picked, out_rowptr, T, first, rank,
                            (long long *)out_n_id, newid);
-        hipLaunchKernelGGL(k_sample_relabel, dim3((nnz + 255) / 256), dim3(256), 0, stream, picked, nnz, T, map, newid, out_col);
+        hipLaunchKernelGGL(k_sample_relabel, dim3((cap + 255) / 256), dim3(256), 0, stream, picked, out_rowptr, T, map, newid, out_col);
     }
     hipLaunchKernelGGL(k_sample_report, dim3(1), dim3(1), 0, stream, out_rowptr, rank, T, report);
     POPE_HIP(hipMemcpyAsync(rep, report, 2 * sizeof(long long), hipMemcpyDeviceToHost, stream));
     POPE_HIP(hipStreamSynchronize(stream));
     POPE_HIP(hipGetLastError());
+    if (rep[0] > nnz_capacity) {
+        set_error("sage_sample_hop: %lld sampled edges exceed nnz_capacity %lld", rep[0], (long long)nnz_capacity);
+        return POPE_ERR_WORKSPACE;
+    }
     *nnz_host = rep[0];
     *n_src_host = rep[1];
     return POPE_OK;

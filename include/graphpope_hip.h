@@ -209,7 +209,7 @@ int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src,
  *                   of first appearance; out_col indexes into it.
  *   nnz_host / n_src_host   (out, host) edges kept and length of out_n_id.
  * nnz_capacity >= n_targets * fanout (fanout > 0) or the sum of the targets' degrees (fanout < 0).
- * Synchronises `stream` twice (the two counts come back to the host).
+ * Synchronises `stream` once (the two counts come back to the host).
  * ------------------------------------------------------------------------------------------------ */
 size_t sage_sample_scratch_bytes(int64_t N, int64_t n_targets, int64_t nnz_capacity);
 int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *targets, int64_t n_targets,

@@ -54,7 +54,7 @@ def pope_step(x, ei, n, anchors, world):
     csr = engine.build_csr(ei, n, defer_check=True)
     return pdist.sharded_geodesic_features(x, n, anchors, None,
                                            bfs_fn=lambda a: engine.bfs(csr, a),
-                                           finalize_fn=engine.finalize)
+                                           finalize_fn=engine.finalize, finalize_all_fn=engine.finalize_shards)
 
 
 def pope_phases(x, ei, n, anchors, timers):
@@ -272,8 +272,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local_rank %= max(torch.cuda.device_count(), 1)          # rehearsals put several ranks on one card
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("GRAPHPOPE_BENCH_BACKEND", "nccl")          # "gloo": rehearsal on a one-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = engine.require_gpu()
 

@@ -35,6 +35,8 @@ SIGNATURES = {
                                   c_int32, c_void_p, c_size_t, POINTER(c_int32), POINTER(c_int32), c_void_p]),
     "pope_profile_levels": (None, [c_int32]),
     "pope_profile_read": (c_int32, [c_void_p, c_void_p, c_int32]),
+    "pope_geodesic_finalize_shards": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int64, c_int32, c_void_p, c_int32,
+                                              c_void_p, c_int64, c_void_p]),
     "pope_geodesic_hops": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
     "pope_pairwise_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "pope_pairwise_minmax": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,

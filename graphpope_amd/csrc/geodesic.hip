@@ -519,11 +519,14 @@ __global__ __launch_bounds__(256) void k_finalize(const u64 *__restrict__ planes
 //  * the four hop counts of a lane are pulled out of the packed plane nibbles with one multiply each;
 //  * x is read with non-temporal loads (read once); stores are plain -- non-temporal stores measured 23 % slower.
 // MODE: 0 plain stores (default), 1 non-temporal stores (kept for A/B, tools/ab_finalize.py).
+// n_shards > 1 (multi-GPU): `planes` holds the all-gathered shards back to back (shard_elems words apart, K anchors
+// each); a row's columns of ALL shards are written in one pass, so the [N, F + shards*K] matrix is streamed once.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ planes, size_t plane_elems,
                                                        int n_hop_bits, const int *__restrict__ max_hop_dev, int N, int K,
                                                        int Wp, const float *__restrict__ x, int F,
-                                                       float *__restrict__ out, long long out_cols, int c0) {
+                                                       float *__restrict__ out, long long out_cols, int c0,
+                                                       int n_shards, size_t shard_elems) {
     __shared__ float inv[16];
     if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
     __syncthreads();
@@ -549,9 +552,10 @@ __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ p
         }
         f32x4 *erow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols + F + c0);
         const size_t wbase = (size_t)v * Wp;
-        for (int q = lane; q < K4; q += 64) {
-            const int j = q * 4;                               // four anchors of one word
-            const size_t widx = wbase + (j >> 6);
+        for (int q = lane; q < K4 * n_shards; q += 64) {
+            const int shard = q / K4;
+            const int j = (q - shard * K4) * 4;                // four anchors of one word of that shard
+            const size_t widx = (size_t)shard * shard_elems + wbase + (j >> 6);
             const int bit = j & 63;
             const unsigned reach = (unsigned)(planes[widx] >> bit) & 15u;
             unsigned t = 0;                                    // nibble b = the four anchors' hop bit b
@@ -934,19 +938,28 @@ extern "C" void pope_debug_finalize_variant(int v) { g_finalize_variant = v; }
 extern "C" void pope_debug_finalize_blocks(int b) { g_finalize_blocks = b; }
 
 static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_hop_dev, int64_t N, int32_t K,
-                            const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, hipStream_t stream) {
+                            const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, hipStream_t stream,
+                            int n_shards = 1, size_t shard_elems = 0) {
     const int Wp = words_for(K);
     const size_t plane_elems = (size_t)N * Wp;
     const bool vec = F % 4 == 0 && K % 4 == 0 && c0 % 4 == 0 && out_cols % 4 == 0 && aligned16(out) && (!x || aligned16(x));
     dim3 grid(capped_grid((size_t)N * 64, 256)), block(256);
     // The device-side depth (max_hop_dev) is only used by pope_geodesic_run, whose speculative window stops at
     // LEVEL_BATCH = 12 levels: at most 4 hop bits.  With a host-side count the fast path needs n_hop_bits <= 4.
-    if (vec && g_finalize_variant > 0 && (max_hop_dev || n_hop_bits <= 4)) {
+    if (n_shards > 1 && !(vec && n_hop_bits <= 4)) {          // generic kernel: one launch per shard
+        for (int g = 0; g < n_shards; ++g) {
+            int rc = finalize_enqueue(planes + (size_t)g * shard_elems, n_hop_bits, max_hop_dev, N, K, g == 0 ? x : nullptr, F, out,
+                                      out_cols, c0 + g * K, stream);
+            if (rc) return rc;
+        }
+        return POPE_OK;
+    }
+    if (vec && (g_finalize_variant > 0 || n_shards > 1) && (max_hop_dev || n_hop_bits <= 4)) {
         dim3 fgrid(g_finalize_blocks);                          // 8 blocks per CU, contiguous row blocks per wave
         if (g_finalize_variant == 2)
-            hipLaunchKernelGGL(k_finalize_fast<1>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0);
+            hipLaunchKernelGGL(k_finalize_fast<1>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems);
         else
-            hipLaunchKernelGGL(k_finalize_fast<0>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0);
+            hipLaunchKernelGGL(k_finalize_fast<0>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems);
         POPE_HIP(hipGetLastError());
         return POPE_OK;
     }
@@ -1053,6 +1066,19 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     if (max_hop_host) *max_hop_host = last_active;
     if (n_hop_bits_host) *n_hop_bits_host = hop_bits(last_active);
     return POPE_OK;
+}
+
+extern "C" int pope_geodesic_finalize_shards(const uint64_t *planes, int32_t n_shards, int64_t shard_stride_words,
+                                             int32_t n_hop_bits, int64_t N, int32_t K_shard, const float *x, int32_t F,
+                                             float *out, int64_t out_cols, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(planes && out, "pope_geodesic_finalize_shards: null pointer");
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && K_shard > 0 && F >= 0 && n_shards >= 1 && n_hop_bits >= 0 && n_hop_bits <= 31,
+                 "pope_geodesic_finalize_shards: bad size");
+    POPE_REQUIRE(shard_stride_words >= (int64_t)(1 + n_hop_bits) * N * words_for(K_shard), "pope_geodesic_finalize_shards: shard stride too small");
+    POPE_REQUIRE(out_cols >= (int64_t)F + (int64_t)n_shards * K_shard, "pope_geodesic_finalize_shards: out_cols too small");
+    return finalize_enqueue((const u64 *)planes, n_hop_bits, nullptr, N, K_shard, x, F, out, out_cols, 0, (hipStream_t)stream_,
+                            n_shards, (size_t)shard_stride_words);
 }
 
 extern "C" int pope_geodesic_hops(const uint64_t *planes, int32_t n_hop_bits, int64_t N, int32_t K, int32_t *hops,

@@ -59,11 +59,13 @@ def _all_gather(local: torch.Tensor, group) -> torch.Tensor:
     return out
 
 
-def sharded_geodesic_features(x: torch.Tensor, num_nodes: int, anchors: np.ndarray, group, bfs_fn, finalize_fn) -> torch.Tensor:
+def sharded_geodesic_features(x: torch.Tensor, num_nodes: int, anchors: np.ndarray, group, bfs_fn, finalize_fn,
+                              finalize_all_fn=None) -> torch.Tensor:
     """Every rank returns the full [N, F+K] float32 matrix.
 
     bfs_fn(anchors) -> object with .planes ([>= 1 + n_hop_bits, N, W] int64), .n_hop_bits
-    finalize_fn(planes, n_hop_bits, N, K_shard, x_or_None, F, out, c0) writes x and one shard's columns.
+    finalize_fn(planes, n_hop_bits, N, K_shard, x_or_None, F, out, c0) writes x and one shard's columns;
+    finalize_all_fn(gathered, n_hop_bits, N, K_shard, x, F, out), if given, writes every shard in one pass instead.
     """
     world, rnk = dist.get_world_size(group), dist.get_rank(group)
     anchors = np.asarray(anchors, dtype=np.int64)
@@ -82,8 +84,11 @@ def sharded_geodesic_features(x: torch.Tensor, num_nodes: int, anchors: np.ndarr
 
     cols = f + world * size
     out = torch.empty((num_nodes, cols), dtype=torch.float32, device=x.device)
-    for g in range(world):
-        finalize_fn(gathered[g], bits, num_nodes, size, x if g == 0 else None, f, out, g * size)
+    if finalize_all_fn is not None:
+        finalize_all_fn(gathered, bits, num_nodes, size, x, f, out)
+    else:
+        for g in range(world):
+            finalize_fn(gathered[g], bits, num_nodes, size, x if g == 0 else None, f, out, g * size)
     if cols != f + k:                                               # K not divisible by world: drop the padding
         out = out[:, : f + k].contiguous()
     return out

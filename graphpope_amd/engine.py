@@ -121,6 +121,17 @@ def finalize(planes: torch.Tensor, n_hop_bits: int, num_nodes: int, k: int, x, f
                                          c0, _stream()))
 
 
+def finalize_shards(gathered: torch.Tensor, n_hop_bits: int, num_nodes: int, k_shard: int, x, f: int, out: torch.Tensor):
+    """All shards of an all-gathered [world, 1 + bits, N, W] plane tensor in one pass over ``out``."""
+    lib = _lib.load()
+    assert gathered.is_contiguous() and gathered.dim() == 4 and gathered.shape[1] >= 1 + n_hop_bits
+    world = gathered.shape[0]
+    stride = gathered.shape[1] * gathered.shape[2] * gathered.shape[3]
+    with torch.cuda.device(out.device):
+        check(lib.pope_geodesic_finalize_shards(ptr(gathered), world, stride, n_hop_bits, num_nodes, k_shard, ptr(x), f,
+                                                ptr(out), out.shape[1], _stream()))
+
+
 def hop_matrix(hp: HopPlanes) -> torch.Tensor:
     """int32 [N, K], -1 = unreachable (the integers behind the reference's floats)."""
     lib = _lib.load()
@@ -195,7 +206,7 @@ def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int,
     return pdist.sharded_geodesic_features(
         x, num_nodes, anc, group,
         bfs_fn=lambda a: bfs(csr, a),
-        finalize_fn=finalize)
+        finalize_fn=finalize, finalize_all_fn=finalize_shards)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -107,6 +107,9 @@ def attach_distance_embedding(data, dataset, num_anchor_nodes, sampling_method, 
     print('sampling anchor nodes...')
     data.anchor_nodes = sample_anchor_nodes(data=data, num_anchor_nodes=num_anchor_nodes, sampling_method=sampling_method)
     print('deriving shortest paths to anchor nodes...')
+    if len(data.anchor_nodes) == 0:                                  # --num_anchor_nodes 0: cat((x, [N, 0])) is a copy of x
+        print('feature matrix is blessed by the POPE!')
+        return data.x.detach().clone()
     extended_features = _geodesic_device(data, _device()).cpu()
     print('feature matrix is blessed by the POPE!')
     return extended_features

@@ -123,6 +123,15 @@ int pope_geodesic_finalize(const uint64_t *planes, int32_t n_hop_bits, int64_t N
                            const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, void *stream);
 
 /*
+ * Multi-GPU form: `planes` holds n_shards all-gathered shards back to back, shard g at planes + g * shard_stride_words,
+ * each [1 + n_hop_bits, N, W(K_shard)] for K_shard anchors; writes x and the columns of ALL shards
+ * (out[v, F + g * K_shard + j]) in one pass over the output.  Asynchronous on `stream`.
+ */
+int pope_geodesic_finalize_shards(const uint64_t *planes, int32_t n_shards, int64_t shard_stride_words, int32_t n_hop_bits,
+                                  int64_t N, int32_t K_shard, const float *x, int32_t F, float *out, int64_t out_cols,
+                                  void *stream);
+
+/*
  * The whole geodesic hot path in ONE call (what utils.py:137-147 does after sampling the anchors):
  * edge_index -> CSR -> multi-source BFS -> out[v, 0:F] = x[v, :], out[v, F + j] = 1 / (hops(v, anchor j) + 1).
  * Everything is enqueued speculatively (sorted-CSR fast path, 12 BFS levels, the finalise kernel reading the

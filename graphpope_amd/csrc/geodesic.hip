@@ -180,6 +180,11 @@ __device__ __forceinline__ Words<WT> load_words(const u64 *__restrict__ p) {
     return r;
 }
 
+// Frontier gathers go through L1 like any load: reading them with the non-temporal hint was measured 57 % slower
+// (BFS 349 us against 223 us, tools/ab_lib.py) -- the rows of hubs are gathered again and again and L1 serves them.
+template <int WT>
+__device__ __forceinline__ Words<WT> gather_words(const u64 *__restrict__ p) { return load_words<WT>(p); }
+
 template <int WT>
 __device__ __forceinline__ void store_words(u64 *__restrict__ p, const Words<WT> &r) {
     if constexpr (WT == 1) {
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
 #pragma unroll
         for (int i = 0; i < WT; ++i) c0.w[i] = c1.w[i] = c2.w[i] = c3.w[i] = s0.w[i] = s1.w[i] = s2.w[i] = s3.w[i] = 0;
         if (v0 >= 0) {
-            c0 = load_words<WT>(front + (size_t)u0 * Wp + woff);
+            c0 = gather_words<WT>(front + (size_t)u0 * Wp + woff);
             s0 = load_words<WT>(seen + (size_t)v0 * Wp + woff);
             if (x0) {                                                    // deferred commit: level l-1 may not be in seen yet
                 const Words<WT> f = load_words<WT>(front + (size_t)v0 * Wp + woff);
@@ -317,10 +322,10 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
                 for (int i = 0; i < WT; ++i) s0.w[i] |= f.w[i];
             }
         }
-        if (v1 >= 0) c1 = load_words<WT>(front + (size_t)u1 * Wp + woff);
-        if (v2 >= 0) c2 = load_words<WT>(front + (size_t)u2 * Wp + woff);
+        if (v1 >= 0) c1 = gather_words<WT>(front + (size_t)u1 * Wp + woff);
+        if (v2 >= 0) c2 = gather_words<WT>(front + (size_t)u2 * Wp + woff);
         if (v3 >= 0) {
-            c3 = load_words<WT>(front + (size_t)u3 * Wp + woff);
+            c3 = gather_words<WT>(front + (size_t)u3 * Wp + woff);
             if (v3 == v0) {
                 s3 = s0;
             } else {

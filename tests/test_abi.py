@@ -51,3 +51,19 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("SURVEY", ""), f
+
+
+def test_argument_validation_needs_no_gpu():
+    """Bad sizes / null pointers are rejected before any HIP call, with a message behind pope_last_error()."""
+    from graphpope_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    assert lib.pope_csr_build(null, 5, -1, null, null, null, null, null, 0, 0, null) == _lib.ERR_INVALID
+    assert b"pope_csr_build" in lib.pope_last_error()
+    assert lib.pope_geodesic_finalize(null, 0, 10, 4, null, 0, null, 4, 0, null) == _lib.ERR_INVALID
+    assert lib.pope_pairwise_minmax(null, 10, 4, null, 2, 7, null, 2, 0, null, 0, null) == _lib.ERR_INVALID
+    assert lib.sage_conv_forward(null, null, 5, 9, 0, null, 4, null, null, null, 4, null, null, null) == _lib.ERR_INVALID
+    assert lib.pope_geodesic_run_workspace_bytes(10, 10, 0, 8) == 0 and lib.pope_geodesic_run_workspace_bytes(89250, 899756, 256, 8) > 0
+    import pytest
+    with pytest.raises(_lib.PopeError, match="null pointer"):
+        _lib.check(lib.pope_concat(null, 4, 4, null, 8, null))

@@ -230,3 +230,30 @@ def test_random_graphs_property_sweep(dev, oracle):
         got = engine.hop_matrix(hp).cpu().numpy()
         want = oracle.geodesic_hops(ei, n, anchors)
         assert np.array_equal(got, want), (trial, n, ei.shape[1], k)
+
+
+def test_persisted_plane_cache(dev, tmp_path, monkeypatch):
+    """GRAPHPOPE_CACHE_DIR: the second process-independent call expands cached planes instead of running the BFS."""
+    from graphpope_amd import engine, utils as gp
+    g = load_golden(os.path.join(GOLDEN, "geodesic_powerlaw4k_seed42.npz"))
+
+    class Data:
+        pass
+    d = Data()
+    d.x, d.edge_index, d.num_nodes = torch.as_tensor(g["x"]), torch.as_tensor(g["edge_index"].astype(np.int64)), int(g["num_nodes"])
+    monkeypatch.setenv("GRAPHPOPE_CACHE_DIR", str(tmp_path))
+    outs = []
+    for attempt in range(2):
+        gp.clear_cache()
+        np.random.seed(42)
+        if attempt == 1:
+            monkeypatch.setattr(engine, "geodesic_run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("BFS ran on a cache hit")))
+        outs.append(gp.Graphpope(d, "flickr", "geodesic", "stochastic", 32, None, 2).numpy())
+    gp.clear_cache()
+    assert len(list(tmp_path.glob("pope_*.npz"))) == 1
+    for out in outs:
+        assert np.array_equal(out[:, 3:].view(np.uint32), g["emb"].view(np.uint32))
+    np.random.seed(7)                                    # other anchors -> other key -> miss (the patched BFS raises)
+    with pytest.raises(AssertionError):
+        gp.Graphpope(d, "flickr", "geodesic", "stochastic", 32, None, 2)
+    gp.clear_cache()

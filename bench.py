@@ -54,7 +54,8 @@ def pope_step(x, ei, n, anchors, world):
     csr = engine.build_csr(ei, n, defer_check=True)
     return pdist.sharded_geodesic_features(x, n, anchors, None,
                                            bfs_fn=lambda a: engine.bfs(csr, a),
-                                           finalize_fn=engine.finalize, finalize_all_fn=engine.finalize_shards)
+                                           finalize_fn=engine.finalize, finalize_all_fn=engine.finalize_shards,
+                                           begin_fn=lambda a: engine.PendingBfs(csr, a))
 
 
 def pope_phases(x, ei, n, anchors, timers):

@@ -27,6 +27,10 @@ SIGNATURES = {
     "pope_bfs_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
     "pope_geodesic_bfs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int32,
                                   c_void_p, c_size_t, POINTER(c_int32), POINTER(c_int32), c_void_p]),
+    "pope_geodesic_bfs_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int32,
+                                        c_void_p, c_size_t, c_void_p]),
+    "pope_geodesic_bfs_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int32,
+                                         c_void_p, c_size_t, POINTER(c_int32), POINTER(c_int32), c_void_p]),
     "pope_geodesic_finalize": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int64,
                                        c_int32, c_void_p]),
     "pope_geodesic_run_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),

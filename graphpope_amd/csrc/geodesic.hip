@@ -916,24 +916,55 @@ extern "C" int32_t pope_profile_read(int32_t *levels, float *level_ms, int32_t c
     return written;
 }
 
-extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
-                                 int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
-                                 int32_t plane_capacity, void *scratch, size_t scratch_bytes, int32_t *max_hop_host,
-                                 int32_t *n_hop_bits_host, void *stream_) {
+// The BFS in two halves, so that a caller can put other stream work (an all-gather, the finalise kernel) between the
+// enqueue and the host synchronisation: begin = clears + seed + the first LEVEL_BATCH levels, nothing is waited for;
+// finish = wait, read the verdict, keep going if the graph is deeper.  Both take the same arguments.
+extern "C" int pope_geodesic_bfs_begin(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                                       int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
+                                       int32_t plane_capacity, void *scratch, size_t scratch_bytes, void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     Bfs b;
     int rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes);
     if (rc) return rc;
     if ((rc = bfs_enqueue_init(b, anchors_host, stream))) return rc;
-    int level = 1, last_active = 0;
-    for (bool done = false; !done;) {
+    bfs_enqueue_levels(b, 1, 1 + LEVEL_BATCH, stream);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+extern "C" int pope_geodesic_bfs_finish(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                                        int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
+                                        int32_t plane_capacity, void *scratch, size_t scratch_bytes, int32_t *max_hop_host,
+                                        int32_t *n_hop_bits_host, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    Bfs b;
+    int rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes);
+    if (rc) return rc;
+    int level = 1 + LEVEL_BATCH, last_active = 0;                  // what begin enqueued
+    if (level > b.level_limit) level = (int)b.level_limit;
+    if (b.E == 0) level = 1;
+    bool done = false;
+    if ((rc = bfs_poll(b, level, &last_active, &done, stream))) return rc;
+    while (!done) {
         level = bfs_enqueue_levels(b, level, level + LEVEL_BATCH, stream);
         if ((rc = bfs_poll(b, level, &last_active, &done, stream))) return rc;
     }
     if (max_hop_host) *max_hop_host = last_active;
     if (n_hop_bits_host) *n_hop_bits_host = hop_bits(last_active);
     return POPE_OK;
+}
+
+extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                                 int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
+                                 int32_t plane_capacity, void *scratch, size_t scratch_bytes, int32_t *max_hop_host,
+                                 int32_t *n_hop_bits_host, void *stream_) {
+    int rc = pope_geodesic_bfs_begin(rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch,
+                                     scratch_bytes, stream_);
+    if (rc) return rc;
+    return pope_geodesic_bfs_finish(rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch,
+                                    scratch_bytes, max_hop_host, n_hop_bits_host, stream_);
 }
 
 static int g_finalize_variant = 1;     // 0: generic kernel, 1: fast path with plain stores (A/B: 86 us vs 98 / 106), 2: fast path, non-temporal stores

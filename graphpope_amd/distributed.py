@@ -59,16 +59,47 @@ def _all_gather(local: torch.Tensor, group) -> torch.Tensor:
     return out
 
 
+SPECULATIVE_HOP_BITS = 4
+
+
+def _speculative(x, num_nodes, anchors, group, begin_fn, finalize_all_fn):
+    """Fast path with no host synchronisation in the middle: enqueue the BFS, all-gather seen + 4 hop-bit planes and
+    expand them, THEN look at the verdicts.  Returns the matrix, or None if some rank needs more than 4 hop bits (or its
+    edge list was not sorted): the caller then takes the general path."""
+    world = dist.get_world_size(group)
+    k, f = int(anchors.size), x.shape[1]
+    size = shard_size(k, world)
+    local_anchors, _ = shard_anchors(anchors, world, dist.get_rank(group))
+    pending = begin_fn(local_anchors)
+    gathered = _all_gather(pending.speculative_planes(), group)        # [world, 5, N, W], contiguous slices: no staging copy
+    cols = f + world * size
+    out = torch.empty((num_nodes, cols), dtype=torch.float32, device=x.device)
+    finalize_all_fn(gathered, SPECULATIVE_HOP_BITS, num_nodes, size, x, f, out)
+    hp = pending.finish()                                             # the first host synchronisation of the call
+    ok = torch.tensor([0 if (hp is not None and hp.n_hop_bits <= SPECULATIVE_HOP_BITS) else 1], dtype=torch.int32, device=x.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MAX, group=group)
+    if int(ok.item()):
+        return None
+    if cols != f + k:
+        out = out[:, : f + k].contiguous()
+    return out
+
+
 def sharded_geodesic_features(x: torch.Tensor, num_nodes: int, anchors: np.ndarray, group, bfs_fn, finalize_fn,
-                              finalize_all_fn=None) -> torch.Tensor:
+                              finalize_all_fn=None, begin_fn=None) -> torch.Tensor:
     """Every rank returns the full [N, F+K] float32 matrix.
 
     bfs_fn(anchors) -> object with .planes ([>= 1 + n_hop_bits, N, W] int64), .n_hop_bits
     finalize_fn(planes, n_hop_bits, N, K_shard, x_or_None, F, out, c0) writes x and one shard's columns;
     finalize_all_fn(gathered, n_hop_bits, N, K_shard, x, F, out), if given, writes every shard in one pass instead.
+    begin_fn(anchors) -> object with .speculative_planes() and .finish(): enables the synchronisation-free fast path.
     """
     world, rnk = dist.get_world_size(group), dist.get_rank(group)
     anchors = np.asarray(anchors, dtype=np.int64)
+    if begin_fn is not None and finalize_all_fn is not None:
+        out = _speculative(x, num_nodes, anchors, group, begin_fn, finalize_all_fn)
+        if out is not None:
+            return out
     k, f = int(anchors.size), x.shape[1]
     size = shard_size(k, world)
     local_anchors, _ = shard_anchors(anchors, world, rnk)

@@ -111,6 +111,46 @@ def bfs(csr: Csr, anchors, capacity: int = DEFAULT_PLANE_CAPACITY) -> HopPlanes:
             return HopPlanes(planes, int(bits.value), int(max_hop.value), num_nodes, k)
 
 
+SPECULATIVE_HOP_BITS = 4          # hop-bit planes the library clears up front: hops < 16 are valid without knowing the depth
+
+
+class PendingBfs:
+    """A BFS whose first 12 levels are enqueued but not waited for (pope_geodesic_bfs_begin / _finish)."""
+
+    def __init__(self, csr: Csr, anchors, capacity: int = DEFAULT_PLANE_CAPACITY):
+        lib = _lib.load()
+        self.csr, self.capacity = csr, capacity
+        self.anc = np.ascontiguousarray(np.asarray(anchors), dtype=np.int64)
+        self.k = int(self.anc.size)
+        dev = csr.col.device
+        w = lib.pope_words(self.k)
+        with torch.cuda.device(dev):
+            self.scratch = _bytes(lib.pope_bfs_scratch_bytes(csr.num_nodes, csr.num_edges, self.k), dev)
+            self.planes = torch.empty((capacity + 1, csr.num_nodes, w), dtype=torch.int64, device=dev)
+            check(lib.pope_geodesic_bfs_begin(*self._args(), _stream()))
+
+    def _args(self):
+        c = self.csr
+        return (ptr(c.rowptr), ptr(c.col), ptr(c.erow), ptr(c.aux), c.num_nodes, c.num_edges,
+                ctypes.c_void_p(self.anc.ctypes.data), self.k, ptr(self.planes), self.capacity, ptr(self.scratch),
+                self.scratch.numel())
+
+    def speculative_planes(self) -> torch.Tensor:
+        """planes[0 : 1 + 4]: valid once finish() has reported n_hop_bits <= 4."""
+        return self.planes[: 1 + SPECULATIVE_HOP_BITS]
+
+    def finish(self):
+        """Synchronise and return HopPlanes, or None if this needs the general path (deep graph, unsorted edges, overflow)."""
+        lib = _lib.load()
+        max_hop, bits = ctypes.c_int32(0), ctypes.c_int32(0)
+        with torch.cuda.device(self.csr.col.device):
+            rc = lib.pope_geodesic_bfs_finish(*self._args(), ctypes.byref(max_hop), ctypes.byref(bits), _stream())
+        if rc in (_lib.ERR_UNSORTED, _lib.ERR_HOP_OVERFLOW):
+            return None
+        check(rc)
+        return HopPlanes(self.planes, int(bits.value), int(max_hop.value), self.csr.num_nodes, self.k)
+
+
 def finalize(planes: torch.Tensor, n_hop_bits: int, num_nodes: int, k: int, x, f: int, out: torch.Tensor, c0: int = 0):
     """Write x and 1/(hops+1) for one shard's k anchors into out[:, :f] and out[:, f+c0 : f+c0+k]."""
     lib = _lib.load()
@@ -206,7 +246,7 @@ def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int,
     return pdist.sharded_geodesic_features(
         x, num_nodes, anc, group,
         bfs_fn=lambda a: bfs(csr, a),
-        finalize_fn=finalize, finalize_all_fn=finalize_shards)
+        finalize_fn=finalize, finalize_all_fn=finalize_shards, begin_fn=lambda a: PendingBfs(csr, a))
 
 
 # ------------------------------------------------------------------------------------------------

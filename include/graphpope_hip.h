@@ -114,6 +114,21 @@ int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *
                       int32_t *max_hop_host, int32_t *n_hop_bits_host, void *stream);
 
 /*
+ * The same BFS in two halves (identical arguments): _begin enqueues the clears, the seed and the first 12 levels and
+ * returns without waiting; _finish synchronises `stream`, reads the verdict and keeps going if the graph is deeper.
+ * Work enqueued on `stream` in between (an all-gather of planes[0 .. 5), the finalise kernel) runs speculatively: it is
+ * valid iff _finish reports *n_hop_bits <= 4 (planes 1..4 are cleared up front, so unused hop-bit planes read as zero).
+ * The pinned anchor staging buffer is per device: do not begin a second BFS on the device before finishing the first.
+ */
+int pope_geodesic_bfs_begin(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                            int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
+                            int32_t plane_capacity, void *scratch, size_t scratch_bytes, void *stream);
+int pope_geodesic_bfs_finish(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                             int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
+                             int32_t plane_capacity, void *scratch, size_t scratch_bytes, int32_t *max_hop_host,
+                             int32_t *n_hop_bits_host, void *stream);
+
+/*
  * out[v, 0:F] = x[v, :],  out[v, F + c0 + j] = 1.0f / (hops(v, anchor j) + 1), 0.0f if unreachable,
  * for the K_shard anchors of one shard.  out is float32 [N, out_cols] row-major with out_cols >= F + c0 + K_shard;
  * x may be NULL (then only the embedding columns are written: used for shards after the first).

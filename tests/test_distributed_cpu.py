@@ -59,7 +59,24 @@ def numpy_finalize(planes, bits, n, k, x, f, out, c0):
     out[:, f + c0: f + c0 + k] = torch.from_numpy(emb)
 
 
-def _worker(rank, world, port, k, result_dir):
+class FakePending:
+    """What engine.PendingBfs offers, from the oracle: seen + 4 hop-bit planes now, the verdict at finish()."""
+
+    def __init__(self, hops):
+        planes, bits = encode_planes(hops)
+        self._hp = FakePlanes(planes, bits)
+        spec = planes[:5].clone()
+        spec[1 + min(bits, 4):] = 0                       # the library clears hop-bit planes 1..4 up front
+        self._spec = spec
+
+    def speculative_planes(self):
+        return self._spec
+
+    def finish(self):
+        return self._hp
+
+
+def _worker(rank, world, port, k, result_dir, deep=True):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -69,10 +86,10 @@ def _worker(rank, world, port, k, result_dir):
         from oracle import oracle
         ei, n = synth.rmat(9, edge_factor=4, seed=2)
         # rank-dependent depth: a long tail hangs off node 0 so that only some shards see large hop counts
-        tail = np.arange(n, n + 40)
+        tail = np.arange(n, n + (40 if deep else 3))
         chain = np.stack([np.concatenate([[0], tail[:-1]]), tail])
         ei = np.concatenate([ei, chain, chain[::-1]], axis=1)
-        n += 40
+        n += len(tail)
         anchors = np.random.RandomState(7).choice(np.arange(n), k)
         anchors[0] = n - 1                                           # deep anchor lands in shard 0 only
         x = torch.from_numpy(np.random.RandomState(1).rand(n, 5).astype(np.float32))
@@ -81,7 +98,20 @@ def _worker(rank, world, port, k, result_dir):
             planes, bits = encode_planes(oracle.geodesic_hops(ei, n, a))
             return FakePlanes(planes, bits)
 
-        out = pdist.sharded_geodesic_features(x, n, anchors, None, bfs_fn, numpy_finalize)
+        calls = {"general": 0}
+
+        def counted_bfs(a):
+            calls["general"] += 1
+            return bfs_fn(a)
+
+        def finalize_all(gathered, bits, nn, k_shard, xx, ff, out):
+            for g in range(gathered.shape[0]):
+                numpy_finalize(gathered[g], bits, nn, k_shard, xx if g == 0 else None, ff, out, g * k_shard)
+
+        out = pdist.sharded_geodesic_features(x, n, anchors, None, counted_bfs, numpy_finalize, finalize_all_fn=finalize_all,
+                                              begin_fn=lambda a: FakePending(oracle.geodesic_hops(ei, n, a)))
+        # deep graph (> 15 hops somewhere): the speculative 4-bit exchange is rejected by ALL ranks and redone in general form
+        assert calls["general"] == (1 if deep else 0), calls
         want = oracle.geodesic_features(x.numpy(), ei, n, anchors)
         ok = out.shape == (n, 5 + k) and out.is_contiguous() and np.array_equal(out.numpy().view(np.uint32), want.view(np.uint32))
         open(os.path.join(result_dir, f"rank{rank}"), "w").write("ok" if ok else "MISMATCH")
@@ -95,9 +125,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,k", [(2, 128), (2, 7), (3, 10), (2, 1)])
-def test_sharded_all_gather_reassembles_the_matrix(world, k, tmp_path, oracle):
-    mp.spawn(_worker, args=(world, _free_port(), k, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,k,deep", [(2, 128, True), (2, 7, True), (3, 10, True), (2, 1, True), (2, 128, False), (3, 10, False)])
+def test_sharded_all_gather_reassembles_the_matrix(world, k, deep, tmp_path, oracle):
+    mp.spawn(_worker, args=(world, _free_port(), k, str(tmp_path), deep), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"rank{r}").read() == "ok"
 

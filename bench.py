@@ -184,6 +184,24 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
     torch.cuda.synchronize()
     l0_ms = ev[0].elapsed_time(ev[1]) / 10
     n_dst, _, nnz = shapes[0]
+    # the neighbour gather + mean on its own (memory-bound half of the layer)
+    lib = _lib.load()
+    a0 = adjs[0]
+    agg = torch.empty((a0.n_dst, c_in), dtype=torch.float32, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def gather():
+        _lib.check(lib.sage_gather_mean(_lib.ptr(a0.rowptr), _lib.ptr(a0.col), a0.n_src, a0.n_dst, a0.col.numel(), _lib.ptr(x), c_in,
+                                        _lib.ptr(agg), stream))
+    for _ in range(3):
+        gather()
+    ev[0].record()
+    for _ in range(20):
+        gather()
+    ev[1].record()
+    torch.cuda.synchronize()
+    g_ms = ev[0].elapsed_time(ev[1]) / 20
+    g_bytes = 4.0 * (nnz * c_in + n_dst * c_in) + 4.0 * nnz + 4.0 * (n_dst + 1)
     l0_flops = 2.0 * 2 * n_dst * c_in * HIDDEN
     l0_bytes = 4.0 * (nnz * c_in + 2 * n_dst * c_in + n_dst * HIDDEN) + 4.0 * nnz + 4.0 * (n_dst + 1)
 
@@ -243,6 +261,12 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
         "layer0_forward_ms": l0_ms,
         "layer0_forward_tflops": l0_flops / (l0_ms * 1e-3) / 1e12,
         "layer0_forward_gbs": l0_bytes / (l0_ms * 1e-3) / 1e9,
+        "layer0_gather_mean": {"ms": g_ms, "algorithmic_bytes": g_bytes, "achieved_gbs": g_bytes / (g_ms * 1e-3) / 1e9,
+                               "frac_of_hbm_peak": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "note": "k_gather_mean alone, back to back on the same batch: source rows (115 MB) are served "
+                                       "by the 256 MB Infinity Cache, so the rate can exceed the HBM peak"},
+        "layer0_projection": {"ms": l0_ms - g_ms, "tflops": l0_flops / ((l0_ms - g_ms) * 1e-3) / 1e12,
+                              "frac_of_f32_mfma_peak": l0_flops / ((l0_ms - g_ms) * 1e-3) / 1e12 / 157.3},
         "with_gpu_sampling": sampled,
         "cpu_baseline": cpu,
     }

@@ -244,6 +244,25 @@ extern "C" size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t 
     return gagg + slabs;
 }
 
+static void enqueue_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_dst, const float *x_src, int32_t c_in,
+                                float *agg, hipStream_t stream) {
+    dim3 grid(capped_grid((size_t)n_dst * 64, 256));
+    if ((c_in & 3) == 0 && aligned16(x_src) && aligned16(agg))
+        hipLaunchKernelGGL(k_gather_mean<true>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg);
+    else
+        hipLaunchKernelGGL(k_gather_mean<false>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg);
+}
+
+extern "C" int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
+                                const float *x_src, int32_t c_in, float *agg, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(rowptr && (col || nnz == 0) && x_src && agg, "sage_gather_mean: null pointer");
+    POPE_REQUIRE(n_dst > 0 && n_src > 0 && n_src < INT32_MAX && nnz >= 0 && nnz < INT32_MAX && c_in > 0, "sage_gather_mean: bad size");
+    enqueue_gather_mean(rowptr, col, n_dst, x_src, c_in, agg, (hipStream_t)stream_);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
 extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
                                  const float *x_src, int32_t c_in, const float *w_l, const float *b_l, const float *w_r,
                                  int32_t c_out, float *agg, float *out, void *stream_) {
@@ -252,11 +271,7 @@ extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int6
     POPE_REQUIRE(rowptr && (col || nnz == 0) && x_src && w_l && w_r && agg && out, "sage_conv_forward: null pointer");
     POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && nnz >= 0 && nnz < INT32_MAX && c_in > 0 && c_out > 0,
                  "sage_conv_forward: bad size (destinations must be the first n_dst sources)");
-    dim3 grid(capped_grid((size_t)n_dst * 64, 256));
-    if ((c_in & 3) == 0 && aligned16(x_src) && aligned16(agg))
-        hipLaunchKernelGGL(k_gather_mean<true>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg);
-    else
-        hipLaunchKernelGGL(k_gather_mean<false>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg);
+    enqueue_gather_mean(rowptr, col, n_dst, x_src, c_in, agg, stream);
     // out = agg * w_l^T + b_l + x_dst * w_r^T in one pass
     const Operand A0{agg, c_in, 1}, B0{w_l, c_in, 1}, A1{x_src, c_in, 1}, B1{w_r, c_in, 1};
     return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream);

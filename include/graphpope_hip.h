@@ -212,6 +212,10 @@ int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int64_t n_src, 
                       const float *x_src, int32_t c_in, const float *w_l, const float *b_l, const float *w_r,
                       int32_t c_out, float *agg, float *out, void *stream);
 
+/* The aggregation half on its own: agg[i, :] = mean_{p in row i} x_src[col[p], :] (zero for empty rows).  Asynchronous. */
+int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
+                     const float *x_src, int32_t c_in, float *agg, void *stream);
+
 /*
  * Gradients.  grad_out f32 [n_dst, c_out].  grad_x f32 [n_src, c_in] (may be NULL), grad_w_l, grad_w_r
  * f32 [c_out, c_in], grad_b_l f32 [c_out] (may be NULL) are OVERWRITTEN.  Asynchronous.

@@ -669,7 +669,8 @@ extern "C" int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, i
         return POPE_ERR_WORKSPACE;
     }
     const long long *src = (const long long *)edge_index, *dst = src + E;
-    POPE_HIP(hipMemsetAsync(aux, 0, AUX_HEADER * sizeof(int), stream));
+    if (defer_check != 2)                                       // 2 (internal): the caller's clear kernel zeroed the header
+        POPE_HIP(hipMemsetAsync(aux, 0, AUX_HEADER * sizeof(int), stream));
     if (E == 0) {
         POPE_HIP(hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * sizeof(int), stream));
         return POPE_OK;
@@ -746,7 +747,8 @@ static void launch_level(int E, int Wp, const int *col, const int *erow, const i
 struct DeviceCtx {
     int *report = nullptr;               // pinned host: [0] last_active, [1] csr flags
     int *report_dev = nullptr;           // the same memory as seen from the device
-    long long *anchors = nullptr;        // pinned host staging for the anchor ids
+    long long *anchors = nullptr;        // pinned, device-mapped host staging for the anchor ids
+    long long *anchors_dev = nullptr;    // the same memory as seen from the device (the seed kernel reads it in place)
     size_t anchors_cap = 0;
 };
 static DeviceCtx g_ctx[64];
@@ -763,7 +765,8 @@ static int device_ctx(DeviceCtx **out, size_t n_anchors) {
     if (n_anchors > c.anchors_cap) {
         if (c.anchors) POPE_HIP(hipHostFree(c.anchors));
         c.anchors_cap = n_anchors < 1024 ? 1024 : n_anchors;
-        POPE_HIP(hipHostMalloc((void **)&c.anchors, c.anchors_cap * sizeof(long long), hipHostMallocDefault));
+        POPE_HIP(hipHostMalloc((void **)&c.anchors, c.anchors_cap * sizeof(long long), hipHostMallocMapped));
+        POPE_HIP(hipHostGetDevicePointer((void **)&c.anchors_dev, c.anchors, 0));
     }
     *out = &c;
     return POPE_OK;
@@ -823,16 +826,26 @@ static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const in
     return device_ctx(&b.dev, (size_t)K);
 }
 
-static int bfs_enqueue_init(const Bfs &b, const int64_t *anchors_host, hipStream_t stream) {
-    // one launch clears the control block, the three frontier buffers, the reachability plane and the first hop planes
+// One launch clears the control block, the three frontier buffers, the reachability plane, the first hop planes and
+// (pope_geodesic_run) the CSR status header.
+static void bfs_enqueue_clear(const Bfs &b, int *aux_header, hipStream_t stream) {
     const int eager = b.capacity < EAGER_PLANES ? b.capacity : EAGER_PLANES;
     hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, stream, (uint4 *)b.base,
                        (b.front_off + 3 * align_up(b.plane_bytes, 256)) / 16, (uint4 *)b.seen,
-                       (size_t)(1 + eager) * b.plane_bytes / 16, (uint4 *)nullptr, (size_t)0);
-    memcpy(b.dev->anchors, anchors_host, (size_t)b.K * sizeof(long long));        // pinned staging: the copy below is truly async
-    POPE_HIP(hipMemcpyAsync(b.anchors_dev, b.dev->anchors, (size_t)b.K * sizeof(long long), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_bfs_seed, dim3((b.K + 255) / 256), dim3(256), 0, stream, b.anchors_dev, b.K, b.Wp, b.seen, b.front[0]);
+                       (size_t)(1 + eager) * b.plane_bytes / 16, (uint4 *)aux_header,
+                       aux_header ? (size_t)AUX_HEADER * sizeof(int) / 16 : (size_t)0);
+}
+
+// Anchors go through pinned, device-mapped host memory and the seed kernel reads them in place: no copy kernel.
+static int bfs_enqueue_seed(const Bfs &b, const int64_t *anchors_host, hipStream_t stream) {
+    memcpy(b.dev->anchors, anchors_host, (size_t)b.K * sizeof(long long));
+    hipLaunchKernelGGL(k_bfs_seed, dim3((b.K + 255) / 256), dim3(256), 0, stream, b.dev->anchors_dev, b.K, b.Wp, b.seen, b.front[0]);
     return POPE_OK;
+}
+
+static int bfs_enqueue_init(const Bfs &b, const int64_t *anchors_host, hipStream_t stream) {
+    bfs_enqueue_clear(b, nullptr, stream);
+    return bfs_enqueue_seed(b, anchors_host, stream);
 }
 
 // Enqueue levels [level, stop) (clipped to what the hop-bit capacity can represent); returns the next level.
@@ -1069,12 +1082,13 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     // speculative: sorted-CSR fast path, the first LEVEL_BATCH levels and the finalise kernel are all enqueued
     // before the host looks at anything; the finalise kernel reads the depth from the BFS control block.
     int rc;
-    rc = pope_csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 1, stream_);
-    if (rc) return rc;
     Bfs b;
     if ((rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, (uint64_t *)planes, plane_capacity,
                         ws + L.bfs_scratch, L.total - L.bfs_scratch))) return rc;
-    if ((rc = bfs_enqueue_init(b, anchors_host, stream))) return rc;
+    bfs_enqueue_clear(b, aux, stream);                    // BFS state and the CSR status header in one launch
+    rc = pope_csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, stream_);
+    if (rc) return rc;
+    if ((rc = bfs_enqueue_seed(b, anchors_host, stream))) return rc;
     int level = bfs_enqueue_levels(b, 1, 1 + LEVEL_BATCH, stream);
     if (out && (rc = finalize_enqueue(planes, 0, &b.ctl->last_active, N, K, x, F, out, out_cols, 0, stream))) return rc;
     int last_active = 0;

@@ -41,6 +41,8 @@ SIGNATURES = {
     "pope_profile_read": (c_int32, [c_void_p, c_void_p, c_int32]),
     "pope_geodesic_finalize_shards": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int64, c_int32, c_void_p, c_int32,
                                               c_void_p, c_int64, c_void_p]),
+    "pope_column_stats_scratch_bytes": (c_size_t, [c_int32]),
+    "pope_geodesic_column_stats": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pope_geodesic_hops": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
     "pope_pairwise_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "pope_pairwise_minmax": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,

@@ -599,6 +599,45 @@ __global__ __launch_bounds__(256) void k_hops(const u64 *__restrict__ planes, si
     }
 }
 
+// Per-anchor column statistics of the hop matrix straight from the planes: how many nodes reach anchor j and the sum of
+// their hop counts (closeness centrality = inward distances, utils.py:50-54).  Thread t of a block owns anchor column
+// tile * 256 + t and walks a slice of the rows; 64 threads share each plane word (one L1 line).  Two deterministic stages.
+__global__ __launch_bounds__(256) void k_column_stats_partial(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
+                                                              int N, int K, int Wp, long long *__restrict__ part_sum,
+                                                              long long *__restrict__ part_cnt) {
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    const int per = (N + gridDim.x - 1) / gridDim.x;
+    const int v0 = blockIdx.x * per, v1 = min(N, v0 + per);
+    long long sum = 0, cnt = 0;
+    if (j < K) {
+        const int w = j >> 6, bit = j & 63;
+        for (int v = v0; v < v1; ++v) {
+            const size_t widx = (size_t)v * Wp + w;
+            if ((planes[widx] >> bit) & 1ull) {
+                int h = 0;
+                for (int b = 0; b < n_hop_bits; ++b) h |= (int)((planes[(size_t)(b + 1) * plane_elems + widx] >> bit) & 1ull) << b;
+                sum += h;
+                ++cnt;
+            }
+        }
+        part_sum[(size_t)blockIdx.x * K + j] = sum;
+        part_cnt[(size_t)blockIdx.x * K + j] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_column_stats_final(const long long *__restrict__ part_sum, const long long *__restrict__ part_cnt,
+                                                            int parts, int K, long long *__restrict__ hop_sum, long long *__restrict__ reach) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= K) return;
+    long long s = 0, c = 0;
+    for (int p = 0; p < parts; ++p) {
+        s += part_sum[(size_t)p * K + j];
+        c += part_cnt[(size_t)p * K + j];
+    }
+    hop_sum[j] = s;
+    reach[j] = c;
+}
+
 // out[v, 0:F] = x[v, :].  Every wave owns a contiguous block of rows (see k_finalize_fast).
 __global__ __launch_bounds__(256) void k_concat(const float *__restrict__ x, int N, int F, float *__restrict__ out,
                                                 long long out_cols, bool vec) {
@@ -1140,6 +1179,30 @@ extern "C" int pope_geodesic_hops(const uint64_t *planes, int32_t n_hop_bits, in
     const int Wp = words_for(K);
     hipLaunchKernelGGL(k_hops, dim3(capped_grid((size_t)N * K, 256)), dim3(256), 0, stream, (const u64 *)planes,
                        (size_t)N * Wp, n_hop_bits, (int)N, K, Wp, hops);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+constexpr int STATS_PARTS = 256;
+
+extern "C" size_t pope_column_stats_scratch_bytes(int32_t K) { return K <= 0 ? 0 : 2 * (size_t)STATS_PARTS * K * sizeof(long long); }
+
+extern "C" int pope_geodesic_column_stats(const uint64_t *planes, int32_t n_hop_bits, int64_t N, int32_t K, int64_t *hop_sum,
+                                          int64_t *reach, void *scratch, size_t scratch_bytes, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(planes && hop_sum && reach && scratch, "pope_geodesic_column_stats: null pointer");
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && K > 0 && n_hop_bits >= 0 && n_hop_bits <= 31, "pope_geodesic_column_stats: bad size");
+    if (scratch_bytes < pope_column_stats_scratch_bytes(K)) {
+        set_error("pope_geodesic_column_stats: scratch %zu < %zu bytes", scratch_bytes, pope_column_stats_scratch_bytes(K));
+        return POPE_ERR_WORKSPACE;
+    }
+    const int Wp = words_for(K);
+    long long *ps = (long long *)scratch, *pc = ps + (size_t)STATS_PARTS * K;
+    hipLaunchKernelGGL(k_column_stats_partial, dim3(STATS_PARTS, (K + 255) / 256), dim3(256), 0, stream, (const u64 *)planes,
+                       (size_t)N * Wp, n_hop_bits, (int)N, K, Wp, ps, pc);
+    hipLaunchKernelGGL(k_column_stats_final, dim3((K + 255) / 256), dim3(256), 0, stream, ps, pc, STATS_PARTS, K,
+                       (long long *)hop_sum, (long long *)reach);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }

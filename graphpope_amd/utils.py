@@ -32,8 +32,7 @@ from . import engine
 # where attach_node2vec looks for {dataset}_node2vec.pt (reference: <dir of utils.py>/data, utils.py:155)
 NODE2VEC_DIR = os.environ.get("GRAPHPOPE_DATA_DIR", osp.join(osp.dirname(osp.realpath(__file__)), "data"))
 
-_CENTRALITIES = ("pagerank", "betweenness_centrality", "eigenvector_centrality", "closeness_centrality",
-                 "clustering_coefficient")
+_CENTRALITIES = ("pagerank", "betweenness_centrality", "eigenvector_centrality", "clustering_coefficient")
 
 
 def _device():
@@ -55,8 +54,10 @@ def sample_anchor_nodes(data, num_anchor_nodes, sampling_method):
 
     'degree_centrality' is reproduced on the host from edge_index (in + out degree of the DiGraph
     to_networkx builds: repeated edges collapsed, ascending stable sort, last K kept: utils.py:38-42).
-    The other centralities are one-off CPU NetworkX calls outside the accelerated path
-     and raise NotImplementedError.
+    'closeness_centrality' runs the multi-source BFS kernel from every node (engine.closeness_centrality) and
+    reproduces NetworkX's scores bit for bit, hence the same anchors (utils.py:50-54).
+    The remaining centralities (pagerank, betweenness, eigenvector, clustering) are one-off CPU NetworkX calls outside
+    the accelerated path and raise NotImplementedError.
     """
     if sampling_method == "stochastic":
         node_indices = np.arange(data.num_nodes)
@@ -68,10 +69,17 @@ def sample_anchor_nodes(data, num_anchor_nodes, sampling_method):
         deg = np.bincount(pairs // n, minlength=n) + np.bincount(pairs % n, minlength=n)
         order = np.argsort(deg, kind="stable")                     # ascending, ties in node order
         return order[-num_anchor_nodes:].tolist()
+    if sampling_method == "closeness_centrality":
+        # utils.py:50-54.  All-sources BFS on the GPU (exact integers), NetworkX's float formula on the host: same scores,
+        # same ascending stable sort, same last-K keys.
+        ei = data.edge_index.detach().to(_device(), torch.int64)
+        score = engine.closeness_centrality(ei, int(data.num_nodes))
+        order = np.argsort(score, kind="stable")
+        return order[-num_anchor_nodes:].tolist()
     if sampling_method in _CENTRALITIES:
         raise NotImplementedError(
             f"sampling_method={sampling_method!r}: NetworkX centrality ranking is outside the accelerated hot path "
-            "(SURVEY.md §8f rank 3); use 'stochastic' or 'degree_centrality'")
+            "(SURVEY.md §8f rank 3); use 'stochastic', 'degree_centrality' or 'closeness_centrality'")
     # the reference falls through every `if` and hits `return sampled_anchor_nodes` unbound (utils.py:62)
     raise UnboundLocalError("local variable 'sampled_anchor_nodes' referenced before assignment")
 

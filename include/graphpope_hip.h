@@ -20,6 +20,7 @@
  *   pope_geodesic_finalize   utils.py:73,125,    1/len(path), tensor conversion and torch.cat((x, emb), 1)
  *                            utils.py:129-135
  *   pope_geodesic_run        utils.py:144-145    get_geodesic_distance_vector + concat_into_features in one call
+ *   pope_geodesic_column_stats  utils.py:50-54   the BFS sums behind nx.closeness_centrality (biased anchor selection)
  *   pope_geodesic_hops       (no counterpart)    the integer hop matrix the floats are made of; parity tests
  *   pope_pairwise_minmax     utils.py:158-176    sklearn cosine/euclidean pairwise + MinMaxScaler
  *   pope_concat              utils.py:129-135    torch.cat for the node2vec branch
@@ -174,6 +175,15 @@ int32_t pope_profile_read(int32_t *levels_host, float *level_ms_host, int32_t ca
 /* Integer hop matrix: hops int32 [N, K] node-major, -1 = unreachable.  Asynchronous on `stream`. */
 int pope_geodesic_hops(const uint64_t *planes, int32_t n_hop_bits, int64_t N, int32_t K,
                        int32_t *hops, void *stream);
+
+/*
+ * Column statistics of the hop matrix, straight from the planes: reach[j] = number of nodes with a path to anchor j
+ * (the anchor included), hop_sum[j] = sum of their hop counts; both int64 [K] on the device.  What closeness
+ * centrality needs (utils.py:50-54: nx.closeness_centrality uses inward distances on a DiGraph).  Asynchronous.
+ */
+size_t pope_column_stats_scratch_bytes(int32_t K);
+int pope_geodesic_column_stats(const uint64_t *planes, int32_t n_hop_bits, int64_t N, int32_t K, int64_t *hop_sum,
+                               int64_t *reach, void *scratch, size_t scratch_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * node2vec-space embedding: pairwise distance to the anchor rows + per-column min-max scaling.

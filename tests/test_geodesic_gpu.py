@@ -257,3 +257,24 @@ def test_persisted_plane_cache(dev, tmp_path, monkeypatch):
     with pytest.raises(AssertionError):
         gp.Graphpope(d, "flickr", "geodesic", "stochastic", 32, None, 2)
     gp.clear_cache()
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_closeness_centrality_matches_networkx_bit_for_bit(symmetric, dev):
+    """sampling_method='closeness_centrality' (utils.py:50-54): same float64 scores as NetworkX, hence the same anchors."""
+    import networkx as nx
+    from graphpope_amd import engine, synth, utils as gp
+    ei, n = synth.rmat(9, edge_factor=4, seed=13, symmetric=symmetric)
+    g = nx.DiGraph()
+    g.add_nodes_from(range(n))
+    g.add_edges_from(zip(ei[0].tolist(), ei[1].tolist()))
+    want = nx.closeness_centrality(g)
+    got = engine.closeness_centrality(torch.as_tensor(ei, device=dev), n, batch=200)       # ragged last batch
+    assert np.array_equal(got, np.array([want[v] for v in range(n)]))
+
+    class Data:
+        pass
+    d = Data()
+    d.edge_index, d.num_nodes = torch.as_tensor(ei), n
+    ref = list({k: v for k, v in sorted(want.items(), key=lambda item: item[1])}.keys())[-17:]     # the reference's selection
+    assert gp.sample_anchor_nodes(d, 17, "closeness_centrality") == ref

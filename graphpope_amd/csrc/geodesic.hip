@@ -139,13 +139,15 @@ __global__ __launch_bounds__(256) void k_zero(uint4 *a, size_t na, uint4 *b, siz
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += stride) c[i] = z;
 }
 
-__global__ void k_bfs_seed(const long long *__restrict__ anchors, int K, int Wp, u64 *seen, u64 *front) {
+__global__ void k_bfs_seed(const long long *__restrict__ anchors, int K, int Wp, u64 *seen, u64 *front, unsigned *live) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= K) return;
-    size_t idx = (size_t)anchors[j] * Wp + (j >> 6);
+    const long long a = anchors[j];
+    size_t idx = (size_t)a * Wp + (j >> 6);
     u64 bit = 1ull << (j & 63);
     atomicOr(&seen[idx], bit);       // duplicate anchors share a node: distinct bits of the same words
     atomicOr(&front[idx], bit);
+    atomicOr(&live[a >> 5], 1u << (a & 31));
 }
 
 #ifdef POPE_STAMP
@@ -245,7 +247,7 @@ __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words
 // four slots share one row is "transparent" and passes the carry on).  Work per wave is 256 edges whatever the
 // degree distribution (no long rows, no dependent pointer chase: erow/col are coalesced 16-byte streams).
 //   * A row that lies inside this chunk is complete: its words are stored to acc[v] (the next frontier, zeros
-//     included, so acc needs no clearing) and committed (seen, hop planes) right here -- only this wave ever
+//     included unless the live table makes them unnecessary, so acc needs no clearing) and committed (seen, hop planes) right here -- only this wave ever
 //     touches row v's state.
 //   * A row that spans chunks ("multi-chunk": every hub) receives one piece per chunk, OR-ed into acc[v] with a
 //     device-scope atomic (a few thousand per level, distinct addresses).  Its commit is DEFERRED to the next
@@ -255,14 +257,22 @@ __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words
 //     has not landed yet gives the same result.  One launch per level, no second pass, no inter-block hand-off
 //     inside a launch.
 // Three frontier buffers rotate: front = level l-1 (read), acc = level l (written), idle = level l+1 (cleared).
+// Beside each goes a "live" table, one BIT per node: set when the node's frontier row is not all zero.  It is N/8
+// bytes (11 KB for Flickr) and every block copies it into LDS first (LIVE; graphs up to LIVE_MAX_NODES), so a lane looks
+// its four neighbours up there and gathers the 8*W-byte frontier row -- a random 128-byte line from L2 -- only for
+// live ones.  The first and the last levels of a BFS have few live nodes: their launches skip most gathers, and a
+// chunk with no live neighbour skips its mask loads too.  (Looking the bits up in global memory instead was measured
+// slower than no table at all: each chunk's 256 gathered lines flush the 32 KB L1, so the lookups went to L2 as well.)
 // WT = words per tile (1, 2 or 4); blockIdx.y selects the tile of a node's W words.
-template <int WT>
+template <int WT, bool LIVE>
 __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
                                                    int E, int Wp, const u64 *__restrict__ front,
                                                    u64 *__restrict__ seen, u64 *__restrict__ acc,
                                                    u64 *__restrict__ idle, u64 *__restrict__ hop_planes,
                                                    size_t plane_elems, int level, BfsCtl *ctl, const int *aux,
-                                                   int expand_blocks) {
+                                                   int expand_blocks, const unsigned *__restrict__ live,
+                                                   unsigned *__restrict__ live_acc, unsigned *__restrict__ live_idle,
+                                                   int live_words) {
     if (bfs_over(ctl, aux, level)) return;
     const int lane = threadIdx.x & 63;
     const int woff = blockIdx.y * WT;
@@ -271,6 +281,9 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
         const int n = aux[AUX_N_MROWS];
         const int *mrows = aux + AUX_HEADER;
         const int hb = gridDim.x - expand_blocks;
+        if (LIVE && blockIdx.y == 0)
+            for (int i = ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x; i < live_words; i += hb * blockDim.x)
+                live_idle[i] = 0u;
         Words<WT> zero;
 #pragma unroll
         for (int i = 0; i < WT; ++i) zero.w[i] = 0;
@@ -288,19 +301,37 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (expand_blocks * blockDim.x) >> 6;
     const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
+    // The first chunk's slot loads are issued before the live table is staged: they fly while LDS fills.
+    int4 vr = make_int4(-1, -1, -1, -1), ur = make_int4(0, 0, 0, 0);
+    if (wave < nchunks && wave * CHUNK + lane * SLOTS < E) {
+        vr = *reinterpret_cast<const int4 *>(erow + wave * CHUNK + lane * SLOTS);
+        ur = *reinterpret_cast<const int4 *>(col + wave * CHUNK + lane * SLOTS);
+    }
+    extern __shared__ uint4 live_lds4[];
+    const unsigned *live_lds = reinterpret_cast<const unsigned *>(live_lds4);
+    if constexpr (LIVE) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(live);                   // tables are padded to 256 bytes
+        for (int i = threadIdx.x; i < (live_words + 3) / 4; i += blockDim.x) live_lds4[i] = src[i];
+        __syncthreads();
+    }
     bool found = false;
     STAMP(0);
     for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
         const int base = chunk * CHUNK + lane * SLOTS;
         int v0 = -1, v1 = -1, v2 = -1, v3 = -1, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
         if (base < E) {                       // arrays are padded to a multiple of 4 entries: the 16-byte load is in bounds
-            const int4 vr = *reinterpret_cast<const int4 *>(erow + base);
-            const int4 ur = *reinterpret_cast<const int4 *>(col + base);
+            if (chunk != wave) {
+                vr = *reinterpret_cast<const int4 *>(erow + base);
+                ur = *reinterpret_cast<const int4 *>(col + base);
+            }
             v0 = vr.x; u0 = ur.x;
             if (base + 1 < E) { v1 = vr.y; u1 = ur.y; }
             if (base + 2 < E) { v2 = vr.z; u2 = ur.z; }
             if (base + 3 < E) { v3 = vr.w; u3 = ur.w; }
         }
+        auto is_live = [&](int u) { return !LIVE || ((live_lds[u >> 5] >> (u & 31)) & 1u) != 0; };
+        const bool g0 = v0 >= 0 && is_live(u0), g1 = v1 >= 0 && is_live(u1), g2 = v2 >= 0 && is_live(u2),
+                   g3 = v3 >= 0 && is_live(u3);
         const int vc = __shfl(v0, 0);                                                  // row of the chunk's first slot
         const int vl = __shfl(v3, 63);                                                 // row of its last slot (-1: short chunk)
         STAMP(1);
@@ -313,8 +344,12 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
         Words<WT> c0, c1, c2, c3, s0, s1, s2, s3;
 #pragma unroll
         for (int i = 0; i < WT; ++i) c0.w[i] = c1.w[i] = c2.w[i] = c3.w[i] = s0.w[i] = s1.w[i] = s2.w[i] = s3.w[i] = 0;
-        if (v0 >= 0) {
-            c0 = gather_words<WT>(front + (size_t)u0 * Wp + woff);
+        const bool work = __any(g0 || g1 || g2 || g3);                 // else: no live neighbour behind these 256 slots
+        if (g0) c0 = gather_words<WT>(front + (size_t)u0 * Wp + woff);
+        if (g1) c1 = gather_words<WT>(front + (size_t)u1 * Wp + woff);
+        if (g2) c2 = gather_words<WT>(front + (size_t)u2 * Wp + woff);
+        if (g3) c3 = gather_words<WT>(front + (size_t)u3 * Wp + woff);
+        if (work && v0 >= 0) {
             s0 = load_words<WT>(seen + (size_t)v0 * Wp + woff);
             if (x0) {                                                    // deferred commit: level l-1 may not be in seen yet
                 const Words<WT> f = load_words<WT>(front + (size_t)v0 * Wp + woff);
@@ -322,10 +357,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
                 for (int i = 0; i < WT; ++i) s0.w[i] |= f.w[i];
             }
         }
-        if (v1 >= 0) c1 = gather_words<WT>(front + (size_t)u1 * Wp + woff);
-        if (v2 >= 0) c2 = gather_words<WT>(front + (size_t)u2 * Wp + woff);
-        if (v3 >= 0) {
-            c3 = gather_words<WT>(front + (size_t)u3 * Wp + woff);
+        if (work && v3 >= 0) {
             if (v3 == v0) {
                 s3 = s0;
             } else {
@@ -338,8 +370,8 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
             }
         }
         // an interior row (neither the lane's first nor last row) lies inside the chunk: plain seen is its mask
-        if (v1 >= 0) s1 = v1 == v0 ? s0 : (v1 == v3 ? s3 : load_words<WT>(seen + (size_t)v1 * Wp + woff));
-        if (v2 >= 0) s2 = v2 == v1 ? s1 : (v2 == v3 ? s3 : load_words<WT>(seen + (size_t)v2 * Wp + woff));
+        if (work && v1 >= 0) s1 = v1 == v0 ? s0 : (v1 == v3 ? s3 : load_words<WT>(seen + (size_t)v1 * Wp + woff));
+        if (work && v2 >= 0) s2 = v2 == v1 ? s1 : (v2 == v3 ? s3 : load_words<WT>(seen + (size_t)v2 * Wp + woff));
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
             c0.w[i] &= ~s0.w[i];
@@ -400,14 +432,45 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
             for (int i = 0; i < WT; ++i)
                 if (c.w[i]) atomicOr(&acc[idx + i], c.w[i]);
         };
-        if (e0) { if (x0) piece(i0, c0); else store_words<WT>(acc + i0, c0); }
-        if (e1) { if (x1) piece(i1, c1); else store_words<WT>(acc + i1, c1); }
-        if (e2) { if (x2) piece(i2, c2); else store_words<WT>(acc + i2, c2); }
-        if (e3) { if (x3) piece(i3, c3); else store_words<WT>(acc + i3, c3); }
-        STAMP(4);
         const bool n0 = e0 && any_bits<WT>(c0) != 0, n1 = e1 && any_bits<WT>(c1) != 0, n2 = e2 && any_bits<WT>(c2) != 0,
                    n3 = e3 && any_bits<WT>(c3) != 0;
+        // With the live table an all-zero row need not be written: nobody gathers a row whose live bit is clear.
+        // (Several tiles share one live bit per node: then zeros are written too, so a live row is exact in every tile.)
+        const bool dense = !LIVE || gridDim.y > 1;
+        if (e0 && (n0 || dense)) { if (x0) piece(i0, c0); else store_words<WT>(acc + i0, c0); }
+        if (e1 && (n1 || dense)) { if (x1) piece(i1, c1); else store_words<WT>(acc + i1, c1); }
+        if (e2 && (n2 || dense)) { if (x2) piece(i2, c2); else store_words<WT>(acc + i2, c2); }
+        if (e3 && (n3 || dense)) { if (x3) piece(i3, c3); else store_words<WT>(acc + i3, c3); }
+        STAMP(4);
         found |= n0 || n1 || n2 || n3;
+        if constexpr (LIVE) {
+            // Mark the rows that received something.  The chunk's rows are a short ascending run of node ids: build each
+            // 32-bit table word with a wave-wide OR and let one lane publish it (per-row atomics -- ~30 to every word
+            // from a few waves -- cost 14 us per dense level).
+            if (__any(n0 || n1 || n2 || n3)) {
+                const int wfirst = vc >> 5;
+                const int last_slot = min((chunk + 1) * CHUNK, E) - 1;
+                const int kmax = (erow[last_slot] >> 5) - wfirst;
+                if (kmax < 8) {
+                    for (int k = 0; k <= kmax; ++k) {
+                        const int wk = wfirst + k;
+                        unsigned m = 0;
+                        if (n0 && (v0 >> 5) == wk) m |= 1u << (v0 & 31);
+                        if (n1 && (v1 >> 5) == wk) m |= 1u << (v1 & 31);
+                        if (n2 && (v2 >> 5) == wk) m |= 1u << (v2 & 31);
+                        if (n3 && (v3 >> 5) == wk) m |= 1u << (v3 & 31);
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) m |= (unsigned)__shfl_xor((int)m, d);
+                        if (lane == 0 && m) atomicOr(&live_acc[wk], m);
+                    }
+                } else {                                       // a run with wide gaps (isolated nodes in between)
+                    if (n0) atomicOr(&live_acc[v0 >> 5], 1u << (v0 & 31));
+                    if (n1) atomicOr(&live_acc[v1 >> 5], 1u << (v1 & 31));
+                    if (n2) atomicOr(&live_acc[v2 >> 5], 1u << (v2 & 31));
+                    if (n3) atomicOr(&live_acc[v3 >> 5], 1u << (v3 & 31));
+                }
+            }
+        }
         const bool m0 = n0 && !x0, m1 = n1 && !x1, m2 = n2 && !x2, m3 = n3 && !x3;     // complete rows: commit now
         if (__any(m0 || m1 || m2 || m3)) {
 #pragma unroll
@@ -736,13 +799,16 @@ extern "C" size_t pope_plane_bytes(int64_t N, int32_t K) {
     return (size_t)N * words_for(K) * sizeof(u64);
 }
 
+static size_t live_bytes(int64_t N) { return align_up((size_t)((N + 31) / 32) * sizeof(unsigned), 256); }
+
 extern "C" size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K) {
     if (N < 0 || E < 0 || K <= 0) return 0;
     (void)E;
-    // control block | anchors[K] | three rotating frontier planes
-    return 256 + align_up((size_t)K * sizeof(long long), 256) + 3 * align_up(pope_plane_bytes(N, K), 256);
+    // control block | anchors[K] | three rotating frontier planes | their three live-bit tables
+    return 256 + align_up((size_t)K * sizeof(long long), 256) + 3 * align_up(pope_plane_bytes(N, K), 256) + 3 * live_bytes(N);
 }
 
+constexpr int LIVE_MAX_NODES = 256 * 1024;   // live table of 32 KB per block in LDS (4 blocks per CU); beyond: no table
 constexpr int EAGER_PLANES = 4;      // hop-bit planes cleared up front (levels < 16); deeper ones when first needed
 
 // Optional per-launch timing of the level kernels with HIP events on the launch stream (bench.py's roofline leg).
@@ -765,15 +831,21 @@ static void profile_mark(hipStream_t stream, int level, int which) {
 template <int WT>
 static void launch_level(int E, int Wp, const int *col, const int *erow, const int *aux, const u64 *front, u64 *seen,
                          u64 *acc, u64 *idle, u64 *hop_planes, size_t plane_elems, int level, BfsCtl *ctl,
-                         hipStream_t stream) {
+                         const unsigned *live, unsigned *live_acc, unsigned *live_idle, int live_words, hipStream_t stream) {
     const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
     int expand_blocks = (nchunks + 3) / 4;                           // one wave per chunk ...
     if (expand_blocks > 256 * 8) expand_blocks = 256 * 8;            // ... up to 8 blocks per CU, then waves loop
     int house_blocks = (nchunks + 255) / 256;                        // rows that span chunks: at most one per chunk
     if (house_blocks > 64) house_blocks = 64;
     profile_mark(stream, level, 0);
-    hipLaunchKernelGGL((k_bfs_level<WT>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow, col, E,
-                       Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks);
+    if (live_words <= LIVE_MAX_NODES / 32)
+        hipLaunchKernelGGL((k_bfs_level<WT, true>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256),
+                           align_up((size_t)live_words * sizeof(unsigned), 16), stream, erow, col, E, Wp, front, seen, acc, idle, hop_planes,
+                           plane_elems, level, ctl, aux, expand_blocks, live, live_acc, live_idle, live_words);
+    else
+        hipLaunchKernelGGL((k_bfs_level<WT, false>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow,
+                           col, E, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
+                           live_acc, live_idle, live_words);
     profile_mark(stream, level, 1);
 }
 
@@ -824,6 +896,8 @@ struct Bfs {
     int N, E, K, Wp, capacity;
     size_t plane_elems, plane_bytes, front_off;
     u64 *seen, *hop_planes, *front[3];
+    unsigned *live[3];           // one bit per node beside each frontier buffer: row not all zero
+    int live_words;
     char *base;
     BfsCtl *ctl;
     long long *anchors_dev;
@@ -861,6 +935,10 @@ static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const in
     b.front[0] = (u64 *)(b.base + b.front_off);
     b.front[1] = (u64 *)((char *)b.front[0] + align_up(b.plane_bytes, 256));
     b.front[2] = (u64 *)((char *)b.front[1] + align_up(b.plane_bytes, 256));
+    b.live[0] = (unsigned *)((char *)b.front[2] + align_up(b.plane_bytes, 256));
+    b.live[1] = (unsigned *)((char *)b.live[0] + live_bytes(N));
+    b.live[2] = (unsigned *)((char *)b.live[1] + live_bytes(N));
+    b.live_words = (int)((N + 31) / 32);
     b.level_limit = 1ll << plane_capacity;
     return device_ctx(&b.dev, (size_t)K);
 }
@@ -870,7 +948,7 @@ static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const in
 static void bfs_enqueue_clear(const Bfs &b, int *aux_header, hipStream_t stream) {
     const int eager = b.capacity < EAGER_PLANES ? b.capacity : EAGER_PLANES;
     hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, stream, (uint4 *)b.base,
-                       (b.front_off + 3 * align_up(b.plane_bytes, 256)) / 16, (uint4 *)b.seen,
+                       (b.front_off + 3 * align_up(b.plane_bytes, 256) + 3 * live_bytes(b.N)) / 16, (uint4 *)b.seen,
                        (size_t)(1 + eager) * b.plane_bytes / 16, (uint4 *)aux_header,
                        aux_header ? (size_t)AUX_HEADER * sizeof(int) / 16 : (size_t)0);
 }
@@ -878,7 +956,7 @@ static void bfs_enqueue_clear(const Bfs &b, int *aux_header, hipStream_t stream)
 // Anchors go through pinned, device-mapped host memory and the seed kernel reads them in place: no copy kernel.
 static int bfs_enqueue_seed(const Bfs &b, const int64_t *anchors_host, hipStream_t stream) {
     memcpy(b.dev->anchors, anchors_host, (size_t)b.K * sizeof(long long));
-    hipLaunchKernelGGL(k_bfs_seed, dim3((b.K + 255) / 256), dim3(256), 0, stream, b.dev->anchors_dev, b.K, b.Wp, b.seen, b.front[0]);
+    hipLaunchKernelGGL(k_bfs_seed, dim3((b.K + 255) / 256), dim3(256), 0, stream, b.dev->anchors_dev, b.K, b.Wp, b.seen, b.front[0], b.live[0]);
     return POPE_OK;
 }
 
@@ -900,9 +978,11 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
         const u64 *prev = b.front[(level - 1) % 3];           // frontier of level - 1
         u64 *next = b.front[level % 3];                          // receives the frontier of this level
         u64 *idle = b.front[(level + 1) % 3];                    // next level's accumulator: rows spanning chunks cleared now
-        if (b.Wp == 1)      launch_level<1>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, stream);
-        else if (b.Wp == 2) launch_level<2>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, stream);
-        else                launch_level<4>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, stream);
+        const unsigned *lp = b.live[(level - 1) % 3];
+        unsigned *ln = b.live[level % 3], *li = b.live[(level + 1) % 3];
+        if (b.Wp == 1)      launch_level<1>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
+        else if (b.Wp == 2) launch_level<2>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
+        else                launch_level<4>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
     }
     return level;
 }

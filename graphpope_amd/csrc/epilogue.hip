@@ -1,0 +1,323 @@
+// BatchNorm1d + ReLU + dropout of the GraphSAGE hidden layers as ONE op, forward and backward
+// (/root/reference/main.py:207-209: x = self.bns[i](x); x = x.relu_(); x = F.dropout(x, p, training)).
+//
+// The matrix is [M, C] float32 row-major (M = destination nodes of the hop, C = hidden_channels), a few MB: every
+// kernel is a streaming pass, so the op is three launches per direction instead of torch's seven:
+//   forward   k_bn_partial (column sums of x, x^2 over row slabs, f64)  ->  k_bn_final (mean, rstd, running stats)
+//             ->  k_bn_apply (normalise, scale/shift, ReLU, dropout mask from a counter hash: no mask tensor)
+//   backward  k_bn_bwd_partial (sums of g and g*xhat, g = dy through dropout and ReLU, recomputed from x)
+//             ->  k_bn_bwd_final  ->  k_bn_bwd_apply (dx)
+// Statistics follow torch.nn.BatchNorm1d: biased variance for normalisation, unbiased for running_var, momentum
+// update, eps inside the square root.  Sums are accumulated in f64 (torch: f32 Welford); results agree to ~1e-6.
+#include "common.h"
+
+namespace pope {
+
+constexpr int BN_MAX_PARTS = 256;
+
+__device__ __forceinline__ unsigned fmix32(unsigned h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// Dropout decision of element `idx`: a 24-bit uniform from a counter hash of (seed, idx), kept if >= p * 2^24.
+__device__ __forceinline__ bool keep_element(unsigned long long seed, unsigned long long idx, unsigned threshold) {
+    unsigned h = fmix32((unsigned)idx ^ (unsigned)seed);
+    h = fmix32(h ^ ((unsigned)(idx >> 32) * 0x9e3779b1u) ^ (unsigned)(seed >> 32));
+    return (h >> 8) >= threshold;
+}
+
+template <int VEC> struct Pack { float v[VEC]; };
+
+template <int VEC>
+__device__ __forceinline__ Pack<VEC> load_pack(const float *p) {
+    Pack<VEC> r;
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else {
+        r.v[0] = p[0];
+    }
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_pack(float *p, const Pack<VEC> &r) {
+    if constexpr (VEC == 4) *reinterpret_cast<float4 *>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    else p[0] = r.v[0];
+}
+
+// A block = 4 waves; a wave walks rows r0 + wave, r0 + wave + 4, ... of its slab, lane l owns VEC columns.
+// BWD: accumulate (g, g * xhat) instead of (x, x^2).
+template <int VEC, bool BWD>
+__global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x, const float *__restrict__ dy, int M, int C,
+                                                    int rows_per_part, const float *__restrict__ mean,
+                                                    const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                    const float *__restrict__ beta, unsigned long long seed,
+                                                    unsigned threshold, float inv_keep, double *__restrict__ pa,
+                                                    double *__restrict__ pb) {
+    __shared__ double sh[2][4][64 * VEC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (blockIdx.y * 64 + lane) * VEC;
+    const bool valid = c0 < C;
+    const int r0 = blockIdx.x * rows_per_part, r1 = min(M, r0 + rows_per_part);
+    double a[VEC], b[VEC];
+    float mu[VEC], rs[VEC], ga[VEC], be[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        a[i] = b[i] = 0.0;
+        mu[i] = rs[i] = ga[i] = be[i] = 0.f;
+        if (BWD && valid) { mu[i] = mean[c0 + i]; rs[i] = rstd[c0 + i]; ga[i] = gamma[c0 + i]; be[i] = beta[c0 + i]; }
+    }
+    if (valid)
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const size_t off = (size_t)r * C + c0;
+            const Pack<VEC> xv = load_pack<VEC>(x + off);
+            if constexpr (!BWD) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    a[i] += (double)xv.v[i];
+                    b[i] += (double)xv.v[i] * (double)xv.v[i];
+                }
+            } else {
+                const Pack<VEC> gv = load_pack<VEC>(dy + off);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float xhat = (xv.v[i] - mu[i]) * rs[i];
+                    const bool on = xhat * ga[i] + be[i] > 0.f && keep_element(seed, off + i, threshold);
+                    const float g = on ? gv.v[i] * inv_keep : 0.f;
+                    a[i] += (double)g;
+                    b[i] += (double)g * (double)xhat;
+                }
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        sh[0][wave][lane * VEC + i] = a[i];
+        sh[1][wave][lane * VEC + i] = b[i];
+    }
+    __syncthreads();
+    if (wave == 0 && valid) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int j = lane * VEC + i;
+            pa[(size_t)blockIdx.x * C + c0 + i] = sh[0][0][j] + sh[0][1][j] + sh[0][2][j] + sh[0][3][j];
+            pb[(size_t)blockIdx.x * C + c0 + i] = sh[1][0][j] + sh[1][1][j] + sh[1][2][j] + sh[1][3][j];
+        }
+    }
+}
+
+// Column totals of the per-slab partials.  A block is 16 columns x 16 slab-groups: a thread adds every 16th slab, LDS
+// folds the groups in a fixed order (one thread per column walking all slabs was 2 x 256 dependent-latency loads: 69 us).
+__device__ __forceinline__ void fold_parts(const double *__restrict__ pa, const double *__restrict__ pb, int parts, int C, int c,
+                                           double &s, double &q) {
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+#pragma unroll 4
+        for (int p = grp; p < parts; p += 16) {
+            a += pa[(size_t)p * C + c];
+            b += pb[(size_t)p * C + c];
+        }
+    red[0][grp][cl] = a;
+    red[1][grp][cl] = b;
+    __syncthreads();
+    s = q = 0.0;
+    if (grp == 0)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            s += red[0][g][cl];
+            q += red[1][g][cl];
+        }
+}
+
+// training: batch statistics + running-stat update; else: the running statistics.  Launch: 256 threads, C/16 blocks.
+__global__ __launch_bounds__(256) void k_bn_final(const double *__restrict__ pa, const double *__restrict__ pb, int parts, int M, int C, int training,
+                           float momentum, float eps, float *__restrict__ running_mean, float *__restrict__ running_var,
+                           float *__restrict__ mean, float *__restrict__ rstd) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool owner = (threadIdx.x >> 4) == 0 && c < C;
+    if (!training) {
+        if (owner) {
+            mean[c] = running_mean[c];
+            rstd[c] = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+        }
+        return;
+    }
+    double s, q;
+    fold_parts(pa, pb, parts, C, c, s, q);
+    if (!owner) return;
+    const double mu = s / M;
+    double var = q / M - mu * mu;                                  // biased
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_final(const double *__restrict__ pa, const double *__restrict__ pb, int parts, int M, int C,
+                               int training, float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ c1,
+                               float *__restrict__ c2) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    double s, q;
+    fold_parts(pa, pb, parts, C, c, s, q);
+    if ((threadIdx.x >> 4) != 0 || c >= C) return;
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)q;
+    c1[c] = training ? (float)(s / M) : 0.f;                       // eval: the statistics are constants
+    c2[c] = training ? (float)(q / M) : 0.f;
+}
+
+// y = dropout(relu((x - mean) * rstd * gamma + beta));  BWD: dx = gamma * rstd * (g - c1 - xhat * c2)
+template <int VEC, bool BWD>
+__global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, const float *__restrict__ dy, size_t total, int C,
+                                                  const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                  const float *__restrict__ c1, const float *__restrict__ c2,
+                                                  unsigned long long seed, unsigned threshold, float inv_keep,
+                                                  float *__restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * VEC;
+    for (size_t off = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; off < total; off += stride) {
+        const int c0 = (int)(off % C);                             // VEC == 4 only when C % 4 == 0: one row per pack
+        const Pack<VEC> xv = load_pack<VEC>(x + off);
+        Pack<VEC> gv, r;
+        if constexpr (BWD) gv = load_pack<VEC>(dy + off);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int c = c0 + i;
+            const float xhat = (xv.v[i] - mean[c]) * rstd[c];
+            const float z = xhat * gamma[c] + beta[c];
+            const bool on = z > 0.f && keep_element(seed, off + i, threshold);
+            if constexpr (!BWD) {
+                r.v[i] = on ? z * inv_keep : 0.f;
+            } else {
+                const float g = on ? gv.v[i] * inv_keep : 0.f;
+                r.v[i] = gamma[c] * rstd[c] * (g - c1[c] - xhat * c2[c]);
+            }
+        }
+        store_pack<VEC>(out + off, r);
+    }
+}
+
+struct BnPlan {
+    int parts, rows_per_part, vec;
+    double *pa, *pb;
+    float *c1, *c2;
+};
+
+static size_t bn_scratch(int C) { return 2 * (size_t)BN_MAX_PARTS * C * sizeof(double) + 2 * align_up((size_t)C * sizeof(float), 256); }
+
+static BnPlan bn_plan(int64_t M, int C, void *scratch, const void *p0, const void *p1, const void *p2) {
+    BnPlan p;
+    p.parts = (int)((M + 15) / 16);
+    if (p.parts > BN_MAX_PARTS) p.parts = BN_MAX_PARTS;
+    if (p.parts < 1) p.parts = 1;
+    p.rows_per_part = (int)((M + p.parts - 1) / p.parts);
+    const bool aligned = (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) == 0;
+    p.vec = (C % 4 == 0 && aligned) ? 4 : 1;
+    p.pa = (double *)scratch;
+    p.pb = p.pa + (size_t)BN_MAX_PARTS * C;
+    p.c1 = (float *)(p.pb + (size_t)BN_MAX_PARTS * C);
+    p.c2 = (float *)((char *)p.c1 + align_up((size_t)C * sizeof(float), 256));
+    return p;
+}
+
+static unsigned drop_threshold(float p) {
+    if (!(p > 0.f)) return 0u;
+    if (p >= 1.f) return 1u << 24;                                  // above every 24-bit draw: nothing kept
+    return (unsigned)((double)p * 16777216.0);
+}
+
+}  // namespace pope
+
+using namespace pope;
+
+extern "C" size_t sage_bn_scratch_bytes(int32_t C) { return C <= 0 ? 0 : bn_scratch(C); }
+
+extern "C" int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C, const float *gamma, const float *beta,
+                                            float *running_mean, float *running_var, float momentum, float eps,
+                                            int32_t training, float p, uint64_t seed, float *y, float *save_mean,
+                                            float *save_rstd, void *scratch, size_t scratch_bytes, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && scratch, "sage_bn_relu_dropout_forward: null pointer");
+    POPE_REQUIRE(M > 0 && M < INT32_MAX && C > 0 && (size_t)M * C < ((size_t)1 << 40), "sage_bn_relu_dropout_forward: bad size");
+    POPE_REQUIRE(training || (running_mean && running_var), "sage_bn_relu_dropout_forward: eval mode needs running statistics");
+    POPE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sage_bn_relu_dropout_forward: running_mean/var go together");
+    POPE_REQUIRE(p >= 0.f && p <= 1.f && eps > 0.f, "sage_bn_relu_dropout_forward: need 0 <= p <= 1, eps > 0");
+    if (scratch_bytes < bn_scratch(C)) {
+        set_error("sage_bn_relu_dropout_forward: scratch %zu < %zu bytes", scratch_bytes, bn_scratch(C));
+        return POPE_ERR_WORKSPACE;
+    }
+    const BnPlan pl = bn_plan(M, C, scratch, x, y, nullptr);
+    if (training) {
+        const dim3 grid(pl.parts, (C + 64 * pl.vec - 1) / (64 * pl.vec));
+        if (pl.vec == 4)
+            hipLaunchKernelGGL((k_bn_partial<4, false>), grid, dim3(256), 0, stream, x, nullptr, (int)M, C, pl.rows_per_part,
+                               nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb);
+        else
+            hipLaunchKernelGGL((k_bn_partial<1, false>), grid, dim3(256), 0, stream, x, nullptr, (int)M, C, pl.rows_per_part,
+                               nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb);
+    }
+    hipLaunchKernelGGL(k_bn_final, dim3((C + 15) / 16), dim3(256), 0, stream, pl.pa, pl.pb, pl.parts, (int)M, C, training,
+                       momentum, eps, running_mean, running_var, save_mean, save_rstd);
+    const unsigned thr = training ? drop_threshold(p) : 0u;
+    const float inv_keep = (training && p > 0.f && p < 1.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
+    const size_t total = (size_t)M * C;
+    const unsigned blocks = capped_grid(total / pl.vec, 256);
+    if (pl.vec == 4)
+        hipLaunchKernelGGL((k_bn_apply<4, false>), dim3(blocks), dim3(256), 0, stream, x, nullptr, total, C, save_mean, save_rstd,
+                           gamma, beta, nullptr, nullptr, (unsigned long long)seed, thr, inv_keep, y);
+    else
+        hipLaunchKernelGGL((k_bn_apply<1, false>), dim3(blocks), dim3(256), 0, stream, x, nullptr, total, C, save_mean, save_rstd,
+                           gamma, beta, nullptr, nullptr, (unsigned long long)seed, thr, inv_keep, y);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+extern "C" int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,
+                                             const float *beta, const float *save_mean, const float *save_rstd,
+                                             int32_t training, float p, uint64_t seed, float *grad_x, float *grad_gamma,
+                                             float *grad_beta, void *scratch, size_t scratch_bytes, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(x && grad_y && gamma && beta && save_mean && save_rstd && grad_x && scratch,
+                 "sage_bn_relu_dropout_backward: null pointer");
+    POPE_REQUIRE(M > 0 && M < INT32_MAX && C > 0 && (size_t)M * C < ((size_t)1 << 40), "sage_bn_relu_dropout_backward: bad size");
+    POPE_REQUIRE(p >= 0.f && p <= 1.f, "sage_bn_relu_dropout_backward: need 0 <= p <= 1");
+    if (scratch_bytes < bn_scratch(C)) {
+        set_error("sage_bn_relu_dropout_backward: scratch %zu < %zu bytes", scratch_bytes, bn_scratch(C));
+        return POPE_ERR_WORKSPACE;
+    }
+    const BnPlan pl = bn_plan(M, C, scratch, x, grad_y, grad_x);
+    const unsigned thr = training ? drop_threshold(p) : 0u;
+    const float inv_keep = (training && p > 0.f && p < 1.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
+    const dim3 grid(pl.parts, (C + 64 * pl.vec - 1) / (64 * pl.vec));
+    if (pl.vec == 4)
+        hipLaunchKernelGGL((k_bn_partial<4, true>), grid, dim3(256), 0, stream, x, grad_y, (int)M, C, pl.rows_per_part, save_mean,
+                           save_rstd, gamma, beta, (unsigned long long)seed, thr, inv_keep, pl.pa, pl.pb);
+    else
+        hipLaunchKernelGGL((k_bn_partial<1, true>), grid, dim3(256), 0, stream, x, grad_y, (int)M, C, pl.rows_per_part, save_mean,
+                           save_rstd, gamma, beta, (unsigned long long)seed, thr, inv_keep, pl.pa, pl.pb);
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3((C + 15) / 16), dim3(256), 0, stream, pl.pa, pl.pb, pl.parts, (int)M, C, training,
+                       grad_gamma, grad_beta, pl.c1, pl.c2);
+    const size_t total = (size_t)M * C;
+    const unsigned blocks = capped_grid(total / pl.vec, 256);
+    if (pl.vec == 4)
+        hipLaunchKernelGGL((k_bn_apply<4, true>), dim3(blocks), dim3(256), 0, stream, x, grad_y, total, C, save_mean, save_rstd,
+                           gamma, beta, pl.c1, pl.c2, (unsigned long long)seed, thr, inv_keep, grad_x);
+    else
+        hipLaunchKernelGGL((k_bn_apply<1, true>), dim3(blocks), dim3(256), 0, stream, x, grad_y, total, C, save_mean, save_rstd,
+                           gamma, beta, pl.c1, pl.c2, (unsigned long long)seed, thr, inv_keep, grad_x);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}

@@ -98,12 +98,24 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
     if (wave == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// 16 columns x 16 split-groups per block: a one-thread-per-column loop over the 64 partials is 64 dependent-latency
+// loads (15 us measured); here every thread adds 4 and LDS folds the 16 groups in a fixed order.
 __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ part, int splits, int C, float *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += part[(size_t)z * C + c];
-    out[c] = s;
+    if (c < C)
+#pragma unroll 4
+        for (int z = grp; z < splits; z += 16) s += part[(size_t)z * C + c];
+    red[grp][cl] = s;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][cl];
+        out[c] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -302,7 +314,7 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
     if ((rc = gemm(Gt, XdT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_r, c_in, splits, slab, stream))) return rc;
     if (grad_b_l) {                                             // the slab region is free again: stream order
         hipLaunchKernelGGL(k_colsum_partial, dim3((c_out + 63) / 64, COLSUM_SPLITS), dim3(256), 0, stream, grad_out, (int)n_dst, c_out, slab);
-        hipLaunchKernelGGL(k_colsum_final, dim3((c_out + 255) / 256), dim3(256), 0, stream, slab, COLSUM_SPLITS, c_out, grad_b_l);
+        hipLaunchKernelGGL(k_colsum_final, dim3((c_out + 15) / 16), dim3(256), 0, stream, slab, COLSUM_SPLITS, c_out, grad_b_l);
     }
     if (grad_x) {
         // grad_x[:n_dst] = grad_out * w_r ; rows >= n_dst start at zero; then scatter grad_agg = grad_out * w_l

@@ -116,6 +116,70 @@ class SAGEConv(nn.Module):
                                  adj_t.size(0))
 
 
+class _BnReluDropoutFn(torch.autograd.Function):
+    """BatchNorm1d -> ReLU -> dropout in three launches per direction (csrc/epilogue.hip), main.py:207-209."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, p, seed):
+        lib = _lib.load()
+        if not x.is_cuda:
+            raise RuntimeError("the fused BatchNorm/ReLU/dropout epilogue runs on the GPU only (no CPU fallback)")
+        x = x.contiguous()
+        m, c = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        rstd = torch.empty(c, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            scratch = torch.empty(lib.sage_bn_scratch_bytes(c), dtype=torch.uint8, device=dev)
+            check(lib.sage_bn_relu_dropout_forward(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                                   momentum, eps, int(training), p, seed, ptr(y), ptr(mean), ptr(rstd),
+                                                   ptr(scratch), scratch.numel(), _stream()))
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (bool(training), float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        lib = _lib.load()
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, p, seed = ctx.cfg
+        m, c = x.shape
+        dev = x.device
+        grad_y = grad_y.contiguous()
+        grad_x = torch.empty_like(x)
+        grad_gamma = torch.empty_like(gamma)
+        grad_beta = torch.empty_like(beta)
+        with torch.cuda.device(dev):
+            scratch = torch.empty(lib.sage_bn_scratch_bytes(c), dtype=torch.uint8, device=dev)
+            check(lib.sage_bn_relu_dropout_backward(ptr(x), ptr(grad_y), m, c, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+                                                    int(training), p, seed, ptr(grad_x), ptr(grad_gamma), ptr(grad_beta),
+                                                    ptr(scratch), scratch.numel(), _stream()))
+        return grad_x, grad_gamma, grad_beta, None, None, None, None, None, None, None
+
+
+def bn_relu_dropout(x: torch.Tensor, bn: nn.BatchNorm1d, p: float, training: bool, seed: int | None = None) -> torch.Tensor:
+    """``F.dropout(bn(x).relu_(), p, training)`` (main.py:207-209) on the fused HIP epilogue.
+
+    `bn` stays an ordinary ``nn.BatchNorm1d`` (same state-dict keys as the reference's checkpoints); its running
+    statistics and ``num_batches_tracked`` are updated as torch does.  The dropout mask is a counter hash of
+    (seed, element): `seed` defaults to a draw from torch's global generator, so ``torch.manual_seed`` makes runs
+    repeatable; the mask itself is not torch's Philox stream.
+    """
+    if bn.weight is None or bn.momentum is None:
+        raise NotImplementedError("fused epilogue: affine BatchNorm1d with a fixed momentum only (the reference's default)")
+    use_batch_stats = training or bn.running_mean is None
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p > 0) else 0
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    out = _BnReluDropoutFn.apply(x, bn.weight, bn.bias, rm, rv, float(bn.momentum), float(bn.eps), use_batch_stats,
+                                 float(p) if training else 0.0, seed)
+    return out
+
+
 class SAGE(nn.Module):
     """main.py:182-211 without the Lightning plumbing.  Keeps the reference's depth quirk: ``forward`` iterates over
     the sampled adjs (two of them, sizes=[25, 10]), so with num_layers=3 the last conv / bn are never executed and
@@ -137,9 +201,7 @@ class SAGE(nn.Module):
         for i, adj_t in enumerate(adjs):
             x = self.convs[i]((x, x[:adj_t.size(0)]), adj_t)
             if i < len(adjs) - 1:
-                x = self.bns[i](x)
-                x = x.relu_()
-                x = F.dropout(x, p=self.dropout, training=self.training)
+                x = bn_relu_dropout(x, self.bns[i], self.dropout, self.training)
         return x
 
 

@@ -26,6 +26,8 @@
  *   pope_concat              utils.py:129-135    torch.cat for the node2vec branch
  *   sage_conv_forward /      main.py:206 and     PyG SAGEConv((x_src, x_dst), adj_t): mean aggregation over the
  *   sage_conv_backward       PyG SAGEConv [3p]   sampled CSR + lin_l + lin_r, and its gradients
+ *   sage_bn_relu_dropout_forward / _backward   main.py:207-209
+ *                                BatchNorm1d + relu_ + F.dropout of the hidden layers, forward and backward
  *   sage_sample_hop          main.py:100-116     NeighborSampler -> torch_sparse.sample_adj (one hop), relabelled block
  */
 #ifndef GRAPHPOPE_HIP_H
@@ -254,6 +256,30 @@ int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_t N, const 
                     int32_t fanout, uint64_t seed, int32_t hop, int32_t *out_rowptr, int32_t *out_col, int64_t nnz_capacity,
                     int64_t *out_n_id, int64_t *nnz_host, int64_t *n_src_host, void *scratch, size_t scratch_bytes,
                     void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Hidden-layer epilogue: BatchNorm1d + ReLU + dropout as one op  (main.py:207-209)
+ *
+ * Replaces   x = self.bns[i](x); x = x.relu_(); x = F.dropout(x, p=self.dropout, training=self.training)
+ * and its autograd.  x, y and the grad_x / grad_y matrices are [M, C] float32 row-major on the device; gamma, beta, the running and
+ * the saved statistics and grad_gamma / grad_beta are [C].
+ *   training != 0: batch statistics (biased variance), running_mean / running_var updated in place with `momentum`
+ *                  (unbiased variance), as torch.nn.BatchNorm1d; both running pointers may be NULL (track_running_stats=False).
+ *                  Dropout keeps an element with probability 1 - p and scales it by 1 / (1 - p); the mask is a pure
+ *                  function of (seed, element index), recomputed in backward: no mask tensor.
+ *   training == 0: running statistics, no dropout.
+ * save_mean / save_rstd (out) feed the backward call.  grad_gamma / grad_beta may be NULL.  Asynchronous.
+ * scratch: sage_bn_scratch_bytes(C) bytes.
+ * ------------------------------------------------------------------------------------------------ */
+size_t sage_bn_scratch_bytes(int32_t C);
+int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C, const float *gamma, const float *beta,
+                                 float *running_mean, float *running_var, float momentum, float eps, int32_t training,
+                                 float p, uint64_t seed, float *y, float *save_mean, float *save_rstd, void *scratch,
+                                 size_t scratch_bytes, void *stream);
+int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,
+                                  const float *beta, const float *save_mean, const float *save_rstd, int32_t training,
+                                  float p, uint64_t seed, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
+                                  size_t scratch_bytes, void *stream);
 
 #ifdef __cplusplus
 }

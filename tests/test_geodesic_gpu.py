@@ -124,6 +124,16 @@ def test_large_rmat_waves_loop_over_chunks(k, dev, oracle):
     assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), oracle.geodesic_hops(ei, n, anchors))
 
 
+def test_graph_too_large_for_the_lds_live_table(dev, oracle):
+    """More than 256 Ki nodes: the level kernel runs without the per-node live-bit table (k_bfs_level<WT, false>)."""
+    from graphpope_amd import engine, synth
+    ei, n = synth.rmat(19, edge_factor=3, seed=23)
+    assert n > 256 * 1024
+    anchors = np.random.RandomState(5).choice(np.arange(n), 70)
+    _, hp = engine.geodesic_run(None, torch.as_tensor(ei, device=dev), n, anchors, want_out=False)
+    assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), oracle.geodesic_hops(ei, n, anchors))
+
+
 def test_repeated_launches_are_deterministic(dev):
     """Chunk-spanning rows are accumulated with atomics and committed a level late: the planes must not depend on timing."""
     from graphpope_amd import engine, synth

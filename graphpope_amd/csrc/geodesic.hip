@@ -24,17 +24,36 @@ namespace pope {
 // CSR build
 // ------------------------------------------------------------------------------------------------
 enum { CSR_FLAG_BAD_INDEX = 1, CSR_FLAG_UNSORTED = 2 };
-enum { AUX_N_MROWS = 0, AUX_FLAGS = 2, AUX_HEADER = 16 };
+enum { AUX_FLAGS = 2, AUX_HEADER = 16 };
 constexpr int SLOTS = 4;                      // CSR slots per lane in the BFS expand kernel
 constexpr int CHUNK_SHIFT = 8, CHUNK = 1 << CHUNK_SHIFT;   // slots per wave pass = 64 lanes x SLOTS
+
+// Anchor j starts its BFS at node a: bit j of a's words in the reachability plane and the level-0 frontier, and a's
+// live bit.  Atomics: duplicate anchors share a node (distinct bits of the same words).
+__device__ __forceinline__ void seed_anchor(long long a, int j, int Wp, u64 *seen, u64 *front, unsigned *live) {
+    const size_t idx = (size_t)a * Wp + (j >> 6);
+    const u64 bit = 1ull << (j & 63);
+    atomicOr(&seen[idx], bit);
+    atomicOr(&front[idx], bit);
+    atomicOr(&live[a >> 5], 1u << (a & 31));
+}
 
 // Fast path, speculative: PyG stores edge_index grouped by source (coalesced), so slot e of the CSR is edge e
 // and rowptr is where the source changes.  One streaming pass, no atomics, no scan.  If a pair is out of
 // order the flag is raised and the counting path redoes the build.
+// The BFS walks the CSR in chunks of CHUNK = 256 slots; a row that spans several chunks is accumulated with atomics
+// and committed one level late (k_bfs_level).  aux = header | mrow[chunk]: the row that first continues INTO that
+// chunk, or -1 -- written here by the thread that owns the chunk's first slot (fixed position: no counter, no atomics).
+// pope_geodesic_run also seeds the BFS from the last block (K > 0): one launch less; the planes were zeroed by the
+// launch before this one.
 __global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict__ src,
                                                     const long long *__restrict__ dst, int E, int N,
                                                     int *__restrict__ rowptr, int *__restrict__ col,
-                                                    int *__restrict__ erow, int *aux) {
+                                                    int *__restrict__ erow, int *aux,
+                                                    const long long *__restrict__ anchors, int K, int Wp, u64 *seen,
+                                                    u64 *front, unsigned *live) {
+    if (K > 0 && blockIdx.x == gridDim.x - 1)
+        for (int j = threadIdx.x; j < K; j += blockDim.x) seed_anchor(anchors[j], j, Wp, seen, front, live);
     int flags = 0;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
         const long long s = src[e], d = dst[e];
@@ -52,6 +71,12 @@ __global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict_
             for (long long r = s + 1; r <= N; ++r) rowptr[r] = E;
         col[e] = (int)d;
         erow[e] = (int)s;
+        if ((e & (CHUNK - 1)) == 0) {
+            const int c = e >> CHUNK_SHIFT;
+            // row s runs in from chunk c-1 and its first slot lies there (not further back)
+            const bool first_continuation = c > 0 && prev == s && (c == 1 || src[e - CHUNK - 1] != s);
+            aux[AUX_HEADER + c] = first_continuation ? (int)s : -1;
+        }
     }
     if (flags) atomicOr(&aux[AUX_FLAGS], flags);
 }
@@ -74,30 +99,17 @@ __global__ __launch_bounds__(256) void k_csr_scatter(const long long *__restrict
     }
 }
 
-// The BFS walks the CSR in chunks of CHUNK = 256 slots.  Rows that span several chunks are accumulated with
-// atomics and committed one level late (k_bfs_level): list them once per graph (a row is listed by its first
-// continuation chunk).  aux = header | mrows.
+// mrow[chunk] for a CSR built by the counting path (same format as k_csr_sorted writes): one thread per chunk.
 __global__ __launch_bounds__(256) void k_csr_lists(const int *__restrict__ rowptr, const int *__restrict__ erow,
-                                                   int E, int *aux, int cap) {
-    if (aux[AUX_FLAGS]) return;                                   // speculative CSR was rejected: arrays are garbage
-    (void)cap;
+                                                   int E, int *aux) {
     const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
-    int *mrows = aux + AUX_HEADER;
-    const int lane = threadIdx.x & 63;
-    // wave-uniform trip count; appends are aggregated per wave (one same-address atomic costs tens of ns)
-    for (int base = blockIdx.x * blockDim.x + 1; base < nchunks; base += gridDim.x * blockDim.x) {
-        const int c = base + threadIdx.x;
-        int v = -1;
-        bool first_continuation = false;
-        if (c < nchunks) {
-            v = erow[c * CHUNK];
-            first_continuation = erow[c * CHUNK - 1] == v && (rowptr[v] >> CHUNK_SHIFT) == c - 1;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += gridDim.x * blockDim.x) {
+        int m = -1;
+        if (c > 0) {
+            const int v = erow[c * CHUNK];
+            if (erow[c * CHUNK - 1] == v && (rowptr[v] >> CHUNK_SHIFT) == c - 1) m = v;
         }
-        const u64 m = __ballot(first_continuation);
-        int pos = 0;
-        if (lane == 0 && m) pos = atomicAdd(&aux[AUX_N_MROWS], __popcll(m));
-        pos = __shfl(pos, 0);
-        if (first_continuation) mrows[pos + __popcll(m & ((1ull << lane) - 1ull))] = v;
+        aux[AUX_HEADER + c] = m;
     }
 }
 
@@ -141,13 +153,7 @@ __global__ __launch_bounds__(256) void k_zero(uint4 *a, size_t na, uint4 *b, siz
 
 __global__ void k_bfs_seed(const long long *__restrict__ anchors, int K, int Wp, u64 *seen, u64 *front, unsigned *live) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= K) return;
-    const long long a = anchors[j];
-    size_t idx = (size_t)a * Wp + (j >> 6);
-    u64 bit = 1ull << (j & 63);
-    atomicOr(&seen[idx], bit);       // duplicate anchors share a node: distinct bits of the same words
-    atomicOr(&front[idx], bit);
-    atomicOr(&live[a >> 5], 1u << (a & 31));
+    if (j < K) seed_anchor(anchors[j], j, Wp, seen, front, live);
 }
 
 #ifdef POPE_STAMP
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
     const int woff = blockIdx.y * WT;
     if ((int)blockIdx.x >= expand_blocks) {
         // housekeeping for the rows that span chunks: one thread per (row, tile)
-        const int n = aux[AUX_N_MROWS];
+        const int n = (E + CHUNK - 1) >> CHUNK_SHIFT;              // one slot per chunk, -1 = no row continues into it
         const int *mrows = aux + AUX_HEADER;
         const int hb = gridDim.x - expand_blocks;
         if (LIVE && blockIdx.y == 0)
@@ -288,7 +294,9 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
 #pragma unroll
         for (int i = 0; i < WT; ++i) zero.w[i] = 0;
         for (int i = ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x; i < n; i += hb * blockDim.x) {
-            const size_t idx = (size_t)mrows[i] * Wp + woff;
+            const int mv = mrows[i];
+            if (mv < 0) continue;
+            const size_t idx = (size_t)mv * Wp + woff;
             store_words<WT>(idle + idx, zero);
             if (level > 1) {
                 const Words<WT> fresh = load_words<WT>(front + idx);       // complete: every piece landed last launch
@@ -511,6 +519,18 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
     if (__any(found) && lane == 0) raise_level(ctl, level);
 }
 
+// pope_geodesic_run: the finalise kernel doubles as the report (deepest active level, CSR flags) into pinned,
+// device-mapped host memory, which the host reads after its one stream synchronisation.
+// The ticket is stored last (system-scope release): a host thread spinning on it sees the verdict as soon as the
+// kernel STARTS, i.e. when the BFS levels before it in the stream are done, not when the 100 us expansion ends.
+__device__ __forceinline__ void write_report(int last_active, const int *aux, int *report, int ticket) {
+    if (report && blockIdx.x == 0 && threadIdx.x == 0) {
+        report[0] = last_active;
+        report[1] = aux[AUX_FLAGS];
+        __hip_atomic_store(&report[2], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: what the non-temporal builtins accept
 
 // ------------------------------------------------------------------------------------------------
@@ -530,10 +550,12 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void k_finalize(const u64 *__restrict__ planes, size_t plane_elems,
                                                   int n_hop_bits, const int *__restrict__ max_hop_dev, int N, int K,
                                                   int Wp, const float *__restrict__ x, int F,
-                                                  float *__restrict__ out, long long out_cols, int c0) {
+                                                  float *__restrict__ out, long long out_cols, int c0,
+                                                  const int *__restrict__ aux, int *report, int ticket) {
     if (max_hop_dev) {                        // enqueued before the host knew the depth: read it from the BFS control block
         const int m = *max_hop_dev;
         n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
+        write_report(m, aux, report, ticket);
     }
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -594,7 +616,9 @@ __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ p
                                                        int n_hop_bits, const int *__restrict__ max_hop_dev, int N, int K,
                                                        int Wp, const float *__restrict__ x, int F,
                                                        float *__restrict__ out, long long out_cols, int c0,
-                                                       int n_shards, size_t shard_elems) {
+                                                       int n_shards, size_t shard_elems, const int *__restrict__ aux,
+                                                       int *report, int ticket) {
+    if (max_hop_dev) write_report(*max_hop_dev, aux, report, ticket);
     __shared__ float inv[16];
     if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
     __syncthreads();
@@ -753,16 +777,32 @@ static int csr_fallback(const long long *src, const long long *dst, int E, int N
     POPE_HIP(hipMemsetAsync(cnt, 0, (size_t)(N + 1) * sizeof(int), stream));
     hipLaunchKernelGGL(k_csr_scatter, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, E, rowptr, cnt, col, erow);
     POPE_HIP(hipMemsetAsync(aux, 0, AUX_HEADER * sizeof(int), stream));
-    hipLaunchKernelGGL(k_csr_lists, dim3(capped_grid((size_t)aux_cap(E), 256)), dim3(256), 0, stream, rowptr, erow, E, aux, aux_cap(E));
+    hipLaunchKernelGGL(k_csr_lists, dim3(capped_grid((size_t)aux_cap(E), 256)), dim3(256), 0, stream, rowptr, erow, E, aux);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
+
+struct SeedArgs {                         // pope_geodesic_run: seed the BFS from the CSR launch
+    const long long *anchors = nullptr;
+    int K = 0, Wp = 0;
+    u64 *seen = nullptr, *front = nullptr;
+    unsigned *live = nullptr;
+};
+
+static int csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col, int32_t *erow,
+                     int32_t *aux, void *scratch, size_t scratch_bytes, int32_t defer_check, const SeedArgs &seed,
+                     hipStream_t stream);
 
 extern "C" int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col,
                               int32_t *erow, int32_t *aux, void *scratch, size_t scratch_bytes, int32_t defer_check,
                               void *stream_) {
     clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
+    return csr_build(edge_index, E, N, rowptr, col, erow, aux, scratch, scratch_bytes, defer_check, SeedArgs(), (hipStream_t)stream_);
+}
+
+static int csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col, int32_t *erow,
+                     int32_t *aux, void *scratch, size_t scratch_bytes, int32_t defer_check, const SeedArgs &seed,
+                     hipStream_t stream) {
     POPE_REQUIRE(N >= 0 && N < INT32_MAX && E >= 0 && E < INT32_MAX, "pope_csr_build: need 0 <= N, E < 2^31 (N=%lld E=%lld)",
                  (long long)N, (long long)E);
     POPE_REQUIRE(rowptr && aux && scratch && ((edge_index && col && erow) || E == 0), "pope_csr_build: null pointer");
@@ -775,10 +815,13 @@ extern "C" int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, i
         POPE_HIP(hipMemsetAsync(aux, 0, AUX_HEADER * sizeof(int), stream));
     if (E == 0) {
         POPE_HIP(hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * sizeof(int), stream));
+        if (seed.K > 0)
+            hipLaunchKernelGGL(k_bfs_seed, dim3((seed.K + 255) / 256), dim3(256), 0, stream, seed.anchors, seed.K, seed.Wp, seed.seen,
+                               seed.front, seed.live);
         return POPE_OK;
     }
-    hipLaunchKernelGGL(k_csr_sorted, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, aux);
-    hipLaunchKernelGGL(k_csr_lists, dim3(capped_grid((size_t)aux_cap(E), 256)), dim3(256), 0, stream, rowptr, erow, (int)E, aux, aux_cap(E));
+    hipLaunchKernelGGL(k_csr_sorted, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, aux,
+                       seed.anchors, seed.K, seed.Wp, seed.seen, seed.front, seed.live);
     POPE_HIP(hipGetLastError());
     if (defer_check) return POPE_OK;                 // pope_geodesic_bfs reports what the speculative pass found
     int flags = 0;
@@ -856,7 +899,8 @@ static void launch_level(int E, int Wp, const int *col, const int *erow, const i
 // streaming copy saturates the memory queues and the latency-bound level kernels run 2-4x slower beside it; the
 // serial order is faster.)
 struct DeviceCtx {
-    int *report = nullptr;               // pinned host: [0] last_active, [1] csr flags
+    int *report = nullptr;               // pinned host: [0] last_active, [1] csr flags, [2] ticket of the call that wrote them
+    int ticket = 0;
     int *report_dev = nullptr;           // the same memory as seen from the device
     long long *anchors = nullptr;        // pinned, device-mapped host staging for the anchor ids
     long long *anchors_dev = nullptr;    // the same memory as seen from the device (the seed kernel reads it in place)
@@ -870,7 +914,8 @@ static int device_ctx(DeviceCtx **out, size_t n_anchors) {
     POPE_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
     DeviceCtx &c = g_ctx[dev];
     if (!c.report) {
-        POPE_HIP(hipHostMalloc((void **)&c.report, 256, hipHostMallocMapped));
+        POPE_HIP(hipHostMalloc((void **)&c.report, 256, hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: visible mid-kernel
+        memset(c.report, 0, 256);
         POPE_HIP(hipHostGetDevicePointer((void **)&c.report_dev, c.report, 0));
     }
     if (n_anchors > c.anchors_cap) {
@@ -988,9 +1033,28 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
 }
 
 // Wait for the stream and read the verdicts.  Returns POPE_OK with *done set, or an error code.
-static int bfs_poll(const Bfs &b, int next_level, int *last_active, bool *done, hipStream_t stream) {
-    hipLaunchKernelGGL(k_bfs_report, dim3(1), dim3(1), 0, stream, b.ctl, b.aux, b.dev->report_dev);
-    POPE_HIP(hipStreamSynchronize(stream));
+// ticket != 0: the finalise kernel enqueued last writes the report when it STARTS; spin on the pinned ticket word instead
+// of waiting for the stream to drain (the expansion keeps running; its output is complete in stream order).
+static int bfs_poll(const Bfs &b, int next_level, int *last_active, bool *done, hipStream_t stream, int ticket = 0) {
+    if (ticket) {
+        bool seen_ticket = false;
+        for (long it = 0; !seen_ticket; ++it) {
+            if (__atomic_load_n(&b.dev->report[2], __ATOMIC_ACQUIRE) == ticket) {
+                seen_ticket = true;
+            } else if ((it & 1023) == 1023) {
+                const hipError_t q = hipStreamQuery(stream);           // a fault or a drained stream ends the spin
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+            }
+        }
+        if (!seen_ticket) {
+            POPE_HIP(hipStreamSynchronize(stream));
+            POPE_REQUIRE(__atomic_load_n(&b.dev->report[2], __ATOMIC_ACQUIRE) == ticket, "geodesic bfs: the report was not written");
+        }
+    } else {
+        hipLaunchKernelGGL(k_bfs_report, dim3(1), dim3(1), 0, stream, b.ctl, b.aux, b.dev->report_dev);
+        POPE_HIP(hipStreamSynchronize(stream));
+    }
     POPE_HIP(hipGetLastError());
     *last_active = b.dev->report[0];
     const int flags = b.dev->report[1];
@@ -1107,7 +1171,8 @@ extern "C" void pope_debug_finalize_blocks(int b) { g_finalize_blocks = b; }
 
 static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_hop_dev, int64_t N, int32_t K,
                             const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, hipStream_t stream,
-                            int n_shards = 1, size_t shard_elems = 0) {
+                            int n_shards = 1, size_t shard_elems = 0, const int *aux = nullptr, int *report = nullptr,
+                            int ticket = 0) {
     const int Wp = words_for(K);
     const size_t plane_elems = (size_t)N * Wp;
     const bool vec = F % 4 == 0 && K % 4 == 0 && c0 % 4 == 0 && out_cols % 4 == 0 && aligned16(out) && (!x || aligned16(x));
@@ -1125,16 +1190,16 @@ static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_ho
     if (vec && (g_finalize_variant > 0 || n_shards > 1) && (max_hop_dev || n_hop_bits <= 4)) {
         dim3 fgrid(g_finalize_blocks);                          // 8 blocks per CU, contiguous row blocks per wave
         if (g_finalize_variant == 2)
-            hipLaunchKernelGGL(k_finalize_fast<1>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems);
+            hipLaunchKernelGGL(k_finalize_fast<1>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket);
         else
-            hipLaunchKernelGGL(k_finalize_fast<0>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems);
+            hipLaunchKernelGGL(k_finalize_fast<0>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket);
         POPE_HIP(hipGetLastError());
         return POPE_OK;
     }
     if (vec)
-        hipLaunchKernelGGL(k_finalize<true>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0);
+        hipLaunchKernelGGL(k_finalize<true>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, aux, report, ticket);
     else
-        hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0);
+        hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, aux, report, ticket);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
@@ -1205,14 +1270,23 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     if ((rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, (uint64_t *)planes, plane_capacity,
                         ws + L.bfs_scratch, L.total - L.bfs_scratch))) return rc;
     bfs_enqueue_clear(b, aux, stream);                    // BFS state and the CSR status header in one launch
-    rc = pope_csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, stream_);
+    memcpy(b.dev->anchors, anchors_host, (size_t)K * sizeof(long long));     // pinned, device-mapped: read in place
+    SeedArgs seed;
+    seed.anchors = b.dev->anchors_dev; seed.K = K; seed.Wp = b.Wp; seed.seen = b.seen; seed.front = b.front[0]; seed.live = b.live[0];
+    rc = csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, seed, stream);
     if (rc) return rc;
-    if ((rc = bfs_enqueue_seed(b, anchors_host, stream))) return rc;
     int level = bfs_enqueue_levels(b, 1, 1 + LEVEL_BATCH, stream);
-    if (out && (rc = finalize_enqueue(planes, 0, &b.ctl->last_active, N, K, x, F, out, out_cols, 0, stream))) return rc;
+    // The finalise kernel writes the verdict into the pinned report when it starts: no report launch, and the host
+    // returns as soon as the BFS is known to be complete -- `out` is finished in stream order.
+    int ticket = 0;
+    if (out) {
+        ticket = b.dev->ticket = b.dev->ticket == INT32_MAX ? 1 : b.dev->ticket + 1;
+        if ((rc = finalize_enqueue(planes, 0, &b.ctl->last_active, N, K, x, F, out, out_cols, 0, stream, 1, 0, aux,
+                                   b.dev->report_dev, ticket))) return rc;
+    }
     int last_active = 0;
     bool done = false;
-    rc = bfs_poll(b, level, &last_active, &done, stream);
+    rc = bfs_poll(b, level, &last_active, &done, stream, ticket);
     if (rc == POPE_ERR_UNSORTED) {                        // general path: counting sort, then start over
         clear_error();
         if ((rc = csr_fallback((const long long *)edge_index, (const long long *)edge_index + E, (int)E, (int)N, rowptr, col,

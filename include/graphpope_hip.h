@@ -153,8 +153,11 @@ int pope_geodesic_finalize_shards(const uint64_t *planes, int32_t n_shards, int6
  * The whole geodesic hot path in ONE call (what utils.py:137-147 does after sampling the anchors):
  * edge_index -> CSR -> multi-source BFS -> out[v, 0:F] = x[v, :], out[v, F + j] = 1 / (hops(v, anchor j) + 1).
  * Everything is enqueued speculatively (sorted-CSR fast path, 12 BFS levels, the finalise kernel reading the
- * depth from device memory) and the host synchronises `stream` ONCE to read the verdicts; unsorted edge lists
- * and graphs deeper than 10 hops transparently take the general path (more synchronisations).
+ * depth from device memory).  The host then waits ONCE, for the BFS verdict only: the finalise kernel publishes it
+ * in pinned host memory when it starts, and the call returns while `out` is still being written -- `out`, like the
+ * result of any asynchronous call, is complete in `stream` order (synchronise `stream` before reading it from the
+ * host or from another stream).  Unsorted edge lists and graphs deeper than 10 hops transparently take the general
+ * path (stream synchronisations in between).
  * workspace: pope_geodesic_run_workspace_bytes(N, E, K, plane_capacity) bytes, device memory, no initialisation
  * needed; afterwards pope_geodesic_run_planes() locates the hop planes inside it (planes [0, 1 + *n_hop_bits) valid).
  * out may be NULL (BFS only).  Returns POPE_ERR_HOP_OVERFLOW if plane_capacity bits cannot hold the depth.

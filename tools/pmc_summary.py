@@ -46,9 +46,10 @@ def main(tag, rnd):
            "units": "bytes per launch; FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count correction), WRITE_SIZE KiB x 1024",
            "kernels": {}}
     for name in fetch:
-        if "pope::" not in name:
+        head = name.split("(")[0].replace("void ", "").strip()          # function name incl. template arguments
+        if "pope::" not in name or head.startswith("at::") or head.startswith("__amd"):
             continue
-        short = name.split("pope::")[1].split("(")[0]
+        short = head.replace("pope::", "")
         f_mean, f_act, f_all = active_mean(fetch[name])
         w_mean, _, _ = active_mean(write.get(name, [0.0]))
         out["kernels"][short] = {"fetch_kib_raw": f_mean, "write_kib_raw": w_mean, "active_launches": f_act, "launches": f_all,

@@ -55,7 +55,7 @@ def pope_step(x, ei, n, anchors, world):
     return pdist.sharded_geodesic_features(x, n, anchors, None,
                                            bfs_fn=lambda a: engine.bfs(csr, a),
                                            finalize_fn=engine.finalize, finalize_all_fn=engine.finalize_shards,
-                                           begin_fn=lambda a: engine.PendingBfs(csr, a))
+                                           begin_fn=lambda a: engine.PendingBfs(csr, a), copy_x_fn=engine.copy_features)
 
 
 def pope_phases(x, ei, n, anchors, timers):

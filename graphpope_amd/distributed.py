@@ -49,20 +49,42 @@ def shard_anchors(anchors: np.ndarray, world: int, rnk: int):
     return padded, int(real.size)
 
 
-def _all_gather(local: torch.Tensor, group) -> torch.Tensor:
+def _all_gather_begin(local: torch.Tensor, group):
+    """Start the all-gather of one [..] tensor per rank; returns (gathered [world, ..], work).
+
+    With RCCL the collective runs on the communicator's stream once the producer of `local` on the current stream is
+    done: whatever the caller enqueues next on the current stream runs UNDERNEATH the exchange; ``work.wait()`` makes
+    the current stream (not the host) wait for the gathered planes.
+    """
     world = dist.get_world_size(group)
     out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
     if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(out, local, group=group)       # one RCCL all-gather, no staging copies
+        work = dist.all_gather_into_tensor(out, local, group=group, async_op=True)   # one RCCL all-gather, no staging copies
     else:
-        dist.all_gather(list(out.unbind(0)), local, group=group)
+        work = dist.all_gather(list(out.unbind(0)), local, group=group, async_op=True)
+    return out, work
+
+
+def _exchange_and_expand(local, group, x, f, num_nodes, cols, bits, size, finalize_fn, finalize_all_fn, copy_x_fn):
+    """all-gather the planes; copy the features into ``out`` while they travel; expand every shard's columns."""
+    gathered, work = _all_gather_begin(local, group)                 # [world, 1 + bits, N, W]
+    out = torch.empty((num_nodes, cols), dtype=torch.float32, device=x.device)
+    if copy_x_fn is not None:
+        copy_x_fn(x, f, out)                 # out[:, :F] = x: 2/3 of the expansion's HBM traffic, hidden under the xGMI exchange
+        x = None
+    work.wait()
+    if finalize_all_fn is not None:
+        finalize_all_fn(gathered, bits, num_nodes, size, x, f, out)
+    else:
+        for g in range(gathered.shape[0]):
+            finalize_fn(gathered[g], bits, num_nodes, size, x if g == 0 else None, f, out, g * size)
     return out
 
 
 SPECULATIVE_HOP_BITS = 4
 
 
-def _speculative(x, num_nodes, anchors, group, begin_fn, finalize_all_fn):
+def _speculative(x, num_nodes, anchors, group, begin_fn, finalize_all_fn, copy_x_fn):
     """Fast path with no host synchronisation in the middle: enqueue the BFS, all-gather seen + 4 hop-bit planes and
     expand them, THEN look at the verdicts.  Returns the matrix, or None if some rank needs more than 4 hop bits (or its
     edge list was not sorted): the caller then takes the general path."""
@@ -71,10 +93,9 @@ def _speculative(x, num_nodes, anchors, group, begin_fn, finalize_all_fn):
     size = shard_size(k, world)
     local_anchors, _ = shard_anchors(anchors, world, dist.get_rank(group))
     pending = begin_fn(local_anchors)
-    gathered = _all_gather(pending.speculative_planes(), group)        # [world, 5, N, W], contiguous slices: no staging copy
     cols = f + world * size
-    out = torch.empty((num_nodes, cols), dtype=torch.float32, device=x.device)
-    finalize_all_fn(gathered, SPECULATIVE_HOP_BITS, num_nodes, size, x, f, out)
+    out = _exchange_and_expand(pending.speculative_planes(), group, x, f, num_nodes, cols, SPECULATIVE_HOP_BITS, size,
+                               None, finalize_all_fn, copy_x_fn)       # [world, 5, N, W] slices: no staging copy
     hp = pending.finish()                                             # the first host synchronisation of the call
     ok = torch.tensor([0 if (hp is not None and hp.n_hop_bits <= SPECULATIVE_HOP_BITS) else 1], dtype=torch.int32, device=x.device)
     dist.all_reduce(ok, op=dist.ReduceOp.MAX, group=group)
@@ -86,18 +107,20 @@ def _speculative(x, num_nodes, anchors, group, begin_fn, finalize_all_fn):
 
 
 def sharded_geodesic_features(x: torch.Tensor, num_nodes: int, anchors: np.ndarray, group, bfs_fn, finalize_fn,
-                              finalize_all_fn=None, begin_fn=None) -> torch.Tensor:
+                              finalize_all_fn=None, begin_fn=None, copy_x_fn=None) -> torch.Tensor:
     """Every rank returns the full [N, F+K] float32 matrix.
 
     bfs_fn(anchors) -> object with .planes ([>= 1 + n_hop_bits, N, W] int64), .n_hop_bits
     finalize_fn(planes, n_hop_bits, N, K_shard, x_or_None, F, out, c0) writes x and one shard's columns;
     finalize_all_fn(gathered, n_hop_bits, N, K_shard, x, F, out), if given, writes every shard in one pass instead.
     begin_fn(anchors) -> object with .speculative_planes() and .finish(): enables the synchronisation-free fast path.
+    copy_x_fn(x, F, out), if given, writes out[:, :F] = x on its own; it is enqueued right after the all-gather has
+    been started, so the feature copy overlaps the exchange and the expansion afterwards only writes the K columns.
     """
     world, rnk = dist.get_world_size(group), dist.get_rank(group)
     anchors = np.asarray(anchors, dtype=np.int64)
     if begin_fn is not None and finalize_all_fn is not None:
-        out = _speculative(x, num_nodes, anchors, group, begin_fn, finalize_all_fn)
+        out = _speculative(x, num_nodes, anchors, group, begin_fn, finalize_all_fn, copy_x_fn)
         if out is not None:
             return out
     k, f = int(anchors.size), x.shape[1]
@@ -111,15 +134,8 @@ def sharded_geodesic_features(x: torch.Tensor, num_nodes: int, anchors: np.ndarr
     bits = int(bits_t.item())
     local = torch.zeros((1 + bits,) + tuple(hp.planes.shape[1:]), dtype=hp.planes.dtype, device=hp.planes.device)
     local[: 1 + hp.n_hop_bits] = hp.planes[: 1 + hp.n_hop_bits]
-    gathered = _all_gather(local, group)                            # [world, 1 + bits, N, W]
-
     cols = f + world * size
-    out = torch.empty((num_nodes, cols), dtype=torch.float32, device=x.device)
-    if finalize_all_fn is not None:
-        finalize_all_fn(gathered, bits, num_nodes, size, x, f, out)
-    else:
-        for g in range(world):
-            finalize_fn(gathered[g], bits, num_nodes, size, x if g == 0 else None, f, out, g * size)
+    out = _exchange_and_expand(local, group, x, f, num_nodes, cols, bits, size, finalize_fn, finalize_all_fn, copy_x_fn)
     if cols != f + k:                                               # K not divisible by world: drop the padding
         out = out[:, : f + k].contiguous()
     return out

@@ -161,6 +161,14 @@ def finalize(planes: torch.Tensor, n_hop_bits: int, num_nodes: int, k: int, x, f
                                          c0, _stream()))
 
 
+def copy_features(x: torch.Tensor, f: int, out: torch.Tensor):
+    """out[:, :f] = x on the current stream (pope_concat): the feature half of the expansion on its own."""
+    lib = _lib.load()
+    assert out.is_cuda and out.is_contiguous() and x.is_contiguous() and x.shape == (out.shape[0], f)
+    with torch.cuda.device(out.device):
+        check(lib.pope_concat(ptr(x), out.shape[0], f, ptr(out), out.shape[1], _stream()))
+
+
 def finalize_shards(gathered: torch.Tensor, n_hop_bits: int, num_nodes: int, k_shard: int, x, f: int, out: torch.Tensor):
     """All shards of an all-gathered [world, 1 + bits, N, W] plane tensor in one pass over ``out``."""
     lib = _lib.load()
@@ -285,7 +293,8 @@ def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int,
     return pdist.sharded_geodesic_features(
         x, num_nodes, anc, group,
         bfs_fn=lambda a: bfs(csr, a),
-        finalize_fn=finalize, finalize_all_fn=finalize_shards, begin_fn=lambda a: PendingBfs(csr, a))
+        finalize_fn=finalize, finalize_all_fn=finalize_shards, begin_fn=lambda a: PendingBfs(csr, a),
+        copy_x_fn=copy_features)
 
 
 # ------------------------------------------------------------------------------------------------

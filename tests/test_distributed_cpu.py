@@ -104,12 +104,18 @@ def _worker(rank, world, port, k, result_dir, deep=True):
             calls["general"] += 1
             return bfs_fn(a)
 
+        def copy_x(xx, ff, out):                                     # the feature copy that overlaps the exchange
+            calls["copy_x"] = calls.get("copy_x", 0) + 1
+            out[:, :ff] = xx
+
         def finalize_all(gathered, bits, nn, k_shard, xx, ff, out):
+            assert xx is None                                        # the features were written by copy_x
             for g in range(gathered.shape[0]):
-                numpy_finalize(gathered[g], bits, nn, k_shard, xx if g == 0 else None, ff, out, g * k_shard)
+                numpy_finalize(gathered[g], bits, nn, k_shard, None, ff, out, g * k_shard)
 
         out = pdist.sharded_geodesic_features(x, n, anchors, None, counted_bfs, numpy_finalize, finalize_all_fn=finalize_all,
-                                              begin_fn=lambda a: FakePending(oracle.geodesic_hops(ei, n, a)))
+                                              begin_fn=lambda a: FakePending(oracle.geodesic_hops(ei, n, a)), copy_x_fn=copy_x)
+        assert calls["copy_x"] == (2 if deep else 1)
         # deep graph (> 15 hops somewhere): the speculative 4-bit exchange is rejected by ALL ranks and redone in general form
         assert calls["general"] == (1 if deep else 0), calls
         want = oracle.geodesic_features(x.numpy(), ei, n, anchors)

@@ -300,8 +300,10 @@ def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int,
 # ------------------------------------------------------------------------------------------------
 # node2vec-space embedding (utils.py:149-180)
 # ------------------------------------------------------------------------------------------------
-def pairwise_features(x: torch.Tensor, emb: torch.Tensor, anchors, distance_function: str) -> torch.Tensor:
-    """[N, F+K] float32 on the device: min-max scaled distance of every node2vec row to the anchor rows."""
+def pairwise_features(x: torch.Tensor, emb: torch.Tensor, anchors, distance_function: str,
+                      anchor_embeddings=None) -> torch.Tensor:
+    """[N, F+K] float32 on the device: min-max scaled distance of every node2vec row to the anchor rows
+    (``anchors`` = row indices, utils.py:165-167) or to ``anchor_embeddings`` [K, D] (K-means centres, utils.py:168-170)."""
     lib = _lib.load()
     dev = require_gpu(x.device)
     metric = _lib.METRIC[distance_function]          # KeyError for unknown names, as utils.py:164
@@ -309,8 +311,12 @@ def pairwise_features(x: torch.Tensor, emb: torch.Tensor, anchors, distance_func
     emb = emb.to(dev, torch.float32).contiguous()
     n, f = x.shape
     d = emb.shape[1]
-    idx = torch.as_tensor(np.asarray(anchors, dtype=np.int64), device=dev)
-    a = emb.index_select(0, idx).contiguous()        # the K anchor rows (utils.py:167)
+    if anchor_embeddings is not None:
+        a = torch.as_tensor(anchor_embeddings).to(dev, torch.float32).contiguous()
+        assert a.dim() == 2 and a.shape[1] == d
+    else:
+        idx = torch.as_tensor(np.asarray(anchors, dtype=np.int64), device=dev)
+        a = emb.index_select(0, idx).contiguous()        # the K anchor rows (utils.py:167)
     k = a.shape[0]
     with torch.cuda.device(dev):
         out = torch.empty((n, f + k), dtype=torch.float32, device=dev)

@@ -148,14 +148,21 @@ def attach_node2vec(data, dataset, num_anchor_nodes, sampling_method, distance_f
     node2vec_embeddings = torch.load(loading_path, map_location="cpu").detach()
     if distance_function not in ('distance', 'similarity', 'euclidean'):
         raise KeyError(distance_function)
+    anchor_nodes = anchor_embeddings = None
     if sampling_method == 'stochastic':
         anchor_nodes = sample_anchor_nodes(data, num_anchor_nodes, sampling_method='stochastic')
     else:
-        raise NotImplementedError("K-means anchors (utils.py:168-170) are outside the accelerated hot path "
-                                  "(SURVEY.md §8f rank 3); use sampling_method='stochastic'")
+        # utils.py:168-170: every other sampling_method means K-means centres as anchors.  The clustering is the
+        # reference's own one-off scikit-learn call on the host (same call, same global NumPy RNG -> same centres);
+        # the N x K distance matrix and the min-max scaling -- the hot part -- run on the GPU.
+        from sklearn.cluster import KMeans
+        kmeans = KMeans(n_clusters=num_anchor_nodes).fit(node2vec_embeddings.numpy())
+        anchor_embeddings = kmeans.cluster_centers_
+        print('K means cluster anchor nodes derived!')
     dev = _device()
     x = data.x.detach().to(dev, torch.float32)
-    extended_features = engine.pairwise_features(x, node2vec_embeddings.to(dev), anchor_nodes, distance_function).cpu()
+    extended_features = engine.pairwise_features(x, node2vec_embeddings.to(dev), anchor_nodes, distance_function,
+                                                 anchor_embeddings=anchor_embeddings).cpu()
     print('feature matrix is blessed by the POPE')
     return extended_features
 

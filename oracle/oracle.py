@@ -176,10 +176,11 @@ def minmax_scale_columns(e: np.ndarray) -> np.ndarray:
     return (e * scale + mn).astype(np.float32)
 
 
-def node2vec_features(x, node2vec_emb, anchors, distance_function) -> np.ndarray:
-    """utils.py:149-180, stochastic branch, given the anchors: [N, F+K] float32."""
+def node2vec_features(x, node2vec_emb, anchors, distance_function, anchor_embeddings=None) -> np.ndarray:
+    """utils.py:149-180 given the anchors: [N, F+K] float32.  Stochastic branch: `anchors` are row indices
+    (utils.py:165-167); K-means branch: `anchor_embeddings` are the cluster centres (utils.py:168-170)."""
     emb = np.asarray(node2vec_emb, dtype=np.float32)
-    a = emb[np.asarray(anchors, dtype=np.int64)]
+    a = emb[np.asarray(anchors, dtype=np.int64)] if anchor_embeddings is None else np.asarray(anchor_embeddings)
     return concat_into_features(x, minmax_scale_columns(pairwise(emb, a, distance_function)))
 
 

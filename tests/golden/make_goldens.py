@@ -255,8 +255,33 @@ def node2vec_fixtures():
     # identical rows: every column is constant (range < 10 eps -> scale 1)
     family("const40", torch.ones(40, 8), 40, 4, 1)
 
+    # K-means anchors (utils.py:168-170: every non-stochastic sampling_method of the node2vec branch): 8 well separated
+    # blobs so the clustering does not hinge on float summation order; the centres are recovered by repeating the
+    # reference's own call from the same global RNG state.
+    from sklearn.cluster import KMeans
+    g = torch.Generator().manual_seed(5)
+    blob_centres = torch.randn(8, 16, generator=g) * 6
+    tab3 = (blob_centres.repeat_interleave(64, 0) + torch.randn(512, 16, generator=g) * 0.5).contiguous()
+    pack = {}
+    for fn in ("distance", "similarity", "euclidean"):
+        _reset_cache()
+        data = Data(_features(512, f, 11), np.zeros((2, 0), dtype=np.int64), 512)
+        ref.torch.load = lambda *a, **kw: tab3.clone().requires_grad_(True)
+        try:
+            np.random.seed(9)
+            out = ref.Graphpope(data, "flickr", "node2vec", "kmeans", 8, fn, 2).numpy().astype(np.float32)
+        finally:
+            ref.torch.load = real_load
+            _reset_cache()
+        np.random.seed(9)
+        centres = KMeans(n_clusters=8).fit(tab3.numpy()).cluster_centers_
+        pack.update(x=data.x.numpy(), centres=centres, **{f"scaled_{fn}": out[:, f:]})
+        print(f"node2vec_kmeans512/{fn}: {out.shape} centres {centres.dtype} min {out[:, f:].min():.3g} max {out[:, f:].max():.3g}")
+    np.savez_compressed(os.path.join(HERE, "node2vec_kmeans512.npz"), emb=tab3.numpy(), **pack)
+
 
 if __name__ == "__main__":
-    geodesic_fixtures()
-    anchor_fixtures()
+    if "--node2vec-only" not in sys.argv:
+        geodesic_fixtures()
+        anchor_fixtures()
     node2vec_fixtures()

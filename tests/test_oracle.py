@@ -76,6 +76,15 @@ def test_node2vec_oracle_matches_reference(oracle, family, fn):
     np.testing.assert_allclose(out[:, f:], g[f"scaled_{fn}"], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("fn", ["distance", "similarity", "euclidean"])
+def test_node2vec_kmeans_anchors_oracle_matches_reference(oracle, fn):
+    """utils.py:168-170: K-means centres as anchors (golden = the reference's own Graphpope(..., 'kmeans', ...))."""
+    g = load_golden(os.path.join(GOLDEN, "node2vec_kmeans512.npz"))
+    out = oracle.node2vec_features(g["x"], g["emb"], None, fn, anchor_embeddings=g["centres"])
+    f = g["x"].shape[1]
+    np.testing.assert_allclose(out[:, f:], g[f"scaled_{fn}"], rtol=0, atol=1e-5)
+
+
 def test_node2vec_unknown_distance_function_is_keyerror(oracle):
     with pytest.raises(KeyError):
         oracle.pairwise(np.zeros((2, 2), np.float32), np.zeros((1, 2), np.float32), "manhattan")

@@ -71,6 +71,27 @@ def test_unknown_metric_is_keyerror(dev):
         engine.pairwise_features(torch.zeros(4, 2, device=dev), torch.zeros(4, 3, device=dev), [0, 1], "manhattan")
 
 
+@pytest.mark.parametrize("fn", ["distance", "similarity", "euclidean"])
+def test_kmeans_anchors_entry_matches_reference_golden(fn, dev, tmp_path, monkeypatch):
+    """Any non-stochastic sampling_method of the node2vec branch = K-means centres (utils.py:168-170): the host repeats the
+    reference's scikit-learn call from the same RNG state, the distances and the scaling run on the GPU."""
+    from graphpope_amd import utils as gp
+    g = load_golden(os.path.join(GOLDEN, "node2vec_kmeans512.npz"))
+    torch.save(torch.nn.Parameter(torch.as_tensor(g["emb"])), tmp_path / "flickr_node2vec.pt")
+    monkeypatch.setattr(gp, "NODE2VEC_DIR", str(tmp_path))
+
+    class Data:
+        pass
+    d = Data()
+    d.x, d.edge_index, d.num_nodes = torch.as_tensor(g["x"]), torch.zeros(2, 0, dtype=torch.int64), 512
+    gp.clear_cache()
+    np.random.seed(9)
+    out = gp.Graphpope(d, "flickr", "node2vec", "kmeans", 8, fn, 2)
+    gp.clear_cache()
+    assert tuple(out.shape) == (512, 5 + 8) and np.array_equal(out.numpy()[:, :5], g["x"])
+    np.testing.assert_allclose(out.numpy()[:, 5:], g[f"scaled_{fn}"], rtol=0, atol=ATOL)
+
+
 def test_graphpope_node2vec_entry(dev, tmp_path, monkeypatch):
     from graphpope_amd import utils as gp
     g = load_golden(os.path.join(GOLDEN, "node2vec_randn2048.npz"))

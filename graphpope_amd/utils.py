@@ -32,6 +32,18 @@ from . import engine
 # where attach_node2vec looks for {dataset}_node2vec.pt (reference: <dir of utils.py>/data, utils.py:155)
 NODE2VEC_DIR = os.environ.get("GRAPHPOPE_DATA_DIR", osp.join(osp.dirname(osp.realpath(__file__)), "data"))
 
+def _host_rankings():
+    """utils.py:26-60: the one-off NetworkX rankings that stay on the host, call for call.
+    nx.pagerank_scipy was folded into nx.pagerank in NetworkX 3 (same SciPy power iteration)."""
+    import networkx as nx
+    return {
+        "pagerank": getattr(nx, "pagerank_scipy", nx.pagerank),                  # utils.py:28
+        "betweenness_centrality": nx.betweenness_centrality,                      # utils.py:34
+        "eigenvector_centrality": nx.eigenvector_centrality_numpy,                # utils.py:46
+        "clustering_coefficient": nx.clustering,                                  # utils.py:58
+    }
+
+
 _CENTRALITIES = ("pagerank", "betweenness_centrality", "eigenvector_centrality", "clustering_coefficient")
 
 
@@ -56,8 +68,9 @@ def sample_anchor_nodes(data, num_anchor_nodes, sampling_method):
     to_networkx builds: repeated edges collapsed, ascending stable sort, last K kept: utils.py:38-42).
     'closeness_centrality' runs the multi-source BFS kernel from every node (engine.closeness_centrality) and
     reproduces NetworkX's scores bit for bit, hence the same anchors (utils.py:50-54).
-    The remaining centralities (pagerank, betweenness, eigenvector, clustering) are one-off CPU NetworkX calls outside
-    the accelerated path and raise NotImplementedError.
+    The remaining rankings (pagerank, betweenness, eigenvector, clustering) are the reference's own one-off NetworkX
+    calls, repeated on the host on the DiGraph to_networkx would build (anchor selection is not
+    the accelerated path; the BFS from the chosen anchors is).
     """
     if sampling_method == "stochastic":
         node_indices = np.arange(data.num_nodes)
@@ -77,9 +90,14 @@ def sample_anchor_nodes(data, num_anchor_nodes, sampling_method):
         order = np.argsort(score, kind="stable")
         return order[-num_anchor_nodes:].tolist()
     if sampling_method in _CENTRALITIES:
-        raise NotImplementedError(
-            f"sampling_method={sampling_method!r}: NetworkX centrality ranking is outside the accelerated hot path "
-            "(SURVEY.md §8f rank 3); use 'stochastic', 'degree_centrality' or 'closeness_centrality'")
+        import networkx as nx
+        ei = data.edge_index.detach().cpu().numpy()
+        G = nx.DiGraph()                                           # torch_geometric.utils.to_networkx(data), utils.py:27
+        G.add_nodes_from(range(int(data.num_nodes)))
+        G.add_edges_from(zip(ei[0].tolist(), ei[1].tolist()))
+        score = _host_rankings()[sampling_method](G)
+        ranked = {k: v for k, v in sorted(score.items(), key=lambda item: item[1])}      # ascending, ties in node order
+        return list(ranked.keys())[-num_anchor_nodes:]
     # the reference falls through every `if` and hits `return sampled_anchor_nodes` unbound (utils.py:62)
     raise UnboundLocalError("local variable 'sampled_anchor_nodes' referenced before assignment")
 

@@ -215,6 +215,24 @@ def anchor_fixtures():
     print("anchors_stochastic:", {k: v[:4].tolist() for k, v in out.items()})
 
 
+def anchor_centrality_fixtures():
+    """utils.py:26-60: the biased anchor selections, from the reference itself on a small directed graph with repeated
+    edges (a ring keeps it strongly connected: NetworkX 3 refuses eigenvector_centrality_numpy on disconnected graphs).
+    nx.pagerank_scipy left NetworkX in 3.0 (folded into nx.pagerank): aliased for this run."""
+    ei, n = synth.rmat(8, edge_factor=3, seed=21, symmetric=False)
+    ring = np.stack([np.arange(n), (np.arange(n) + 1) % n])
+    ei = np.concatenate([ei, ring, ei[:, :40]], axis=1)           # repeated edges: the DiGraph keeps one
+    data = Data(_features(n, 3, 1), ei, n)
+    if not hasattr(nx, "pagerank_scipy"):
+        nx.pagerank_scipy = nx.pagerank
+    out = {"edge_index": ei.astype(np.int32), "num_nodes": np.int64(n)}
+    for method in ("pagerank", "betweenness_centrality", "degree_centrality", "eigenvector_centrality", "closeness_centrality",
+                   "clustering_coefficient"):
+        out[method] = np.asarray(ref.sample_anchor_nodes(data, 24, method), dtype=np.int64)
+        print(f"anchors_centrality/{method}:", out[method][-6:].tolist())
+    np.savez_compressed(os.path.join(HERE, "anchors_centrality.npz"), **out)
+
+
 def node2vec_fixtures():
     n, d, k, f = 2048, 128, 64, 5
     table = torch.randn(n, d, generator=torch.Generator().manual_seed(0))
@@ -281,7 +299,11 @@ def node2vec_fixtures():
 
 
 if __name__ == "__main__":
+    if "--centrality-only" in sys.argv:
+        anchor_centrality_fixtures()
+        sys.exit(0)
     if "--node2vec-only" not in sys.argv:
         geodesic_fixtures()
         anchor_fixtures()
+        anchor_centrality_fixtures()
     node2vec_fixtures()

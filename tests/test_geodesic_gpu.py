@@ -288,3 +288,15 @@ def test_closeness_centrality_matches_networkx_bit_for_bit(symmetric, dev):
     d.edge_index, d.num_nodes = torch.as_tensor(ei), n
     ref = list({k: v for k, v in sorted(want.items(), key=lambda item: item[1])}.keys())[-17:]     # the reference's selection
     assert gp.sample_anchor_nodes(d, 17, "closeness_centrality") == ref
+
+
+def test_closeness_anchors_match_reference_golden(dev):
+    """tests/golden/anchors_centrality.npz: the reference's own sample_anchor_nodes(..., 'closeness_centrality')."""
+    from graphpope_amd import utils as gp
+    g = np.load(os.path.join(GOLDEN, "anchors_centrality.npz"))
+
+    class Data:
+        pass
+    d = Data()
+    d.edge_index, d.num_nodes = torch.as_tensor(g["edge_index"].astype(np.int64)), int(g["num_nodes"])
+    assert gp.sample_anchor_nodes(d, 24, "closeness_centrality") == g["closeness_centrality"].tolist()

@@ -107,3 +107,20 @@ def test_sampler_restatement_properties(oracle):
         assert sorted(oracle.feistel_perm(i, d, 0xC0FFEE) for i in range(d)) == list(range(d))
     assert oracle.sample_hop(rowptr, col, seeds, 5, 42, 0)[1].tolist() == cl.tolist()            # pure function of its arguments
     assert oracle.sample_hop(rowptr, col, seeds, 5, 43, 0)[1].tolist() != cl.tolist()
+
+
+@pytest.mark.parametrize("method", ["pagerank", "betweenness_centrality", "degree_centrality", "eigenvector_centrality",
+                                    "clustering_coefficient"])
+def test_biased_anchor_selection_matches_reference(method):
+    """utils.py:26-60 (host rankings): same anchors, same order as the reference's own sample_anchor_nodes
+    (tests/golden/anchors_centrality.npz).  closeness_centrality runs on the GPU: tests/test_geodesic_gpu.py."""
+    import torch
+    from graphpope_amd import utils as gp
+    g = np.load(os.path.join(GOLDEN, "anchors_centrality.npz"))
+
+    class Data:
+        pass
+    d = Data()
+    d.edge_index, d.num_nodes = torch.as_tensor(g["edge_index"].astype(np.int64)), int(g["num_nodes"])
+    got = gp.sample_anchor_nodes(d, 24, method)
+    assert [int(v) for v in got] == g[method].tolist()

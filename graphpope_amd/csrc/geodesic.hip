@@ -264,13 +264,15 @@ __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words
 //     inside a launch.
 // Three frontier buffers rotate: front = level l-1 (read), acc = level l (written), idle = level l+1 (cleared).
 // Beside each goes a "live" table, one BIT per node: set when the node's frontier row is not all zero.  It is N/8
-// bytes (11 KB for Flickr) and every block copies it into LDS first (LIVE; graphs up to LIVE_MAX_NODES), so a lane looks
+// bytes (11 KB for Flickr) and every block copies it into LDS first (LIVE = 1; graphs up to LIVE_MAX_NODES), so a lane looks
 // its four neighbours up there and gathers the 8*W-byte frontier row -- a random 128-byte line from L2 -- only for
 // live ones.  The first and the last levels of a BFS have few live nodes: their launches skip most gathers, and a
 // chunk with no live neighbour skips its mask loads too.  (Looking the bits up in global memory instead was measured
-// slower than no table at all: each chunk's 256 gathered lines flush the 32 KB L1, so the lookups went to L2 as well.)
+// slower than no table at all FOR FLICKR: each chunk's 256 gathered lines flush the 32 KB L1, so the lookups went to L2
+// as well.  Beyond LIVE_MAX_NODES the table is read from global memory (LIVE = 2): there the frontier rows come from the
+// Infinity Cache or HBM while the table still sits in L2 -- R-MAT scale 22 runs 20 % faster with it than without.)
 // WT = words per tile (1, 2 or 4); blockIdx.y selects the tile of a node's W words.
-template <int WT, bool LIVE>
+template <int WT, int LIVE>      // LIVE: 0 no table, 1 table staged in LDS, 2 table read from global memory (big graphs)
 __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
                                                    int E, int Wp, const u64 *__restrict__ front,
                                                    u64 *__restrict__ seen, u64 *__restrict__ acc,
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
     }
     extern __shared__ uint4 live_lds4[];
     const unsigned *live_lds = reinterpret_cast<const unsigned *>(live_lds4);
-    if constexpr (LIVE) {
+    if constexpr (LIVE == 1) {
         const uint4 *src = reinterpret_cast<const uint4 *>(live);                   // tables are padded to 256 bytes
         for (int i = threadIdx.x; i < (live_words + 3) / 4; i += blockDim.x) live_lds4[i] = src[i];
         __syncthreads();
@@ -337,7 +339,11 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
             if (base + 2 < E) { v2 = vr.z; u2 = ur.z; }
             if (base + 3 < E) { v3 = vr.w; u3 = ur.w; }
         }
-        auto is_live = [&](int u) { return !LIVE || ((live_lds[u >> 5] >> (u & 31)) & 1u) != 0; };
+        auto is_live = [&](int u) {
+            if constexpr (LIVE == 0) return true;
+            const unsigned w = LIVE == 1 ? live_lds[u >> 5] : live[u >> 5];
+            return ((w >> (u & 31)) & 1u) != 0;
+        };
         const bool g0 = v0 >= 0 && is_live(u0), g1 = v1 >= 0 && is_live(u1), g2 = v2 >= 0 && is_live(u2),
                    g3 = v3 >= 0 && is_live(u3);
         const int vc = __shfl(v0, 0);                                                  // row of the chunk's first slot
@@ -851,7 +857,7 @@ extern "C" size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K) {
     return 256 + align_up((size_t)K * sizeof(long long), 256) + 3 * align_up(pope_plane_bytes(N, K), 256) + 3 * live_bytes(N);
 }
 
-constexpr int LIVE_MAX_NODES = 256 * 1024;   // live table of 32 KB per block in LDS (4 blocks per CU); beyond: no table
+constexpr int LIVE_MAX_NODES = 256 * 1024;   // live table of 32 KB per block in LDS (4 blocks per CU); beyond: read from global
 constexpr int EAGER_PLANES = 4;      // hop-bit planes cleared up front (levels < 16); deeper ones when first needed
 
 // Optional per-launch timing of the level kernels with HIP events on the launch stream (bench.py's roofline leg).
@@ -871,6 +877,9 @@ static void profile_mark(hipStream_t stream, int level, int which) {
     if (which == 0) g_profile.level.push_back(level);
 }
 
+static int g_live_mode = -1;            // -1: by graph size (LDS table up to LIVE_MAX_NODES, global table beyond); A/B hook
+extern "C" void pope_debug_live_mode(int m) { g_live_mode = m; }
+
 template <int WT>
 static void launch_level(int E, int Wp, const int *col, const int *erow, const int *aux, const u64 *front, u64 *seen,
                          u64 *acc, u64 *idle, u64 *hop_planes, size_t plane_elems, int level, BfsCtl *ctl,
@@ -881,12 +890,17 @@ static void launch_level(int E, int Wp, const int *col, const int *erow, const i
     int house_blocks = (nchunks + 255) / 256;                        // rows that span chunks: at most one per chunk
     if (house_blocks > 64) house_blocks = 64;
     profile_mark(stream, level, 0);
-    if (live_words <= LIVE_MAX_NODES / 32)
-        hipLaunchKernelGGL((k_bfs_level<WT, true>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256),
+    const int mode = g_live_mode >= 0 ? g_live_mode : (live_words <= LIVE_MAX_NODES / 32 ? 1 : 2);
+    if (mode == 1 && live_words <= LIVE_MAX_NODES / 32)
+        hipLaunchKernelGGL((k_bfs_level<WT, 1>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256),
                            align_up((size_t)live_words * sizeof(unsigned), 16), stream, erow, col, E, Wp, front, seen, acc, idle, hop_planes,
                            plane_elems, level, ctl, aux, expand_blocks, live, live_acc, live_idle, live_words);
+    else if (mode == 2)
+        hipLaunchKernelGGL((k_bfs_level<WT, 2>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow,
+                           col, E, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
+                           live_acc, live_idle, live_words);
     else
-        hipLaunchKernelGGL((k_bfs_level<WT, false>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow,
+        hipLaunchKernelGGL((k_bfs_level<WT, 0>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow,
                            col, E, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
                            live_acc, live_idle, live_words);
     profile_mark(stream, level, 1);

@@ -124,13 +124,22 @@ def test_large_rmat_waves_loop_over_chunks(k, dev, oracle):
     assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), oracle.geodesic_hops(ei, n, anchors))
 
 
-def test_graph_too_large_for_the_lds_live_table(dev, oracle):
-    """More than 256 Ki nodes: the level kernel runs without the per-node live-bit table (k_bfs_level<WT, false>)."""
-    from graphpope_amd import engine, synth
+@pytest.mark.parametrize("mode", [-1, 0, 1])
+def test_graph_too_large_for_the_lds_live_table(mode, dev, oracle):
+    """More than 256 Ki nodes: the level kernel reads the live-bit table from global memory (k_bfs_level<WT, 2>);
+    mode 0 forces the table-less variant kept for A/B (tools/ab_live_mode.py), mode 1 must fall back the same way."""
+    import ctypes
+    from graphpope_amd import engine, synth, _lib
     ei, n = synth.rmat(19, edge_factor=3, seed=23)
     assert n > 256 * 1024
     anchors = np.random.RandomState(5).choice(np.arange(n), 70)
-    _, hp = engine.geodesic_run(None, torch.as_tensor(ei, device=dev), n, anchors, want_out=False)
+    lib = _lib.load()
+    lib.pope_debug_live_mode.argtypes = [ctypes.c_int]
+    lib.pope_debug_live_mode(mode)
+    try:
+        _, hp = engine.geodesic_run(None, torch.as_tensor(ei, device=dev), n, anchors, want_out=False)
+    finally:
+        lib.pope_debug_live_mode(-1)
     assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), oracle.geodesic_hops(ei, n, anchors))
 
 

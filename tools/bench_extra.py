@@ -46,4 +46,11 @@ _, hp = engine.geodesic_run(None, eid, nn, anc, want_out=False)
 res["rmat20_64anchors_bfs_only"] = {"ms": t * 1e3, "N": nn, "E": int(ei.shape[1]), "max_hop": hp.max_hop,
                                     "embeddings_per_s": nn * 64 / t, "per_source_model_gbs": 64 * (4.0 * ei.shape[1] + 8.0 * nn) / t / 1e9,
                                     "graph_generation_s": gen}
+# closeness-centrality anchors (utils.py:50-54): every node an anchor, 256 at a time, on the Flickr-shaped graph
+ei_f, n_f = synth.flickr_like()
+eif = torch.as_tensor(ei_f, device=dev)
+engine.closeness_centrality(eif, n_f)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+score = engine.closeness_centrality(eif, n_f)
+res["closeness_centrality_flickr"] = {"s": time.perf_counter() - t0, "batches": -(-n_f // 256), "bfs_sources_per_s": n_f / (time.perf_counter() - t0)}
 print(json.dumps(res))

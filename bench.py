@@ -346,19 +346,12 @@ def main():
                        "anchors_total": k_total,
                        "parallelism": f"anchor-shard x{world} + RCCL all-gather of hop planes" if world > 1 else "single GPU"},
         }
-    if world == 1:
-        # per-phase device time with HIP events on the launch stream, separate from the wall-clock loop above
-        timers = {"csr": [], "bfs": [], "finalize": []}
-        for _ in range(max(10, min(args.steps, 50))):
-            pope_phases(x, ei, n, anchors, timers)
-        med = {p: float(np.median(timers[p])) for p in ("csr", "bfs", "finalize")}
-        exp_ms, active_levels, hp = level_kernel_times(ei, n, anchors, reps=10)
+    if rank == 0:
+        # dominant kernel by total time: k_bfs_level (one launch per level), timed on this rank's own anchor shard with HIP
+        # events on the launch stream.  Algorithmic bytes of ONE launch: per CSR slot erow + col (8 B) + the
+        # neighbour's frontier words (8W B); per node seen (read) + frontier (write) (16W B).  W = 4 words for 256 anchors.
+        exp_ms, active_levels, hp = level_kernel_times(ei, n, anchors[:K_PER_GPU], reps=10)
         wp = hp.planes.shape[2]
-        result["phases_ms"] = med
-        result["max_hop"] = timers["max_hop"]
-        # dominant kernel by total time: k_bfs_level (one launch per level).  Algorithmic bytes of ONE launch
-        # (DESIGN.md §5): per CSR slot erow + col (8 B) + the neighbour's frontier words (8W B); per node seen (read)
-        # + frontier (write) (16W B).  W = 4 words for 256 anchors.
         exp_bytes = e * (8.0 + 8.0 * wp) + n * 16.0 * wp
         exp_gbs = exp_bytes / (exp_ms * 1e-3) / 1e9
         pmc = pmc_traffic() or {}
@@ -366,22 +359,31 @@ def main():
             "kernel": "k_bfs_level<4>", "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": exp_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch"),
             "algorithmic_bytes_per_launch": exp_bytes, "avg_launch_ms": exp_ms, "launches_per_step": active_levels,
-            "note": "working set (CSR 7.2 MB + 3 planes of 2.9 MB) is L2 / Infinity-Cache resident; the kernel is bounded by "
-                    "32-byte gathers and wave-instruction issue, not by HBM (DESIGN.md §5)"}
+            "note": "per GPU; working set (CSR 7.2 MB + planes of 2.9 MB) is L2 / Infinity-Cache resident: the dense levels run at the "
+                    "L2 line-fill rate of 32-byte gathers, not at the HBM rate (DESIGN.md §5; live-bit table skips quiet neighbours, "
+                    "so sparse levels move fewer bytes than this dense-level model)"}
+        src_bytes = k_total * (4.0 * e + 4.0 * (n + 1) + 4.0 * n)           # SURVEY.md §8d per-source model, all GPUs
+        geo_gbs = src_bytes / (ms * 1e-3) / 1e9
+        result["roofline_per_source_model"] = {
+            "scope": "whole step, all GPUs (CSR + BFS + exchange + finalise)", "bound": "hbm", "achieved": geo_gbs,
+            "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": geo_gbs / (HBM_PEAK_GBS * world), "algorithmic_bytes": src_bytes,
+            "note": "SURVEY 8d per-source byte model (every anchor reads the CSR once and writes one f32 column); the "
+                    "bit-parallel BFS shares each CSR pass between 64 anchors per word, so this is a model, not traffic"}
+        result["level_kernel_ms"] = {"avg": exp_ms, "active_levels": active_levels}
+    if world == 1:
+        # per-phase device time with HIP events on the launch stream, separate from the wall-clock loop above
+        timers = {"csr": [], "bfs": [], "finalize": []}
+        for _ in range(max(10, min(args.steps, 50))):
+            pope_phases(x, ei, n, anchors, timers)
+        med = {p: float(np.median(timers[p])) for p in ("csr", "bfs", "finalize")}
+        result["phases_ms"] = med
+        result["max_hop"] = timers["max_hop"]
         fin_bytes = 4.0 * n * F + 4.0 * n * (F + K_PER_GPU) + 8.0 * n * wp * (1 + timers["n_hop_bits"])
         fin_gbs = fin_bytes / (med["finalize"] * 1e-3) / 1e9
         result["roofline_finalize"] = {
             "kernel": "k_finalize_fast<0>", "bound": "hbm", "achieved": fin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": fin_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_finalize_hbm_bytes_per_launch"),
             "algorithmic_bytes_per_launch": fin_bytes, "avg_launch_ms": med["finalize"]}
-        src_bytes = K_PER_GPU * (4.0 * e + 4.0 * (n + 1) + 4.0 * n)      # SURVEY.md §8d per-source model
-        geo_gbs = src_bytes / (ms * 1e-3) / 1e9
-        result["roofline_per_source_model"] = {
-            "scope": "whole step (CSR + BFS + finalise)", "bound": "hbm", "achieved": geo_gbs, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": geo_gbs / HBM_PEAK_GBS, "algorithmic_bytes": src_bytes,
-            "note": "SURVEY 8d per-source byte model (every anchor reads the CSR once and writes one f32 column); the "
-                    "bit-parallel BFS shares each CSR pass between 64 anchors per word, so this is a model, not traffic"}
-        result["level_kernel_ms"] = {"avg": exp_ms, "active_levels": active_levels}
         if not args.no_sage:
             result["sage"] = sage_leg(out, ei_np, n, dev, steps=max(10, min(args.steps, 50)), warmup=3)
         if not args.no_cpu_baseline:

@@ -84,22 +84,38 @@ def _exchange_and_expand(local, group, x, f, num_nodes, cols, bits, size, finali
 SPECULATIVE_HOP_BITS = 4
 
 
+SPECULATIVE_LEVELS = 12           # levels begin_fn enqueues without waiting (engine.SPECULATIVE_LEVELS)
+
+
 def _speculative(x, num_nodes, anchors, group, begin_fn, finalize_all_fn, copy_x_fn):
     """Fast path with no host synchronisation in the middle: enqueue the BFS, all-gather seen + 4 hop-bit planes and
     expand them, THEN look at the verdicts.  Returns the matrix, or None if some rank needs more than 4 hop bits (or its
-    edge list was not sorted): the caller then takes the general path."""
+    edge list was not sorted): the caller then takes the general path.
+
+    If the pending BFS offers ``verdict()`` (a tiny device tensor), the verdicts travel with the planes -- a second
+    all-gather of 8 bytes per rank on the same communicator -- and every rank reads ALL of them with its one
+    synchronisation at the end: no all-reduce, no second host wait."""
     world = dist.get_world_size(group)
     k, f = int(anchors.size), x.shape[1]
     size = shard_size(k, world)
     local_anchors, _ = shard_anchors(anchors, world, dist.get_rank(group))
     pending = begin_fn(local_anchors)
+    verdicts = None
+    if hasattr(pending, "verdict"):
+        verdicts = _all_gather_begin(pending.verdict(), group)         # ([world, 2] int32, work)
     cols = f + world * size
     out = _exchange_and_expand(pending.speculative_planes(), group, x, f, num_nodes, cols, SPECULATIVE_HOP_BITS, size,
                                None, finalize_all_fn, copy_x_fn)       # [world, 5, N, W] slices: no staging copy
-    hp = pending.finish()                                             # the first host synchronisation of the call
-    ok = torch.tensor([0 if (hp is not None and hp.n_hop_bits <= SPECULATIVE_HOP_BITS) else 1], dtype=torch.int32, device=x.device)
-    dist.all_reduce(ok, op=dist.ReduceOp.MAX, group=group)
-    if int(ok.item()):
+    if verdicts is not None:
+        verdicts[1].wait()
+        v = verdicts[0].cpu()                                         # the first host synchronisation of the call
+        failed = bool(((v[:, 1] != 0) | (v[:, 0] >= SPECULATIVE_LEVELS)).any())
+    else:
+        hp = pending.finish()                                         # the first host synchronisation of the call
+        ok = torch.tensor([0 if (hp is not None and hp.n_hop_bits <= SPECULATIVE_HOP_BITS) else 1], dtype=torch.int32, device=x.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MAX, group=group)
+        failed = bool(int(ok.item()))
+    if failed:
         return None
     if cols != f + k:
         out = out[:, : f + k].contiguous()

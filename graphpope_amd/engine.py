@@ -112,6 +112,7 @@ def bfs(csr: Csr, anchors, capacity: int = DEFAULT_PLANE_CAPACITY) -> HopPlanes:
 
 
 SPECULATIVE_HOP_BITS = 4          # hop-bit planes the library clears up front: hops < 16 are valid without knowing the depth
+SPECULATIVE_LEVELS = 12           # levels pope_geodesic_bfs_begin enqueues (LEVEL_BATCH in csrc/geodesic.hip)
 
 
 class PendingBfs:
@@ -138,6 +139,13 @@ class PendingBfs:
     def speculative_planes(self) -> torch.Tensor:
         """planes[0 : 1 + 4]: valid once finish() has reported n_hop_bits <= 4."""
         return self.planes[: 1 + SPECULATIVE_HOP_BITS]
+
+    def verdict(self) -> torch.Tensor:
+        """Device int32 [2], valid in stream order: (deepest level that reached something, CSR status flags).  The BFS is
+        complete inside the speculative window iff flags == 0 and the level is < SPECULATIVE_LEVELS (then hops < 16:
+        4 hop bits).  Lets the sharded path exchange the verdicts with the planes instead of synchronising here."""
+        last_active = self.scratch[:4].view(torch.int32)             # BfsCtl.last_active heads the BFS scratch
+        return torch.cat([last_active, self.csr.aux[2:3]])
 
     def finish(self):
         """Synchronise and return HopPlanes, or None if this needs the general path (deep graph, unsorted edges, overflow)."""

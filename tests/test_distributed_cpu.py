@@ -76,7 +76,21 @@ class FakePending:
         return self._hp
 
 
-def _worker(rank, world, port, k, result_dir, deep=True):
+class FakePendingWithVerdict(FakePending):
+    """engine.PendingBfs also offers verdict(): (deepest active level, CSR flags), exchanged with the planes."""
+
+    def __init__(self, hops):
+        super().__init__(hops)
+        self._verdict = torch.tensor([int(hops.max()), 0], dtype=torch.int32)
+
+    def verdict(self):
+        return self._verdict
+
+    def finish(self):
+        raise AssertionError("finish() must not be needed when the verdicts travel with the planes")
+
+
+def _worker(rank, world, port, k, result_dir, deep=True, with_verdict=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -114,7 +128,8 @@ def _worker(rank, world, port, k, result_dir, deep=True):
                 numpy_finalize(gathered[g], bits, nn, k_shard, None, ff, out, g * k_shard)
 
         out = pdist.sharded_geodesic_features(x, n, anchors, None, counted_bfs, numpy_finalize, finalize_all_fn=finalize_all,
-                                              begin_fn=lambda a: FakePending(oracle.geodesic_hops(ei, n, a)), copy_x_fn=copy_x)
+                                              begin_fn=lambda a: (FakePendingWithVerdict if with_verdict else FakePending)(
+                                                  oracle.geodesic_hops(ei, n, a)), copy_x_fn=copy_x)
         assert calls["copy_x"] == (2 if deep else 1)
         # deep graph (> 15 hops somewhere): the speculative 4-bit exchange is rejected by ALL ranks and redone in general form
         assert calls["general"] == (1 if deep else 0), calls
@@ -131,9 +146,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,k,deep", [(2, 128, True), (2, 7, True), (3, 10, True), (2, 1, True), (2, 128, False), (3, 10, False)])
-def test_sharded_all_gather_reassembles_the_matrix(world, k, deep, tmp_path, oracle):
-    mp.spawn(_worker, args=(world, _free_port(), k, str(tmp_path), deep), nprocs=world, join=True)
+@pytest.mark.parametrize("world,k,deep,with_verdict", [(2, 128, True, False), (2, 7, True, True), (3, 10, True, True), (2, 1, True, False),
+                                                       (2, 128, False, True), (3, 10, False, False), (2, 40, False, True)])
+def test_sharded_all_gather_reassembles_the_matrix(world, k, deep, with_verdict, tmp_path, oracle):
+    mp.spawn(_worker, args=(world, _free_port(), k, str(tmp_path), deep, with_verdict), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"rank{r}").read() == "ok"
 

@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p, POINTER
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphpope_hip.so")
@@ -62,6 +62,8 @@ SIGNATURES = {
     "sage_bn_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_int32, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                               c_void_p]),
+    "sage_adam_step": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
+                               c_double, c_int64, c_void_p]),
     "sage_sample_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "sage_sample_hop": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_uint64, c_int32, c_void_p,
                                 c_void_p, c_int64, c_void_p, POINTER(c_int64), POINTER(c_int64), c_void_p, c_size_t, c_void_p]),

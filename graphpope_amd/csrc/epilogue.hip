@@ -321,3 +321,85 @@ extern "C" int sage_bn_relu_dropout_backward(const float *x, const float *grad_y
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Adam step over every parameter tensor in ONE launch (main.py:244 torch.optim.Adam(self.parameters(), lr=args.lr)).
+// torch's default implementation is eight foreach launches plus ~80 us of Python per step; the training step is
+// launch-bound, so the optimiser is one kernel whose argument block carries up to ADAM_MAX_TENSORS tensor descriptors.
+// Update rule = torch.optim.Adam (amsgrad=False, maximize=False):
+//   g' = g + wd * p;  m = m + (g' - m) * (1 - b1);  v = b2 * v + (1 - b2) * g'^2;
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// ------------------------------------------------------------------------------------------------
+namespace pope {
+
+constexpr int ADAM_MAX_TENSORS = 24;
+constexpr int ADAM_CHUNK = 4096;               // elements per block
+
+struct AdamTable {
+    float *p[ADAM_MAX_TENSORS];
+    const float *g[ADAM_MAX_TENSORS];
+    float *m[ADAM_MAX_TENSORS];
+    float *v[ADAM_MAX_TENSORS];
+    long long n[ADAM_MAX_TENSORS];
+    int first_block[ADAM_MAX_TENSORS + 1];     // prefix sum of ceil(n / ADAM_CHUNK)
+    int count;
+};
+
+// one_minus_b1 / one_minus_b2 are formed in double on the host, as Python does for torch (1 - 0.999f != float(1 - 0.999)).
+__global__ __launch_bounds__(256) void k_adam(AdamTable t, float step_size, float one_minus_b1, float beta2, float one_minus_b2,
+                                              float eps, float weight_decay, float inv_bc2_sqrt) {
+    int k = 0;
+    while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
+    const long long base = (long long)((int)blockIdx.x - t.first_block[k]) * ADAM_CHUNK;
+    const long long end = min(t.n[k], base + ADAM_CHUNK);
+    float *__restrict__ p = t.p[k];
+    const float *__restrict__ g = t.g[k];
+    float *__restrict__ m = t.m[k];
+    float *__restrict__ v = t.v[k];
+    for (long long i = base + threadIdx.x; i < end; i += blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (weight_decay != 0.f) gi += weight_decay * pi;
+        float mi = m[i], vi = v[i];
+        mi = mi + (gi - mi) * one_minus_b1;
+        vi = beta2 * vi + one_minus_b2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+    }
+}
+
+}  // namespace pope
+
+extern "C" int sage_adam_step(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                              float *const *exp_avg_sq, const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, int64_t step, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (params && grads && exp_avg && exp_avg_sq && numel)), "sage_adam_step: null pointer");
+    POPE_REQUIRE(step >= 1 && lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0,
+                 "sage_adam_step: need step >= 1, lr >= 0, 0 <= beta < 1, eps >= 0");
+    // scalars are formed in double, as Python does for torch.optim.Adam, and rounded to float once
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MAX_TENSORS) {
+        AdamTable tab;
+        tab.count = 0;
+        int blocks = 0;
+        for (int t = t0; t < n_tensors && tab.count < ADAM_MAX_TENSORS; ++t) {
+            POPE_REQUIRE(numel[t] >= 0 && (numel[t] == 0 || (params[t] && grads[t] && exp_avg[t] && exp_avg_sq[t])),
+                         "sage_adam_step: tensor %d has a null pointer", t);
+            if (numel[t] == 0) continue;
+            const int c = tab.count++;
+            tab.p[c] = params[t]; tab.g[c] = grads[t]; tab.m[c] = exp_avg[t]; tab.v[c] = exp_avg_sq[t]; tab.n[c] = numel[t];
+            tab.first_block[c] = blocks;
+            blocks += (int)((numel[t] + ADAM_CHUNK - 1) / ADAM_CHUNK);
+        }
+        if (tab.count == 0) continue;
+        tab.first_block[tab.count] = blocks;
+        hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, stream, tab, step_size, (float)(1.0 - beta1), (float)beta2,
+                           (float)(1.0 - beta2), (float)eps, (float)weight_decay, inv_bc2_sqrt);
+    }
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}

@@ -63,20 +63,39 @@ __global__ __launch_bounds__(256) void k_gather_mean(const int *__restrict__ row
     }
 }
 
-// grad_x[col[p], :] += grad_agg[i, :] / deg(i).  One wave per destination row.
+// grad_x[col[p], :] += grad_agg[i, :] / deg(i).  One wave per (destination row, 256-column slab): the row's neighbour
+// ids are loaded once, 64 at a time, and broadcast with shuffles, and the slab's four gradient values per lane are in
+// registers before the first atomic -- the loop issues nothing but no-return atomics (256 contiguous bytes per wave
+// instruction), instead of a dependent col[p] load in front of every one (38 us -> see DESIGN.md §7).
 __global__ __launch_bounds__(256) void k_scatter_mean(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                       int n_dst, const float *__restrict__ gagg, int C,
                                                       float *__restrict__ gx) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int i = wave; i < n_dst; i += nwaves) {
+    const int slabs = (C + 255) / 256;
+    for (int w = wave; w < n_dst * slabs; w += nwaves) {
+        const int i = w / slabs, c0 = (w - i * slabs) * 256;
         const int beg = rowptr[i], end = rowptr[i + 1];
         if (end == beg) continue;
         const float inv = 1.0f / (float)(end - beg);
-        for (int c = lane; c < C; c += 64) {
-            const float g = gagg[(size_t)i * C + c] * inv;
-            for (int p = beg; p < end; ++p) atomicAdd(&gx[(size_t)col[p] * C + c], g);   // 256 contiguous bytes per wave op
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k * 64 + lane;
+            g[k] = c < C ? gagg[(size_t)i * C + c] * inv : 0.f;
+        }
+        for (int p0 = beg; p0 < end; p0 += 64) {
+            const int mine = p0 + lane < end ? col[p0 + lane] : 0;
+            const int cnt = min(64, end - p0);
+            for (int p = 0; p < cnt; ++p) {
+                float *row = gx + (size_t)__shfl(mine, p) * C;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = c0 + k * 64 + lane;
+                    if (c < C) atomicAdd(&row[c], g[k]);
+                }
+            }
         }
     }
 }
@@ -124,18 +143,34 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ 
 // C[M, N] = sum_{p < 2} A_p[M, K_p] * B_p[N, K_p]^T (+ bias[n]).  grid = (ceil(M/TM), ceil(N/TN), splits).
 // splits > 1: every z handles a slice of the depth of every product and writes its partial tile to
 // slab[z][M][N]; k_slab_reduce adds them (fixed order: deterministic).
+// Twin mode (twin.tiles_n > 0): TWO results that share the A operand, C = A0 * B0^T and twin.C = A0 * twin.B^T, in one
+// launch -- grid.y covers the tile columns of both (the weight gradients of lin_l and lin_r both multiply grad_out^T;
+// grad_x and grad_agg both multiply grad_out): twice the blocks per launch, half the split-K slabs, one launch less.
+struct Twin {
+    Operand B;
+    float *C;
+    int tiles_n;               // tile columns of the first result; 0 = plain GEMM
+};
+
 template <int TM, int TN, int WM, int WN, int LA, int LB>
 __global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Operand A1, Operand B1, int K1, int M, int N,
                                               const float *__restrict__ bias, float *__restrict__ C, long long ldc,
-                                              float *__restrict__ slab) {
+                                              float *__restrict__ slab, Twin twin) {
     constexpr int NT = TN / WN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *As = reinterpret_cast<float *>(smem);
     float *Bs = As + Tile<TM>::FLOATS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave % WM, wn = wave / WM;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
     const int splits = gridDim.z, z = blockIdx.z;
+    int by = blockIdx.y;
+    if (twin.tiles_n > 0 && by >= twin.tiles_n) {           // second result: its own B, C and slab region
+        by -= twin.tiles_n;
+        B0 = twin.B;
+        C = twin.C;
+        slab += (size_t)splits * M * N;
+    }
+    const int m0 = blockIdx.x * TM, n0 = by * TN;
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -162,27 +197,35 @@ __global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Op
     }
 }
 
+// results = 2 in twin mode: the second result's slabs follow the first's.
 __global__ __launch_bounds__(256) void k_slab_reduce(const float *__restrict__ slab, int splits, size_t elems, int N,
-                                                     float *__restrict__ C, long long ldc) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
+                                                     float *__restrict__ C, float *__restrict__ C2, int results, long long ldc) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < elems * results; t += (size_t)gridDim.x * blockDim.x) {
+        const int which = t >= elems;
+        const size_t i = t - (which ? elems : 0);
+        const float *src = slab + (size_t)which * splits * elems + i;
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += slab[(size_t)z * elems + i];
-        C[(i / N) * ldc + (i % N)] = s;
+#pragma unroll 4
+        for (int z = 0; z < splits; ++z) s += src[(size_t)z * elems];
+        (which ? C2 : C)[(i / N) * ldc + (i % N)] = s;
     }
 }
 
 template <int TM, int TN, int WM, int WN, int LA, int LB>
 static int launch_gemm_layout(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1,
                               int M, int N, const float *bias, float *C, long long ldc, int splits, float *slab,
-                              hipStream_t stream) {
+                              const Twin &twin, hipStream_t stream) {
     const size_t lds = tile_lds_bytes<TM, TN>();
     static bool opt_in = false;
     if (!opt_in) {
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm<TM, TN, WM, WN, LA, LB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         opt_in = true;
     }
-    dim3 grid((M + TM - 1) / TM, (N + TN - 1) / TN, splits);
-    hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN, LA, LB>), grid, dim3(256), lds, stream, A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, slab);
+    Twin tw = twin;
+    const int tiles_n = (N + TN - 1) / TN;
+    if (tw.C) tw.tiles_n = tiles_n;
+    dim3 grid((M + TM - 1) / TM, tw.C ? 2 * tiles_n : tiles_n, splits);
+    hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN, LA, LB>), grid, dim3(256), lds, stream, A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, slab, tw);
     return POPE_OK;
 }
 
@@ -190,16 +233,18 @@ static int launch_gemm_layout(const Operand &A0, const Operand &B0, int K0, cons
 // prefetch code, anything else the generic kernel.
 template <int TM, int TN, int WM, int WN>
 static int launch_gemm(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1, int M,
-                       int N, const float *bias, float *C, long long ldc, int splits, float *slab, hipStream_t stream) {
+                       int N, const float *bias, float *C, long long ldc, int splits, float *slab, const Twin &twin,
+                       hipStream_t stream) {
     Layout la = pick_layout(A0, M, K0), lb = pick_layout(B0, N, K0);
     if (K1 > 0 && (pick_layout(A1, M, K1) != la || pick_layout(B1, N, K1) != lb)) la = lb = LAYOUT_GENERIC;
+    if (twin.C && pick_layout(twin.B, N, K0) != lb) la = lb = LAYOUT_GENERIC;
     if (la == LAYOUT_KC_VEC && lb == LAYOUT_KC_VEC)
-        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_KC_VEC, LAYOUT_KC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, stream);
+        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_KC_VEC, LAYOUT_KC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
     if (la == LAYOUT_OC_VEC && lb == LAYOUT_OC_VEC)
-        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_OC_VEC, LAYOUT_OC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, stream);
+        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_OC_VEC, LAYOUT_OC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
     if (la == LAYOUT_KC_VEC && lb == LAYOUT_OC_VEC)
-        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_KC_VEC, LAYOUT_OC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, stream);
-    return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_GENERIC, LAYOUT_GENERIC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, stream);
+        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_KC_VEC, LAYOUT_OC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
+    return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_GENERIC, LAYOUT_GENERIC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
 }
 
 static long long tiles(int M, int N, int tm, int tn) { return (long long)((M + tm - 1) / tm) * ((N + tn - 1) / tn); }
@@ -207,18 +252,20 @@ static long long tiles(int M, int N, int tm, int tn) { return (long long)((M + t
 // Tile choice: the largest tile that still gives every CU about two blocks (2 x 256 = 512): co-resident blocks overlap
 // one block's staging waits with another's MFMAs, and many small blocks balance better over 256 CUs than 1.2 per CU.
 static int gemm(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1, int M, int N,
-                const float *bias, float *C, long long ldc, int splits, float *slab, hipStream_t stream) {
+                const float *bias, float *C, long long ldc, int splits, float *slab, hipStream_t stream,
+                const Twin &twin = Twin{Operand{nullptr, 0, 0}, nullptr, 0}) {
     int rc;
-    if (tiles(M, N, 128, 256) * splits >= 512)
-        rc = launch_gemm<128, 256, 4, 1>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, stream);
-    else if (tiles(M, N, 64, 128) * splits >= 384)
-        rc = launch_gemm<64, 128, 2, 2>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, stream);
+    const int results = twin.C ? 2 : 1;
+    if (tiles(M, N, 128, 256) * splits * results >= 512)
+        rc = launch_gemm<128, 256, 4, 1>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
+    else if (tiles(M, N, 64, 128) * splits * results >= 384)
+        rc = launch_gemm<64, 128, 2, 2>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
     else
-        rc = launch_gemm<64, 64, 2, 2>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, stream);
+        rc = launch_gemm<64, 64, 2, 2>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
     if (rc) return rc;
     if (splits > 1)
-        hipLaunchKernelGGL(k_slab_reduce, dim3(capped_grid((size_t)M * N, 256)), dim3(256), 0, stream, slab, splits,
-                           (size_t)M * N, N, C, ldc);
+        hipLaunchKernelGGL(k_slab_reduce, dim3(capped_grid((size_t)M * N * results, 256)), dim3(256), 0, stream, slab, splits,
+                           (size_t)M * N, N, C, twin.C, results, ldc);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
@@ -226,7 +273,7 @@ static int gemm(const Operand &A0, const Operand &B0, int K0, const Operand &A1,
 // Weight gradients reduce over the n_dst rows: split that depth so the 64 x 128 tiles give ~400 blocks
 // (measured: 85 us per gradient at 756 x 256 x 10 000 against 148 us with 64 x 64 tiles and fewer, longer splits).
 static int weight_grad_splits(int64_t n_dst, int c_in, int c_out) {
-    const long long t = tiles(c_out, c_in, 64, 128);
+    const long long t = 2 * tiles(c_out, c_in, 64, 128);            // both weight gradients in one twin launch
     int s = (int)((400 + t - 1) / t);
     const int max_s = (int)((n_dst + 4 * GK - 1) / (4 * GK));       // at least four LDS stages of depth per block
     if (s > max_s) s = max_s;
@@ -248,9 +295,9 @@ extern "C" int pope_debug_read_gemm_stamps(unsigned long long *host, int count) 
 extern "C" size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t nnz, int32_t c_in, int32_t c_out) {
     (void)n_src; (void)nnz;
     if (n_dst <= 0 || c_in <= 0 || c_out <= 0) return 0;
-    // backward: grad_agg [n_dst, c_in] | split-K slabs for one weight gradient at a time
+    // backward: grad_agg [n_dst, c_in] | split-K slabs of the two weight gradients (one twin launch)
     const size_t gagg = align_up((size_t)n_dst * c_in * sizeof(float), 256);
-    size_t slabs = (size_t)weight_grad_splits(n_dst, c_in, c_out) * c_out * c_in * sizeof(float);
+    size_t slabs = 2 * (size_t)weight_grad_splits(n_dst, c_in, c_out) * c_out * c_in * sizeof(float);
     if (slabs < (size_t)COLSUM_SPLITS * c_out * sizeof(float)) slabs = (size_t)COLSUM_SPLITS * c_out * sizeof(float);
     slabs = align_up(slabs, 256);
     return gagg + slabs;
@@ -310,8 +357,8 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
     // grad_w_l[o, c] = sum_i grad_out[i, o] * agg[i, c];  grad_w_r likewise with x_dst   (depth = rows i)
     const Operand Gt{grad_out, 1, c_out};                       // (outer o, depth i) -> grad_out[i * c_out + o]
     const Operand AggT{agg, 1, c_in}, XdT{x_src, 1, c_in};      // (outer c, depth i)
-    if ((rc = gemm(Gt, AggT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_l, c_in, splits, slab, stream))) return rc;
-    if ((rc = gemm(Gt, XdT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_r, c_in, splits, slab, stream))) return rc;
+    if ((rc = gemm(Gt, AggT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_l, c_in, splits, slab, stream,
+                   Twin{XdT, grad_w_r, 0}))) return rc;
     if (grad_b_l) {                                             // the slab region is free again: stream order
         hipLaunchKernelGGL(k_colsum_partial, dim3((c_out + 63) / 64, COLSUM_SPLITS), dim3(256), 0, stream, grad_out, (int)n_dst, c_out, slab);
         hipLaunchKernelGGL(k_colsum_final, dim3((c_out + 15) / 16), dim3(256), 0, stream, slab, COLSUM_SPLITS, c_out, grad_b_l);
@@ -321,10 +368,10 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
         POPE_HIP(hipMemsetAsync(grad_x + (size_t)n_dst * c_in, 0, (size_t)(n_src - n_dst) * c_in * sizeof(float), stream));
         const Operand G{grad_out, c_out, 1};                    // (outer i, depth o)
         const Operand WrT{w_r, 1, c_in}, WlT{w_l, 1, c_in};     // (outer c, depth o) -> w[o * c_in + c]
-        if ((rc = gemm(G, WrT, c_out, none, none, 0, (int)n_dst, c_in, nullptr, grad_x, c_in, 1, nullptr, stream))) return rc;
-        if ((rc = gemm(G, WlT, c_out, none, none, 0, (int)n_dst, c_in, nullptr, gagg, c_in, 1, nullptr, stream))) return rc;
+        if ((rc = gemm(G, WrT, c_out, none, none, 0, (int)n_dst, c_in, nullptr, grad_x, c_in, 1, nullptr, stream,
+                       Twin{WlT, gagg, 0}))) return rc;
         if (nnz > 0)
-            hipLaunchKernelGGL(k_scatter_mean, dim3(capped_grid((size_t)n_dst * 64, 256)), dim3(256), 0, stream, rowptr, col,
+            hipLaunchKernelGGL(k_scatter_mean, dim3(capped_grid((size_t)n_dst * ((c_in + 255) / 256) * 64, 256)), dim3(256), 0, stream, rowptr, col,
                                (int)n_dst, gagg, c_in, grad_x);
     }
     POPE_HIP(hipGetLastError());

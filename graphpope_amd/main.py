@@ -25,6 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from . import synth
+from .optim import Adam
 from .sage import SAGE, sample_batch
 from .utils import Graphpope
 
@@ -126,7 +127,7 @@ def main(argv=None):
                            distance_function=args.distance_function, num_workers=args.num_workers)
     in_channels = int(500 + args.num_anchor_nodes)                                       # main.py:77-79 (hard-coded 500 + K)
     model = SAGE(in_channels, num_classes, args.hidden_layer_size, args.num_layers).to(dev)   # dropout NOT passed: main.py:272
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr, fused=True)                   # main.py:244 Adam; one launch per step
+    opt = Adam(model.parameters(), lr=args.lr)                                           # main.py:244 torch.optim.Adam rule, one launch per step
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt)                              # monitors val_loss
     ei = data.edge_index.numpy()
     order = np.lexsort((ei[1], ei[0]))

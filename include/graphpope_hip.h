@@ -28,6 +28,7 @@
  *   sage_conv_backward       PyG SAGEConv [3p]   sampled CSR + lin_l + lin_r, and its gradients
  *   sage_bn_relu_dropout_forward / _backward   main.py:207-209
  *                                BatchNorm1d + relu_ + F.dropout of the hidden layers, forward and backward
+ *   sage_adam_step           main.py:244         torch.optim.Adam step, all parameter tensors in one launch
  *   sage_sample_hop          main.py:100-116     NeighborSampler -> torch_sparse.sample_adj (one hop), relabelled block
  */
 #ifndef GRAPHPOPE_HIP_H
@@ -283,6 +284,17 @@ int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M
                                   const float *beta, const float *save_mean, const float *save_rstd, int32_t training,
                                   float p, uint64_t seed, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
                                   size_t scratch_bytes, void *stream);
+
+/*
+ * One Adam step over every parameter tensor in a single launch  (main.py:244: torch.optim.Adam(self.parameters(), lr)).
+ * params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors device pointers (float32, contiguous, numel[t] elements).
+ * Update rule of torch.optim.Adam (amsgrad off): decoupled nothing, weight_decay added to the gradient, bias
+ * corrections from `step` (1-based, the step being taken).  Hyper-parameters are doubles: 1 - beta, lr / (1 - beta1^t)
+ * and sqrt(1 - beta2^t) are formed in double and rounded to float once, as torch does.  Asynchronous.
+ */
+int sage_adam_step(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                   float *const *exp_avg_sq, const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int64_t step, void *stream);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from graphpope_amd import engine, synth, sage
+from graphpope_amd.optim import Adam
 import torch.nn.functional as F
 
 dev = engine.require_gpu()
@@ -37,7 +38,7 @@ def run(fused, steps=100, adam=False):
             return x
     else:
         fwd = model
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=FUSED_ADAM)
+    opt = Adam(model.parameters(), lr=1e-3) if FUSED_ADAM else torch.optim.Adam(model.parameters(), lr=1e-3)
 
     def step(i):
         n_id, adjs, y = batches[i % 8]
@@ -56,7 +57,7 @@ def run(fused, steps=100, adam=False):
     return {"wall_ms": t_wall * 1e3, "host_enqueue_ms": t_host * 1e3}
 
 if len(sys.argv) > 1:
-    res = {sys.argv[1]: run(sys.argv[1] == "fused")}
+    res = {sys.argv[1]: run(sys.argv[1] == "fused", adam=True)}
 else:
     res = {"fused": run(True), "torch_bn": run(False), "fused+fused_adam": run(True, adam=True), "torch_bn+fused_adam": run(False, adam=True)}
 print(json.dumps(res))

@@ -16,7 +16,14 @@
 
 namespace pope {
 
-constexpr int PM = 64, PN = 128;     // rows of X x anchor columns per block: 4 waves as 2 x 2, each 32 x 64 (two MFMA tiles)
+#ifndef PW_TILE
+#define PW_TILE 0
+#endif
+#if PW_TILE == 1
+constexpr int PM = 128, PN = 128, PWM = 4, PWN = 1;   // A/B: 4 waves stacked, each 32 x 128 (four MFMA tiles)
+#else
+constexpr int PM = 64, PN = 128, PWM = 2, PWN = 2;    // rows of X x anchor columns per block: 4 waves as 2 x 2, each 32 x 64 (two MFMA tiles)
+#endif
 
 // One wave per row: sum of squares in f64 (sklearn row_norms on the upcast chunk).
 __global__ __launch_bounds__(256) void k_sqnorm(const float *__restrict__ m, long long rows, int D, double *__restrict__ out) {
@@ -34,12 +41,16 @@ __global__ __launch_bounds__(256) void k_sqnorm(const float *__restrict__ m, lon
     }
 }
 
-__device__ __forceinline__ float direct_sqdist(const float *__restrict__ x, const float *__restrict__ a, int D) {
+// sum_k (x[k] - a[k])^2 by a whole wave: lane l takes k = l, l + 64, ...; fixed shuffle tree, so the value does not
+// depend on scheduling.  Every lane returns the total.
+__device__ __forceinline__ float wave_sqdist(const float *__restrict__ x, const float *__restrict__ a, int D, int lane) {
     float acc = 0.0f;
-    for (int k = 0; k < D; ++k) {
+    for (int k = lane; k < D; k += 64) {
         const float d = x[k] - a[k];
         acc = fmaf(d, d, acc);
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     return acc;
 }
 
@@ -50,13 +61,13 @@ __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, i
                                                   int K, int metric, const double *__restrict__ xx, const double *__restrict__ aa,
                                                   float *__restrict__ out, long long out_cols, int c0,
                                                   float *__restrict__ part_min, float *__restrict__ part_max, int Kpad) {
-    constexpr int NT = 2;
+    constexpr int NT = PN / PWN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *As = reinterpret_cast<float *>(smem);
     float *Bs = As + Tile<PM>::FLOATS;
-    __shared__ float red_min[2][PN], red_max[2][PN];
+    __shared__ float red_min[PWM][PN], red_max[PWM][PN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % 2, wn = wave / 2;
+    const int wm = wave % PWM, wn = wave / PWM;
     const int row0 = blockIdx.x * PM, col0 = blockIdx.y * PN;
     f32x16 acc[NT];
 #pragma unroll
@@ -64,39 +75,79 @@ __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const Operand Xo{X, D, 1}, Ao{A, D, 1}, none{nullptr, 0, 0};
-    mfma_accumulate<PM, PN, 2, 2, LAYOUT, LAYOUT>(acc, Xo, Ao, 0, D, none, none, 0, 0, row0, col0, N, K, As, Bs);
+    mfma_accumulate<PM, PN, PWM, PWN, LAYOUT, LAYOUT>(acc, Xo, Ao, 0, D, none, none, 0, 0, row0, col0, N, K, As, Bs);
 
-    // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // It is instruction-bound (32 outputs per thread), so everything that depends on the row only is hoisted out of the
+    // tile loop and the per-element arithmetic is f32: the f32-accumulated MFMA dot carries ~1e-6 of |x||a| already, a
+    // f64 sum of the norms on top of it buys nothing (the reference's f64 accuracy is restored where it matters, by the
+    // cancellation fix-up below).  80 -> ~25 instructions per output: 48 us -> 15 us of the kernel.
     const float inf = __builtin_huge_valf();
+    float x2f[16], rnx[16];
+    long long obase[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const double x2 = row < N ? xx[row] : 1.0;
+        x2f[r] = (float)x2;
+        rnx[r] = x2 == 0.0 ? 1.0f : 1.0f / sqrtf((float)x2);        // sklearn normalize(): zero rows stay zero
+        obase[r] = (long long)row * out_cols + c0;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int cl = wn * (PN / 2) + t * 32 + (lane & 31);              // column inside the block
+        const int cl = wn * (PN / PWN) + t * 32 + (lane & 31);            // column inside the block
         const int col = col0 + cl;
         const bool col_ok = col < K;
         const double a2 = col_ok ? aa[col] : 0.0;
-        const float na = col_ok ? (a2 == 0.0 ? 1.0f : (float)sqrt(a2)) : 1.0f;
+        const float a2f = (float)a2;
+        const float rna = (!col_ok || a2 == 0.0) ? 1.0f : 1.0f / sqrtf(a2f);
         float cmin = inf, cmax = -inf;
+        float e[16];
+        if (metric == POPE_METRIC_EUCLIDEAN) {
+            unsigned flagged = 0;                                      // bit r: output r of this lane lost its digits
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float norms = x2f[r] + a2f;
+                e[r] = fmaf(-2.0f, acc[t][r], norms);                  // squared distance
+                if (row < N && col_ok && e[r] < 1e-2f * norms) flagged |= 1u << r;
+            }
+            // cancellation (d2 small against the norms, e.g. an anchor against its own row): recompute exactly as a sum of
+            // squared differences.  Rare, and kept out of the straight-line code above: ONE wave-wide test per tile, then
+            // the whole wave does each flagged output together -- 64 lanes over the depth, shuffle reduction -- instead
+            // of one lane walking D dependent loads while the other 63 wait (that was a 90 us tail on a 140 us kernel).
+            if (__any(flagged != 0)) {
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    unsigned long long fix = __ballot((flagged >> r) & 1u);
+                    while (fix) {
+                        const int src = __ffsll((long long)fix) - 1;
+                        fix &= fix - 1;
+                        const float v = wave_sqdist(X + (size_t)__shfl(row, src) * D, A + (size_t)__shfl(col, src) * D, D, lane);
+                        if (lane == src) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q)
+                                if (q == r) e[q] = v;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_sqrtf(fmaxf(e[r], 0.0f));   // v_sqrt_f32 (1 ulp): the IEEE expansion is ~15 instructions per output
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sim = acc[t][r] * rnx[r] * rna;
+                e[r] = metric == POPE_METRIC_COSINE_SIMILARITY ? sim : fminf(fmaxf(1.0f - sim, 0.0f), 2.0f);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < N && col_ok) {
-                const float dot = acc[t][r];
-                const double x2 = xx[row];
-                float e;
-                if (metric == POPE_METRIC_EUCLIDEAN) {
-                    const double d2 = x2 + a2 - 2.0 * (double)dot;
-                    float d2f = (float)d2;
-                    if (d2 < 1e-2 * (x2 + a2))                                 // cancellation: recompute exactly
-                        d2f = direct_sqdist(X + (size_t)row * D, A + (size_t)col * D, D);
-                    e = sqrtf(fmaxf(d2f, 0.0f));
-                } else {
-                    const float nx = x2 == 0.0 ? 1.0f : (float)sqrt(x2);
-                    const float s = dot / (nx * na);
-                    e = metric == POPE_METRIC_COSINE_SIMILARITY ? s : fminf(fmaxf(1.0f - s, 0.0f), 2.0f);
-                }
-                out[(size_t)row * out_cols + c0 + col] = e;
-                cmin = fminf(cmin, e);
-                cmax = fmaxf(cmax, e);
+                out[obase[r] + col] = e[r];
+                cmin = fminf(cmin, e[r]);
+                cmax = fmaxf(cmax, e[r]);
             }
         }
         cmin = fminf(cmin, __shfl_xor(cmin, 32));
@@ -108,8 +159,14 @@ __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, i
     }
     __syncthreads();
     if (tid < PN && col0 + tid < K) {
-        part_min[(size_t)blockIdx.x * Kpad + col0 + tid] = fminf(red_min[0][tid], red_min[1][tid]);
-        part_max[(size_t)blockIdx.x * Kpad + col0 + tid] = fmaxf(red_max[0][tid], red_max[1][tid]);
+        float mn = red_min[0][tid], mx = red_max[0][tid];
+#pragma unroll
+        for (int w = 1; w < PWM; ++w) {
+            mn = fminf(mn, red_min[w][tid]);
+            mx = fmaxf(mx, red_max[w][tid]);
+        }
+        part_min[(size_t)blockIdx.x * Kpad + col0 + tid] = mn;
+        part_max[(size_t)blockIdx.x * Kpad + col0 + tid] = mx;
     }
 }
 

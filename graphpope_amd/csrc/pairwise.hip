@@ -9,9 +9,10 @@
 //                     epilogue, raw values written straight into the [N, F+K] output, per-block column min/max
 //   k_minmax_fold / k_minmax_reduce   column min/max over blocks (two stages) -> scale_ = 1/range (range < 10 eps -> 1), min_ = 0 - min*scale_
 //   k_minmax_apply    y = e * scale_ + min_ in place (two roundings, like NumPy's X *= scale_; X += min_)
-// Euclidean: sklearn upcasts f32 inputs to f64 (pairwise.py:582-653).  Here d2 = xx + aa - 2 dot is formed in f64
-// from the f32 MFMA dot; where d2 is small against the norms (cancellation) the entry is recomputed as a direct
-// sum of squared differences, so coincident rows give exactly 0 instead of ~1e-2.
+// Euclidean: sklearn upcasts f32 inputs to f64 (pairwise.py:582-653).  Here the row norms are accumulated in f64,
+// d2 = xx + aa - 2 dot is one f32 fma on the f32-accumulated MFMA dot (whose own error, ~1e-6 |x||a|, dominates);
+// where d2 is small against the norms (cancellation) the entry is recomputed as a direct sum of squared
+// differences, so coincident rows give exactly 0 instead of ~1e-2.  Gate: 1e-5 absolute on the scaled values.
 #include "gemm_tile.h"
 
 namespace pope {

@@ -180,24 +180,30 @@ __device__ __forceinline__ void mfma_accumulate(f32x16 (&acc)[TN / WN / 32], con
         const float *xb = b_kc ? Bs + (wn * (TN / WN) + (lane & 31)) * GLD + (lane >> 5)
                                : Bs + (lane >> 5) * TB::LDK + wn * (TN / WN) + (lane & 31);
         const int ask = a_kc ? 1 : TA::LDK, bsk = b_kc ? 1 : TB::LDK, bst = b_kc ? 32 * GLD : 32;
-        // Fragments are read from LDS in batches of KB k-steps into registers BEFORE the MFMAs that use them: with one
-        // wave per SIMD nothing else hides the LDS latency, and a read-wait-MFMA sequence per step idles the matrix pipe.
-        constexpr int KB = NT <= 2 ? 16 : 4;
-#pragma unroll 1
-        for (int k0 = 0; k0 < GK / 2; k0 += KB) {
-            float fa[KB], fb[NT][KB];
+        // Fragments are read from LDS in batches of KB k-steps into registers BEFORE the MFMAs that use them, and the
+        // reads of batch b+1 are issued before the MFMAs of batch b (two register sets): with one wave per SIMD nothing
+        // else hides the LDS latency, and a read-wait-MFMA sequence per batch idles the matrix pipe for that latency.
+        constexpr int KB = NT <= 2 ? 8 : 4;
+        constexpr int NB = GK / 2 / KB;
+        float fa[2][KB], fb[2][NT][KB];
+        auto read_batch = [&](int b, int set) {
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
-                fa[j] = xa[(k0 + j) * 2 * ask];
+                fa[set][j] = xa[(b * KB + j) * 2 * ask];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) fb[t][j] = xb[t * bst + (k0 + j) * 2 * bsk];
+                for (int t = 0; t < NT; ++t) fb[set][t][j] = xb[t * bst + (b * KB + j) * 2 * bsk];
             }
-            __builtin_amdgcn_sched_barrier(0);                  // all of the batch's LDS reads are issued above this line
+        };
+        read_batch(0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b + 1 < NB) read_batch(b + 1, (b + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);                  // the next batch's LDS reads are issued above this line
 #pragma unroll
             for (int j = 0; j < KB; ++j)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[t][j], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[b & 1][j], fb[b & 1][t][j], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         // keep the masking / LDS stores of the prefetched registers BELOW the MFMAs: hoisted above them they wait for

@@ -46,6 +46,16 @@ _, hp = engine.geodesic_run(None, eid, nn, anc, want_out=False)
 res["rmat20_64anchors_bfs_only"] = {"ms": t * 1e3, "N": nn, "E": int(ei.shape[1]), "max_hop": hp.max_hop,
                                     "embeddings_per_s": nn * 64 / t, "per_source_model_gbs": 64 * (4.0 * ei.shape[1] + 8.0 * nn) / t / 1e9,
                                     "graph_generation_s": gen}
+# anchor-count sweep on the Flickr-shaped graph (config 4's per-GPU share is 128 anchors; 1 024 = all of config 4 on one GPU)
+xf = torch.rand(synth.FLICKR_N, 500, device=dev)
+ei_s, n_s = synth.flickr_like()
+eis = torch.as_tensor(ei_s, device=dev)
+res["anchor_sweep"] = {}
+for kk in (64, 128, 256, 512, 1024):
+    anc = synth.seeded_anchors(n_s, kk, 42)
+    t = timed(lambda: engine.geodesic_run(xf, eis, n_s, anc, reuse_workspace=True), reps=20, warm=3)
+    res["anchor_sweep"][str(kk)] = {"ms": t * 1e3, "embeddings_per_s": n_s * kk / t}
+
 # closeness-centrality anchors (utils.py:50-54): every node an anchor, 256 at a time, on the Flickr-shaped graph
 ei_f, n_f = synth.flickr_like()
 eif = torch.as_tensor(ei_f, device=dev)

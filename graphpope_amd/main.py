@@ -26,7 +26,9 @@ import torch.nn.functional as F
 
 from . import synth
 from .optim import Adam
-from .sage import SAGE, sample_batch
+from . import engine
+from .sage import SAGE
+from .sampler import NeighborSampler
 from .utils import Graphpope
 
 
@@ -84,33 +86,39 @@ def load_dataset(name: str, data_dir: str) -> tuple[GraphData, int]:
     return GraphData(x, y, torch.as_tensor(ei), split < 0.5, (split >= 0.5) & (split < 0.75), split >= 0.75), classes
 
 
-def _batches(node_idx, batch_size, shuffle, rng):
-    idx = node_idx[rng.permutation(len(node_idx))] if shuffle else node_idx
-    for i in range(0, len(idx), batch_size):
+def _batches(node_idx, batch_size, shuffle, gen):
+    idx = node_idx[torch.randperm(node_idx.numel(), device=node_idx.device, generator=gen)] if shuffle else node_idx
+    for i in range(0, idx.numel(), batch_size):
         yield idx[i:i + batch_size]
 
 
-def _run_epoch(model, data, rowptr, col, node_idx, args, dev, rng, opt=None):
+def _run_epoch(model, feats, labels, sampler, node_idx, args, gen, epoch, opt=None):
+    """One pass over node_idx.  Everything stays on the device: the fan-out sampler (main.py:100-116), the feature
+    gather of convert_batch (main.py:118-123), the model, the optimiser; loss / accuracy are accumulated on the
+    device and read once per epoch."""
     train = opt is not None
     model.train(train)
-    tot_loss = tot_correct = tot = 0
-    for seeds in _batches(node_idx, args.batch_size, train, rng):
-        n_id, adjs = sample_batch(rowptr, col, seeds, sizes=(25, 10), rng=rng)          # main.py:101
-        x = data.x[n_id].to(dev)                                                         # main.py:118-123 convert_batch
-        y = data.y[torch.as_tensor(seeds)].to(dev)
-        adjs = [a.to(dev) for a in adjs]
+    dev = feats.device
+    tot_loss = torch.zeros((), device=dev)
+    tot_correct = torch.zeros((), device=dev, dtype=torch.int64)
+    tot = 0
+    for b, seeds in enumerate(_batches(node_idx, args.batch_size, train, gen)):
+        n_id, adjs = sampler.sample(seeds, seed=(args.seed << 20) + (epoch << 10) + b)       # NeighborSampler(sizes=[25, 10])
+        x = feats.index_select(0, n_id)                                                  # Batch.x = data.x[n_id]
+        y = labels.index_select(0, seeds)                                                # Batch.y = data.y[n_id[:batch_size]]
         with torch.set_grad_enabled(train):
             y_hat = model(x, adjs)
             loss = F.cross_entropy(y_hat, y)
         if train:
-            opt.zero_grad()
+            for p in model.parameters():
+                p.grad = None
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)                      # gradient_clip_val=0.5
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)                      # gradient_clip_val=0.5 (main.py:286)
             opt.step()
-        tot_loss += float(loss) * len(seeds)
-        tot_correct += int((y_hat.argmax(-1) == y).sum())
-        tot += len(seeds)
-    return tot_loss / max(tot, 1), tot_correct / max(tot, 1)
+        tot_loss += loss.detach() * seeds.numel()
+        tot_correct += (y_hat.argmax(-1) == y).sum()
+        tot += seeds.numel()
+    return float(tot_loss) / max(tot, 1), int(tot_correct) / max(tot, 1)
 
 
 def main(argv=None):
@@ -129,16 +137,17 @@ def main(argv=None):
     model = SAGE(in_channels, num_classes, args.hidden_layer_size, args.num_layers).to(dev)   # dropout NOT passed: main.py:272
     opt = Adam(model.parameters(), lr=args.lr)                                           # main.py:244 torch.optim.Adam rule, one launch per step
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt)                              # monitors val_loss
-    ei = data.edge_index.numpy()
-    order = np.lexsort((ei[1], ei[0]))
-    rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei[0], minlength=data.num_nodes))])
-    col = ei[1][order]
-    rng = np.random.default_rng(args.seed)
-    idx = {k: np.flatnonzero(getattr(data, f'{k}_mask').numpy()) for k in ('train', 'val', 'test')}
+    # HBM-resident training data: features (+ POPE columns), labels, and adj_t as a device CSR whose row v lists the nodes v
+    # aggregates from (main.py:84 ToSparseTensor: the transposed adjacency; the same CSR for the symmetric Flickr / PubMed)
+    feats, labels = data.x.to(dev, torch.float32).contiguous(), data.y.to(dev)
+    adj_t = engine.build_csr(data.edge_index.flip(0).contiguous().to(dev), data.num_nodes)
+    sampler = NeighborSampler(adj_t.rowptr, adj_t.col, data.num_nodes, sizes=(25, 10))
+    gen = torch.Generator(device=dev).manual_seed(args.seed)
+    idx = {k: torch.nonzero(getattr(data, f'{k}_mask'), as_tuple=False).flatten().to(dev) for k in ('train', 'val', 'test')}
     best, bad = -1.0, 0
     for epoch in range(args.epochs):
-        tr_loss, tr_acc = _run_epoch(model, data, rowptr, col, idx['train'], args, dev, rng, opt)
-        va_loss, va_acc = _run_epoch(model, data, rowptr, col, idx['val'], args, dev, rng)
+        tr_loss, tr_acc = _run_epoch(model, feats, labels, sampler, idx['train'], args, gen, epoch, opt)
+        va_loss, va_acc = _run_epoch(model, feats, labels, sampler, idx['val'], args, gen, epoch)
         sched.step(va_loss)
         print(f'epoch {epoch}: train_loss {tr_loss:.4f} train_acc {tr_acc:.4f} val_loss {va_loss:.4f} val_acc {va_acc:.4f}')
         if va_acc > best:
@@ -147,7 +156,7 @@ def main(argv=None):
             bad += 1
             if bad >= 20:                                                                # EarlyStopping(val_acc, patience=20)
                 break
-    _, te_acc = _run_epoch(model, data, rowptr, col, idx['test'], args, dev, rng)
+    _, te_acc = _run_epoch(model, feats, labels, sampler, idx['test'], args, gen, args.epochs)
     print(f'test_acc {te_acc:.4f}')
     return te_acc
 

@@ -80,12 +80,15 @@ def pope_phases(x, ei, n, anchors, timers):
 
 
 def level_kernel_times(ei, n, anchors, reps):
-    """Per-launch durations of the BFS level kernels (HIP events recorded by the library on the launch stream)."""
+    """Average duration of a k_bfs_level launch: HIP events recorded by the library on the launch stream around each
+    enqueued run of level launches (no events between the kernels, so this is what rocprofv3 --stats averages too:
+    every launch of the kernel, the trailing early-exit ones included).  Returns (ms per launch, launches per BFS,
+    levels that did work, HopPlanes)."""
     lib = _lib.load()
     csr = engine.build_csr(ei, n)
     engine.bfs(csr, anchors)
     torch.cuda.synchronize()
-    lib.pope_profile_levels(1)
+    lib.pope_profile_levels(2)
     for _ in range(reps):
         hp = engine.bfs(csr, anchors)
     torch.cuda.synchronize()
@@ -94,9 +97,10 @@ def level_kernel_times(ei, n, anchors, reps):
     ex = (ctypes.c_float * cap)()
     cnt = lib.pope_profile_read(lv, ex, cap)
     lib.pope_profile_levels(0)
+    launches = sum(-lv[i] for i in range(cnt))
+    total_ms = sum(ex[i] for i in range(cnt))
     active = hp.max_hop + 1                     # levels 1 .. max_hop reach something, level max_hop + 1 proves the end
-    exp = [ex[i] for i in range(cnt) if lv[i] <= active]
-    return float(np.mean(exp)), active, hp
+    return total_ms / launches, launches // reps, active, hp
 
 
 def cpu_baselines(ei, n, anchors):
@@ -351,18 +355,21 @@ def main():
         # dominant kernel by total time: k_bfs_level (one launch per level), timed on this rank's own anchor shard with HIP
         # events on the launch stream.  Algorithmic bytes of ONE launch: per CSR slot erow + col (8 B) + the
         # neighbour's frontier words (8W B); per node seen (read) + frontier (write) (16W B).  W = 4 words for 256 anchors.
-        exp_ms, active_levels, hp = level_kernel_times(ei, n, anchors[:K_PER_GPU], reps=10)
+        exp_ms, launches, active_levels, hp = level_kernel_times(ei, n, anchors[:K_PER_GPU], reps=10)
         wp = hp.planes.shape[2]
-        exp_bytes = e * (8.0 + 8.0 * wp) + n * 16.0 * wp
+        dense_bytes = e * (8.0 + 8.0 * wp) + n * 16.0 * wp           # one level that does work
+        exp_bytes = dense_bytes * active_levels / launches            # per launch, the early-exit launches included
         exp_gbs = exp_bytes / (exp_ms * 1e-3) / 1e9
         pmc = pmc_traffic() or {}
         result["roofline"] = {
             "kernel": "k_bfs_level<4>", "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": exp_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch"),
-            "algorithmic_bytes_per_launch": exp_bytes, "avg_launch_ms": exp_ms, "launches_per_step": active_levels,
-            "note": "per GPU; working set (CSR 7.2 MB + planes of 2.9 MB) is L2 / Infinity-Cache resident: the dense levels run at the "
-                    "L2 line-fill rate of 32-byte gathers, not at the HBM rate (DESIGN.md §5; live-bit table skips quiet neighbours, "
-                    "so sparse levels move fewer bytes than this dense-level model)"}
+            "algorithmic_bytes_per_launch": exp_bytes, "avg_launch_ms": exp_ms, "launches_per_step": launches,
+            "active_levels": active_levels, "algorithmic_bytes_per_active_level": dense_bytes,
+            "note": "per GPU; average over EVERY launch of the kernel in a step (what rocprofv3 --stats averages): "
+                    f"{active_levels} levels do work, the other {launches - active_levels} exit at once.  The working set (CSR 7.2 MB + planes of "
+                    "2.9 MB) is L2 / Infinity-Cache resident: the dense levels run at the L2 line-fill rate of 32-byte gathers, not at the "
+                    "HBM rate (DESIGN.md §5); the live-bit table skips quiet neighbours, so sparse levels move fewer bytes than the model"}
         src_bytes = k_total * (4.0 * e + 4.0 * (n + 1) + 4.0 * n)           # SURVEY.md §8d per-source model, all GPUs
         geo_gbs = src_bytes / (ms * 1e-3) / 1e9
         result["roofline_per_source_model"] = {

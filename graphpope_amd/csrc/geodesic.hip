@@ -863,13 +863,14 @@ constexpr int EAGER_PLANES = 4;      // hop-bit planes cleared up front (levels 
 // Optional per-launch timing of the level kernels with HIP events on the launch stream (bench.py's roofline leg).
 struct LevelProfile {
     bool enabled = false;
+    bool span_only = false;              // mode 2: one event pair around each enqueued run of levels, not around every launch
     std::vector<hipEvent_t> ev;          // 2 per level: before and after the level kernel
     std::vector<int> level;
 };
 static LevelProfile g_profile;
 
-static void profile_mark(hipStream_t stream, int level, int which) {
-    if (!g_profile.enabled) return;
+static void profile_mark(hipStream_t stream, int level, int which, bool span = false) {
+    if (!g_profile.enabled || g_profile.span_only != span) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, stream);
@@ -1026,6 +1027,8 @@ static int bfs_enqueue_init(const Bfs &b, const int64_t *anchors_host, hipStream
 
 // Enqueue levels [level, stop) (clipped to what the hop-bit capacity can represent); returns the next level.
 static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t stream) {
+    const int first = level;
+    profile_mark(stream, 0, 0, true);                                // span mode: one event pair around the whole run
     for (; level < stop; ++level) {
         if (level >= b.level_limit || b.E == 0) break;
         if ((level & (level - 1)) == 0 && level >= (1 << EAGER_PLANES)) {   // first level with this hop bit
@@ -1043,6 +1046,9 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
         else if (b.Wp == 2) launch_level<2>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
         else                launch_level<4>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
     }
+    profile_mark(stream, 0, 1, true);
+    if (g_profile.enabled && g_profile.span_only && !g_profile.level.empty())
+        g_profile.level.back() = -(level - first);                  // span entries carry minus the number of launches
     return level;
 }
 
@@ -1109,6 +1115,7 @@ extern "C" void pope_profile_levels(int32_t enable) {
     g_profile.ev.clear();
     g_profile.level.clear();
     g_profile.enabled = enable != 0;
+    g_profile.span_only = enable == 2;
 }
 
 extern "C" int32_t pope_profile_read(int32_t *levels, float *level_ms, int32_t capacity) {

@@ -171,9 +171,12 @@ int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N, const int
                       void *stream);
 
 /*
- * Measurement hook (bench.py): while enabled, every BFS level launch is bracketed by HIP events on the launch
- * stream.  pope_profile_read returns, per level launched since enabling, the level number and the elapsed
- * milliseconds of its kernel (waits for the events).  Not thread-safe; off by default.
+ * Measurement hook (bench.py): enable = 1: every BFS level launch is bracketed by HIP events on the launch stream and
+ * pope_profile_read returns, per level launched since enabling, the level number and the elapsed milliseconds of its
+ * kernel (waits for the events).  enable = 2: ONE event pair around each enqueued run of level launches (no events
+ * between the kernels, so the pipeline is undisturbed); pope_profile_read then returns one entry per run with
+ * levels[i] = -(number of launches in the run) and the elapsed milliseconds of the whole run.  0 disables.
+ * Not thread-safe; off by default.
  */
 void pope_profile_levels(int32_t enable);
 int32_t pope_profile_read(int32_t *levels_host, float *level_ms_host, int32_t capacity);

@@ -15,7 +15,7 @@ anchors = synth.seeded_anchors(n, int(sys.argv[1]) if len(sys.argv) > 1 else 256
 csr = engine.build_csr(ei, n)
 for _ in range(3): hp = engine.bfs(csr, anchors)
 torch.cuda.synchronize()
-lib.pope_profile_levels(1)
+lib.pope_profile_levels(1)  # per-level events
 reps = 20
 for _ in range(reps): hp = engine.bfs(csr, anchors)
 torch.cuda.synchronize()

@@ -52,10 +52,15 @@ def main(tag, rnd):
         short = head.replace("pope::", "")
         f_mean, f_act, f_all = active_mean(fetch[name])
         w_mean, _, _ = active_mean(write.get(name, [0.0]))
+        f_every = sum(fetch[name]) / len(fetch[name])
+        w_every = sum(write[name]) / len(write[name]) if name in write else 0.0
         out["kernels"][short] = {"fetch_kib_raw": f_mean, "write_kib_raw": w_mean, "active_launches": f_act, "launches": f_all,
-                                 "hbm_bytes_per_launch": f_mean * 1024 * 2 + w_mean * 1024}
+                                 "hbm_bytes_per_launch": f_mean * 1024 * 2 + w_mean * 1024,
+                                 "hbm_bytes_per_launch_every_launch": f_every * 1024 * 2 + w_every * 1024}
     k = out["kernels"]
-    out["k_bfs_level_hbm_bytes_per_launch"] = next(v["hbm_bytes_per_launch"] for n, v in k.items() if n.startswith("k_bfs_level"))
+    # bench.py's roofline averages over EVERY launch of the level kernel (the early-exit ones included), as rocprofv3 --stats does
+    out["k_bfs_level_hbm_bytes_per_launch"] = next(v["hbm_bytes_per_launch_every_launch"] for n, v in k.items() if n.startswith("k_bfs_level"))
+    out["k_bfs_level_hbm_bytes_per_active_launch"] = next(v["hbm_bytes_per_launch"] for n, v in k.items() if n.startswith("k_bfs_level"))
     out["k_finalize_hbm_bytes_per_launch"] = next(v["hbm_bytes_per_launch"] for n, v in k.items() if n.startswith("k_finalize"))
     with open(os.path.join(dst, f"{rnd}_pmc_summary.json"), "w") as fh:
         json.dump(out, fh, indent=1)

@@ -66,9 +66,14 @@ __global__ __launch_bounds__(256) void k_sample_count(const int *__restrict__ ro
 }
 
 // map[g] = smallest "position key" at which node g occurs: targets occupy keys [0, T), sampled slot p key T + p.
-__global__ __launch_bounds__(256) void k_sample_targets(const long long *__restrict__ targets, int T, int *__restrict__ map) {
+__global__ __launch_bounds__(256) void k_sample_targets(const long long *__restrict__ targets, int T, int *__restrict__ map,
+                                                        long long *__restrict__ out_n_id) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < T) map[targets[i]] = i;                               // target lists hold distinct nodes
+    if (i < T) {
+        const long long v = targets[i];
+        map[v] = i;                                               // target lists hold distinct nodes
+        out_n_id[i] = v;                                          // n_id starts with the targets, in order
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sample_pick(const int *__restrict__ rowptr, const int *__restrict__ col,
@@ -141,6 +146,22 @@ __global__ void k_sample_report(const int *__restrict__ out_rowptr, const int *_
     const int nnz = out_rowptr[T];
     report[0] = nnz;
     report[1] = T + rank[nnz];                                     // n_src: targets + distinct new nodes
+    __threadfence_system();                                        // `report` is pinned host memory: no copy kernel
+}
+
+// Per (device, host thread) pinned report slot, created on first use (a worker thread may sample beside the main thread).
+static int pinned_report(long long **host, long long **dev) {
+    static thread_local long long *h[64] = {nullptr}, *d[64] = {nullptr};
+    int id = 0;
+    POPE_HIP(hipGetDevice(&id));
+    POPE_REQUIRE(id >= 0 && id < 64, "device index %d out of range", id);
+    if (!h[id]) {
+        POPE_HIP(hipHostMalloc((void **)&h[id], 64, hipHostMallocMapped));
+        POPE_HIP(hipHostGetDevicePointer((void **)&d[id], h[id], 0));
+    }
+    *host = h[id];
+    *dev = d[id];
+    return POPE_OK;
 }
 
 static size_t scan_bytes(size_t n) {
@@ -208,8 +229,8 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
     hipLaunchKernelGGL(k_sample_count, dim3((T + 256) / 256), dim3(256), 0, stream, rowptr, (const long long *)targets, T, fanout, cnt);
     POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, cnt, out_rowptr, 0, (size_t)T + 1, rocprim::plus<int>(), stream));
     POPE_HIP(hipMemsetAsync(map, 0x7F, (size_t)N * 4, stream));                       // 0x7F7F7F7F: larger than any key
-    hipLaunchKernelGGL(k_sample_targets, dim3((T + 255) / 256), dim3(256), 0, stream, (const long long *)targets, T, map);
-    POPE_HIP(hipMemcpyAsync(out_n_id, targets, (size_t)T * sizeof(long long), hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(k_sample_targets, dim3((T + 255) / 256), dim3(256), 0, stream, (const long long *)targets, T, map,
+                       (long long *)out_n_id);
     if (fanout < 0) {
         // all neighbours: the total is only known on the device; the caller sized nnz_capacity for it
         hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, (int)nnz_capacity, picked, map);
@@ -218,7 +239,9 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
                            (const long long *)targets, T, fanout, (unsigned long long)seed, hop, out_rowptr, picked, map);
     }
     const int cap = (int)nnz_capacity;
-    long long rep[2] = {0, 0};
+    long long *rep = nullptr, *rep_dev = nullptr;                 // the two counts come back through pinned, device-mapped memory
+    int rc_pin = pinned_report(&rep, &rep_dev);
+    if (rc_pin) return rc_pin;
     hipLaunchKernelGGL(k_sample_flag, dim3((cap + 256) / 256), dim3(256), 0, stream, picked, out_rowptr, cap, T, map, first);
     POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, first, rank, 0, (size_t)cap + 1, rocprim::plus<int>(), stream));
     if (cap > 0) {
@@ -226,8 +249,8 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
                            (long long *)out_n_id, newid);
         hipLaunchKernelGGL(k_sample_relabel, dim3((cap + 255) / 256), dim3(256), 0, stream, picked, out_rowptr, T, map, newid, out_col);
     }
-    hipLaunchKernelGGL(k_sample_report, dim3(1), dim3(1), 0, stream, out_rowptr, rank, T, report);
-    POPE_HIP(hipMemcpyAsync(rep, report, 2 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+    (void)report;
+    hipLaunchKernelGGL(k_sample_report, dim3(1), dim3(1), 0, stream, out_rowptr, rank, T, rep_dev);
     POPE_HIP(hipStreamSynchronize(stream));
     POPE_HIP(hipGetLastError());
     if (rep[0] > nnz_capacity) {

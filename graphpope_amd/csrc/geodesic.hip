@@ -6,8 +6,9 @@
 //  * anchors are packed 64 per uint64 word; every node carries W words, so one pass over the CSR advances
 //    the BFS of all K anchors by one level ("MS-BFS");
 //  * the level kernel is BOTTOM-UP (pull): node v ORs the frontier words of its out-neighbours, because
-//    hop(v -> anchor) = 1 + min over edges v -> u of hop(u -> anchor).  Only v's owner writes v's state, so
-//    there are no atomics and the result is independent of scheduling;
+//    hop(v -> anchor) = 1 + min over edges v -> u of hop(u -> anchor).  It is edge-parallel (256 CSR slots per wave);
+//    OR is the only combining operation, so the result is independent of scheduling; the only atomics are ORs for the
+//    rows that span several waves' chunks.  A one-bit-per-node "live" table (staged in LDS) skips quiet neighbours;
 //  * hop counts are stored bit-sliced: plane b gets `new` OR-ed in when bit b of the level is set.  State is
 //    a few N*W*8-byte planes that live in L2 / Infinity Cache; the 4*N*K-byte float matrix is written once,
 //    coalesced, by the finalise kernel straight into the [N, F+K] output (no transpose, no torch.cat).

@@ -368,16 +368,36 @@ __global__ __launch_bounds__(256) void k_adam(AdamTable t, float step_size, floa
     const float *__restrict__ g = t.g[k];
     float *__restrict__ m = t.m[k];
     float *__restrict__ v = t.v[k];
-    for (long long i = base + threadIdx.x; i < end; i += blockDim.x) {
-        float gi = g[i];
-        const float pi = p[i];
+    auto update = [&](float &pi, float gi, float &mi, float &vi) {
         if (weight_decay != 0.f) gi += weight_decay * pi;
-        float mi = m[i], vi = v[i];
         mi = mi + (gi - mi) * one_minus_b1;
         vi = beta2 * vi + one_minus_b2 * gi * gi;
+        pi = pi - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+    };
+    long long i = base + threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+          reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        // 16-byte packs: 7 memory instructions per 4 parameters instead of 28 (chunks start at multiples of 4096)
+        const long long end4 = base + ((end - base) & ~3ll);
+        for (long long q = base + 4ll * threadIdx.x; q < end4; q += 4ll * blockDim.x) {
+            float4 p4 = *reinterpret_cast<float4 *>(p + q), m4 = *reinterpret_cast<float4 *>(m + q), v4 = *reinterpret_cast<float4 *>(v + q);
+            const float4 g4 = *reinterpret_cast<const float4 *>(g + q);
+            update(p4.x, g4.x, m4.x, v4.x);
+            update(p4.y, g4.y, m4.y, v4.y);
+            update(p4.z, g4.z, m4.z, v4.z);
+            update(p4.w, g4.w, m4.w, v4.w);
+            *reinterpret_cast<float4 *>(m + q) = m4;
+            *reinterpret_cast<float4 *>(v + q) = v4;
+            *reinterpret_cast<float4 *>(p + q) = p4;
+        }
+        i = end4 + threadIdx.x;                                    // scalar tail (< 4 elements)
+    }
+    for (; i < end; i += blockDim.x) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        update(pi, g[i], mi, vi);
         m[i] = mi;
         v[i] = vi;
-        p[i] = pi - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+        p[i] = pi;
     }
 }
 

@@ -154,16 +154,22 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
     torch.manual_seed(0)
     model = SAGE(c_in, 7, HIDDEN, 3).to(dev)                     # --num_layers 3: two convs execute, logits 256 wide
     opt = Adam(model.parameters(), lr=1e-3)   # torch.optim.Adam rule, one launch per step (the step is launch-bound)
+    params = list(model.parameters())
 
     def step(i):
         n_id, adjs, y = batches[i % len(batches)]
         x = feats.index_select(0, n_id)                          # main.py:118-123 convert_batch, on the device
-        opt.zero_grad(set_to_none=True)
+        for p in params:                                         # opt.zero_grad(set_to_none=True) without its bookkeeping
+            p.grad = None
         loss = torch.nn.functional.cross_entropy(model(x, adjs), y)
         loss.backward()
         opt.step()
         return loss
 
+    # The step is launch-bound on the host: run the backward pass in the calling thread (no hand-off to autograd's
+    # device thread: -35 % host time per step, tools/host_overhead.py).  The whole leg runs under this setting.
+    single_thread = torch.autograd.set_multithreading_enabled(False)
+    single_thread.__enter__()
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
@@ -223,7 +229,8 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
             seeds = perm[(i * BATCH) % (n - BATCH): (i * BATCH) % (n - BATCH) + BATCH]
             n_id_s, adjs_s = sampler.sample(seeds, seed=i)
             xs = feats.index_select(0, n_id_s)
-            opt.zero_grad(set_to_none=True)
+            for p in params:
+                p.grad = None
             loss = torch.nn.functional.cross_entropy(model(xs, adjs_s), batches[0][2])
             loss.backward()
             opt.step()
@@ -259,6 +266,7 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
                "sample": f"1 batch fwd + bwd, torch CPU restatement (oracle.sage_conv_torch), {cdt:.2f} s"}
     except Exception as exc:                                    # the CPU leg must never take the bench down
         cpu = {"error": repr(exc)}
+    single_thread.__exit__(None, None, None)
     return {
         "nodes_per_s": BATCH / dt, "ms_per_step": dt * 1e3, "steps": steps, "batch_seed_nodes": BATCH,
         "model": f"SAGE {c_in}->{HIDDEN}->{HIDDEN} (num_layers 3, 2 executed), fan-out [25, 10], fp32, fused BN+ReLU+dropout epilogue, one-launch Adam",

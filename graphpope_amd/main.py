@@ -145,6 +145,7 @@ def main(argv=None):
     gen = torch.Generator(device=dev).manual_seed(args.seed)
     idx = {k: torch.nonzero(getattr(data, f'{k}_mask'), as_tuple=False).flatten().to(dev) for k in ('train', 'val', 'test')}
     best, bad = -1.0, 0
+    torch.autograd.set_multithreading_enabled(False)          # backward in the calling thread: the step is launch-bound on the host
     for epoch in range(args.epochs):
         tr_loss, tr_acc = _run_epoch(model, feats, labels, sampler, idx['train'], args, gen, epoch, opt)
         va_loss, va_acc = _run_epoch(model, feats, labels, sampler, idx['val'], args, gen, epoch)

@@ -13,7 +13,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import check
+from ._lib import check, on_device
 
 
 class Adam(torch.optim.Optimizer):
@@ -22,6 +22,28 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self._tables = {}            # per group: cached ctypes pointer arrays, rebuilt when the set of tensors changes
+
+    def _build(self, group, live):
+        """Slow path, taken when the set of parameters with gradients changes: checks, state creation, pointer tables."""
+        for p in live:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise RuntimeError("graphpope_amd.optim.Adam: float32 contiguous CUDA parameters only (no CPU fallback)")
+            st = self.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        steps = {int(self.state[p]["step"]) for p in live}
+        if len(steps) != 1:
+            raise RuntimeError("graphpope_amd.optim.Adam: the parameters of a group must share one step count")
+        n = len(live)
+        arr = ctypes.c_void_p * n
+        return {"live": live, "ids": [id(p) for p in live], "pptr": [p.data_ptr() for p in live], "n": n, "step": steps.pop(),
+                "pp": arr(*[p.data_ptr() for p in live]), "gg": arr(*([0] * n)), "gptr": [0] * n,
+                "mm": arr(*[self.state[p]["exp_avg"].data_ptr() for p in live]),
+                "vv": arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in live]),
+                "nn": (ctypes.c_int64 * n)(*[p.numel() for p in live]), "dev": live[0].device,
+                "states": [self.state[p] for p in live]}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -34,38 +56,29 @@ class Adam(torch.optim.Optimizer):
             live = [p for p in group["params"] if p.grad is not None]
             if not live:
                 continue
-            for p in live:
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
-                    raise RuntimeError("graphpope_amd.optim.Adam: float32 contiguous CUDA parameters only (no CPU fallback)")
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            steps = {int(self.state[p]["step"]) for p in live}
-            if len(steps) != 1:
-                raise RuntimeError("graphpope_amd.optim.Adam: the parameters of a group must share one step count")
-            step = steps.pop() + 1
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in live]
-            key = tuple((p.data_ptr(), g.data_ptr()) for p, g in zip(live, grads))
             tab = self._tables.get(gi)
-            if tab is None or tab[0] != key:          # gradients are fresh tensors every step: only their addresses change
-                n = len(live)
-                arr = ctypes.c_void_p * n
-                tab = (key, n, arr(*[p.data_ptr() for p in live]), arr(*[g.data_ptr() for g in grads]),
-                       arr(*[self.state[p]["exp_avg"].data_ptr() for p in live]),
-                       arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in live]),
-                       (ctypes.c_int64 * n)(*[p.numel() for p in live]))
-                self._tables[gi] = tab
-            _, n, pp, gg, mm, vv, nn = tab
+            if (tab is None or tab["n"] != len(live) or any(a != id(b) for a, b in zip(tab["ids"], live))
+                    or any(a != b.data_ptr() for a, b in zip(tab["pptr"], live))):      # e.g. module.to() swapped the storage
+                tab = self._tables[gi] = self._build(group, live)
+            keep = []                                         # gradients are fresh tensors every step: refresh their addresses
+            gptr, gg = tab["gptr"], tab["gg"]
+            for i, p in enumerate(live):
+                g = p.grad
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                    keep.append(g)
+                a = g.data_ptr()
+                if a != gptr[i]:
+                    gptr[i] = a
+                    gg[i] = a
+            step = tab["step"] = tab["step"] + 1
             b1, b2 = group["betas"]
-            dev = live[0].device
-            with torch.cuda.device(dev):
-                check(lib.sage_adam_step(n, pp, gg, mm, vv, nn, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                         float(group["weight_decay"]), step,
-                                         ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-            for p in live:
-                self.state[p]["step"] = step
+            with on_device(tab["dev"]):
+                check(lib.sage_adam_step(tab["n"], tab["pp"], gg, tab["mm"], tab["vv"], tab["nn"], float(group["lr"]), float(b1),
+                                         float(b2), float(group["eps"]), float(group["weight_decay"]), step,
+                                         ctypes.c_void_p(torch.cuda.current_stream(tab["dev"]).cuda_stream)))
+            for st in tab["states"]:
+                st["step"] = step
         return loss
 
     def state_dict(self):

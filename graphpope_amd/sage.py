@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from ._lib import check, ptr
+from ._lib import check, on_device, ptr
 
 
 def _stream():
@@ -50,12 +50,13 @@ class _SageConvFn(torch.autograd.Function):
         lib = _lib.load()
         if not x_src.is_cuda:
             raise RuntimeError("SAGEConv runs on the GPU only (no CPU fallback)")
-        x_src, w_l, w_r = x_src.contiguous(), w_l.contiguous(), w_r.contiguous()
+        if not (x_src.is_contiguous() and w_l.is_contiguous() and w_r.is_contiguous()):
+            x_src, w_l, w_r = x_src.contiguous(), w_l.contiguous(), w_r.contiguous()
         n_src, c_in = x_src.shape
         c_out = w_l.shape[0]
         agg = torch.empty((n_dst, c_in), dtype=torch.float32, device=x_src.device)
         out = torch.empty((n_dst, c_out), dtype=torch.float32, device=x_src.device)
-        with torch.cuda.device(x_src.device):
+        with on_device(x_src.device):
             check(lib.sage_conv_forward(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), c_in, ptr(w_l),
                                         ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(out), _stream()))
         ctx.save_for_backward(x_src, agg, w_l, w_r, rowptr, col)
@@ -76,7 +77,7 @@ class _SageConvFn(torch.autograd.Function):
         grad_w_l = torch.empty_like(w_l)
         grad_w_r = torch.empty_like(w_r)
         grad_b = torch.empty(c_out, dtype=torch.float32, device=dev) if ctx.has_bias else None
-        with torch.cuda.device(dev):
+        with on_device(dev):
             scratch = torch.empty(max(lib.sage_conv_scratch_bytes(n_src, n_dst, col.numel(), c_in, c_out), 16),
                                   dtype=torch.uint8, device=dev)
             check(lib.sage_conv_backward(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), ptr(agg), c_in,
@@ -130,7 +131,7 @@ class _BnReluDropoutFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(c, dtype=torch.float32, device=dev)
         rstd = torch.empty(c, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             scratch = torch.empty(lib.sage_bn_scratch_bytes(c), dtype=torch.uint8, device=dev)
             check(lib.sage_bn_relu_dropout_forward(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                                    momentum, eps, int(training), p, seed, ptr(y), ptr(mean), ptr(rstd),
@@ -150,7 +151,7 @@ class _BnReluDropoutFn(torch.autograd.Function):
         grad_x = torch.empty_like(x)
         grad_gamma = torch.empty_like(gamma)
         grad_beta = torch.empty_like(beta)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             scratch = torch.empty(lib.sage_bn_scratch_bytes(c), dtype=torch.uint8, device=dev)
             check(lib.sage_bn_relu_dropout_backward(ptr(x), ptr(grad_y), m, c, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                                     int(training), p, seed, ptr(grad_x), ptr(grad_gamma), ptr(grad_beta),

@@ -16,7 +16,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import check, ptr
+from ._lib import check, on_device, ptr
 from .sage import SampledAdj
 
 
@@ -46,7 +46,7 @@ class NeighborSampler:
         out_col = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
         n_id = torch.empty(t + cap, dtype=torch.int64, device=dev)
         nnz, n_src = ctypes.c_int64(0), ctypes.c_int64(0)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(lib.sage_sample_hop(ptr(self.rowptr), ptr(self.col), self.num_nodes, ptr(targets), t, fanout, seed, hop,
                                       ptr(out_rowptr), ptr(out_col), cap, ptr(n_id), ctypes.byref(nnz), ctypes.byref(n_src),
                                       ptr(self._scratch), self._scratch.numel(), _stream()))

@@ -20,14 +20,18 @@ for b in range(8):
     batches.append((torch.as_tensor(n_id, device=dev), [a.to(dev) for a in adjs], torch.randint(0, 7, (1550,), device=dev)))
 torch.manual_seed(0)
 model = sage.SAGE(756, 7, 256, 3).to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+from graphpope_amd.optim import Adam
+opt = Adam(model.parameters(), lr=1e-3)
+params = list(model.parameters())
 T = {}
 def tick(name, t0):
     T[name] = T.get(name, 0.0) + time.perf_counter() - t0
 def step(i):
     n_id, adjs, y = batches[i % 8]
     t = time.perf_counter(); x = feats.index_select(0, n_id); tick("index_select", t)
-    t = time.perf_counter(); opt.zero_grad(set_to_none=True); tick("zero_grad", t)
+    t = time.perf_counter()
+    for p_ in params: p_.grad = None
+    tick("zero_grad", t)
     t = time.perf_counter(); out = model(x, adjs); tick("forward", t)
     t = time.perf_counter(); loss = F.cross_entropy(out, y); tick("loss", t)
     t = time.perf_counter(); loss.backward(); tick("backward", t)

@@ -101,20 +101,38 @@ __global__ __launch_bounds__(256) void k_scatter_mean(const int *__restrict__ ro
 }
 
 // Column sums in two deterministic stages: part[s][c] = sum over row slice s, then out[c] = sum_s part[s][c].
-constexpr int COLSUM_SPLITS = 64;
+constexpr int COLSUM_SPLITS = 256;
 
+// VEC: lane l owns 4 adjacent columns (16-byte loads, a wave covers 256 columns of a row); else one column per lane.
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ g, int rows, int C, float *__restrict__ part) {
-    __shared__ float red[4][64];
+    constexpr int W = VEC ? 4 : 1;
+    __shared__ float red[4][64 * W];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = (blockIdx.x * 64 + lane) * W;
     const int per = (rows + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-    float s = 0.f;
+    float s[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) s[k] = 0.f;
     if (c < C)
-        for (int i = r0 + wave; i < r1; i += 4) s += g[(size_t)i * C + c];
-    red[wave][lane] = s;
+        for (int i = r0 + wave; i < r1; i += 4) {
+            if constexpr (VEC) {
+                const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)i * C + c);
+                s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            } else {
+                s[0] += g[(size_t)i * C + c];
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < W; ++k) red[wave][lane * W + k] = s[k];
     __syncthreads();
-    if (wave == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0 && c < C)
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const int j = lane * W + k;
+            part[(size_t)blockIdx.y * C + c + k] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+        }
 }
 
 // 16 columns x 16 split-groups per block: a one-thread-per-column loop over the 64 partials is 64 dependent-latency
@@ -368,7 +386,10 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
     if ((rc = gemm(Gt, AggT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_l, c_in, splits, slab, stream,
                    Twin{XdT, grad_w_r, 0}))) return rc;
     if (grad_b_l) {                                             // the slab region is free again: stream order
-        hipLaunchKernelGGL(k_colsum_partial, dim3((c_out + 63) / 64, COLSUM_SPLITS), dim3(256), 0, stream, grad_out, (int)n_dst, c_out, slab);
+        if ((c_out & 3) == 0 && aligned16(grad_out))
+            hipLaunchKernelGGL(k_colsum_partial<true>, dim3((c_out + 255) / 256, COLSUM_SPLITS), dim3(256), 0, stream, grad_out, (int)n_dst, c_out, slab);
+        else
+            hipLaunchKernelGGL(k_colsum_partial<false>, dim3((c_out + 63) / 64, COLSUM_SPLITS), dim3(256), 0, stream, grad_out, (int)n_dst, c_out, slab);
         hipLaunchKernelGGL(k_colsum_final, dim3((c_out + 15) / 16), dim3(256), 0, stream, slab, COLSUM_SPLITS, c_out, grad_b_l);
     }
     if (grad_x) {

@@ -52,6 +52,8 @@ SIGNATURES = {
     "sage_conv_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p,
                                   c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "sage_gather_mean": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
+    "sage_conv_forward_indexed": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32,
+                                          c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sage_conv_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int32,
                                    c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),

@@ -20,10 +20,15 @@ namespace pope {
 // ------------------------------------------------------------------------------------------------
 // neighbour gather + mean
 // ------------------------------------------------------------------------------------------------
+// n_id != nullptr (indexed mode): x is the WHOLE feature matrix and block-local source j lives in row n_id[j]
+// (convert_batch's x = data.x[n_id], main.py:118-123, never materialised); destination i's own row goes to x_dst[i].
+__device__ __forceinline__ long long src_row(int j, const long long *__restrict__ n_id) { return n_id ? n_id[j] : (long long)j; }
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_gather_mean(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                      int n_dst, const float *__restrict__ x, int C,
-                                                     float *__restrict__ agg) {
+                                                     float *__restrict__ agg, const long long *__restrict__ n_id,
+                                                     float *__restrict__ x_dst) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -36,7 +41,7 @@ __global__ __launch_bounds__(256) void k_gather_mean(const int *__restrict__ row
                 float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
                 int p = beg;
                 for (; p + 3 < end; p += 4) {                              // four neighbour rows in flight
-                    const int j0 = col[p], j1 = col[p + 1], j2 = col[p + 2], j3 = col[p + 3];
+                    const long long j0 = src_row(col[p], n_id), j1 = src_row(col[p + 1], n_id), j2 = src_row(col[p + 2], n_id), j3 = src_row(col[p + 3], n_id);
                     const float4 a = reinterpret_cast<const float4 *>(x + (size_t)j0 * C)[q];
                     const float4 b = reinterpret_cast<const float4 *>(x + (size_t)j1 * C)[q];
                     const float4 c = reinterpret_cast<const float4 *>(x + (size_t)j2 * C)[q];
@@ -47,17 +52,19 @@ __global__ __launch_bounds__(256) void k_gather_mean(const int *__restrict__ row
                     s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
                 }
                 for (; p < end; ++p) {
-                    const float4 a = reinterpret_cast<const float4 *>(x + (size_t)col[p] * C)[q];
+                    const float4 a = reinterpret_cast<const float4 *>(x + (size_t)src_row(col[p], n_id) * C)[q];
                     s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
                 }
                 s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
                 reinterpret_cast<float4 *>(agg + (size_t)i * C)[q] = s;
+                if (x_dst) reinterpret_cast<float4 *>(x_dst + (size_t)i * C)[q] = reinterpret_cast<const float4 *>(x + (size_t)n_id[i] * C)[q];
             }
         } else {
             for (int c = lane; c < C; c += 64) {
                 float s = 0.f;
-                for (int p = beg; p < end; ++p) s += x[(size_t)col[p] * C + c];
+                for (int p = beg; p < end; ++p) s += x[(size_t)src_row(col[p], n_id) * C + c];
                 agg[(size_t)i * C + c] = s * inv;
+                if (x_dst) x_dst[(size_t)i * C + c] = x[(size_t)n_id[i] * C + c];
             }
         }
     }
@@ -326,12 +333,14 @@ extern "C" size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t 
 }
 
 static void enqueue_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_dst, const float *x_src, int32_t c_in,
-                                float *agg, hipStream_t stream) {
+                                float *agg, hipStream_t stream, const int64_t *n_id = nullptr, float *x_dst = nullptr) {
     dim3 grid(capped_grid((size_t)n_dst * 64, 256));
-    if ((c_in & 3) == 0 && aligned16(x_src) && aligned16(agg))
-        hipLaunchKernelGGL(k_gather_mean<true>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg);
+    if ((c_in & 3) == 0 && aligned16(x_src) && aligned16(agg) && (!x_dst || aligned16(x_dst)))
+        hipLaunchKernelGGL(k_gather_mean<true>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
+                           (const long long *)n_id, x_dst);
     else
-        hipLaunchKernelGGL(k_gather_mean<false>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg);
+        hipLaunchKernelGGL(k_gather_mean<false>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
+                           (const long long *)n_id, x_dst);
 }
 
 extern "C" int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
@@ -359,6 +368,23 @@ extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int6
         if (!g_debug_slab) POPE_HIP(hipMalloc((void **)&g_debug_slab, (size_t)256 << 20));
         return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, nullptr, out, c_out, g_fwd_splits, g_debug_slab, stream);
     }
+    return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream);
+}
+
+// The same layer on rows of the resident feature matrix: source j of the block is feats[n_id[j]].  Replaces
+// Batch.x = data.x[n_id] (main.py:118-123) + the layer: x[n_id] is never materialised, only the n_dst destination rows
+// (x_dst, needed again by the backward pass) are.
+extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
+                                         int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l,
+                                         const float *b_l, const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out,
+                                         void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(rowptr && (col || nnz == 0) && n_id && feats && w_l && w_r && agg && x_dst && out, "sage_conv_forward_indexed: null pointer");
+    POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && n_rows > 0 && nnz >= 0 && nnz < INT32_MAX && c_in > 0 && c_out > 0,
+                 "sage_conv_forward_indexed: bad size (destinations must be the first n_dst entries of n_id)");
+    enqueue_gather_mean(rowptr, col, n_dst, feats, c_in, agg, stream, n_id, x_dst);
+    const Operand A0{agg, c_in, 1}, B0{w_l, c_in, 1}, A1{x_dst, c_in, 1}, B1{w_r, c_in, 1};
     return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream);
 }
 

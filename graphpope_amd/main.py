@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from . import synth
 from .optim import Adam
 from . import engine
-from .sage import SAGE
+from .sage import SAGE, IndexedFeatures
 from .sampler import NeighborSampler
 from .utils import Graphpope
 
@@ -104,7 +104,7 @@ def _run_epoch(model, feats, labels, sampler, node_idx, args, gen, epoch, opt=No
     tot = 0
     for b, seeds in enumerate(_batches(node_idx, args.batch_size, train, gen)):
         n_id, adjs = sampler.sample(seeds, seed=(args.seed << 20) + (epoch << 10) + b)       # NeighborSampler(sizes=[25, 10])
-        x = feats.index_select(0, n_id)                                                  # Batch.x = data.x[n_id]
+        x = IndexedFeatures(feats, n_id)                                                 # Batch.x = data.x[n_id], never materialised
         y = labels.index_select(0, seeds)                                                # Batch.y = data.y[n_id[:batch_size]]
         with torch.set_grad_enabled(train):
             y_hat = model(x, adjs)

@@ -86,6 +86,57 @@ class _SageConvFn(torch.autograd.Function):
         return grad_x, grad_w_l, grad_b, grad_w_r, None, None, None
 
 
+class IndexedFeatures:
+    """``Batch.x = data.x[n_id]`` (main.py:118-123) WITHOUT the copy: the resident feature matrix plus the batch's node
+    ids.  Passed to :class:`SAGE` / :class:`SAGEConv` in place of the gathered ``x``, the first layer reads its
+    neighbours' rows straight from ``feats`` (sage_conv_forward_indexed); only the destination rows are materialised."""
+
+    def __init__(self, feats: torch.Tensor, n_id: torch.Tensor):
+        assert feats.dim() == 2 and feats.dtype == torch.float32 and feats.is_contiguous() and not feats.requires_grad
+        assert n_id.dtype == torch.int64 and n_id.dim() == 1 and n_id.device == feats.device
+        self.feats, self.n_id = feats, n_id.contiguous()
+
+    def materialize(self) -> torch.Tensor:
+        return self.feats.index_select(0, self.n_id)
+
+
+class _SageConvIndexedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w_l, b_l, w_r, feats, n_id, rowptr, col, n_dst):
+        lib = _lib.load()
+        if not feats.is_cuda:
+            raise RuntimeError("SAGEConv runs on the GPU only (no CPU fallback)")
+        if not (w_l.is_contiguous() and w_r.is_contiguous()):
+            w_l, w_r = w_l.contiguous(), w_r.contiguous()
+        c_in, c_out, dev = feats.shape[1], w_l.shape[0], feats.device
+        agg = torch.empty((n_dst, c_in), dtype=torch.float32, device=dev)
+        x_dst = torch.empty((n_dst, c_in), dtype=torch.float32, device=dev)
+        out = torch.empty((n_dst, c_out), dtype=torch.float32, device=dev)
+        with on_device(dev):
+            check(lib.sage_conv_forward_indexed(ptr(rowptr), ptr(col), ptr(n_id), n_id.numel(), n_dst, col.numel(), ptr(feats),
+                                                feats.shape[0], c_in, ptr(w_l), ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(x_dst),
+                                                ptr(out), _stream()))
+        ctx.save_for_backward(x_dst, agg, w_l, w_r, rowptr, col)
+        ctx.has_bias = b_l is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        x_dst, agg, w_l, w_r, rowptr, col = ctx.saved_tensors
+        n_dst, c_in = x_dst.shape
+        c_out, dev = w_l.shape[0], x_dst.device
+        grad_out = grad_out.contiguous()
+        grad_w_l, grad_w_r = torch.empty_like(w_l), torch.empty_like(w_r)
+        grad_b = torch.empty(c_out, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        with on_device(dev):
+            scratch = torch.empty(max(lib.sage_conv_scratch_bytes(n_dst, n_dst, col.numel(), c_in, c_out), 16), dtype=torch.uint8, device=dev)
+            check(lib.sage_conv_backward(ptr(rowptr), ptr(col), n_dst, n_dst, col.numel(), ptr(x_dst), ptr(agg), c_in, ptr(w_l),
+                                         ptr(w_r), c_out, ptr(grad_out), None, ptr(grad_w_l), ptr(grad_b), ptr(grad_w_r),
+                                         ptr(scratch), scratch.numel(), _stream()))
+        return grad_w_l, grad_b, grad_w_r, None, None, None, None, None
+
+
 class _Linear(nn.Module):
     """Weight (+ bias) holder named like torch.nn.Linear so state dicts line up with PyG's lin_l / lin_r."""
 
@@ -112,6 +163,9 @@ class SAGEConv(nn.Module):
         self.lin_r = _Linear(in_channels, out_channels, bias=False)
 
     def forward(self, x, adj_t: SampledAdj):
+        if isinstance(x, IndexedFeatures):                        # neighbours read straight from the resident feature matrix
+            return _SageConvIndexedFn.apply(self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, x.feats, x.n_id, adj_t.rowptr,
+                                            adj_t.col, adj_t.size(0))
         x_src = x[0] if isinstance(x, (tuple, list)) else x       # x_dst = x_src[:n_dst] by construction (main.py:206)
         return _SageConvFn.apply(x_src, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, adj_t.rowptr, adj_t.col,
                                  adj_t.size(0))
@@ -200,7 +254,7 @@ class SAGE(nn.Module):
 
     def forward(self, x, adjs):
         for i, adj_t in enumerate(adjs):
-            x = self.convs[i]((x, x[:adj_t.size(0)]), adj_t)
+            x = self.convs[i](x if isinstance(x, IndexedFeatures) else (x, x[:adj_t.size(0)]), adj_t)
             if i < len(adjs) - 1:
                 x = bn_relu_dropout(x, self.bns[i], self.dropout, self.training)
         return x

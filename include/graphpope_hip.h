@@ -239,6 +239,16 @@ int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_src, i
  * Gradients.  grad_out f32 [n_dst, c_out].  grad_x f32 [n_src, c_in] (may be NULL), grad_w_l, grad_w_r
  * f32 [c_out, c_in], grad_b_l f32 [c_out] (may be NULL) are OVERWRITTEN.  Asynchronous.
  */
+/*
+ * sage_conv_forward on rows of a resident feature matrix: block-local source j is feats[n_id[j]] (feats: [n_rows, c_in],
+ * n_id: int64 [n_src] on the device, its first n_dst entries are the destinations).  Replaces convert_batch's
+ * x = data.x[n_id] (main.py:118-123) followed by the layer: the [n_src, c_in] gather is never materialised.
+ * x_dst (out): [n_dst, c_in] = feats[n_id[:n_dst]], to be passed to sage_conv_backward as x_src (with n_src = n_dst and
+ * grad_x = NULL: features have no gradient).
+ */
+int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
+                              int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l, const float *b_l,
+                              const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out, void *stream);
 int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
                        const float *x_src, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
                        int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l,

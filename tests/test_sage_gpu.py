@@ -101,3 +101,29 @@ def test_model_depth_quirk_and_training_step(dev):
         losses.append(loss.item())
     assert losses[-1] < 0.7 * losses[0]
     assert model.convs[2].lin_l.weight.grad is None          # never executed
+
+
+def test_indexed_features_equal_the_materialised_batch(dev):
+    """IndexedFeatures(feats, n_id) (neighbours read straight from the resident feature matrix, main.py:118-123 without the
+    copy) gives bit-identical logits to x = feats[n_id] followed by the same model, and the same parameter gradients up to
+    the order of the float atomics in k_scatter_mean (layer 1's grad_x, which feeds every layer-0 gradient)."""
+    from graphpope_amd.sage import SAGE, IndexedFeatures, SampledAdj
+    torch.manual_seed(3)
+    n_all, c = 5000, 36
+    feats = torch.randn(n_all, c, device=dev)
+    n_id = torch.randperm(n_all, device=dev)[:900]
+    rp0, col0 = _random_block(300, 900, 9, seed=1)
+    rp1, col1 = _random_block(64, 300, 5, seed=2)
+    adjs = [SampledAdj(rp0, col0, 900).to(dev), SampledAdj(rp1, col1, 300).to(dev)]
+    a, b = SAGE(c, 4, 32, 3, dropout=0.0).to(dev), SAGE(c, 4, 32, 3, dropout=0.0).to(dev)
+    b.load_state_dict(a.state_dict())
+    out_a = a(feats.index_select(0, n_id), adjs)
+    out_b = b(IndexedFeatures(feats, n_id), adjs)
+    assert torch.equal(out_a, out_b)
+    g = torch.randn_like(out_a)
+    out_a.backward(g); out_b.backward(g)
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pa.grad is None:
+            assert pb.grad is None
+        else:      # 1e-5 of the gradient's scale, with a floor of 1: layer 0's bias gradient is analytically 0 under BatchNorm
+            assert float((pa.grad - pb.grad).abs().max()) <= 1e-5 * max(float(pa.grad.abs().max()), 1.0), name

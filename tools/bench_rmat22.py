@@ -26,3 +26,20 @@ if "--check" in sys.argv:
     got = engine.hop_matrix(hp).cpu().numpy()
     print(json.dumps({"bit_exact": bool(np.array_equal(got, want)), "oracle_s": cpu, "oracle_embeddings_per_s": n * 64 / cpu,
                       "emb_exact": bool(np.array_equal(out.cpu().numpy().view(np.uint32), oracle.hops_to_embedding(want).view(np.uint32)))}))
+if "--all512" in sys.argv:
+    # all of config 5 on ONE GPU: 512 anchors (W = 8 words, two 4-word tiles per node); 8 random columns checked against the oracle
+    anchors512 = synth.seeded_anchors(n, 512, 42)
+    def run512(): return engine.geodesic_run(x0, eid, n, anchors512, reuse_workspace=True)
+    for _ in range(2): out5, hp5 = run512()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3): out5, hp5 = run512()
+    torch.cuda.synchronize(); t5 = (time.perf_counter() - t0) / 3
+    r5 = {"K": 512, "ms": t5 * 1e3, "embeddings_per_s": n * 512 / t5, "max_hop": hp5.max_hop}
+    if "--check" in sys.argv:
+        from oracle import oracle
+        cols = np.random.RandomState(0).choice(512, 8, replace=False)
+        want = oracle.geodesic_hops(ei, n, anchors512[cols])
+        got = engine.hop_matrix(hp5)[:, torch.as_tensor(cols, device=dev)].cpu().numpy()
+        r5["sampled_columns_bit_exact"] = bool(np.array_equal(got, want))
+    print(json.dumps(r5), flush=True)
+

@@ -309,3 +309,22 @@ def test_closeness_anchors_match_reference_golden(dev):
     d = Data()
     d.edge_index, d.num_nodes = torch.as_tensor(g["edge_index"].astype(np.int64)), int(g["num_nodes"])
     assert gp.sample_anchor_nodes(d, 24, "closeness_centrality") == g["closeness_centrality"].tolist()
+
+
+def test_back_to_back_runs_keep_their_outputs(dev, oracle):
+    """pope_geodesic_run returns once the BFS verdict is known, while the expansion may still be running: a second call on
+    the same stream and the same (reused) workspace must neither disturb the first call's output nor its own."""
+    from graphpope_amd import engine, synth
+    ei, n = synth.rmat(13, edge_factor=8, seed=17)
+    eid = torch.as_tensor(ei, device=dev)
+    x = torch.rand(n, 20, device=dev)
+    a1 = np.random.RandomState(1).choice(np.arange(n), 256)
+    a2 = np.random.RandomState(2).choice(np.arange(n), 256)
+    outs = []
+    for rep in range(3):
+        for a in (a1, a2):
+            outs.append((a, engine.geodesic_run(x, eid, n, a, reuse_workspace=True)[0]))     # no synchronisation in between
+    torch.cuda.synchronize()
+    want = {id(a): oracle.geodesic_features(x.cpu().numpy(), ei, n, a) for a in (a1, a2)}
+    for a, out in outs:
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want[id(a)].view(np.uint32))

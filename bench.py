@@ -138,7 +138,7 @@ def cpu_baselines(ei, n, anchors):
 
 def sage_leg(feats, ei_np, n, dev, steps, warmup):
     """SAGE nodes/s: fwd + bwd + Adam on pre-sampled Flickr-shaped batches over the features + POPE matrix."""
-    from graphpope_amd.sage import SAGE, IndexedFeatures, sample_batch
+    from graphpope_amd.sage import SAGE, IndexedFeatures, cross_entropy, sample_batch
     from graphpope_amd.optim import Adam
     from oracle import oracle
     rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei_np[0], minlength=n))])
@@ -161,7 +161,7 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
         x = IndexedFeatures(feats, n_id)                         # main.py:118-123 convert_batch without the copy: layer 0 reads feats[n_id[j]]
         for p in params:                                         # opt.zero_grad(set_to_none=True) without its bookkeeping
             p.grad = None
-        loss = torch.nn.functional.cross_entropy(model(x, adjs), y)
+        loss = cross_entropy(model(x, adjs), y)              # main.py:216 F.cross_entropy, two launches
         loss.backward()
         opt.step()
         return loss
@@ -231,7 +231,7 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
             xs = IndexedFeatures(feats, n_id_s)
             for p in params:
                 p.grad = None
-            loss = torch.nn.functional.cross_entropy(model(xs, adjs_s), batches[0][2])
+            loss = cross_entropy(model(xs, adjs_s), batches[0][2])
             loss.backward()
             opt.step()
 

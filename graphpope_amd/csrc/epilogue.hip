@@ -435,3 +435,99 @@ extern "C" int sage_adam_step(int32_t n_tensors, float *const *params, const flo
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Cross-entropy of the logits against integer labels, mean over the rows whose label is not `ignore_index`
+// (main.py:216 F.cross_entropy(y_hat, y)): loss AND the gradient of the mean loss in two launches
+// (torch: log_softmax + nll_loss forward, then two more for the backward).
+//   k_xent_rows   one wave per row: max, sum of exponentials, loss_i = logsumexp - logit[y]; grad_i = softmax - onehot
+//   k_xent_final  one block: loss = sum loss_i / count, grad scale 1 / count (both stay on the device)
+// The backward pass is grad_logits = grad * (upstream * 1/count): one more elementwise launch.
+// ------------------------------------------------------------------------------------------------
+namespace pope {
+
+__global__ __launch_bounds__(256) void k_xent_rows(const float *__restrict__ logits, const long long *__restrict__ target, int N,
+                                                   int C, long long ignore_index, float *__restrict__ grad,
+                                                   float *__restrict__ row_loss, int *__restrict__ bad_label) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < N; i += nwaves) {
+        const float *row = logits + (size_t)i * C;
+        float *g = grad + (size_t)i * C;
+        const long long y = target[i];
+        if (y == ignore_index || y < 0 || y >= C) {
+            if (y != ignore_index && lane == 0) *bad_label = 1;
+            for (int c = lane; c < C; c += 64) g[c] = 0.f;
+            if (lane == 0) row_loss[i] = -1.f;                    // marks "not counted" (a loss is never negative)
+            continue;
+        }
+        float mx = -__builtin_huge_valf();
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float sum = 0.f;
+        for (int c = lane; c < C; c += 64) sum += expf(row[c] - mx);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        const float lse = logf(sum) + mx, inv = 1.f / sum;
+        for (int c = lane; c < C; c += 64) g[c] = expf(row[c] - mx) * inv - (c == (int)y ? 1.f : 0.f);
+        if (lane == 0) row_loss[i] = lse - row[y];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_xent_final(const float *__restrict__ row_loss, int N, float *__restrict__ loss,
+                                                    float *__restrict__ inv_count) {
+    __shared__ double ssum[256];
+    __shared__ int scnt[256];
+    double s = 0.0;
+    int n = 0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float v = row_loss[i];
+        if (v >= 0.f) { s += (double)v; ++n; }
+    }
+    ssum[threadIdx.x] = s;
+    scnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { ssum[threadIdx.x] += ssum[threadIdx.x + off]; scnt[threadIdx.x] += scnt[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *loss = scnt[0] > 0 ? (float)(ssum[0] / scnt[0]) : __builtin_nanf("");      // torch: nan when every label is ignored
+        *inv_count = scnt[0] > 0 ? 1.f / (float)scnt[0] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_xent_scale(const float *__restrict__ g, size_t n, const float *__restrict__ upstream,
+                                                    const float *__restrict__ inv_count, float *__restrict__ out) {
+    const float k = *upstream * *inv_count;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = g[i] * k;
+}
+
+}  // namespace pope
+
+extern "C" int sage_cross_entropy_forward(const float *logits, const int64_t *target, int64_t N, int32_t C, int64_t ignore_index,
+                                          float *loss, float *grad_unscaled, float *inv_count, float *row_scratch,
+                                          int32_t *bad_label, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(logits && target && loss && grad_unscaled && inv_count && row_scratch && bad_label, "sage_cross_entropy_forward: null pointer");
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && C > 0, "sage_cross_entropy_forward: bad size");
+    hipLaunchKernelGGL(k_xent_rows, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, logits, (const long long *)target,
+                       (int)N, C, (long long)ignore_index, grad_unscaled, row_scratch, bad_label);
+    hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, stream, row_scratch, (int)N, loss, inv_count);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+extern "C" int sage_cross_entropy_backward(const float *grad_unscaled, int64_t N, int32_t C, const float *grad_loss,
+                                           const float *inv_count, float *grad_logits, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(grad_unscaled && grad_loss && inv_count && grad_logits, "sage_cross_entropy_backward: null pointer");
+    POPE_REQUIRE(N > 0 && C > 0, "sage_cross_entropy_backward: bad size");
+    hipLaunchKernelGGL(k_xent_scale, dim3(capped_grid((size_t)N * C, 256)), dim3(256), 0, (hipStream_t)stream_, grad_unscaled,
+                       (size_t)N * C, grad_loss, inv_count, grad_logits);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from . import synth
 from .optim import Adam
 from . import engine
-from .sage import SAGE, IndexedFeatures
+from .sage import SAGE, IndexedFeatures, cross_entropy
 from .sampler import NeighborSampler
 from .utils import Graphpope
 
@@ -108,7 +108,7 @@ def _run_epoch(model, feats, labels, sampler, node_idx, args, gen, epoch, opt=No
         y = labels.index_select(0, seeds)                                                # Batch.y = data.y[n_id[:batch_size]]
         with torch.set_grad_enabled(train):
             y_hat = model(x, adjs)
-            loss = F.cross_entropy(y_hat, y)
+            loss = cross_entropy(y_hat, y)                                               # main.py:216 F.cross_entropy
         if train:
             for p in model.parameters():
                 p.grad = None

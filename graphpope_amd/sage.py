@@ -235,6 +235,58 @@ def bn_relu_dropout(x: torch.Tensor, bn: nn.BatchNorm1d, p: float, training: boo
     return out
 
 
+_BAD_LABEL = {}          # per device: int32 [1], set to 1 by the kernel when a label is out of range (never cleared here)
+
+
+def bad_label_flag(device) -> torch.Tensor:
+    """Device int32 [1]: non-zero once :func:`cross_entropy` has met a label outside [0, C) that is not ignore_index
+    (such rows are left out of the mean, as ignored ones; torch raises a device-side assert instead)."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _BAD_LABEL:
+        _BAD_LABEL[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return _BAD_LABEL[key]
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        lib = _lib.load()
+        if not logits.is_cuda:
+            raise RuntimeError("cross_entropy runs on the GPU only (no CPU fallback)")
+        logits = logits.contiguous()
+        n, c = logits.shape
+        dev = logits.device
+        out = torch.empty(2, dtype=torch.float32, device=dev)                # [loss, 1 / count]
+        grad = torch.empty_like(logits)
+        rows = torch.empty(n, dtype=torch.float32, device=dev)
+        with on_device(dev):
+            check(lib.sage_cross_entropy_forward(ptr(logits), ptr(target), n, c, ignore_index, ptr(out), ptr(grad),
+                                                 ctypes.c_void_p(out.data_ptr() + 4), ptr(rows), ptr(bad_label_flag(dev)), _stream()))
+        ctx.save_for_backward(grad, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        lib = _lib.load()
+        grad, out = ctx.saved_tensors
+        n, c = grad.shape
+        grad_loss = grad_loss.contiguous()
+        res = torch.empty_like(grad)
+        with on_device(grad.device):
+            check(lib.sage_cross_entropy_backward(ptr(grad), n, c, ptr(grad_loss), ctypes.c_void_p(out.data_ptr() + 4), ptr(res),
+                                                  _stream()))
+        return res, None, None
+
+
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """``F.cross_entropy(logits, target)`` (main.py:216: mean over the rows, integer labels) in two launches forward and
+    one backward: the softmax - onehot gradient is produced with the loss and only scaled in the backward pass."""
+    if target.dtype != torch.int64 or target.dim() != 1 or logits.dim() != 2 or target.shape[0] != logits.shape[0]:
+        raise ValueError("cross_entropy: logits [N, C] float32 and int64 labels [N] expected")
+    return _CrossEntropyFn.apply(logits, target.contiguous(), int(ignore_index))
+
+
 class SAGE(nn.Module):
     """main.py:182-211 without the Lightning plumbing.  Keeps the reference's depth quirk: ``forward`` iterates over
     the sampled adjs (two of them, sizes=[25, 10]), so with num_layers=3 the last conv / bn are never executed and

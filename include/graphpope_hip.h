@@ -28,6 +28,7 @@
  *   sage_conv_backward       PyG SAGEConv [3p]   sampled CSR + lin_l + lin_r, and its gradients
  *   sage_bn_relu_dropout_forward / _backward   main.py:207-209
  *                                BatchNorm1d + relu_ + F.dropout of the hidden layers, forward and backward
+ *   sage_cross_entropy_*     main.py:216         F.cross_entropy(y_hat, y): loss and gradient in two launches
  *   sage_adam_step           main.py:244         torch.optim.Adam step, all parameter tensors in one launch
  *   sage_sample_hop          main.py:100-116     NeighborSampler -> torch_sparse.sample_adj (one hop), relabelled block
  */
@@ -308,6 +309,19 @@ int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M
 int sage_adam_step(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                    float *const *exp_avg_sq, const int64_t *numel, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int64_t step, void *stream);
+
+/*
+ * Cross-entropy with integer labels, mean over the rows whose label is not ignore_index  (main.py:216, 224, 233:
+ * F.cross_entropy(y_hat, y)).  Forward writes the scalar loss, 1 / (number of counted rows) and the UNSCALED gradient
+ * softmax(logits) - onehot(target) [N, C] (zero rows for ignored labels); backward multiplies it by the upstream scalar
+ * gradient and by 1 / count, both read on the device.  row_scratch: N floats.  *bad_label (device int, zeroed by the
+ * caller) is set when a label lies outside [0, C) and is not ignore_index.  Asynchronous.
+ */
+int sage_cross_entropy_forward(const float *logits, const int64_t *target, int64_t N, int32_t C, int64_t ignore_index,
+                               float *loss, float *grad_unscaled, float *inv_count, float *row_scratch, int32_t *bad_label,
+                               void *stream);
+int sage_cross_entropy_backward(const float *grad_unscaled, int64_t N, int32_t C, const float *grad_loss, const float *inv_count,
+                                float *grad_logits, void *stream);
 
 #ifdef __cplusplus
 }

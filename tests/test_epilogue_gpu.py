@@ -129,3 +129,33 @@ def test_model_uses_the_fused_epilogue(dev, monkeypatch):
     out = model(torch.randn(8, 16, device=dev), [adj0, adj1])
     out.sum().backward()
     assert calls == [1] and out.shape == (4, 32)
+
+
+@pytest.mark.parametrize("n,c", [(1550, 256), (1550, 7), (33, 3), (5, 1000)])
+def test_cross_entropy_matches_torch(n, c, dev):
+    """graphpope_amd.sage.cross_entropy against F.cross_entropy (main.py:216): loss and gradient, 1e-6 relative, including
+    ignored labels (-100) and a non-unit upstream gradient."""
+    from graphpope_amd.sage import cross_entropy
+    torch.manual_seed(n + c)
+    logits = (torch.randn(n, c, device=dev) * 3)
+    y = torch.randint(0, c, (n,), device=dev)
+    y[::7] = -100
+    a, b = logits.clone().requires_grad_(True), logits.clone().requires_grad_(True)
+    la, lb = F.cross_entropy(a, y), cross_entropy(b, y)
+    assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(la)))
+    (la * 1.7).backward(); (lb * 1.7).backward()
+    _close(b.grad, a.grad, 1e-5)
+    assert float(b.grad[::7].abs().max()) == 0.0                          # ignored rows get no gradient
+
+
+def test_cross_entropy_all_ignored_and_bad_labels(dev):
+    from graphpope_amd.sage import bad_label_flag, cross_entropy
+    logits = torch.randn(8, 5, device=dev)
+    assert torch.isnan(cross_entropy(logits, torch.full((8,), -100, device=dev)))      # torch gives nan too
+    assert int(bad_label_flag(dev)) == 0
+    y = torch.tensor([0, 1, 2, 3, 4, 5, 1, 1], device=dev)                # 5 is out of range: left out and flagged
+    got = cross_entropy(logits, y)
+    keep = torch.tensor([0, 1, 2, 3, 4, 6, 7], device=dev)
+    want = F.cross_entropy(logits[keep], y[keep])
+    assert abs(float(got) - float(want)) < 1e-6 and int(bad_label_flag(dev)) == 1
+    bad_label_flag(dev).zero_()

@@ -261,3 +261,29 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
     *n_src_host = rep[1];
     return POPE_OK;
 }
+
+// All hops of a mini-batch in one call (main.py:100-116 NeighborSampler(sizes=[25, 10]) draws every hop of a batch at once):
+// hop h samples around hop h-1's node list, so the per-hop synchronisations stay, but the host-side glue between the hops
+// (allocation, slicing, argument marshalling in Python: ~25 us per hop in a launch-bound training step) is gone.
+// Buffers are sized by CAPACITY: hop h may meet up to t_capacity[h] targets (t_capacity[0] = n_seeds,
+// t_capacity[h] = t_capacity[h-1] * (1 + fanout[h-1])) and keep up to t_capacity[h] * fanout[h] edges.
+extern "C" int sage_sample_batch(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *seeds, int64_t n_seeds,
+                                 const int32_t *fanouts_host, int32_t n_hops, uint64_t seed, int32_t *const *out_rowptr,
+                                 int32_t *const *out_col, int64_t *const *out_n_id, int64_t *nnz_host, int64_t *n_src_host,
+                                 void *scratch, size_t scratch_bytes, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(fanouts_host && out_rowptr && out_col && out_n_id && nnz_host && n_src_host && n_hops > 0 && n_hops <= 16,
+                 "sage_sample_batch: null pointer or bad hop count");
+    const int64_t *targets = seeds;
+    int64_t T = n_seeds;
+    for (int h = 0; h < n_hops; ++h) {
+        POPE_REQUIRE(fanouts_host[h] > 0, "sage_sample_batch: fan-outs must be positive (use sage_sample_hop for 'all neighbours')");
+        const int rc = sage_sample_hop(rowptr, col, N, targets, T, fanouts_host[h], seed, h, out_rowptr[h], out_col[h],
+                                       T * (int64_t)fanouts_host[h], out_n_id[h], &nnz_host[h], &n_src_host[h], scratch, scratch_bytes,
+                                       stream_);
+        if (rc) return rc;
+        targets = out_n_id[h];
+        T = n_src_host[h];
+    }
+    return POPE_OK;
+}

@@ -55,12 +55,44 @@ class NeighborSampler:
     def sample(self, seeds: torch.Tensor, seed: int = 0):
         """(n_id int64 on the device, [SampledAdj outer ... inner])."""
         n_id = seeds.to(self.rowptr.device, torch.int64).contiguous()
+        if all(int(f) > 0 for f in self.sizes):
+            return self._sample_batch(n_id, int(seed) & 0xFFFFFFFFFFFFFFFF)
         adjs = []
-        for hop, size in enumerate(self.sizes):
+        for hop, size in enumerate(self.sizes):                    # 'all neighbours' hops: sized hop by hop
             n_id, adj = self._hop(n_id, int(size), int(seed) & 0xFFFFFFFFFFFFFFFF, hop)
             adjs.append(adj)
         return n_id, adjs[::-1]
 
+    def _sample_batch(self, seeds: torch.Tensor, seed: int):
+        """Every hop in ONE library call (sage_sample_batch): buffers sized by capacity, sliced to the counts it returns."""
+        lib = _lib.load()
+        dev = seeds.device
+        h = len(self.sizes)
+        t_cap, caps = [], []
+        t = seeds.numel()
+        for f in self.sizes:
+            t_cap.append(t)
+            caps.append(t * int(f))
+            t = t + t * int(f)
+        need = lib.sage_sample_scratch_bytes(self.num_nodes, t_cap[-1], caps[-1])
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+        rowptrs = [torch.empty(tc + 1, dtype=torch.int32, device=dev) for tc in t_cap]
+        cols = [torch.empty(max(c, 1), dtype=torch.int32, device=dev) for c in caps]
+        n_ids = [torch.empty(tc + c, dtype=torch.int64, device=dev) for tc, c in zip(t_cap, caps)]
+        arr = ctypes.c_void_p * h
+        nnz, n_src = (ctypes.c_int64 * h)(), (ctypes.c_int64 * h)()
+        with on_device(dev):
+            check(lib.sage_sample_batch(ptr(self.rowptr), ptr(self.col), self.num_nodes, ptr(seeds), seeds.numel(),
+                                        (ctypes.c_int32 * h)(*[int(f) for f in self.sizes]), h, seed,
+                                        arr(*[r.data_ptr() for r in rowptrs]), arr(*[c.data_ptr() for c in cols]),
+                                        arr(*[n.data_ptr() for n in n_ids]), nnz, n_src, ptr(self._scratch),
+                                        self._scratch.numel(), _stream()))
+        adjs, t = [], seeds.numel()
+        for i in range(h):
+            adjs.append(SampledAdj(rowptrs[i][: t + 1], cols[i][: nnz[i]], n_src[i]))
+            t = n_src[i]
+        return n_ids[-1][: n_src[h - 1]], adjs[::-1]
 
 class BatchPrefetcher:
     """Mini-batches drawn ahead of the training step on a side stream by a worker thread (the device-side counterpart of

@@ -275,6 +275,19 @@ int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_t N, const 
                     int64_t *out_n_id, int64_t *nnz_host, int64_t *n_src_host, void *scratch, size_t scratch_bytes,
                     void *stream);
 
+/*
+ * Every hop of a mini-batch in one call: hop h samples `fanouts_host[h]` neighbours around hop h-1's node list (hop 0:
+ * `seeds`), exactly as n_hops successive sage_sample_hop calls with hop = h would.  out_rowptr / out_col / out_n_id:
+ * HOST arrays of n_hops device pointers sized by capacity -- with t_cap[0] = n_seeds and
+ * t_cap[h] = t_cap[h-1] * (1 + fanouts[h-1]):  out_rowptr[h] t_cap[h] + 1 ints, out_col[h] t_cap[h] * fanouts[h] ints,
+ * out_n_id[h] t_cap[h] * (1 + fanouts[h]) int64.  nnz_host / n_src_host: (out, host) [n_hops].
+ * scratch: sage_sample_scratch_bytes(N, t_cap[last], t_cap[last] * fanouts[last]).  Synchronises `stream` once per hop.
+ */
+int sage_sample_batch(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *seeds, int64_t n_seeds,
+                      const int32_t *fanouts_host, int32_t n_hops, uint64_t seed, int32_t *const *out_rowptr,
+                      int32_t *const *out_col, int64_t *const *out_n_id, int64_t *nnz_host, int64_t *n_src_host, void *scratch,
+                      size_t scratch_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Hidden-layer epilogue: BatchNorm1d + ReLU + dropout as one op  (main.py:207-209)
  *

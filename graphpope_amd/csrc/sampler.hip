@@ -53,7 +53,8 @@ __host__ __device__ __forceinline__ int feistel_perm(int i, int d, unsigned key)
 }
 
 __global__ __launch_bounds__(256) void k_sample_count(const int *__restrict__ rowptr, const long long *__restrict__ targets,
-                                                      int T, int fanout, int *__restrict__ cnt) {
+                                                      int T, int fanout, int *__restrict__ cnt, int *__restrict__ map,
+                                                      long long *__restrict__ out_n_id) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > T) return;
     int c = 0;
@@ -61,21 +62,13 @@ __global__ __launch_bounds__(256) void k_sample_count(const int *__restrict__ ro
         const long long g = targets[i];
         const int d = rowptr[g + 1] - rowptr[g];
         c = (fanout < 0 || d <= fanout) ? d : fanout;
+        map[g] = i;                        // position key of a target = its index (target lists hold distinct nodes)
+        out_n_id[i] = g;                   // n_id starts with the targets, in order
     }
     cnt[i] = c;                                                    // cnt[T] = 0: the scan then yields rowptr_out[T] = nnz
 }
 
-// map[g] = smallest "position key" at which node g occurs: targets occupy keys [0, T), sampled slot p key T + p.
-__global__ __launch_bounds__(256) void k_sample_targets(const long long *__restrict__ targets, int T, int *__restrict__ map,
-                                                        long long *__restrict__ out_n_id) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < T) {
-        const long long v = targets[i];
-        map[v] = i;                                               // target lists hold distinct nodes
-        out_n_id[i] = v;                                          // n_id starts with the targets, in order
-    }
-}
-
+// map[g] = smallest "position key" at which node g occurs: targets occupy keys [0, T) (k_sample_count), sampled slot p key T + p.
 __global__ __launch_bounds__(256) void k_sample_pick(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                      const long long *__restrict__ targets, int T, int fanout,
                                                      unsigned long long seed, int hop, const int *__restrict__ out_rowptr,
@@ -122,31 +115,29 @@ __global__ __launch_bounds__(256) void k_sample_flag(const int *__restrict__ pic
     first[p] = (p < nnz && map[picked[p]] == T + p) ? 1 : 0;      // zeros from nnz on: rank[nnz] = number of new nodes
 }
 
-__global__ __launch_bounds__(256) void k_sample_assign(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int T,
-                                                       const int *__restrict__ first, const int *__restrict__ rank,
-                                                       long long *__restrict__ n_id, int *__restrict__ newid) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= out_rowptr[T] || !first[p]) return;
-    const int u = picked[p];
-    n_id[T + rank[p]] = u;
-    newid[u] = T + rank[p];                                        // separate array: map still holds keys other threads compare
-}
-
+// Local ids.  A node's position key tells everything: a target keeps its index; a new node first seen at slot p0 = key - T
+// gets T + rank[p0] (rank = exclusive scan of the first-occurrence flags), and the thread that owns p0 also writes it into
+// n_id.  One pass, no per-node id table; thread 0 reports the two counts into pinned host memory.
 __global__ __launch_bounds__(256) void k_sample_relabel(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int T,
-                                                        const int *__restrict__ map, const int *__restrict__ newid,
-                                                        int *__restrict__ out_col) {
+                                                        const int *__restrict__ map, const int *__restrict__ rank,
+                                                        int *__restrict__ out_col, long long *__restrict__ n_id,
+                                                        long long *__restrict__ report) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= out_rowptr[T]) return;
-    const int u = picked[p], k = map[u];
-    out_col[p] = k < T ? k : newid[u];
-}
-
-__global__ void k_sample_report(const int *__restrict__ out_rowptr, const int *__restrict__ rank, int T,
-                                long long *__restrict__ report) {
     const int nnz = out_rowptr[T];
-    report[0] = nnz;
-    report[1] = T + rank[nnz];                                     // n_src: targets + distinct new nodes
-    __threadfence_system();                                        // `report` is pinned host memory: no copy kernel
+    if (p == 0) {
+        report[0] = nnz;
+        report[1] = T + rank[nnz];                                 // n_src: targets + distinct new nodes
+        __threadfence_system();                                    // `report` is pinned host memory: no copy kernel
+    }
+    if (p >= nnz) return;
+    const int u = picked[p], k = map[u];
+    if (k < T) {
+        out_col[p] = k;
+    } else {
+        const int id = T + rank[k - T];
+        out_col[p] = id;
+        if (k - T == p) n_id[id] = u;
+    }
 }
 
 // Per (device, host thread) pinned report slot, created on first use (a worker thread may sample beside the main thread).
@@ -226,11 +217,10 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
     size_t sb = L.total - L.scan;
     const int T = (int)n_targets;
 
-    hipLaunchKernelGGL(k_sample_count, dim3((T + 256) / 256), dim3(256), 0, stream, rowptr, (const long long *)targets, T, fanout, cnt);
-    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, cnt, out_rowptr, 0, (size_t)T + 1, rocprim::plus<int>(), stream));
     POPE_HIP(hipMemsetAsync(map, 0x7F, (size_t)N * 4, stream));                       // 0x7F7F7F7F: larger than any key
-    hipLaunchKernelGGL(k_sample_targets, dim3((T + 255) / 256), dim3(256), 0, stream, (const long long *)targets, T, map,
-                       (long long *)out_n_id);
+    hipLaunchKernelGGL(k_sample_count, dim3((T + 256) / 256), dim3(256), 0, stream, rowptr, (const long long *)targets, T, fanout, cnt,
+                       map, (long long *)out_n_id);
+    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, cnt, out_rowptr, 0, (size_t)T + 1, rocprim::plus<int>(), stream));
     if (fanout < 0) {
         // all neighbours: the total is only known on the device; the caller sized nnz_capacity for it
         hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, (int)nnz_capacity, picked, map);
@@ -244,13 +234,10 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
     if (rc_pin) return rc_pin;
     hipLaunchKernelGGL(k_sample_flag, dim3((cap + 256) / 256), dim3(256), 0, stream, picked, out_rowptr, cap, T, map, first);
     POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, first, rank, 0, (size_t)cap + 1, rocprim::plus<int>(), stream));
-    if (cap > 0) {
-        hipLaunchKernelGGL(k_sample_assign, dim3((cap + 255) / 256), dim3(256), 0, stream, picked, out_rowptr, T, first, rank,
-                           (long long *)out_n_id, newid);
-        hipLaunchKernelGGL(k_sample_relabel, dim3((cap + 255) / 256), dim3(256), 0, stream, picked, out_rowptr, T, map, newid, out_col);
-    }
     (void)report;
-    hipLaunchKernelGGL(k_sample_report, dim3(1), dim3(1), 0, stream, out_rowptr, rank, T, rep_dev);
+    (void)newid;
+    hipLaunchKernelGGL(k_sample_relabel, dim3((cap + 256) / 256), dim3(256), 0, stream, picked, out_rowptr, T, map, rank, out_col,
+                       (long long *)out_n_id, rep_dev);        // at least one block: thread 0 also reports the counts
     POPE_HIP(hipStreamSynchronize(stream));
     POPE_HIP(hipGetLastError());
     if (rep[0] > nnz_capacity) {

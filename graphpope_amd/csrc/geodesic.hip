@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
                                                    int live_words) {
     if (bfs_over(ctl, aux, level)) return;
     const int lane = threadIdx.x & 63;
-    const int woff = blockIdx.y * WT;
+    int woff = blockIdx.y * WT;                                    // housekeeping: tile = blockIdx.y
     if ((int)blockIdx.x >= expand_blocks) {
         // housekeeping for the rows that span chunks: one thread per (row, tile)
         const int n = (E + CHUNK - 1) >> CHUNK_SHIFT;              // one slot per chunk, -1 = no row continues into it
@@ -309,7 +309,13 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
         }
         return;
     }
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // Expand waves: with more than one word tile per node (K > 256) the tiles of ONE chunk go to adjacent waves of the
+    // same block, so the 128-byte frontier line that all of them gather from is fetched from L2 once and served to the
+    // others by the CU's L1 (one tile per launch row of blocks fetched it once per tile, from different CUs).
+    const int tiles = gridDim.y;
+    const int wid = ((blockIdx.y * expand_blocks + blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int wave = wid / tiles;                                  // which stream of chunks this wave walks
+    woff = (wid - wave * tiles) * WT;
     const int nwaves = (expand_blocks * blockDim.x) >> 6;
     const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
     // The first chunk's slot loads are issued before the live table is staged: they fly while LDS fills.

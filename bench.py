@@ -14,8 +14,16 @@ is reported in the same line under "sage".  For N > 1 GPUs the POPE pass is WEAK
 anchors (K_total = 256 * N), planes are all-gathered (RCCL) and every rank materialises the full
 [N, F + K_total] matrix, as every DDP rank of the reference needs it.
 
-Rank 0 prints ONE JSON line.  At N = 1 it also carries the roofline of the dominant kernel (durations measured
-live with HIP events on the launch stream) and the CPU baselines timed on this host's cores.
+Rank 0 prints ONE JSON line.  At N = 1 it also carries
+  roofline               the dominant kernel (k_bfs_level), duration measured live with HIP events on the launch stream
+  cpu_baseline           Baseline A: the reference's CPU path (NetworkX per-pair loop under multiprocessing.Pool(6),
+                         utils.py:92-107; main.py:39 default) on a bounded node sample; *_all_cores: the same on every core;
+                         cpu_baseline_bfs: one C BFS per anchor (the honest CPU algorithm)
+  boundary_host_to_host  SURVEY.md §8(d)'s primary metric: utils.Graphpope() from CPU tensors to the returned CPU tensor,
+                         with the PCIe roofline of the bytes that cross the link
+  pairwise               configs[2]: node2vec-euclidean, 256 anchors, with the f32-MFMA roofline and the sklearn baseline
+  config3 / config4      configs[3] (1 024 anchors) and configs[4] (R-MAT scale 22, 512 anchors) on this one GPU
+  sage                   SAGE nodes/s + per-kernel view of layer 0
 """
 from __future__ import annotations
 
@@ -37,10 +45,13 @@ from graphpope_amd import _lib, engine, synth  # noqa: E402
 from graphpope_amd import distributed as pdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3     # same guide: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PCIE_GBS = 63.0              # same guide: PCIe Gen5 x16 host link (spec)
 F = 500                      # /root/reference/main.py:77-79
 K_PER_GPU = 256
 BATCH = 1550                 # main.py:44
 HIDDEN = 256
+NUM_WORKERS = 6              # main.py:39 --num_workers default: the reference's Pool size
 
 
 def _event():
@@ -103,37 +114,213 @@ def level_kernel_times(ei, n, anchors, reps):
     return total_ms / launches, launches // reps, active, hp
 
 
-def cpu_baselines(ei, n, anchors):
-    """Timed on this host's cores, bounded samples (rank 0, N = 1 only).  The oracle is the measured CPU port."""
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only; run BEFORE anything touches the GPU: Baseline A forks a multiprocessing.Pool)
+# ------------------------------------------------------------------------------------------------
+def cpu_baselines_before_gpu(ei, n, anchors, sample_nodes):
+    """Baseline A (the >= 50x contract): the reference's per-pair NetworkX loop under
+    multiprocessing.Pool(W), W = 6 (CLI default) and W = every core, on a bounded random node sample; Baseline B: one C
+    BFS per anchor (oracle), all anchors, one core."""
     from oracle import oracle
     res = {}
-    # (A) the reference's algorithm, statement for statement: nx.shortest_path per (node, anchor) pair (utils.py:64-81)
-    nodes = np.random.RandomState(0).choice(n, 1200, replace=False)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nodes = np.random.RandomState(0).choice(n, sample_nodes, replace=False)
+    want = None
     try:
         import networkx  # noqa: F401
-        t0 = time.perf_counter()
-        oracle.geodesic_pairs_networkx(ei, n, anchors, nodes)
-        dt = time.perf_counter() - t0
-        pairs = len(nodes) * len(anchors)
-        res["cpu_baseline"] = {
-            "value": pairs / dt, "unit": "embeddings/s", "cores": 1, "kind": "port",
-            "sample": f"{len(nodes)} random nodes x {len(anchors)} anchors = {pairs} pairs of the same Flickr-shaped graph: "
-                      f"networkx DiGraph build + nx.shortest_path per pair as utils.py:64-81,121 on 1 core, {dt:.1f} s "
-                      "(the reference spreads this loop over --num_workers processes, default 6)",
-        }
+        for key, w in (("cpu_baseline", NUM_WORKERS), ("cpu_baseline_all_cores", cores)):
+            if key == "cpu_baseline_all_cores" and w == NUM_WORKERS:
+                continue
+            emb, tm = oracle.geodesic_pairs_networkx_pool(ei, n, anchors, nodes, w)
+            pairs = emb.shape[0] * emb.shape[1]
+            per_pair = tm["pool_s"] / pairs
+            res[key] = {
+                "value": pairs / tm["pool_s"], "unit": "embeddings/s", "cores": w, "kind": "port",
+                "sample": f"{emb.shape[0]} random nodes (RandomState(0)) x {len(anchors)} anchors = {pairs} pairs of the same "
+                          f"Flickr-shaped graph: nx.shortest_path per pair under multiprocessing.Pool({w}), float-indexed node "
+                          f"slices, the DiGraph pickled to every job (utils.py:64-107), {tm['pool_s']:.1f} s; "
+                          f"DiGraph build (utils.py:121) {tm['graph_build_s']:.1f} s not included",
+                "graph_build_s": tm["graph_build_s"], "pool_s": tm["pool_s"],
+                "extrapolated_full_graph_s": tm["graph_build_s"] + per_pair * n * len(anchors),
+            }
+            want = (nodes[: emb.shape[0]], emb)
     except ImportError:
         pass
-    # (B) honest CPU: the C oracle, one BFS per anchor, single core, all anchors
     t0 = time.perf_counter()
     hops = oracle.geodesic_hops(ei, n, anchors)
-    oracle.hops_to_embedding(hops)
+    emb_all = oracle.hops_to_embedding(hops)
     dt = time.perf_counter() - t0
     res["cpu_baseline_bfs"] = {
         "value": n * len(anchors) / dt, "unit": "embeddings/s", "cores": 1, "kind": "port",
         "sample": f"full N x K = {n} x {len(anchors)}, oracle/pope_oracle.c one BFS per anchor over the reversed CSR, {dt:.2f} s",
     }
+    if want is not None:
+        res["cpu_baseline"]["matches_c_oracle"] = bool(np.array_equal(want[1], emb_all[want[0]]))
     res.setdefault("cpu_baseline", res["cpu_baseline_bfs"])
     return res, hops
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY.md §8(d) primary metric: the host -> host boundary call
+# ------------------------------------------------------------------------------------------------
+def boundary_leg(ei_np, n, x_cpu, want_hops, reps=5):
+    """utils.Graphpope(data, ...) exactly as Flickr.setup calls it (main.py:94-98): CPU tensors in, CPU tensor out."""
+    from graphpope_amd import utils as gp
+
+    class Data:
+        pass
+    d = Data()
+    d.x, d.edge_index, d.num_nodes = x_cpu, torch.as_tensor(ei_np), n
+    times = []
+    out = None
+    for _ in range(reps + 1):
+        gp.clear_cache()
+        np.random.seed(42)
+        t0 = time.perf_counter()
+        out = gp.Graphpope(d, "flickr", "geodesic", "stochastic", K_PER_GPU, None, NUM_WORKERS)
+        times.append(time.perf_counter() - t0)
+    gp.clear_cache()
+    e, k = ei_np.shape[1], K_PER_GPU
+    crossed = 16.0 * e + 4.0 * n * k                   # edge_index int64 up, [N, K] float32 down; x stays on the host
+    warm = float(np.median(times[1:]))
+    from oracle import oracle
+    ok = bool(np.array_equal(out.numpy()[:, F:].view(np.uint32), oracle.hops_to_embedding(want_hops).view(np.uint32))
+              and torch.equal(out[:, :F], x_cpu))
+    return {
+        "ms": warm * 1e3, "first_call_ms": times[0] * 1e3, "embeddings_per_s": n * k / warm,
+        "what": "utils.Graphpope(data, 'flickr', 'geodesic', 'stochastic', 256) from CPU tensors (x [N, 500] f32, edge_index "
+                "[2, E] int64) to the returned CPU [N, 756] f32 tensor: anchor draw, H2D of edge_index, CSR + BFS + K-column "
+                "expansion on the GPU, D2H of the [N, 256] block into the result, data.x copied host to host by "
+                f"{engine.host_threads()} threads (median of {reps} calls after the first; the first also pays pinned allocations)",
+        "pcie": {"bound": "pcie", "bytes_crossed": crossed, "peak": PCIE_GBS, "unit": "GB/s",
+                 "floor_ms": crossed / (PCIE_GBS * 1e9) * 1e3, "achieved": crossed / warm / 1e9,
+                 "frac": crossed / warm / 1e9 / PCIE_GBS},
+        "host_copy_bytes": 2.0 * 4.0 * n * F,
+        "bit_exact_vs_cpu": ok,
+    }
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[2]: node2vec-euclidean pairwise, 256 anchors
+# ------------------------------------------------------------------------------------------------
+def pairwise_leg(n, anchors, x, dev, steps):
+    lib = _lib.load()
+    d = 128
+    table_cpu = torch.randn((n, d), generator=torch.Generator().manual_seed(0))      # generate_node2vec_embedding.py:23-28: an untrained N(0,1) table
+    table = table_cpu.to(dev)
+    k = len(anchors)
+    for _ in range(3):
+        out = engine.pairwise_features(x, table, anchors, "euclidean")
+    ev = [_event() for _ in range(2)]
+    ev[0].record()
+    for _ in range(steps):
+        out = engine.pairwise_features(x, table, anchors, "euclidean")
+    ev[1].record()
+    torch.cuda.synchronize()
+    call_ms = ev[0].elapsed_time(ev[1]) / steps
+    # the MFMA kernel on its own: the embedding-only entry point (no feature copy), events around the library call
+    a = table.index_select(0, torch.as_tensor(np.asarray(anchors, dtype=np.int64), device=dev)).contiguous()
+    emb = torch.empty((n, k), dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.pope_pairwise_scratch_bytes(n, k, d), dtype=torch.uint8, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def emb_only():
+        _lib.check(lib.pope_pairwise_minmax(_lib.ptr(table), n, d, _lib.ptr(a), k, _lib.METRIC["euclidean"], _lib.ptr(emb), k, 0,
+                                            _lib.ptr(scratch), scratch.numel(), stream))
+    for _ in range(3):
+        emb_only()
+    ev[0].record()
+    for _ in range(steps):
+        emb_only()
+    ev[1].record()
+    torch.cuda.synchronize()
+    emb_ms = ev[0].elapsed_time(ev[1]) / steps
+    flops = 2.0 * n * k * d
+    res = {
+        "workload": f"configs[2]: node2vec-euclidean, X [{n}, {d}] f32 N(0,1) (torch seed 0), {k} anchors (np seed 42), "
+                    "features [N, 500] resident in HBM -> [N, 756] f32 in HBM (feature copy + pairwise + column min-max)",
+        "ms_per_call": call_ms, "embeddings_per_s": n * k / (call_ms * 1e-3),
+        "embedding_only_ms": emb_ms,
+        "roofline": {"kernel": "pope_pairwise_minmax (all its launches: norms, MFMA tile passes, min-max)", "bound": "mfma",
+                     "achieved": flops / (emb_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": flops / (emb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                     "algorithmic_flops": flops,
+                     "note": "2*N*K*D flops of the distance matrix (a tile recomputed in a second pass is not counted twice) over "
+                             "the time of the whole embedding call without the feature copy, HIP events on the launch stream"},
+        "whole_call_frac_of_mfma_peak": flops / (call_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+    }
+    # parity on a row sample + CPU baseline (sklearn, the calls of utils.py:174-176, all cores)
+    try:
+        from sklearn.metrics.pairwise import euclidean_distances
+        from sklearn.preprocessing import MinMaxScaler
+        X = table_cpu.numpy()
+        A = X[np.asarray(anchors, dtype=np.int64)]
+        t0 = time.perf_counter()
+        e = euclidean_distances(X, A)
+        scaler = MinMaxScaler()
+        scaler.fit(e)
+        want = scaler.transform(e)
+        dt = time.perf_counter() - t0
+        got = out[:, F:].cpu().numpy()
+        res["max_abs_err_vs_sklearn"] = float(np.abs(got - want).max())
+        res["cpu_baseline"] = {"value": n * k / dt, "unit": "embeddings/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"full [{n}, {k}]: sklearn euclidean_distances + MinMaxScaler fit/transform (utils.py:174-176), {dt:.2f} s"}
+    except Exception as exc:                                   # never take the bench down
+        res["cpu_baseline"] = {"error": repr(exc)}
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[3] and configs[4] on this one GPU
+# ------------------------------------------------------------------------------------------------
+def config3_leg(x, ei, n, steps):
+    anchors = synth.seeded_anchors(n, 1024, 42)
+    for _ in range(2):
+        out = engine.geodesic_run(x, ei, n, anchors, reuse_workspace=True)[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = engine.geodesic_run(x, ei, n, anchors, reuse_workspace=True)[0]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del out
+    return {"workload": "configs[3] on ONE GPU: flickr-shaped graph, 1024 anchors (np seed 42, 1020 distinct), x resident -> [N, 1524] f32",
+            "ms_per_step": dt * 1e3, "embeddings_per_s": n * 1024 / dt,
+            "note": "the 8-GPU form shards 128 anchors per rank (tests/test_configs_gpu.py runs it sharded over 2 ranks)"}
+
+
+def config4_leg(dev, steps=3):
+    from oracle import oracle
+    t0 = time.perf_counter()
+    ei_np, n = synth.rmat(22, edge_factor=8, seed=1)
+    gen = time.perf_counter() - t0
+    anchors = synth.seeded_anchors(n, 512, 42)
+    ei = torch.as_tensor(ei_np, device=dev)
+    for _ in range(2):
+        out, hp = engine.geodesic_run(None, ei, n, anchors, reuse_workspace=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out, hp = engine.geodesic_run(None, ei, n, anchors, reuse_workspace=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    cols = np.random.RandomState(0).choice(512, 8, replace=False)
+    t0 = time.perf_counter()
+    want = oracle.geodesic_hops(ei_np, n, anchors[cols])
+    cpu = time.perf_counter() - t0
+    got = engine.hop_matrix(hp)[:, torch.as_tensor(cols, device=dev)].cpu().numpy()
+    e = ei_np.shape[1]
+    res = {"workload": f"configs[4] on ONE GPU: R-MAT scale 22 (a,b,c,d)=(.57,.19,.19,.05), N={n}, E={e} CSR slots, 512 anchors "
+                       "(np seed 42), F=0: edge_index resident -> [N, 512] f32 (graph generation outside the timed region)",
+           "ms_per_step": dt * 1e3, "embeddings_per_s": n * 512 / dt, "max_hop": hp.max_hop, "graph_generation_s": gen,
+           "sampled_columns_bit_exact": bool(np.array_equal(got, want)),
+           "per_source_model_gbs": 512 * (4.0 * e + 8.0 * n) / dt / 1e9,
+           "cpu_baseline": {"value": n * 8 / cpu, "unit": "embeddings/s", "cores": 1, "kind": "port",
+                            "sample": f"8 of the 512 anchor columns (RandomState(0)), full N, oracle/pope_oracle.c one BFS per anchor, {cpu:.1f} s"}}
+    del out, hp, ei
+    engine._WORKSPACE.clear()
+    torch.cuda.empty_cache()
+    return res
 
 
 def sage_leg(feats, ei_np, n, dev, steps, warmup):
@@ -215,6 +402,19 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
     g_bytes = 4.0 * (nnz * c_in + n_dst * c_in) + 4.0 * nnz + 4.0 * (n_dst + 1)
     l0_flops = 2.0 * 2 * n_dst * c_in * HIDDEN
     l0_bytes = 4.0 * (nnz * c_in + 2 * n_dst * c_in + n_dst * HIDDEN) + 4.0 * nnz + 4.0 * (n_dst + 1)
+    # the vendor library on the same product (torch.addmm -> hipBLASLt), as a yardstick for the hand-written projection
+    xcat = torch.cat([agg, x[:n_dst]], 1)
+    wcat = torch.cat([conv.lin_l.weight, conv.lin_r.weight], 1).detach()
+    with torch.no_grad():
+        for _ in range(3):
+            torch.addmm(conv.lin_l.bias, xcat, wcat.t())
+        ev[0].record()
+        for _ in range(10):
+            torch.addmm(conv.lin_l.bias, xcat, wcat.t())
+        ev[1].record()
+    torch.cuda.synchronize()
+    lib_ms = ev[0].elapsed_time(ev[1]) / 10
+    del xcat, wcat
 
     # the same step with the batch sampled ON THE DEVICE each step (graphpope_amd.sampler: SURVEY §8f rank 1) instead of
     # taken from the pre-sampled pool: what an epoch actually costs when nothing is prepared on the host
@@ -248,25 +448,29 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
     except Exception as exc:
         sampled = {"error": repr(exc)}
 
-    # CPU baseline: the torch restatement, one fwd + bwd of the same model shape on the host cores
+    # CPU baseline: the torch restatement, fwd + bwd of the same model shape on the host cores (1 warm-up, median of 3)
     try:
         xc = x.cpu()
         adj_cpu = [(a.rowptr.cpu(), a.col.cpu()) for a in adjs]
         w = [(c.lin_l.weight.detach().cpu().requires_grad_(True), c.lin_l.bias.detach().cpu().requires_grad_(True),
               c.lin_r.weight.detach().cpu().requires_grad_(True)) for c in model.convs[:2]]
-        t0 = time.perf_counter()
-        h = xc
-        for li, (rp, cl) in enumerate(adj_cpu):
-            h = oracle.sage_conv_torch(h, rp, cl, *w[li])
-            if li == 0:
-                h = torch.relu(h)
-        h.sum().backward()
-        cdt = time.perf_counter() - t0
+        cts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            h = xc
+            for li, (rp, cl) in enumerate(adj_cpu):
+                h = oracle.sage_conv_torch(h, rp, cl, *w[li])
+                if li == 0:
+                    h = torch.relu(h)
+            h.sum().backward()
+            cts.append(time.perf_counter() - t0)
+        cdt = float(np.median(cts[1:]))
         cpu = {"value": BATCH / cdt, "unit": "seed nodes/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"1 batch fwd + bwd, torch CPU restatement (oracle.sage_conv_torch), {cdt:.2f} s"}
+               "sample": f"1 batch fwd + bwd, torch CPU restatement (oracle.sage_conv_torch), median of 3 passes after 1 warm-up, {cdt:.3f} s"}
     except Exception as exc:                                    # the CPU leg must never take the bench down
         cpu = {"error": repr(exc)}
     single_thread.__exit__(None, None, None)
+    proj_ms = l0_ms - g_ms
     return {
         "nodes_per_s": BATCH / dt, "ms_per_step": dt * 1e3, "steps": steps, "batch_seed_nodes": BATCH,
         "model": f"SAGE {c_in}->{HIDDEN}->{HIDDEN} (num_layers 3, 2 executed), fan-out [25, 10], fp32, fused BN+ReLU+dropout epilogue, one-launch Adam",
@@ -278,21 +482,28 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
                                "frac_of_hbm_peak": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "note": "k_gather_mean alone, back to back on the same batch: source rows (115 MB) are served "
                                        "by the 256 MB Infinity Cache, so the rate can exceed the HBM peak"},
-        "layer0_projection": {"ms": l0_ms - g_ms, "tflops": l0_flops / ((l0_ms - g_ms) * 1e-3) / 1e12,
-                              "frac_of_f32_mfma_peak": l0_flops / ((l0_ms - g_ms) * 1e-3) / 1e12 / 157.3},
+        "layer0_projection": {"ms": proj_ms, "tflops": l0_flops / (proj_ms * 1e-3) / 1e12,
+                              "roofline": {"bound": "mfma", "achieved": l0_flops / (proj_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF,
+                                           "unit": "TFLOP/s", "frac": l0_flops / (proj_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF},
+                              "vendor_library_ms": lib_ms,
+                              "note": "layer-0 forward minus the gather, HIP events; vendor_library_ms = torch.addmm (hipBLASLt) on "
+                                      "the concatenated operands of the same product, timed in the same run"},
         "with_gpu_sampling": sampled,
         "cpu_baseline": cpu,
     }
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernels from the committed rocprofv3 --pmc summary, if any."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh)
-    except (OSError, ValueError):
-        return None
+    """HBM bytes per launch of the dominant kernels from the committed rocprofv3 --pmc summary of the same command
+    (separate profiling run, newest round first); None if no summary is committed."""
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as fh:
+                return json.load(fh), "profiles/" + name
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def main():
@@ -302,11 +513,26 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sage", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the boundary / pairwise / config3 / config4 legs")
+    ap.add_argument("--cpu-sample-nodes", type=int, default=2400, help="nodes of the Baseline A sample (x 256 anchors)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    ei_np, n = synth.flickr_like(seed=1)
+    k_total = K_PER_GPU * world
+    anchors = synth.seeded_anchors(n, k_total, 42)
+    e = ei_np.shape[1]
+
+    # Baseline A forks a multiprocessing.Pool like the reference does: run it before this process touches the GPU
+    base, want_hops = {}, None
+    if world == 1 and not args.no_cpu_baseline:
+        base, want_hops = cpu_baselines_before_gpu(ei_np, n, anchors, args.cpu_sample_nodes)
+
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -317,15 +543,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = engine.require_gpu()
 
-    ei_np, n = synth.flickr_like(seed=1)
-    k_total = K_PER_GPU * world
-    anchors = synth.seeded_anchors(n, k_total, 42)
     x = torch.rand((n, F), device=dev, generator=torch.Generator(device=dev).manual_seed(0))
     ei = torch.as_tensor(ei_np, device=dev)
-    e = ei_np.shape[1]
 
     def barrier():
         if world > 1:
@@ -340,10 +561,14 @@ def main():
         out = pope_step(x, ei, n, anchors, world)
     barrier()
     elapsed = time.perf_counter() - t0
+    rccl_ranks = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ones = torch.ones(1, device=dev, dtype=torch.int32)          # how many ranks the collective backend really joined
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(ones.item())
 
     result = None
     ms = elapsed / args.steps * 1e3
@@ -359,6 +584,9 @@ def main():
                        "anchors_total": k_total,
                        "parallelism": f"anchor-shard x{world} + RCCL all-gather of hop planes" if world > 1 else "single GPU"},
         }
+        if world > 1:
+            result["backend"] = backend
+            result["rccl_ranks"] = rccl_ranks
     if rank == 0:
         # dominant kernel by total time: k_bfs_level (one launch per level), timed on this rank's own anchor shard with HIP
         # events on the launch stream.  Algorithmic bytes of ONE launch: per CSR slot erow + col (8 B) + the
@@ -368,10 +596,12 @@ def main():
         dense_bytes = e * (8.0 + 8.0 * wp) + n * 16.0 * wp           # one level that does work
         exp_bytes = dense_bytes * active_levels / launches            # per launch, the early-exit launches included
         exp_gbs = exp_bytes / (exp_ms * 1e-3) / 1e9
-        pmc = pmc_traffic() or {}
+        pmc, pmc_src = pmc_traffic()
+        pmc = pmc or {}
         result["roofline"] = {
             "kernel": "k_bfs_level<4>", "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": exp_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch"),
+            "traffic_source": (pmc_src + " (rocprofv3 --pmc passes of this command, collected in a separate run: not measured live)") if pmc_src else None,
             "algorithmic_bytes_per_launch": exp_bytes, "avg_launch_ms": exp_ms, "launches_per_step": launches,
             "active_levels": active_levels, "algorithmic_bytes_per_active_level": dense_bytes,
             "note": "per GPU; average over EVERY launch of the kernel in a step (what rocprofv3 --stats averages): "
@@ -385,6 +615,9 @@ def main():
             "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": geo_gbs / (HBM_PEAK_GBS * world), "algorithmic_bytes": src_bytes,
             "note": "SURVEY 8d per-source byte model (every anchor reads the CSR once and writes one f32 column); the "
                     "bit-parallel BFS shares each CSR pass between 64 anchors per word, so this is a model, not traffic"}
+        floor_bytes = 16.0 * e + 4.0 * n * F + 4.0 * n * (F + K_PER_GPU)    # edge list in, x in, [N, F+K] out: each once
+        result["compulsory_floor"] = {"bytes": floor_bytes, "ms_at_6.29TBs": floor_bytes / 6.29e12 * 1e3,
+                                      "step_over_floor": ms / (floor_bytes / 6.29e12 * 1e3) if world == 1 else None}
         result["level_kernel_ms"] = {"avg": exp_ms, "active_levels": active_levels}
     if world == 1:
         # per-phase device time with HIP events on the launch stream, separate from the wall-clock loop above
@@ -403,16 +636,32 @@ def main():
         if not args.no_sage:
             result["sage"] = sage_leg(out, ei_np, n, dev, steps=max(10, min(args.steps, 50)), warmup=3)
         if not args.no_cpu_baseline:
-            base, want_hops = cpu_baselines(ei_np, n, anchors)
             result.update(base)
             got = engine.hop_matrix(engine.geodesic_run(None, ei, n, anchors, want_out=False)[1]).cpu().numpy()
             result["hops_bit_exact_vs_cpu"] = bool(np.array_equal(got, want_hops))
-            result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+        del out
+        if not args.no_extra:
+            steps = max(5, min(args.steps, 20))
+            if want_hops is None:
+                from oracle import oracle
+                want_hops = oracle.geodesic_hops(ei_np, n, anchors)
+            result["boundary_host_to_host"] = boundary_leg(ei_np, n, x.cpu(), want_hops)
+            if "cpu_baseline" in result and "value" in result["cpu_baseline"]:
+                # like for like: the host -> host call against the reference's host -> host CPU path (Pool(6))
+                result["speedup_vs_cpu_baseline"] = {
+                    "host_to_host_vs_pool6": result["boundary_host_to_host"]["embeddings_per_s"] / result["cpu_baseline"]["value"],
+                    "note": "boundary_host_to_host.embeddings_per_s / cpu_baseline.value: both from host tensors to a host tensor; "
+                            "the HBM-resident `value` is not compared with a CPU figure"}
+            result["pairwise"] = pairwise_leg(n, anchors, x, dev, steps)
+            result["config3"] = config3_leg(x, ei, n, steps)
+            del x, ei
+            engine._WORKSPACE.clear()
+            torch.cuda.empty_cache()
+            result["config4"] = config4_leg(dev)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
-    del out
 
 
 if __name__ == "__main__":

@@ -13,11 +13,16 @@ LIB_PATH = os.path.join(_HERE, "libgraphpope_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_HOP_OVERFLOW, ERR_WORKSPACE, ERR_NO_DEVICE, ERR_UNSORTED = 0, -1, -2, -3, -4, -5, -6, -7
 METRIC = {"distance": 0, "similarity": 1, "euclidean": 2}
+KNOB_LIVE_MODE, KNOB_FINALIZE_VARIANT, KNOB_FINALIZE_BLOCKS, KNOB_GEMM_TILE = 0, 1, 2, 3
 
 # name -> (restype, argtypes); exactly the symbols include/graphpope_hip.h declares
 SIGNATURES = {
     "pope_last_error": (c_char_p, []),
     "pope_version": (c_char_p, []),
+    "pope_require_device": (c_int, [POINTER(c_int32)]),
+    "pope_debug_set": (c_int, [c_int32, c_int32]),
+    "pope_host_copy_2d": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32]),
+    "pope_copy_2d_to_host": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "pope_csr_scratch_bytes": (c_size_t, [c_int64, c_int64]),
     "pope_csr_aux_elems": (c_size_t, [c_int64]),
     "pope_csr_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

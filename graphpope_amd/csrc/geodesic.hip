@@ -12,7 +12,9 @@
 //  * hop counts are stored bit-sliced: plane b gets `new` OR-ed in when bit b of the level is set.  State is
 //    a few N*W*8-byte planes that live in L2 / Infinity Cache; the 4*N*K-byte float matrix is written once,
 //    coalesced, by the finalise kernel straight into the [N, F+K] output (no transpose, no torch.cat).
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <rocprim/device/device_scan.hpp>
@@ -885,8 +887,23 @@ static void profile_mark(hipStream_t stream, int level, int which, bool span = f
     if (which == 0) g_profile.level.push_back(level);
 }
 
-static int g_live_mode = -1;            // -1: by graph size (LDS table up to LIVE_MAX_NODES, global table beyond); A/B hook
-extern "C" void pope_debug_live_mode(int m) { g_live_mode = m; }
+// Diagnostic knobs behind pope_debug_set() (include/graphpope_hip.h): process-global, not thread-safe, A/B tooling only.
+static int g_live_mode = -1;            // -1: by graph size (LDS table up to LIVE_MAX_NODES, global table beyond)
+static int g_finalize_variant = 1;      // 0: generic kernel, 1: fast path with plain stores, 2: fast path, non-temporal stores
+static int g_finalize_blocks = 256 * 8;
+namespace pope { int g_gemm_force_tile = 0; }
+
+extern "C" int pope_debug_set(int32_t knob, int32_t value) {
+    clear_error();
+    switch (knob) {
+    case POPE_KNOB_LIVE_MODE:        g_live_mode = value; break;
+    case POPE_KNOB_FINALIZE_VARIANT: g_finalize_variant = value; break;
+    case POPE_KNOB_FINALIZE_BLOCKS:  g_finalize_blocks = value > 0 ? value : 256 * 8; break;
+    case POPE_KNOB_GEMM_TILE:        pope::g_gemm_force_tile = value; break;
+    default: set_error("pope_debug_set: unknown knob %d", knob); return POPE_ERR_INVALID;
+    }
+    return POPE_OK;
+}
 
 template <int WT>
 static void launch_level(int E, int Wp, const int *col, const int *erow, const int *aux, const u64 *front, u64 *seen,
@@ -914,41 +931,79 @@ static void launch_level(int E, int Wp, const int *col, const int *erow, const i
     profile_mark(stream, level, 1);
 }
 
-// Per-device host-side context, created on first use (the only objects the library ever keeps): small pinned,
-// device-mapped host buffers.  Anchors are staged through one (a pageable hipMemcpyAsync is a synchronous staging
-// copy) and the poll kernel writes the BFS verdict straight into the other (no copy kernels, one stream sync).
+// Per-device host-side context, created on first use (the only objects the library ever keeps): a ring of small
+// pinned, device-mapped host SLOTS.  Every call takes a slot of its own: its anchors are staged there (the seed kernel
+// reads them in place -- a pageable hipMemcpyAsync would be a synchronous staging copy) and its BFS verdict comes back
+// there (the finalise / report kernel writes it straight into host memory: no copy kernel, one stream sync).  A slot is
+// handed out again only after the event recorded behind its last device-side user has completed, so calls on other
+// streams or from other host threads never share staging memory; the ring is guarded by a mutex.
 // (Measured and rejected: running the feature copy out[:, :F] = x on a side stream underneath the BFS levels.  The
 // streaming copy saturates the memory queues and the latency-bound level kernels run 2-4x slower beside it; the
 // serial order is faster.)
-struct DeviceCtx {
+struct Slot {
     int *report = nullptr;               // pinned host: [0] last_active, [1] csr flags, [2] ticket of the call that wrote them
-    int ticket = 0;
     int *report_dev = nullptr;           // the same memory as seen from the device
     long long *anchors = nullptr;        // pinned, device-mapped host staging for the anchor ids
     long long *anchors_dev = nullptr;    // the same memory as seen from the device (the seed kernel reads it in place)
     size_t anchors_cap = 0;
+    hipEvent_t ev = nullptr;             // recorded behind the last kernel that reads / writes this slot
+    bool busy = false;
+    int ticket = 0;
+};
+constexpr int N_SLOTS = 8;
+struct DeviceCtx {
+    std::mutex mu;
+    Slot slots[N_SLOTS];
+    unsigned next = 0;
 };
 static DeviceCtx g_ctx[64];
 
-static int device_ctx(DeviceCtx **out, size_t n_anchors) {
+// Take the next slot of the current device's ring (waits for its previous user), sized for n_anchors ids.
+static int slot_acquire(Slot **out, size_t n_anchors) {
     int dev = 0;
-    POPE_HIP(hipGetDevice(&dev));
+    const hipError_t de = hipGetDevice(&dev);
+    if (de == hipErrorNoDevice || de == hipErrorInvalidDevice) {
+        set_error("no gfx950 device visible (%s)", hipGetErrorString(de));
+        return POPE_ERR_NO_DEVICE;
+    }
+    POPE_HIP(de);
     POPE_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
     DeviceCtx &c = g_ctx[dev];
-    if (!c.report) {
-        POPE_HIP(hipHostMalloc((void **)&c.report, 256, hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: visible mid-kernel
-        memset(c.report, 0, 256);
-        POPE_HIP(hipHostGetDevicePointer((void **)&c.report_dev, c.report, 0));
+    std::lock_guard<std::mutex> lock(c.mu);
+    Slot &s = c.slots[c.next++ % N_SLOTS];
+    if (s.busy) {
+        POPE_HIP(hipEventSynchronize(s.ev));
+        s.busy = false;
     }
-    if (n_anchors > c.anchors_cap) {
-        if (c.anchors) POPE_HIP(hipHostFree(c.anchors));
-        c.anchors_cap = n_anchors < 1024 ? 1024 : n_anchors;
-        POPE_HIP(hipHostMalloc((void **)&c.anchors, c.anchors_cap * sizeof(long long), hipHostMallocMapped));
-        POPE_HIP(hipHostGetDevicePointer((void **)&c.anchors_dev, c.anchors, 0));
+    if (!s.report) {
+        POPE_HIP(hipHostMalloc((void **)&s.report, 256, hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: visible mid-kernel
+        memset(s.report, 0, 256);
+        POPE_HIP(hipHostGetDevicePointer((void **)&s.report_dev, s.report, 0));
+        POPE_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
     }
-    *out = &c;
+    if (n_anchors > s.anchors_cap) {
+        if (s.anchors) POPE_HIP(hipHostFree(s.anchors));
+        s.anchors = nullptr;
+        s.anchors_cap = 0;
+        const size_t cap = n_anchors < 1024 ? 1024 : n_anchors;
+        POPE_HIP(hipHostMalloc((void **)&s.anchors, cap * sizeof(long long), hipHostMallocMapped));
+        POPE_HIP(hipHostGetDevicePointer((void **)&s.anchors_dev, s.anchors, 0));
+        s.anchors_cap = cap;
+    }
+    *out = &s;
     return POPE_OK;
 }
+
+// Everything enqueued on `stream` so far may use the slot; it becomes reusable once that work has completed.
+static void slot_release(Slot *s, hipStream_t stream) {
+    if (s && hipEventRecord(s->ev, stream) == hipSuccess) s->busy = true;
+}
+
+struct SlotGuard {                       // releases the call's slot on every return path
+    Slot *const *slot;
+    hipStream_t stream;
+    ~SlotGuard() { slot_release(*slot, stream); }
+};
 
 // The BFS verdict (deepest active level, CSR status flags) written straight into pinned host memory.
 __global__ void k_bfs_report(const BfsCtl *ctl, const int *aux, int *report) {
@@ -969,9 +1024,10 @@ struct Bfs {
     BfsCtl *ctl;
     long long *anchors_dev;
     long long level_limit;       // levels 1 .. limit-1 fit `capacity` hop bits
-    DeviceCtx *dev;
+    Slot *slot;                  // this call's pinned staging (anchors, verdict)
 };
 
+constexpr double POPE_POLL_TIMEOUT_S = 30.0;   // wall-clock bound of the host spin on the verdict word
 constexpr int LEVEL_BATCH = 12;     // levels enqueued between two polls of the device flag (hops <= 10: one poll)
 
 static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
@@ -1007,7 +1063,7 @@ static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const in
     b.live[2] = (unsigned *)((char *)b.live[1] + live_bytes(N));
     b.live_words = (int)((N + 31) / 32);
     b.level_limit = 1ll << plane_capacity;
-    return device_ctx(&b.dev, (size_t)K);
+    return slot_acquire(&b.slot, (size_t)K);
 }
 
 // One launch clears the control block, the three frontier buffers, the reachability plane, the first hop planes and
@@ -1022,8 +1078,8 @@ static void bfs_enqueue_clear(const Bfs &b, int *aux_header, hipStream_t stream)
 
 // Anchors go through pinned, device-mapped host memory and the seed kernel reads them in place: no copy kernel.
 static int bfs_enqueue_seed(const Bfs &b, const int64_t *anchors_host, hipStream_t stream) {
-    memcpy(b.dev->anchors, anchors_host, (size_t)b.K * sizeof(long long));
-    hipLaunchKernelGGL(k_bfs_seed, dim3((b.K + 255) / 256), dim3(256), 0, stream, b.dev->anchors_dev, b.K, b.Wp, b.seen, b.front[0], b.live[0]);
+    memcpy(b.slot->anchors, anchors_host, (size_t)b.K * sizeof(long long));
+    hipLaunchKernelGGL(k_bfs_seed, dim3((b.K + 255) / 256), dim3(256), 0, stream, b.slot->anchors_dev, b.K, b.Wp, b.seen, b.front[0], b.live[0]);
     return POPE_OK;
 }
 
@@ -1064,27 +1120,35 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
 // of waiting for the stream to drain (the expansion keeps running; its output is complete in stream order).
 static int bfs_poll(const Bfs &b, int next_level, int *last_active, bool *done, hipStream_t stream, int ticket = 0) {
     if (ticket) {
+        // Bounded spin: a kernel that never finishes without faulting leaves hipStreamQuery at NotReady for ever, so the
+        // wait is also limited by the wall clock (POPE_POLL_TIMEOUT_S seconds) and then reported, not sat out.
+        const auto t_start = std::chrono::steady_clock::now();
         bool seen_ticket = false;
         for (long it = 0; !seen_ticket; ++it) {
-            if (__atomic_load_n(&b.dev->report[2], __ATOMIC_ACQUIRE) == ticket) {
+            if (__atomic_load_n(&b.slot->report[2], __ATOMIC_ACQUIRE) == ticket) {
                 seen_ticket = true;
             } else if ((it & 1023) == 1023) {
                 const hipError_t q = hipStreamQuery(stream);           // a fault or a drained stream ends the spin
                 if (q == hipSuccess) break;
                 if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+                if (waited > POPE_POLL_TIMEOUT_S) {
+                    set_error("geodesic bfs: no verdict from the device after %.0f s (stream still busy): giving up the wait", waited);
+                    return POPE_ERR_HIP;
+                }
             }
         }
         if (!seen_ticket) {
             POPE_HIP(hipStreamSynchronize(stream));
-            POPE_REQUIRE(__atomic_load_n(&b.dev->report[2], __ATOMIC_ACQUIRE) == ticket, "geodesic bfs: the report was not written");
+            POPE_REQUIRE(__atomic_load_n(&b.slot->report[2], __ATOMIC_ACQUIRE) == ticket, "geodesic bfs: the report was not written");
         }
     } else {
-        hipLaunchKernelGGL(k_bfs_report, dim3(1), dim3(1), 0, stream, b.ctl, b.aux, b.dev->report_dev);
+        hipLaunchKernelGGL(k_bfs_report, dim3(1), dim3(1), 0, stream, b.ctl, b.aux, b.slot->report_dev);
         POPE_HIP(hipStreamSynchronize(stream));
     }
     POPE_HIP(hipGetLastError());
-    *last_active = b.dev->report[0];
-    const int flags = b.dev->report[1];
+    *last_active = b.slot->report[0];
+    const int flags = b.slot->report[1];
     if (flags & CSR_FLAG_BAD_INDEX) {
         set_error("geodesic bfs: edge_index holds a node id outside [0, %d)", b.N);
         return POPE_ERR_INDEX;
@@ -1149,6 +1213,8 @@ extern "C" int pope_geodesic_bfs_begin(const int32_t *rowptr, const int32_t *col
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     Bfs b;
+    b.slot = nullptr;
+    SlotGuard guard{&b.slot, stream};
     int rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes);
     if (rc) return rc;
     if ((rc = bfs_enqueue_init(b, anchors_host, stream))) return rc;
@@ -1164,6 +1230,8 @@ extern "C" int pope_geodesic_bfs_finish(const int32_t *rowptr, const int32_t *co
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     Bfs b;
+    b.slot = nullptr;
+    SlotGuard guard{&b.slot, stream};
     int rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes);
     if (rc) return rc;
     int level = 1 + LEVEL_BATCH, last_active = 0;                  // what begin enqueued
@@ -1190,12 +1258,6 @@ extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, cons
     return pope_geodesic_bfs_finish(rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch,
                                     scratch_bytes, max_hop_host, n_hop_bits_host, stream_);
 }
-
-static int g_finalize_variant = 1;     // 0: generic kernel, 1: fast path with plain stores (A/B: 86 us vs 98 / 106), 2: fast path, non-temporal stores
-
-static int g_finalize_blocks = 256 * 8;
-extern "C" void pope_debug_finalize_variant(int v) { g_finalize_variant = v; }
-extern "C" void pope_debug_finalize_blocks(int b) { g_finalize_blocks = b; }
 
 static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_hop_dev, int64_t N, int32_t K,
                             const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, hipStream_t stream,
@@ -1295,12 +1357,14 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     // before the host looks at anything; the finalise kernel reads the depth from the BFS control block.
     int rc;
     Bfs b;
+    b.slot = nullptr;
+    SlotGuard guard{&b.slot, stream};
     if ((rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, (uint64_t *)planes, plane_capacity,
                         ws + L.bfs_scratch, L.total - L.bfs_scratch))) return rc;
     bfs_enqueue_clear(b, aux, stream);                    // BFS state and the CSR status header in one launch
-    memcpy(b.dev->anchors, anchors_host, (size_t)K * sizeof(long long));     // pinned, device-mapped: read in place
+    memcpy(b.slot->anchors, anchors_host, (size_t)K * sizeof(long long));     // this call's pinned, device-mapped slot: read in place
     SeedArgs seed;
-    seed.anchors = b.dev->anchors_dev; seed.K = K; seed.Wp = b.Wp; seed.seen = b.seen; seed.front = b.front[0]; seed.live = b.live[0];
+    seed.anchors = b.slot->anchors_dev; seed.K = K; seed.Wp = b.Wp; seed.seen = b.seen; seed.front = b.front[0]; seed.live = b.live[0];
     rc = csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, seed, stream);
     if (rc) return rc;
     int level = bfs_enqueue_levels(b, 1, 1 + LEVEL_BATCH, stream);
@@ -1308,9 +1372,9 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     // returns as soon as the BFS is known to be complete -- `out` is finished in stream order.
     int ticket = 0;
     if (out) {
-        ticket = b.dev->ticket = b.dev->ticket == INT32_MAX ? 1 : b.dev->ticket + 1;
+        ticket = b.slot->ticket = b.slot->ticket == INT32_MAX ? 1 : b.slot->ticket + 1;
         if ((rc = finalize_enqueue(planes, 0, &b.ctl->last_active, N, K, x, F, out, out_cols, 0, stream, 1, 0, aux,
-                                   b.dev->report_dev, ticket))) return rc;
+                                   b.slot->report_dev, ticket))) return rc;
     }
     int last_active = 0;
     bool done = false;

@@ -272,9 +272,7 @@ static int launch_gemm(const Operand &A0, const Operand &B0, int K0, const Opera
     return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_GENERIC, LAYOUT_GENERIC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
 }
 
-static int g_force_tile = 0, g_fwd_splits = 1;      // A/B hooks (tools/ab_gemm_tiles.py): 0 = automatic choice
-static float *g_debug_slab = nullptr;
-extern "C" void pope_debug_gemm_force(int tile, int fwd_splits) { g_force_tile = tile; g_fwd_splits = fwd_splits < 1 ? 1 : fwd_splits; }
+extern int g_gemm_force_tile;          // pope_debug_set(POPE_KNOB_GEMM_TILE, ...) in geodesic.hip: 0 = automatic choice
 
 static long long tiles(int M, int N, int tm, int tn) { return (long long)((M + tm - 1) / tm) * ((N + tn - 1) / tn); }
 
@@ -285,9 +283,9 @@ static int gemm(const Operand &A0, const Operand &B0, int K0, const Operand &A1,
                 const Twin &twin = Twin{Operand{nullptr, 0, 0}, nullptr, 0}) {
     int rc;
     const int results = twin.C ? 2 : 1;
-    if (g_force_tile == 3 || (g_force_tile == 0 && tiles(M, N, 128, 256) * splits * results >= 512))
+    if (g_gemm_force_tile == 3 || (g_gemm_force_tile == 0 && tiles(M, N, 128, 256) * splits * results >= 512))
         rc = launch_gemm<128, 256, 4, 1>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
-    else if (g_force_tile == 2 || (g_force_tile == 0 && tiles(M, N, 64, 128) * splits * results >= 384))
+    else if (g_gemm_force_tile == 2 || (g_gemm_force_tile == 0 && tiles(M, N, 64, 128) * splits * results >= 384))
         rc = launch_gemm<64, 128, 2, 2>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
     else
         rc = launch_gemm<64, 64, 2, 2>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
@@ -364,10 +362,6 @@ extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int6
     enqueue_gather_mean(rowptr, col, n_dst, x_src, c_in, agg, stream);
     // out = agg * w_l^T + b_l + x_dst * w_r^T in one pass
     const Operand A0{agg, c_in, 1}, B0{w_l, c_in, 1}, A1{x_src, c_in, 1}, B1{w_r, c_in, 1};
-    if (g_fwd_splits > 1) {                                      // A/B only: split-K forward through a private slab (bias dropped)
-        if (!g_debug_slab) POPE_HIP(hipMalloc((void **)&g_debug_slab, (size_t)256 << 20));
-        return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, nullptr, out, c_out, g_fwd_splits, g_debug_slab, stream);
-    }
     return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream);
 }
 

@@ -19,10 +19,10 @@ DEFAULT_PLANE_CAPACITY = 8          # hop counts < 256; grown on POPE_ERR_HOP_OV
 
 def require_gpu(device=None) -> torch.device:
     """The product path needs a GPU and the HIP library; it never computes on the CPU."""
-    _lib.load()
-    if not torch.cuda.is_available():
-        raise RuntimeError("graphpope_amd needs an MI355X (torch.cuda.is_available() is False); "
-                           "there is no CPU fallback")
+    lib = _lib.load()
+    if not torch.cuda.is_available() or lib.pope_require_device(None) != _lib.OK:
+        raise RuntimeError("graphpope_amd needs an MI355X (no gfx950 device visible: %s); there is no CPU fallback"
+                           % (lib.pope_last_error().decode() or "torch.cuda.is_available() is False"))
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError(f"graphpope_amd computes on the GPU only, got device {dev}")
@@ -35,6 +35,59 @@ def _stream():
 
 def _bytes(n: int, device) -> torch.Tensor:
     return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# host <-> device plumbing of the host -> host Graphpope call (utils.py:129-147): only edge_index goes up and only the K
+# embedding columns come down; data.x is copied host to host into the result by pope_host_copy_2d.
+# ------------------------------------------------------------------------------------------------
+def host_threads() -> int:
+    """Host threads for the feature copy: GRAPHPOPE_HOST_THREADS, else the cores this process may run on (at most 16)."""
+    import os
+    env = os.environ.get("GRAPHPOPE_HOST_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(cores, 16))
+
+
+def host_copy_2d(src: torch.Tensor, dst: torch.Tensor, threads: int = 0) -> None:
+    """dst[:, :] = src for two HOST matrices whose rows are contiguous (row pitches may differ); blocking, multi-threaded."""
+    lib = _lib.load()
+    assert not src.is_cuda and not dst.is_cuda and src.dim() == 2 and src.shape == dst.shape and src.dtype == dst.dtype
+    if src.numel() == 0:
+        return
+    assert src.stride(1) == 1 and dst.stride(1) == 1
+    es = src.element_size()
+    check(lib.pope_host_copy_2d(ptr(src), src.stride(0) * es, ptr(dst), dst.stride(0) * es, src.shape[1] * es, src.shape[0],
+                                threads or host_threads()))
+
+
+def stage_to_device(t: torch.Tensor, device) -> torch.Tensor:
+    """A pageable host tensor -> device through pinned staging memory (threaded host copy + one asynchronous DMA).
+    torch's pinned allocator keeps the staging block alive until the DMA has run and caches it for the next call."""
+    if t.is_cuda:
+        return t.to(device)
+    t = t.contiguous()
+    if t.is_pinned() or t.numel() == 0:
+        return t.to(device, non_blocking=True)
+    staged = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host_copy_2d(t.view(1, -1), staged.view(1, -1))
+    return staged.to(device, non_blocking=True)
+
+
+def copy_columns_to_host(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst (a HOST [N, K] column block of the result, rows contiguous, ideally pinned) = src (device [N, K], contiguous),
+    asynchronously on the current stream (pope_copy_2d_to_host: one pitched DMA)."""
+    lib = _lib.load()
+    assert src.is_cuda and src.is_contiguous() and not dst.is_cuda and dst.shape == src.shape and dst.stride(1) == 1
+    es = src.element_size()
+    with torch.cuda.device(src.device):
+        check(lib.pope_copy_2d_to_host(ptr(src), src.shape[1] * es, ptr(dst), dst.stride(0) * es, src.shape[1] * es,
+                                       src.shape[0], _stream()))
 
 
 class Csr:
@@ -172,6 +225,8 @@ def finalize(planes: torch.Tensor, n_hop_bits: int, num_nodes: int, k: int, x, f
 def copy_features(x: torch.Tensor, f: int, out: torch.Tensor):
     """out[:, :f] = x on the current stream (pope_concat): the feature half of the expansion on its own."""
     lib = _lib.load()
+    if f == 0:
+        return
     assert out.is_cuda and out.is_contiguous() and x.is_contiguous() and x.shape == (out.shape[0], f)
     with torch.cuda.device(out.device):
         check(lib.pope_concat(ptr(x), out.shape[0], f, ptr(out), out.shape[1], _stream()))
@@ -237,16 +292,16 @@ def hop_matrix(hp: HopPlanes) -> torch.Tensor:
     return hops
 
 
-_WORKSPACE = {}          # (device, bytes) -> uint8 tensor, reused by geodesic_run(reuse_workspace=True)
+_WORKSPACE = {}          # (device, stream, bytes) -> uint8 tensor, reused by geodesic_run(reuse_workspace=True)
 
 
 def geodesic_run(x, edge_index: torch.Tensor, num_nodes: int, anchors, capacity: int = DEFAULT_PLANE_CAPACITY,
                  want_out: bool = True, reuse_workspace: bool = False):
     """The whole geodesic hot path in one library call (one host synchronisation): (out, HopPlanes).
 
-    ``x`` float32 [N, F] on the device (or None with ``want_out=False`` for a BFS-only run).
+    ``x`` float32 [N, F] on the device, or None: then ``out`` is the [N, K] embedding alone (``want_out=False``: BFS only).
     ``reuse_workspace`` keeps the scratch allocation between calls; the returned HopPlanes then only stay valid
-    until the next such call.
+    until the next such call on the same stream.
     """
     lib = _lib.load()
     ei = edge_index.contiguous()
@@ -261,10 +316,14 @@ def geodesic_run(x, edge_index: torch.Tensor, num_nodes: int, anchors, capacity:
         while True:
             nbytes_ws = lib.pope_geodesic_run_workspace_bytes(num_nodes, e, k, capacity)
             if reuse_workspace:
-                ws = _WORKSPACE.get((dev, nbytes_ws))
+                # keyed by the launch stream as well: the finalise kernel of one call may still be reading the hop
+                # planes when the call returns, and only work on the SAME stream is ordered behind it
+                key = (dev, torch.cuda.current_stream().cuda_stream, nbytes_ws)
+                ws = _WORKSPACE.get(key)
                 if ws is None:
-                    _WORKSPACE.clear()
-                    ws = _WORKSPACE.setdefault((dev, nbytes_ws), _bytes(nbytes_ws, dev))
+                    for old in [k for k in _WORKSPACE if k[:2] == key[:2]]:
+                        del _WORKSPACE[old]
+                    ws = _WORKSPACE.setdefault(key, _bytes(nbytes_ws, dev))
             else:
                 ws = _bytes(nbytes_ws, dev)
             max_hop, bits = ctypes.c_int32(0), ctypes.c_int32(0)
@@ -284,19 +343,23 @@ def geodesic_run(x, edge_index: torch.Tensor, num_nodes: int, anchors, capacity:
 def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int, anchors, group=None,
                       shard: bool = True) -> torch.Tensor:
     """[N, F+K] float32 on the device: features next to the geodesic POPE embedding (utils.py:137-147).
+    ``x=None``: the [N, K] embedding alone (the host -> host caller keeps the features on the host).
 
     With an initialised ``torch.distributed`` group of more than one rank the anchors are sharded
     over the ranks and the hop planes are all-gathered; every rank returns the full matrix.
     ``shard=False`` computes all anchors locally even inside a process group.
     """
     from . import distributed as pdist
-    dev = require_gpu(x.device)
-    assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] == num_nodes
-    x = x.contiguous()
+    dev = require_gpu(edge_index.device if x is None else x.device)
     anc = np.asarray(anchors, dtype=np.int64)
     world = pdist.world_size(group) if shard else 1
+    if x is not None:
+        assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] == num_nodes
+        x = x.contiguous()
     if world == 1:
         return geodesic_run(x, edge_index.to(dev), num_nodes, anc, reuse_workspace=True)[0]
+    if x is None:
+        x = torch.empty((num_nodes, 0), dtype=torch.float32, device=dev)
     csr = build_csr(edge_index.to(dev), num_nodes, defer_check=True)
     return pdist.sharded_geodesic_features(
         x, num_nodes, anc, group,
@@ -308,17 +371,16 @@ def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int,
 # ------------------------------------------------------------------------------------------------
 # node2vec-space embedding (utils.py:149-180)
 # ------------------------------------------------------------------------------------------------
-def pairwise_features(x: torch.Tensor, emb: torch.Tensor, anchors, distance_function: str,
-                      anchor_embeddings=None) -> torch.Tensor:
-    """[N, F+K] float32 on the device: min-max scaled distance of every node2vec row to the anchor rows
-    (``anchors`` = row indices, utils.py:165-167) or to ``anchor_embeddings`` [K, D] (K-means centres, utils.py:168-170)."""
+def pairwise_embedding(emb: torch.Tensor, anchors, distance_function: str, anchor_embeddings=None, out: torch.Tensor = None,
+                       c0: int = 0) -> torch.Tensor:
+    """Min-max scaled distance of every node2vec row to the anchor rows (``anchors`` = row indices, utils.py:165-167) or
+    to ``anchor_embeddings`` [K, D] (K-means centres, utils.py:168-170), float32 on the device: a new [N, K] matrix, or
+    columns [c0, c0 + K) of ``out``."""
     lib = _lib.load()
-    dev = require_gpu(x.device)
+    dev = require_gpu(emb.device)
     metric = _lib.METRIC[distance_function]          # KeyError for unknown names, as utils.py:164
-    x = x.contiguous()
     emb = emb.to(dev, torch.float32).contiguous()
-    n, f = x.shape
-    d = emb.shape[1]
+    n, d = emb.shape
     if anchor_embeddings is not None:
         a = torch.as_tensor(anchor_embeddings).to(dev, torch.float32).contiguous()
         assert a.dim() == 2 and a.shape[1] == d
@@ -327,9 +389,25 @@ def pairwise_features(x: torch.Tensor, emb: torch.Tensor, anchors, distance_func
         a = emb.index_select(0, idx).contiguous()        # the K anchor rows (utils.py:167)
     k = a.shape[0]
     with torch.cuda.device(dev):
-        out = torch.empty((n, f + k), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((n, k), dtype=torch.float32, device=dev)
+        assert out.is_cuda and out.is_contiguous() and out.shape[0] == n and out.shape[1] >= c0 + k
         scratch = _bytes(lib.pope_pairwise_scratch_bytes(n, k, d), dev)
-        check(lib.pope_concat(ptr(x), n, f, ptr(out), f + k, _stream()))
-        check(lib.pope_pairwise_minmax(ptr(emb), n, d, ptr(a), k, metric, ptr(out), f + k, f, ptr(scratch),
+        check(lib.pope_pairwise_minmax(ptr(emb), n, d, ptr(a), k, metric, ptr(out), out.shape[1], c0, ptr(scratch),
                                        scratch.numel(), _stream()))
     return out
+
+
+def pairwise_features(x: torch.Tensor, emb: torch.Tensor, anchors, distance_function: str,
+                      anchor_embeddings=None) -> torch.Tensor:
+    """[N, F+K] float32 on the device: the features next to :func:`pairwise_embedding` (device-resident callers)."""
+    lib = _lib.load()
+    dev = require_gpu(x.device)
+    _lib.METRIC[distance_function]
+    x = x.contiguous()
+    n, f = x.shape
+    k = len(anchor_embeddings) if anchor_embeddings is not None else len(anchors)
+    with torch.cuda.device(dev):
+        out = torch.empty((n, f + k), dtype=torch.float32, device=dev)
+        check(lib.pope_concat(ptr(x), n, f, ptr(out), f + k, _stream()))
+    return pairwise_embedding(emb, anchors, distance_function, anchor_embeddings, out=out, c0=f)

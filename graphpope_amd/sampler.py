@@ -93,78 +93,3 @@ class NeighborSampler:
             adjs.append(SampledAdj(rowptrs[i][: t + 1], cols[i][: nnz[i]], n_src[i]))
             t = n_src[i]
         return n_ids[-1][: n_src[h - 1]], adjs[::-1]
-
-class BatchPrefetcher:
-    """Mini-batches drawn ahead of the training step on a side stream by a worker thread (the device-side counterpart of
-    the reference's ``DataLoader(num_workers=..., persistent_workers=True)``, main.py:100-116).
-
-        for seeds, n_id, adjs, x, y in BatchPrefetcher(sampler, seed_batches, base_seed, feats, labels):
-            ...train on (x, adjs, y)...
-
-    The worker draws batch b with ``sampler.sample(seeds_b, seed=base_seed + b)`` -- the draw is a pure function of the
-    seed, so prefetching changes nothing but the timing -- and gathers ``feats[n_id]`` / ``labels[seeds]`` (convert_batch,
-    main.py:118-123) on its own stream; the consumer's stream waits on the batch's event.  The sampler's host
-    synchronisations (the data-dependent block sizes) and its ~30 small launches then overlap the previous step.
-
-    Measured on MI355X with the Flickr-shaped step (1 550 seeds): NOT a win under CPython -- the training step is bound by
-    host-side launch work, and a second Python thread competes for the GIL: 0.91 ms per step sampling in line, 1.08 ms
-    prefetched.  `python -m graphpope_amd.main` therefore samples in line; the class is kept for callers whose step
-    is GPU-bound (larger batches / wider layers).
-    """
-
-    def __init__(self, sampler: NeighborSampler, seed_batches, base_seed: int = 0, feats=None, labels=None, depth: int = 2):
-        import queue
-        import threading
-        self._q = queue.Queue(maxsize=max(1, depth))
-        self._dev = sampler.rowptr.device
-        self._stream = torch.cuda.Stream(device=self._dev)
-        self._err = None
-        self._stop = False
-
-        def work():
-            try:
-                torch.cuda.set_device(self._dev)
-                with torch.cuda.stream(self._stream):
-                    for b, seeds in enumerate(seed_batches):
-                        if self._stop:
-                            break
-                        seeds = seeds.to(self._dev, torch.int64)
-                        n_id, adjs = sampler.sample(seeds, seed=int(base_seed) + b)
-                        x = feats.index_select(0, n_id) if feats is not None else None
-                        y = labels.index_select(0, seeds) if labels is not None else None
-                        ev = torch.cuda.Event()
-                        ev.record(self._stream)
-                        self._q.put((seeds, n_id, adjs, x, y, ev))
-            except BaseException as e:                      # surfaced in the consumer
-                self._err = e
-            finally:
-                self._q.put(None)
-
-        self._thread = threading.Thread(target=work, name="graphpope-sampler", daemon=True)
-        self._thread.start()
-
-    def __iter__(self):
-        cur = torch.cuda.current_stream(self._dev)
-        while True:
-            item = self._q.get()
-            if item is None:
-                break
-            seeds, n_id, adjs, x, y, ev = item
-            cur.wait_event(ev)
-            for t in (seeds, n_id, x, y, *[a.rowptr for a in adjs], *[a.col for a in adjs]):
-                if t is not None:
-                    t.record_stream(cur)                    # allocated on the side stream, consumed on this one
-            yield seeds, n_id, adjs, x, y
-        self._thread.join()
-        if self._err is not None:
-            raise self._err
-
-    def close(self):
-        """Stop early (the worker finishes the batch it is on)."""
-        self._stop = True
-        while self._thread.is_alive():
-            try:
-                self._q.get(timeout=0.05)
-            except Exception:
-                pass
-        self._thread.join()

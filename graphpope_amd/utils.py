@@ -10,7 +10,8 @@ sample_anchor_nodes :18-62     host NumPy ('stochastic' draws from the same glob
 shortest_path_length :64-81    engine.bfs -- batched multi-source BFS kernel
 all_pairs_..._parallel :92     (the mp.Pool fan-out is gone; num_workers is accepted and ignored)
 get_geodesic_distance_vector   engine.build_csr + engine.bfs + engine.finalize
-concat_into_features :129      fused into the finalise kernel / pope_concat
+concat_into_features :129      host -> host: data.x copied on the host cores (pope_host_copy_2d), only the K
+                               embedding columns cross PCIe; device-resident callers: finalise kernel / pope_concat
 attach_distance_embedding      same prints, sets data.anchor_nodes
 attach_node2vec :149           pairwise MFMA tile + column min-max kernel
 Graphpope :182                 same signature, same process-lifetime cache
@@ -102,28 +103,65 @@ def sample_anchor_nodes(data, num_anchor_nodes, sampling_method):
     raise UnboundLocalError("local variable 'sampled_anchor_nodes' referenced before assignment")
 
 
-def _geodesic_device(data, dev):
-    x = data.x.detach().to(dev, torch.float32)
-    ei = data.edge_index.detach().to(dev, torch.int64)
-    n, anchors = int(data.num_nodes), np.asarray(data.anchor_nodes, dtype=np.int64)
-    cache_dir = os.environ.get("GRAPHPOPE_CACHE_DIR")
-    if not cache_dir:
-        return engine.geodesic_features(x, ei, n, anchors, shard=_shard())
-    # Persisted hop planes: the reference only memoises inside one process (utils.py:195-208);
-    # here the bit-sliced hop planes survive on disk, keyed by the graph and the anchor list, so re-runs with the same
-    # seed (or other ranks / later processes) skip the BFS and only expand the planes next to their own features.
+def _host_result(data, k):
+    """The tensor the call returns: a NEW contiguous CPU float32 [N, F+K] (utils.py:134), allocated in pinned memory so
+    that the embedding columns arrive by DMA without a staging copy (and mini-batches later leave it the same way)."""
+    x = data.x.detach()
+    n, f = int(x.shape[0]), int(x.shape[1])
+    return torch.empty((n, f + k), dtype=torch.float32, pin_memory=True), x, f
+
+
+def _assemble_on_host(out, x, f, emb_dev):
+    """out[:, F:] = emb_dev (one pitched DMA on the current stream) while out[:, :F] = data.x is copied host to host by
+    a few threads: data.x never crosses PCIe (utils.py:129-135 torch.cat((data.x, embedding), 1))."""
+    engine.copy_columns_to_host(emb_dev, out[:, f:])
+    if f:
+        xc = x if (x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1) else x.to(torch.float32).contiguous()
+        engine.host_copy_2d(xc, out[:, :f])                       # runs underneath the GPU work and the DMA
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
+def _geodesic_planes(ei, n, anchors, dev):
+    """Hop planes of all anchors on this rank's GPU, through the persisted cache if GRAPHPOPE_CACHE_DIR is set
+    (SURVEY.md §8f rank 4): the reference only memoises inside one process (utils.py:195-208); here the bit-sliced hop
+    planes survive on disk, keyed by the graph and the anchor list, so re-runs with the same seed (or other ranks /
+    later processes) skip the BFS and only expand the planes."""
     from . import plane_cache
+    cache_dir = os.environ["GRAPHPOPE_CACHE_DIR"]
     key = plane_cache.graph_key(ei, n, anchors)
     hit = plane_cache.load(cache_dir, key, dev)
-    if hit is None:
-        _, hp = engine.geodesic_run(None, ei, n, anchors, want_out=False)
-        plane_cache.save(cache_dir, key, hp, anchors)
-        planes, bits = hp.valid(), hp.n_hop_bits
-    else:
-        planes, bits = hit
-    out = torch.empty((n, x.shape[1] + len(anchors)), dtype=torch.float32, device=dev)
-    engine.finalize(planes.contiguous(), bits, n, len(anchors), x.contiguous(), x.shape[1], out, 0)
-    return out
+    if hit is not None:
+        return hit
+    _, hp = engine.geodesic_run(None, ei, n, anchors, want_out=False)
+    plane_cache.save(cache_dir, key, hp, anchors)
+    return hp.valid(), hp.n_hop_bits
+
+
+def _geodesic_embedding_device(edge_index, n, anchors, dev):
+    """float32 [N, K] on the device: 1 / (hops + 1) to every anchor (sharded over the ranks of a process group)."""
+    ei = engine.stage_to_device(edge_index.detach(), dev).to(torch.int64)
+    if not os.environ.get("GRAPHPOPE_CACHE_DIR"):
+        return engine.geodesic_features(None, ei, n, anchors, shard=_shard())
+    planes, bits = _geodesic_planes(ei, n, anchors, dev)
+    emb = torch.empty((n, len(anchors)), dtype=torch.float32, device=dev)
+    engine.finalize(planes.contiguous(), bits, n, len(anchors), None, 0, emb, 0)
+    return emb
+
+
+def _geodesic_features(data, dev):
+    """[N, F+K] for the geodesic branch.  Host-resident data.x (the reference's case): only edge_index goes up and only
+    the K embedding columns come down.  Device-resident data.x: everything stays on the device."""
+    n, anchors = int(data.num_nodes), np.asarray(data.anchor_nodes, dtype=np.int64)
+    if data.x.is_cuda:
+        x = data.x.detach().to(dev, torch.float32)
+        emb_cols = _geodesic_embedding_device(data.edge_index, n, anchors, dev)
+        out = torch.empty((n, x.shape[1] + len(anchors)), dtype=torch.float32, device=dev)
+        out[:, : x.shape[1]] = x
+        out[:, x.shape[1]:] = emb_cols
+        return out.cpu()
+    out, x, f = _host_result(data, len(anchors))
+    return _assemble_on_host(out, x, f, _geodesic_embedding_device(data.edge_index, n, anchors, dev))
 
 
 def get_geodesic_distance_vector(data, num_workers):
@@ -133,7 +171,7 @@ def get_geodesic_distance_vector(data, num_workers):
     """
     dev = _device()
     n = int(data.num_nodes)
-    csr = engine.build_csr(data.edge_index.detach().to(dev, torch.int64), n)
+    csr = engine.build_csr(engine.stage_to_device(data.edge_index.detach(), dev).to(torch.int64), n)
     hp = engine.bfs(csr, data.anchor_nodes)
     out = torch.empty((n, hp.k), dtype=torch.float32, device=dev)
     engine.finalize(hp.planes, hp.n_hop_bits, n, hp.k, None, 0, out, 0)
@@ -154,7 +192,7 @@ def attach_distance_embedding(data, dataset, num_anchor_nodes, sampling_method, 
     if len(data.anchor_nodes) == 0:                                  # --num_anchor_nodes 0: cat((x, [N, 0])) is a copy of x
         print('feature matrix is blessed by the POPE!')
         return data.x.detach().clone()
-    extended_features = _geodesic_device(data, _device()).cpu()
+    extended_features = _geodesic_features(data, _device())
     print('feature matrix is blessed by the POPE!')
     return extended_features
 
@@ -178,9 +216,15 @@ def attach_node2vec(data, dataset, num_anchor_nodes, sampling_method, distance_f
         anchor_embeddings = kmeans.cluster_centers_
         print('K means cluster anchor nodes derived!')
     dev = _device()
-    x = data.x.detach().to(dev, torch.float32)
-    extended_features = engine.pairwise_features(x, node2vec_embeddings.to(dev), anchor_nodes, distance_function,
-                                                 anchor_embeddings=anchor_embeddings).cpu()
+    table = engine.stage_to_device(node2vec_embeddings.to(torch.float32), dev)
+    if data.x.is_cuda:
+        extended_features = engine.pairwise_features(data.x.detach().to(dev, torch.float32), table, anchor_nodes,
+                                                     distance_function, anchor_embeddings=anchor_embeddings).cpu()
+    else:
+        k = len(anchor_embeddings) if anchor_embeddings is not None else len(anchor_nodes)
+        out, x, f = _host_result(data, k)
+        extended_features = _assemble_on_host(out, x, f, engine.pairwise_embedding(table, anchor_nodes, distance_function,
+                                                                                    anchor_embeddings=anchor_embeddings))
     print('feature matrix is blessed by the POPE')
     return extended_features
 

@@ -6,11 +6,15 @@
  * Plain pointers and sizes only; every buffer is allocated by the caller.  Unless a parameter name ends in
  * `_host`, pointers are DEVICE pointers valid on the device that is current on the calling thread
  * (hipSetDevice / torch.cuda.set_device), and work is enqueued on `stream` (a hipStream_t passed as
- * void*, NULL = the default stream).  The library keeps no global mutable state apart from the
- * per-thread error string; the library owns no device memory.
+ * void*, NULL = the default stream).  The library owns no device memory.  What it keeps between calls, all of it
+ * host-side: the per-thread error string; per device, a mutex-guarded ring of small pinned host slots (a call's
+ * anchor ids and its BFS verdict travel through a slot of its own, reused only after the event behind its last
+ * device-side user has completed -- calls from several host threads or on several streams do not share staging);
+ * and two process-global diagnostic facilities that are off by default and NOT thread-safe: the level-timing hook
+ * (pope_profile_levels) and the A/B knobs (pope_debug_set).
  *
  * Every function returns 0 on success or a negative POPE_ERR_* code; pope_last_error() then holds
- * a message for the calling thread.  One host thread per device at a time.
+ * a message for the calling thread.
  *
  * Which reference interface each entry point replaces (file:line into /root/reference):
  *
@@ -23,7 +27,8 @@
  *   pope_geodesic_column_stats  utils.py:50-54   the BFS sums behind nx.closeness_centrality (biased anchor selection)
  *   pope_geodesic_hops       (no counterpart)    the integer hop matrix the floats are made of; parity tests
  *   pope_pairwise_minmax     utils.py:158-176    sklearn cosine/euclidean pairwise + MinMaxScaler
- *   pope_concat              utils.py:129-135    torch.cat for the node2vec branch
+ *   pope_concat              utils.py:129-135    torch.cat for the node2vec branch (device-resident callers)
+ *   pope_host_copy_2d        utils.py:129-135    torch.cat's feature half on the host cores (host -> host callers)
  *   sage_conv_forward /      main.py:206 and     PyG SAGEConv((x_src, x_dst), adj_t): mean aggregation over the
  *   sage_conv_backward       PyG SAGEConv [3p]   sampled CSR + lin_l + lin_r, and its gradients
  *   sage_bn_relu_dropout_forward / _backward   main.py:207-209
@@ -54,8 +59,24 @@ extern "C" {
 /* Message for the last error on the calling thread ("" if none).  Never NULL; valid until the next call. */
 const char *pope_last_error(void);
 
-/* Library / build identification, e.g. "graphpope_hip 0.1 gfx950". */
+/* Library / build identification, e.g. "graphpope_hip 0.2 gfx950". */
 const char *pope_version(void);
+
+/*
+ * POPE_OK if a gfx950 device is visible to the calling process (and, if cu_count is not NULL, its number of compute
+ * units); POPE_ERR_NO_DEVICE otherwise -- the product path has no CPU fallback (utils.Graphpope raises).
+ */
+int pope_require_device(int32_t *cu_count_host);
+
+/*
+ * Diagnostic knobs for A/B runs (tools/ab_*.py and the kernel-variant tests): process-global, not thread-safe, never
+ * needed by a caller.  value < 0 restores the automatic choice where one exists.
+ */
+#define POPE_KNOB_LIVE_MODE         0   /* level kernel: -1 auto, 0 no live-bit table, 1 table in LDS, 2 table in global memory */
+#define POPE_KNOB_FINALIZE_VARIANT  1   /* 0 generic finalise kernel, 1 fast path (default), 2 fast path + non-temporal stores   */
+#define POPE_KNOB_FINALIZE_BLOCKS   2   /* grid of the fast finalise kernel (default 2048)                                       */
+#define POPE_KNOB_GEMM_TILE         3   /* SAGE GEMM: 0 auto, 1 64x64, 2 64x128, 3 128x256 tiles, 4 stream-K full-width tile      */
+int pope_debug_set(int32_t knob, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------
  * Graph: forward CSR (row = source node, columns = targets) in int32, built on the device into
@@ -216,6 +237,24 @@ int pope_pairwise_minmax(const float *X, int64_t N, int32_t D, const float *A, i
 
 /* out[v, 0:F] = x[v, :] for a float32 [N, out_cols] matrix (the feature half of torch.cat). Asynchronous. */
 int pope_concat(const float *x, int64_t N, int32_t F, float *out, int64_t out_cols, void *stream);
+
+/*
+ * HOST memory on both sides: copy `rows` rows of `row_bytes` bytes from src (row pitch src_pitch_bytes) to dst (row
+ * pitch dst_pitch_bytes) with `threads` host threads (<= 0: all hardware threads) and streaming stores; returns when
+ * the copy is complete.  The host half of torch.cat((data.x, embedding), 1) (utils.py:129-135) for the host -> host
+ * Graphpope call: data.x never crosses PCIe -- it goes straight into the result tensor's first F columns on the
+ * host cores while the GPU computes and ships only the K embedding columns.  No HIP call is made.
+ */
+int pope_host_copy_2d(const void *src_host, int64_t src_pitch_bytes, void *dst_host, int64_t dst_pitch_bytes,
+                      int64_t row_bytes, int64_t rows, int32_t threads);
+
+/*
+ * The embedding half of the same torch.cat: `rows` rows of `row_bytes` bytes from DEVICE memory (pitch src_pitch_bytes)
+ * into the last K columns of the host result (dst_host, row pitch dst_pitch_bytes; pinned memory makes it a true
+ * asynchronous DMA on `stream`).  Only these K columns ever cross PCIe.  Asynchronous on `stream`.
+ */
+int pope_copy_2d_to_host(const void *src, int64_t src_pitch_bytes, void *dst_host, int64_t dst_pitch_bytes,
+                         int64_t row_bytes, int64_t rows, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SAGEConv over a sampled bipartite block (CSR by destination; destinations are the first n_dst sources).

@@ -125,6 +125,54 @@ def geodesic_pairs_networkx(edge_index: np.ndarray, num_nodes: int, anchors, nod
     return np.asarray(rows, dtype=np.float32).reshape(len(rows), len(anchors))
 
 
+def _pairs_job(G, anchors, partition):
+    """utils.py:64-81 shortest_path_length: {node: [1 / len(path) or 0 per anchor]} for one partition of the nodes."""
+    import networkx as nx
+    dists_dict = {}
+    for node in partition:
+        distances = []
+        for anchor_node in anchors:
+            try:
+                distances.append(1 / len(nx.shortest_path(G, source=node, target=anchor_node)))
+            except nx.NetworkXNoPath:
+                distances.append(0)
+        dists_dict[node] = distances.copy()
+    return dists_dict
+
+
+def geodesic_pairs_networkx_pool(edge_index: np.ndarray, num_nodes: int, anchors, nodes, workers: int):
+    """The reference's CPU path as it actually runs (utils.py:92-107, 116-121): NetworkX DiGraph, the node list cut into
+    `workers` float-indexed slices, one ``multiprocessing.Pool(workers).apply_async`` job per slice (the whole graph is
+    pickled to every job), results merged in slice order.  `nodes` is the (sub)list of nodes to process -- bench.py's
+    bounded sample; the reference passes all of them.  Returns (float32 [len(nodes), K], {"graph_build_s", "pool_s"}).
+    """
+    import multiprocessing as mp
+    import time
+    import networkx as nx
+    t0 = time.perf_counter()
+    G = nx.DiGraph()
+    G.add_nodes_from(range(num_nodes))
+    G.add_edges_from(zip(edge_index[0].tolist(), edge_index[1].tolist()))
+    t1 = time.perf_counter()
+    nodes = [int(v) for v in nodes]
+    anchors = [int(a) for a in anchors]
+    n = len(nodes)
+    pool = mp.Pool(workers)
+    try:
+        jobs = [pool.apply_async(_pairs_job, (G, anchors, nodes[int(n / workers * i):int(n / workers * (i + 1))]))
+                for i in range(workers)]
+        merged = {}
+        for job in jobs:
+            merged.update(job.get())
+    finally:
+        pool.close()
+        pool.join()
+    t2 = time.perf_counter()
+    rows = [merged[v] for v in nodes if v in merged]              # utils.py:100 can drop the last node for some (n, workers)
+    return (np.asarray(rows, dtype=np.float32).reshape(len(rows), len(anchors)),
+            {"graph_build_s": t1 - t0, "pool_s": t2 - t1})
+
+
 # --------------------------------------------------------------------------------------------
 # node2vec-space pairwise + min-max  (/root/reference/utils.py:149-180)
 # --------------------------------------------------------------------------------------------

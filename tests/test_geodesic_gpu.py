@@ -128,18 +128,16 @@ def test_large_rmat_waves_loop_over_chunks(k, dev, oracle):
 def test_graph_too_large_for_the_lds_live_table(mode, k, dev, oracle):
     """More than 256 Ki nodes: the level kernel reads the live-bit table from global memory (k_bfs_level<WT, 2>);
     mode 0 forces the table-less variant kept for A/B (tools/ab_live_mode.py), mode 1 must fall back the same way."""
-    import ctypes
     from graphpope_amd import engine, synth, _lib
     ei, n = synth.rmat(19, edge_factor=3, seed=23)
     assert n > 256 * 1024
     anchors = np.random.RandomState(5).choice(np.arange(n), k)        # k = 300: two 4-word tiles share the live bits
     lib = _lib.load()
-    lib.pope_debug_live_mode.argtypes = [ctypes.c_int]
-    lib.pope_debug_live_mode(mode)
+    _lib.check(lib.pope_debug_set(_lib.KNOB_LIVE_MODE, mode))
     try:
         _, hp = engine.geodesic_run(None, torch.as_tensor(ei, device=dev), n, anchors, want_out=False)
     finally:
-        lib.pope_debug_live_mode(-1)
+        lib.pope_debug_set(_lib.KNOB_LIVE_MODE, -1)
     assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), oracle.geodesic_hops(ei, n, anchors))
 
 

@@ -124,3 +124,14 @@ def test_biased_anchor_selection_matches_reference(method):
     d.edge_index, d.num_nodes = torch.as_tensor(g["edge_index"].astype(np.int64)), int(g["num_nodes"])
     got = gp.sample_anchor_nodes(d, 24, method)
     assert [int(v) for v in got] == g[method].tolist()
+
+
+def test_pool_restatement_of_the_reference_loop(oracle):
+    """oracle.geodesic_pairs_networkx_pool (bench.py's Baseline A: utils.py:92-107 under multiprocessing.Pool) gives the
+    reference's own numbers: checked against a golden produced by the reference's utils.py."""
+    g = load_golden(os.path.join(GOLDEN, "geodesic_rmat9_directed.npz"))
+    n = int(g["num_nodes"])
+    nodes = np.arange(0, n, 7)
+    emb, tm = oracle.geodesic_pairs_networkx_pool(g["edge_index"], n, g["anchors"], nodes, 3)
+    assert np.array_equal(emb.view(np.uint32), g["emb"][nodes].view(np.uint32))
+    assert tm["pool_s"] > 0 and tm["graph_build_s"] > 0

@@ -127,3 +127,68 @@ def test_indexed_features_equal_the_materialised_batch(dev):
             assert pb.grad is None
         else:      # 1e-5 of the gradient's scale, with a floor of 1: layer 0's bias gradient is analytically 0 under BatchNorm
             assert float((pa.grad - pb.grad).abs().max()) <= 1e-5 * max(float(pa.grad.abs().max()), 1.0), name
+
+
+@pytest.fixture(scope="module")
+def config2_block():
+    """The outer block of a BASELINE configs[1] mini-batch: 1 550 seeds, fan-outs [25, 10] on the Flickr-shaped graph ->
+    about 9 988 destinations x 37 799 sources, nnz ~ 77 k, 756 -> 256 (main.py:44, 100-116)."""
+    from graphpope_amd import synth
+    from graphpope_amd.sage import sample_batch
+    ei, n = synth.flickr_like()
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei[0], minlength=n))])
+    rng = np.random.default_rng(0)
+    seeds = rng.choice(n, 1550, replace=False)
+    n_id, adjs = sample_batch(rowptr, ei[1], seeds, sizes=(25, 10), rng=rng)
+    a0 = adjs[0]
+    assert 8000 < a0.n_dst < 12000 and 30000 < a0.n_src < 45000 and 60000 < a0.col.numel() < 110000
+    return n, torch.as_tensor(n_id), a0
+
+
+@pytest.mark.parametrize("indexed", [False, True], ids=["materialised", "indexed"])
+def test_config2_block_shape_matches_torch(indexed, config2_block, dev, oracle):
+    """Layer 0 at the shape bench.py times (9 988 x 37 799, 756 -> 256): forward and every gradient against
+    oracle.sage_conv_torch, for the plain call and for IndexedFeatures (neighbours read through n_id, no x[n_id] copy)."""
+    from graphpope_amd.sage import SAGEConv, IndexedFeatures
+    n, n_id, a0 = config2_block
+    c_in, c_out = 756, 256
+    torch.manual_seed(0)
+    feats = torch.rand(n, c_in)                                     # features (+) POPE columns are in [0, 1]
+    conv = SAGEConv(c_in, c_out).to(dev)
+    g = torch.randn(a0.n_dst, c_out)
+    adj = a0.to(dev)
+    if indexed:
+        out = conv(IndexedFeatures(feats.to(dev), n_id.to(dev)), adj)
+    else:
+        x = feats[n_id].to(dev)
+        out = conv((x, x[:a0.n_dst]), adj)
+    out.backward(g.to(dev))
+
+    xr = feats[n_id]
+    wl, bl, wr = (p.detach().cpu().clone().requires_grad_(True) for p in (conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight))
+    ref = oracle.sage_conv_torch(xr, a0.rowptr, a0.col, wl, bl, wr)
+    ref.backward(g)
+    _close(out.detach().cpu(), ref.detach(), 1e-4)
+    _close(conv.lin_l.weight.grad.cpu(), wl.grad, 1e-3)
+    _close(conv.lin_l.bias.grad.cpu(), bl.grad, 1e-3)
+    _close(conv.lin_r.weight.grad.cpu(), wr.grad, 1e-3)
+
+
+def test_config2_block_input_gradient(config2_block, dev, oracle):
+    """grad_x at the config-2 block shape (hidden layers need it; layer 0 skips it): GEMM twin + scatter-mean atomics."""
+    from graphpope_amd.sage import SAGEConv
+    n, n_id, a0 = config2_block
+    c_in, c_out = 256, 256
+    torch.manual_seed(1)
+    x = torch.randn(a0.n_src, c_in)
+    conv = SAGEConv(c_in, c_out).to(dev)
+    g = torch.randn(a0.n_dst, c_out)
+    xd = x.to(dev).requires_grad_(True)
+    out = conv((xd, xd[:a0.n_dst]), a0.to(dev))
+    out.backward(g.to(dev))
+    xr = x.clone().requires_grad_(True)
+    wl, bl, wr = (p.detach().cpu().clone().requires_grad_(True) for p in (conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight))
+    ref = oracle.sage_conv_torch(xr, a0.rowptr, a0.col, wl, bl, wr)
+    ref.backward(g)
+    _close(out.detach().cpu(), ref.detach(), 1e-4)
+    _close(xd.grad.cpu(), xr.grad, 1e-3)

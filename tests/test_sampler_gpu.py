@@ -85,32 +85,3 @@ def test_sampled_batch_trains(graph):
         first = loss.item() if first is None else first
         last = loss.item()
     assert last < 0.8 * first
-
-
-def test_prefetcher_yields_the_same_batches_in_order(graph):
-    """BatchPrefetcher (worker thread + side stream) changes the timing, not the draw: same n_id / blocks / features as
-    calling sampler.sample batch by batch, in the same order; worker exceptions surface in the consumer."""
-    from graphpope_amd import engine, synth
-    from graphpope_amd.sampler import BatchPrefetcher, NeighborSampler
-    dev = graph[0]
-    ei, n = synth.rmat(12, edge_factor=6, seed=3)
-    csr = engine.build_csr(torch.as_tensor(ei, device=dev), n)
-    s = NeighborSampler(csr.rowptr, csr.col, n, (5, 3))
-    feats = torch.rand(n, 12, device=dev)
-    labels = torch.arange(n, device=dev)
-    perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
-    seed_batches = [perm[i * 100:(i + 1) * 100] for i in range(12)]
-    want = [s.sample(b, seed=77 + i) for i, b in enumerate(seed_batches)]
-    got = list(BatchPrefetcher(s, iter(seed_batches), 77, feats, labels, depth=3))
-    assert len(got) == 12
-    for (seeds, n_id, adjs, x, y), (w_n_id, w_adjs), b in zip(got, want, seed_batches):
-        assert torch.equal(seeds, b) and torch.equal(n_id, w_n_id) and torch.equal(y, b)
-        assert torch.equal(x, feats[w_n_id])
-        for a, w in zip(adjs, w_adjs):
-            assert torch.equal(a.rowptr, w.rowptr) and torch.equal(a.col, w.col) and a.n_src == w.n_src
-
-    def broken():
-        yield seed_batches[0]
-        raise ValueError("boom")
-    with pytest.raises(ValueError):
-        list(BatchPrefetcher(s, broken(), 0))

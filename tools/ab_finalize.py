@@ -19,8 +19,8 @@ cases = [(0, 2048), (1, 1024), (1, 2048), (1, 4096), (1, 8192), (2, 2048)]
 res = {c: [] for c in cases}
 for rnd in range(10):
     for var, blocks in cases:
-        lib.pope_debug_finalize_variant(var)
-        lib.pope_debug_finalize_blocks(blocks)
+        lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, var)
+        lib.pope_debug_set(_lib.KNOB_FINALIZE_BLOCKS, blocks)
         evict.fill_(1.0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

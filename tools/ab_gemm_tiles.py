@@ -9,7 +9,6 @@ if os.environ.get('POPE_LIB'): _lib.LIB_PATH = os.environ['POPE_LIB']
 from graphpope_amd import engine
 from graphpope_amd.sage import SAGEConv, SampledAdj
 lib = _lib.load(); dev = engine.require_gpu()
-lib.pope_debug_gemm_force.argtypes = [ctypes.c_int, ctypes.c_int]
 n_dst, n_src, c_in, c_out = 9988, 37799, 756, 256
 rowptr = torch.zeros(n_dst + 1, dtype=torch.int32)                       # no neighbours: the gather is a few us of zero fill
 adj = SampledAdj(rowptr, torch.zeros(0, dtype=torch.int32), n_src).to(dev)
@@ -24,6 +23,6 @@ def timed(fn, reps=20):
 def fwd():
     with torch.no_grad(): conv((x, x[:n_dst]), adj)
 for tile, splits in [(0, 1), (1, 1), (2, 1), (1, 2)]:
-    lib.pope_debug_gemm_force(tile, splits)
+    lib.pope_debug_set(_lib.KNOB_GEMM_TILE, tile)
     print(f"forward tile {('auto','64x64','64x128','128x256')[tile]:8s} splits {splits}: {timed(fwd):7.1f} us")
-lib.pope_debug_gemm_force(0, 1)
+lib.pope_debug_set(_lib.KNOB_GEMM_TILE, 0)

@@ -8,7 +8,6 @@ sys.path.insert(0, ROOT)
 from graphpope_amd import engine, synth, _lib
 dev = engine.require_gpu()
 lib = _lib.load()
-lib.pope_debug_live_mode.argtypes = [ctypes.c_int]
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ef = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 ei, n = synth.rmat(scale, edge_factor=ef, seed=1)
@@ -18,7 +17,7 @@ ref = None
 for k in (64, 256):
     anc = synth.seeded_anchors(n, k, 42)
     for mode in (0, 2, 0, 2):
-        lib.pope_debug_live_mode(mode)
+        lib.pope_debug_set(_lib.KNOB_LIVE_MODE, mode)
         for _ in range(2): engine.geodesic_run(None, eid, n, anc, want_out=False, reuse_workspace=True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(5): _, hp = engine.geodesic_run(None, eid, n, anc, want_out=False, reuse_workspace=True)
@@ -29,5 +28,5 @@ for k in (64, 256):
         res.setdefault(f"k{k}_mode{mode}_ms", []).append(round(dt * 1e3, 3))
     ref = None
     res[f"k{k}_max_hop"] = hp.max_hop
-lib.pope_debug_live_mode(-1)
+lib.pope_debug_set(_lib.KNOB_LIVE_MODE, -1)
 print(json.dumps(res))

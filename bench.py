@@ -17,7 +17,8 @@ anchors (K_total = 256 * N), planes are all-gathered (RCCL) and every rank mater
 Rank 0 prints ONE JSON line.  At N = 1 it also carries
   roofline               the dominant kernel (k_bfs_level), duration measured live with HIP events on the launch stream
   cpu_baseline           Baseline A: the reference's CPU path (NetworkX per-pair loop under multiprocessing.Pool(6),
-                         utils.py:92-107; main.py:39 default) on a bounded node sample; *_all_cores: the same on every core;
+                         utils.py:92-107; main.py:39 default) on a bounded node sample; *_all_cores: the same on the box's CPU
+                         share (16 workers);
                          cpu_baseline_bfs: one C BFS per anchor (the honest CPU algorithm)
   boundary_host_to_host  SURVEY.md §8(d)'s primary metric: utils.Graphpope() from CPU tensors to the returned CPU tensor,
                          with the PCIe roofline of the bytes that cross the link
@@ -124,6 +125,7 @@ def cpu_baselines_before_gpu(ei, n, anchors, sample_nodes):
     from oracle import oracle
     res = {}
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)             # a one-GPU box's CPU share (the host shows all 256 hardware threads to every tenant)
     nodes = np.random.RandomState(0).choice(n, sample_nodes, replace=False)
     want = None
     try:
@@ -171,14 +173,16 @@ def boundary_leg(ei_np, n, x_cpu, want_hops, reps=5):
         pass
     d = Data()
     d.x, d.edge_index, d.num_nodes = x_cpu, torch.as_tensor(ei_np), n
+    import contextlib
     times = []
     out = None
-    for _ in range(reps + 1):
-        gp.clear_cache()
-        np.random.seed(42)
-        t0 = time.perf_counter()
-        out = gp.Graphpope(d, "flickr", "geodesic", "stochastic", K_PER_GPU, None, NUM_WORKERS)
-        times.append(time.perf_counter() - t0)
+    with contextlib.redirect_stdout(sys.stderr):           # the reference's banners (utils.py:141-146) stay off the JSON line
+        for _ in range(reps + 1):
+            gp.clear_cache()
+            np.random.seed(42)
+            t0 = time.perf_counter()
+            out = gp.Graphpope(d, "flickr", "geodesic", "stochastic", K_PER_GPU, None, NUM_WORKERS)
+            times.append(time.perf_counter() - t0)
     gp.clear_cache()
     e, k = ei_np.shape[1], K_PER_GPU
     crossed = 16.0 * e + 4.0 * n * k                   # edge_index int64 up, [N, K] float32 down; x stays on the host

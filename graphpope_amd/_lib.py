@@ -54,11 +54,13 @@ SIGNATURES = {
                                      c_int32, c_void_p, c_size_t, c_void_p]),
     "pope_concat": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
     "sage_conv_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int32, c_int32]),
+    "sage_conv_forward_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "sage_conv_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p,
-                                  c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+                                  c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sage_gather_mean": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     "sage_conv_forward_indexed": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32,
-                                          c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                          c_void_p]),
     "sage_conv_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int32,
                                    c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),

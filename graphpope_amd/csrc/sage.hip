@@ -13,7 +13,7 @@
 //                    (reduction over ~40 000 rows), deterministic: no float atomics there.
 //   k_scatter_mean   grad_x[col[p]] += grad_agg[i] / deg(i) (float atomics, whole 16-byte-aligned row segments)
 //   k_colsum_*       grad_bias, two deterministic stages
-#include "gemm_tile.h"
+#include "gemm_streamk.h"
 
 namespace pope {
 
@@ -309,6 +309,60 @@ static int weight_grad_splits(int64_t n_dst, int c_in, int c_out) {
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ---- forward projection as a stream-K launch (gemm_streamk.h) ----
+constexpr int SK_MAX_GRID = 256;                     // one persistent block per CU of an MI355X
+
+static bool streamk_shape_ok(int64_t M, int32_t K0, int32_t K1, int32_t N) {
+    if ((K0 & 3) || (K1 & 3) || M <= 0 || N <= 0) return false;
+    const long long tiles = ((M + SK_TM - 1) / SK_TM) * ((N + SK_TN - 1) / SK_TN);
+    const long long S = (K0 + SK_GK - 1) / SK_GK + (K1 + SK_GK - 1) / SK_GK;
+    return tiles * S >= 4ll * SK_MAX_GRID;           // enough units for every block to amortise its partial tiles
+}
+
+static int device_cu_count(int *out) {
+    static int cus[64];
+    int dev = 0;
+    POPE_HIP(hipGetDevice(&dev));
+    POPE_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    if (!cus[dev]) POPE_HIP(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    *out = cus[dev];
+    return POPE_OK;
+}
+
+// out = A0 * B0^T + A1 * B1^T + bias through k_gemm_streamk + k_streamk_fixup; *used = false if the operands do not
+// qualify (alignment, size, slab too small) and nothing was launched.
+static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A1, const float *B1, int K1, long long lda, long long ldb,
+                        int M, int N, const float *bias, float *C, long long ldc, void *slab, size_t slab_bytes, hipStream_t stream,
+                        bool *used) {
+    *used = false;
+    if (g_gemm_force_tile != 0 && g_gemm_force_tile != 4) return POPE_OK;
+    if (!(g_gemm_force_tile == 4 || streamk_shape_ok(M, K0, K1, N))) return POPE_OK;
+    if (!sk_operand_ok(A0, lda, K0) || !sk_operand_ok(B0, ldb, K0) || (K1 > 0 && (!sk_operand_ok(A1, lda, K1) || !sk_operand_ok(B1, ldb, K1))))
+        return POPE_OK;
+    int cus = 0, rc;
+    if ((rc = device_cu_count(&cus))) return rc;
+    SkArgs a;
+    a.p[0] = SkProduct{A0, B0, lda, ldb, K0};
+    a.p[1] = SkProduct{K1 > 0 ? A1 : A0, K1 > 0 ? B1 : B0, lda, ldb, K1};
+    a.M = M; a.N = N; a.bias = bias; a.C = C; a.ldc = ldc; a.slab = (float *)slab;
+    a.tiles_m = (M + SK_TM - 1) / SK_TM; a.tiles_n = (N + SK_TN - 1) / SK_TN;
+    a.S0 = (K0 + SK_GK - 1) / SK_GK; a.S1 = (K1 + SK_GK - 1) / SK_GK;
+    const long long T = (long long)a.tiles_m * a.tiles_n * (a.S0 + a.S1);
+    long long grid = cus < SK_MAX_GRID ? cus : SK_MAX_GRID;
+    if (grid > T) grid = T;
+    if (!slab || slab_bytes < sk_slab_bytes((int)grid)) return POPE_OK;
+    static bool opt_in = false;
+    if (!opt_in) {
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+        opt_in = true;
+    }
+    hipLaunchKernelGGL(k_gemm_streamk, dim3((unsigned)grid), dim3(SK_THREADS), SK_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(k_streamk_fixup, dim3(a.tiles_m * a.tiles_n, SK_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
+    POPE_HIP(hipGetLastError());
+    *used = true;
+    return POPE_OK;
+}
+
 }  // namespace pope
 
 using namespace pope;
@@ -328,6 +382,11 @@ extern "C" size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t 
     if (slabs < (size_t)COLSUM_SPLITS * c_out * sizeof(float)) slabs = (size_t)COLSUM_SPLITS * c_out * sizeof(float);
     slabs = align_up(slabs, 256);
     return gagg + slabs;
+}
+
+extern "C" size_t sage_conv_forward_scratch_bytes(int64_t n_dst, int32_t c_in, int32_t c_out) {
+    if (n_dst <= 0 || c_in <= 0 || c_out <= 0) return 0;
+    return streamk_shape_ok(n_dst, c_in, c_in, c_out) ? sk_slab_bytes(SK_MAX_GRID) : 0;
 }
 
 static void enqueue_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_dst, const float *x_src, int32_t c_in,
@@ -353,7 +412,7 @@ extern "C" int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64
 
 extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
                                  const float *x_src, int32_t c_in, const float *w_l, const float *b_l, const float *w_r,
-                                 int32_t c_out, float *agg, float *out, void *stream_) {
+                                 int32_t c_out, float *agg, float *out, void *scratch, size_t scratch_bytes, void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(rowptr && (col || nnz == 0) && x_src && w_l && w_r && agg && out, "sage_conv_forward: null pointer");
@@ -361,6 +420,9 @@ extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int6
                  "sage_conv_forward: bad size (destinations must be the first n_dst sources)");
     enqueue_gather_mean(rowptr, col, n_dst, x_src, c_in, agg, stream);
     // out = agg * w_l^T + b_l + x_dst * w_r^T in one pass
+    bool used = false;
+    int rc = gemm_streamk(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used);
+    if (rc || used) return rc;
     const Operand A0{agg, c_in, 1}, B0{w_l, c_in, 1}, A1{x_src, c_in, 1}, B1{w_r, c_in, 1};
     return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream);
 }
@@ -371,13 +433,16 @@ extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int6
 extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
                                          int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l,
                                          const float *b_l, const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out,
-                                         void *stream_) {
+                                         void *scratch, size_t scratch_bytes, void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(rowptr && (col || nnz == 0) && n_id && feats && w_l && w_r && agg && x_dst && out, "sage_conv_forward_indexed: null pointer");
     POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && n_rows > 0 && nnz >= 0 && nnz < INT32_MAX && c_in > 0 && c_out > 0,
                  "sage_conv_forward_indexed: bad size (destinations must be the first n_dst entries of n_id)");
     enqueue_gather_mean(rowptr, col, n_dst, feats, c_in, agg, stream, n_id, x_dst);
+    bool used = false;
+    int rc = gemm_streamk(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used);
+    if (rc || used) return rc;
     const Operand A0{agg, c_in, 1}, B0{w_l, c_in, 1}, A1{x_dst, c_in, 1}, B1{w_r, c_in, 1};
     return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream);
 }

@@ -44,6 +44,15 @@ class SampledAdj:
         return SampledAdj(self.rowptr.to(device), self.col.to(device), self.n_src)
 
 
+def _forward_scratch(lib, n_dst, c_in, c_out, dev):
+    """Partial-tile slabs of the stream-K forward projection (None, 0 for layers too small to use it).  Taken from
+    torch's caching allocator per call: stream-ordered like every other buffer of the step."""
+    nbytes = lib.sage_conv_forward_scratch_bytes(n_dst, c_in, c_out)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
+
+
 class _SageConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_src, w_l, b_l, w_r, rowptr, col, n_dst):
@@ -57,8 +66,9 @@ class _SageConvFn(torch.autograd.Function):
         agg = torch.empty((n_dst, c_in), dtype=torch.float32, device=x_src.device)
         out = torch.empty((n_dst, c_out), dtype=torch.float32, device=x_src.device)
         with on_device(x_src.device):
+            scratch, nbytes = _forward_scratch(lib, n_dst, c_in, c_out, x_src.device)
             check(lib.sage_conv_forward(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), c_in, ptr(w_l),
-                                        ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(out), _stream()))
+                                        ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(out), ptr(scratch), nbytes, _stream()))
         ctx.save_for_backward(x_src, agg, w_l, w_r, rowptr, col)
         ctx.has_bias = b_l is not None
         ctx.n_dst = n_dst
@@ -113,9 +123,10 @@ class _SageConvIndexedFn(torch.autograd.Function):
         x_dst = torch.empty((n_dst, c_in), dtype=torch.float32, device=dev)
         out = torch.empty((n_dst, c_out), dtype=torch.float32, device=dev)
         with on_device(dev):
+            scratch, nbytes = _forward_scratch(lib, n_dst, c_in, c_out, dev)
             check(lib.sage_conv_forward_indexed(ptr(rowptr), ptr(col), ptr(n_id), n_id.numel(), n_dst, col.numel(), ptr(feats),
                                                 feats.shape[0], c_in, ptr(w_l), ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(x_dst),
-                                                ptr(out), _stream()))
+                                                ptr(out), ptr(scratch), nbytes, _stream()))
         ctx.save_for_backward(x_dst, agg, w_l, w_r, rowptr, col)
         ctx.has_bias = b_l is not None
         return out

@@ -260,16 +260,20 @@ int pope_copy_2d_to_host(const void *src, int64_t src_pitch_bytes, void *dst_hos
  * SAGEConv over a sampled bipartite block (CSR by destination; destinations are the first n_dst sources).
  *   out = lin_l(mean_{j in N(i)} x_src[j]) + lin_r(x_src[i]),  lin_l with bias, lin_r without.
  * ------------------------------------------------------------------------------------------------ */
-size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t nnz, int32_t c_in, int32_t c_out);
+size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t nnz, int32_t c_in, int32_t c_out);   /* backward */
+size_t sage_conv_forward_scratch_bytes(int64_t n_dst, int32_t c_in, int32_t c_out);                         /* forward  */
 
 /*
  * rowptr int32 [n_dst + 1], col int32 [nnz] (indices into x_src), x_src f32 [n_src, c_in],
  * w_l / w_r f32 [c_out, c_in], b_l f32 [c_out] or NULL, out f32 [n_dst, c_out].
- * agg (f32 [n_dst, c_in]) receives the mean-aggregated features (kept for backward).  Asynchronous.
+ * agg (f32 [n_dst, c_in]) receives the mean-aggregated features (kept for backward).
+ * scratch: sage_conv_forward_scratch_bytes(n_dst, c_in, c_out) bytes (0 for small layers: scratch may be NULL then) --
+ * the partial-tile slabs of the stream-K projection; with less, the projection falls back to whole-tile kernels.
+ * Asynchronous.
  */
 int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
                       const float *x_src, int32_t c_in, const float *w_l, const float *b_l, const float *w_r,
-                      int32_t c_out, float *agg, float *out, void *stream);
+                      int32_t c_out, float *agg, float *out, void *scratch, size_t scratch_bytes, void *stream);
 
 /* The aggregation half on its own: agg[i, :] = mean_{p in row i} x_src[col[p], :] (zero for empty rows).  Asynchronous. */
 int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
@@ -288,7 +292,8 @@ int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_src, i
  */
 int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
                               int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l, const float *b_l,
-                              const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out, void *stream);
+                              const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out, void *scratch,
+                              size_t scratch_bytes, void *stream);
 int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
                        const float *x_src, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
                        int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l,

@@ -11,8 +11,8 @@
 // accumulators to a slab of its own; k_streamk_fixup adds the (two or three) partials of each cut tile in block order
 // (deterministic, no atomics, no inter-block waiting inside the launch).
 //
-// Staging is direct-to-LDS (global_load_lds_dwordx4: no staging registers, no LDS store instructions), double
-// buffered, one barrier per stage.  The LDS image is [row][8 chunks of 16 B] with the chunk index XOR-swizzled by
+// Staging is direct-to-LDS (global_load_lds_dwordx4: no staging registers, no LDS store instructions) into three
+// rotating buffers (two stages in flight), one barrier per stage.  The LDS image is [row][8 chunks of 16 B] with the chunk index XOR-swizzled by
 // (row >> 1) & 7 -- applied on the SOURCE address of the DMA (its destination is lane-linear) and again on the read --
 // which makes every ds_read_b128 of the fragment loads conflict-free.  A lane's four depth values per 16-byte read feed
 // four consecutive MFMAs: lanes 0-31 own depth chunk 2p, lanes 32-63 chunk 2p + 1 (the two k-slots of
@@ -23,12 +23,28 @@
 
 namespace pope {
 
-constexpr int SK_TM = 64, SK_TN = 256, SK_GK = 32, SK_THREADS = 512;
+constexpr int SK_TM = 64, SK_TN = 256, SK_GK = 32;
 constexpr int SK_A_BYTES = SK_TM * SK_GK * 4, SK_B_BYTES = SK_TN * SK_GK * 4, SK_STAGE_BYTES = SK_A_BYTES + SK_B_BYTES;
-constexpr int SK_LDS_BYTES = 2 * SK_STAGE_BYTES;
+constexpr int SK_NBUF = 3;                                      // 120 KB of LDS: exactly one block per CU, two stages in flight
+constexpr int SK_LDS_BYTES = SK_NBUF * SK_STAGE_BYTES;
 constexpr size_t SK_SLAB_FLOATS = (size_t)SK_TM * SK_TN;        // one partial tile
 
 static __device__ __attribute__((aligned(16))) float g_sk_zero[4];   // never written: the source of depth padding
+
+#ifdef POPE_STAMP
+// Diagnostic build only (make stamp, tools/stamp_streamk.py): shader-clock stamps of one mid-segment stage, waves 0 and 4
+// of every block: [block][wave][slot].
+__device__ unsigned long long g_sk_stamps[256 * 8 * 8];
+#define SK_STAMP(slot)                                                                                  \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if (s == s_begin + 6 && lane == 0 && wave < 8 && blockIdx.x < 256)                              \
+            g_sk_stamps[(blockIdx.x * 8 + wave) * 8 + (slot)] = __builtin_amdgcn_s_memtime();          \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    } while (0)
+#else
+#define SK_STAMP(slot) do { } while (0)
+#endif
 
 struct SkProduct {
     const float *A, *B;          // A[m * lda + k], B[n * ldb + k]
@@ -44,6 +60,7 @@ struct SkArgs {
     long long ldc;
     float *slab;                 // [gridDim.x][2][SK_TM][SK_TN]
     int tiles_m, tiles_n, S0, S1;
+    const float *zero;           // 16 zero bytes in device memory (&g_sk_zero): as an argument it sits in SGPRs from the start
 };
 
 // One LDS-DMA wave-instruction: lane l's 16 bytes at `src` land at LDS byte address lds_wave_base + 16 * l.
@@ -58,38 +75,61 @@ __device__ __forceinline__ void sk_glds16(const float *src, unsigned lds_wave_ba
                  : "=&s"(keep) : "v"(src), "s"(lds_wave_base) : "memory");
 }
 
+// The same with the source as (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset): no vector arithmetic at all
+// in front of the DMA -- f32 MFMAs run on the vector ALUs' issue slots, so every VALU instruction of a wave that shares a
+// SIMD with an MFMA wave waits for a gap in its stream (stamps: 500 cycles per DMA with 64-bit per-lane address arithmetic).
+__device__ __forceinline__ void sk_glds16_saddr(const float *base_uniform, unsigned lane_byte_off, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_byte_off), "s"(base_uniform), "s"(lds_wave_base) : "memory");
+}
+
 // First unit of block b when T units are dealt to G blocks: block b owns [sk_lo(b), sk_lo(b + 1)).
 __host__ __device__ __forceinline__ long long sk_lo(long long b, long long T, long long G) { return b * T / G; }
 
-__global__ __launch_bounds__(SK_THREADS) void k_gemm_streamk(SkArgs a) {
+// WAVES = 4: one wave per SIMD, each 32 rows x 128 columns (four accumulator tiles);  WAVES = 8: two per SIMD, 32 x 64 each.
+// SCHED: 0 = the kernel; 3 / 4 are diagnostics of the stamp build (wrong results): 3 = no DMA inside the stage loop, 4 = no MFMA.
+// (Measured, no gain: leaving the instruction order to the compiler, a sched_group_barrier interleave of one MFMA / one DS
+//  read / a few VALU, one DMA per MFMA group instead of two or three per pass: 5 600-5 850 cycles per stage every time.)
+template <int WAVES, int SCHED>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_streamk(SkArgs a) {
+    constexpr int WN = WAVES / 2;                       // waves along N (2 along M)
+    constexpr int NT = SK_TN / WN / 32;                 // 32 x 32 accumulator tiles per wave
+    constexpr int NA = 8 / WAVES, NB = 32 / WAVES;      // DMA wave-instructions per wave and stage: A rows, B rows
+    constexpr int ND = NA + NB;
+    static_assert(WAVES == 4 || WAVES == 8, "wave layout");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;                           // 2 x 4 waves: rows wm * 32, columns wn * 64
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;   // LDS byte address of the staging buffers
+    const int wm = wave & 1, wn = wave >> 1;
+    // Two waves per SIMD (w and w + 4): the matrix pipe is arbitrated by priority, then age, so the younger half only gets
+    // what the older half leaves and finishes each stage ~1 000 cycles later; static priority for it evens the two out.
+    if constexpr (WAVES == 8) {
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem);   // LDS byte address of the staging buffers
     const int S = a.S0 + a.S1;
     const long long T = (long long)a.tiles_m * a.tiles_n * S, G = gridDim.x;
     long long u = sk_lo(blockIdx.x, T, G);
     const long long u_end = sk_lo(blockIdx.x + 1, T, G);
 
-    // staging geometry of this lane: one DMA wave-instruction moves 8 rows x 8 chunks; wave w issues the A rows
-    // [8w, 8w + 8) and the B rows [32w, 32w + 32)
+    // staging geometry of this lane: one DMA wave-instruction moves 8 rows x 8 chunks of 16 bytes; DMA d of wave w is
+    // instruction w * ND + d of the stage's 40: the first 8 instructions carry the A rows, the other 32 the B rows
     const int sub = lane >> 3, cp = lane & 7;
-    const int a_row = wave * 8 + sub;
-    const int a_koff = (cp ^ ((a_row >> 1) & 7)) * 4;
-    int b_row[4], b_koff[4];
+    int d_row[ND], d_koff[ND];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        b_row[j] = (wave * 4 + j) * 8 + sub;
-        b_koff[j] = (cp ^ ((b_row[j] >> 1) & 7)) * 4;
+    for (int d = 0; d < ND; ++d) {
+        const int instr = d < NA ? wave * NA + d : 8 + wave * NB + (d - NA);
+        d_row[d] = (d < NA ? instr : instr - 8) * 8 + sub;           // row inside the A tile / the B tile
+        d_koff[d] = (cp ^ ((d_row[d] >> 1) & 7)) * 4;
     }
     // fragment geometry
     const int g = lane >> 5;
     const int fa_row = wm * 32 + (lane & 31), fa_swz = (fa_row >> 1) & 7;
-    int fb_row[2], fb_swz[2];
+    int fb_row[NT], fb_swz[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        fb_row[t] = wn * 64 + t * 32 + (lane & 31);
+    for (int t = 0; t < NT; ++t) {
+        fb_row[t] = wn * (SK_TN / WN) + t * 32 + (lane & 31);
         fb_swz[t] = (fb_row[t] >> 1) & 7;
     }
 
@@ -100,82 +140,321 @@ __global__ __launch_bounds__(SK_THREADS) void k_gemm_streamk(SkArgs a) {
         const int s_end = (long long)(S - s_begin) <= left ? S : s_begin + (int)left;
         const int m0 = (tile % a.tiles_m) * SK_TM, n0 = (tile / a.tiles_m) * SK_TN;
 
-        auto issue = [&](int s, int buf) {
-            const bool second = s >= a.S0;                             // wave-uniform: scalar selects, no indexed struct
-            const float *PA = second ? a.p[1].A : a.p[0].A, *PB = second ? a.p[1].B : a.p[0].B;
-            const long long lda = second ? a.p[1].lda : a.p[0].lda, ldb = second ? a.p[1].ldb : a.p[0].ldb;
+        // Row bases of this lane's DMA sources for both products, once per segment: the per-stage address is then one select
+        // and one 64-bit add per DMA (a full row * ld multiply in front of every DMA cost ~500 VALU cycles per stage and wave).
+        const float *rbase[2][ND];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+                rbase[q][d] = d < NA ? a.p[q].A + (long long)min(m0 + d_row[d], a.M - 1) * a.p[q].lda + d_koff[d]
+                                     : a.p[q].B + (long long)min(n0 + d_row[d], a.N - 1) * a.p[q].ldb + d_koff[d];
+        // DMA d of stage s into buffer buf.  Kept as cheap as it can be made -- a select, a 64-bit add, the M0 write and the
+        // DMA -- because a wave starts no MFMA while it issues one; the depth-padding test runs only in a product's last stage.
+        auto issue = [&](int s, int buf, int d) {
+            const bool second = s >= a.S0;                             // wave-uniform
             const int PK = second ? a.p[1].K : a.p[0].K;
             const int k0 = (second ? s - a.S0 : s) * SK_GK;
-            const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + buf * SK_STAGE_BYTES + wave * 1024);
-            {
-                const int r = min(m0 + a_row, a.M - 1), k = k0 + a_koff;
-                sk_glds16(k < PK ? PA + (long long)r * lda + k : g_sk_zero, base);
+            const int instr = d < NA ? wave * NA + d : 8 + wave * NB + (d - NA);
+            const unsigned dst = lds0 + buf * SK_STAGE_BYTES + instr * 1024;   // uniform: lds0, buf and wave live in SGPRs
+            const float *src = (second ? rbase[1][d] : rbase[0][d]) + k0;
+            if (k0 + SK_GK > PK) {                                     // uniform branch: only a product's last stage can run past its depth
+                if (k0 + d_koff[d] >= PK) src = a.zero;
             }
+            sk_glds16(src, dst);
+        };
+        auto issue_all = [&](int s, int buf) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = min(n0 + b_row[j], a.N - 1), k = k0 + b_koff[j];
-                sk_glds16(k < PK ? PB + (long long)r * ldb + k : g_sk_zero, base + SK_A_BYTES + (wave * 3 + j) * 1024);
-            }
+            for (int d = 0; d < ND; ++d) issue(s, buf, d);
         };
 
-        f32x16 acc[2];
+        f32x16 acc[NT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-        __syncthreads();                       // the previous segment's fragment reads are done: buffer 0 may be refilled
-        issue(s_begin, 0);
+        // Three LDS buffers in rotation, two stages of DMA in flight, ONE barrier per stage:
+        //   top of stage s:  wait until this wave's share of stage s has landed (its ND younger DMAs of stage s + 1 may
+        //                    still fly: vmcnt(ND)); barrier -> stage s is complete for everybody AND nobody still reads
+        //                    stage s - 1, whose buffer is refilled with stage s + 2 -- the DMAs are issued a few at a time
+        //                    in the shadow of the passes' MFMAs, not in a burst behind the barrier.
+        // (Measured and rejected: waiting for stage s + 1 one barrier early so that its first fragments can be read before
+        //  the barrier -- that leaves only ONE stage of DMA in flight and the wait at the barrier grew from 18 % to 23 %.)
+        __syncthreads();                       // the previous segment's fragment reads are done: the buffers may be refilled
+        issue_all(s_begin, 0);
+        if (s_begin + 1 < s_end) issue_all(s_begin + 1, 1);
+        int buf = 0;
         for (int s = s_begin; s < s_end; ++s) {
-            const int buf = (s - s_begin) & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of stage s has landed ...
-            __syncthreads();                                           // ... and everybody's; buffer buf ^ 1 is no longer read
-            if (s + 1 < s_end) issue(s + 1, buf ^ 1);                  // in flight underneath this stage's MFMAs
+            SK_STAMP(0);
+            if (s + 1 < s_end) {
+                if constexpr (ND == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            SK_STAMP(1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            SK_STAMP(2);
+            const bool more = s + 2 < s_end;
+            const int nbuf = buf == 0 ? 2 : buf - 1;                   // (buf + 2) % 3
             const char *base = smem + buf * SK_STAGE_BYTES;
-            float4 fa[4], fb[2][4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            // fragments of pass p + 1 are read before the MFMAs of pass p are issued (two register sets)
+            float4 fa[2], fb[NT][2];
+            auto read_pass = [&](int p, int set) {
                 const int c = 2 * p + g;
-                fa[p] = *reinterpret_cast<const float4 *>(base + (fa_row * 8 + (c ^ fa_swz)) * 16);
+                fa[set] = *reinterpret_cast<const float4 *>(base + (fa_row * 8 + (c ^ fa_swz)) * 16);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    fb[t][p] = *reinterpret_cast<const float4 *>(base + SK_A_BYTES + (fb_row[t] * 8 + (c ^ fb_swz[t])) * 16);
-            }
+                for (int t = 0; t < NT; ++t)
+                    fb[t][set] = *reinterpret_cast<const float4 *>(base + SK_A_BYTES + (fb_row[t] * 8 + (c ^ fb_swz[t])) * 16);
+            };
+            read_pass(0, 0);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
+                if (p + 1 < 4) read_pass(p + 1, (p + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);                     // the next pass's LDS reads are issued above this line
+                // 16 groups of NT MFMAs per stage (4 passes x the 4 depth values of a 16-byte fragment)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p].x, fb[t][p].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p].y, fb[t][p].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p].z, fb[t][p].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p].w, fb[t][p].w, acc[t], 0, 0, 0);
+                for (int c = 0; c < 4; ++c) {
+                    const float av = c == 0 ? fa[p & 1].x : c == 1 ? fa[p & 1].y : c == 2 ? fa[p & 1].z : fa[p & 1].w;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float bv = c == 0 ? fb[t][p & 1].x : c == 1 ? fb[t][p & 1].y : c == 2 ? fb[t][p & 1].z : fb[t][p & 1].w;
+                        if constexpr (SCHED != 4) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                        else acc[t][0] += av * bv;                      // diagnostic: no matrix work, the staging alone
+                    }
+                    if (p == 0 && c == 0) SK_STAMP(3);
+                    if (c == 0) {                                      // this pass's DMAs, behind its first group of MFMAs
+                        if constexpr (WAVES == 8) {
+                            // two waves per SIMD (w and w + 4) take turns: waves 0-3 issue in passes 0-1, waves 4-7 in 2-3
+                            if (more && (p >> 1) == (wave >> 2)) {
+                                issue(s + 2, nbuf, 2 * (p & 1));
+                                issue(s + 2, nbuf, 2 * (p & 1) + 1);
+                                if ((p & 1) == 1) issue(s + 2, nbuf, 4);
+                            }
+                        } else if (more && SCHED != 3) {               // one wave per SIMD: 10 DMAs over the 4 passes (3: diagnostic, none)
+                            issue(s + 2, nbuf, p);
+                            issue(s + 2, nbuf, 4 + p);
+                            if (p < 2) issue(s + 2, nbuf, 8 + p);
+                        }
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            SK_STAMP(4);
+            buf = buf == 2 ? 0 : buf + 1;
         }
 
         // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         const bool complete = s_begin == 0 && s_end == S;
         if (complete) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int n = n0 + wn * 64 + t * 32 + (lane & 31);
+            for (int t = 0; t < NT; ++t) {
+                const int n = n0 + wn * (SK_TN / WN) + t * 32 + (lane & 31);
                 if (n >= a.N) continue;
-                const float b = a.bias ? a.bias[n] : 0.0f;
-                float v[16];                                         // bias added ahead of the masked stores: a wait for the bias
-#pragma unroll                                                       // load inside every store branch would also wait for the stores
-                for (int r = 0; r < 16; ++r) v[r] = acc[t][r] + b;
-#pragma unroll
+                float b = a.bias ? a.bias[n] : 0.0f;
+                asm volatile("" : "+v"(b));      // the bias load is waited for HERE, once: left to the compiler, the wait sinks into
+#pragma unroll                                   // every masked store branch below, where vmcnt(0) also waits for the stores before it
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (m < a.M) a.C[(size_t)m * a.ldc + n] = v[r];
+                    if (m < a.M) a.C[(size_t)m * a.ldc + n] = acc[t][r] + b;
                 }
             }
         } else {
             // first segment of the block (the tile began in an earlier block): slot 0; a tile this block begins: slot 1
             float *dst = a.slab + ((size_t)blockIdx.x * 2 + (s_begin > 0 ? 0 : 1)) * SK_SLAB_FLOATS;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int n = wn * 64 + t * 32 + (lane & 31);
+            for (int t = 0; t < NT; ++t) {
+                const int n = wn * (SK_TN / WN) + t * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    dst[(size_t)m * SK_TN + n] = acc[t][r];
+                }
+            }
+        }
+        u += s_end - s_begin;
+    }
+}
+
+// The same stream-K decomposition with the roles split (in-kernel stamps, tools/stamp_streamk.py: a stage of the
+// kernel above takes 5 640 cycles -- 4 100 for its 64 MFMAs per SIMD, 680 at the stage boundary and 850 for the ten
+// DMAs each wave issues, which an in-order wave cannot overlap with its own MFMAs): waves 0-3 only read fragments and
+// issue MFMAs (one per SIMD, 32 x 128 each), waves 4-5 only move data: each issues 20 of the stage's 40 DMA
+// wave-instructions, waits for them two stages later and joins the same one-barrier-per-stage rhythm.
+constexpr int SKL_CONSUMERS = 4, SKL_LOADERS = 4, SKL_THREADS = (SKL_CONSUMERS + SKL_LOADERS) * 64;
+
+__global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_ld(SkArgs a) {
+    constexpr int NT = 4;                               // 32 x 32 accumulator tiles per consumer wave: 32 rows x 128 columns
+    constexpr int ND = 40 / SKL_LOADERS;                // DMA wave-instructions per loader wave and stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= SKL_CONSUMERS;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem);
+    const int S = a.S0 + a.S1;
+    const long long T = (long long)a.tiles_m * a.tiles_n * S, G = gridDim.x;
+    long long u = sk_lo(blockIdx.x, T, G);
+    const long long u_end = sk_lo(blockIdx.x + 1, T, G);
+
+    if (loader) {
+        // ---------------- loader waves: 20 DMA wave-instructions per stage each ----------------
+        // A loader shares its SIMD with a consumer whose MFMA stream would otherwise take every issue slot first (issue is
+        // arbitrated by priority, then age: stamps showed 570 cycles per DMA); its few instructions go ahead of the MFMAs.
+        __builtin_amdgcn_s_setprio(3);
+        const int lw = wave - SKL_CONSUMERS;
+        const int sub = lane >> 3, cp = lane & 7;
+        while (u < u_end) {
+            const int tile = (int)(u / S);
+            const int s_begin = (int)(u - (long long)tile * S);
+            const long long left = u_end - u;
+            const int s_end = (long long)(S - s_begin) <= left ? S : s_begin + (int)left;
+            const int m0 = (tile % a.tiles_m) * SK_TM, n0 = (tile / a.tiles_m) * SK_TN;
+            // Byte offsets of this lane's ND sources from the tile's A / B origin, for both products (instruction i < 8: A rows
+            // 8i.., else B rows 8(i - 8)..); 32 bits are enough (checked on the host: rows * ld * 4 < 2^32).
+            unsigned off[2][ND];
+            int koff[ND];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const int instr = lw * ND + d;
+                const int row = (instr < 8 ? instr : instr - 8) * 8 + sub;
+                koff[d] = (cp ^ ((row >> 1) & 7)) * 4;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    off[q][d] = instr < 8 ? (unsigned)(((long long)min(m0 + row, a.M - 1) * a.p[q].lda + koff[d]) * 4)
+                                          : (unsigned)(((long long)min(n0 + row, a.N - 1) * a.p[q].ldb + koff[d]) * 4);
+            }
+            auto issue_all = [&](int s, int buf) {
+                const bool second = s >= a.S0;                         // wave-uniform
+                const int PK = second ? a.p[1].K : a.p[0].K;
+                const int k0 = (second ? s - a.S0 : s) * SK_GK;
+                const float *A = (second ? a.p[1].A : a.p[0].A) + k0, *B = (second ? a.p[1].B : a.p[0].B) + k0;   // SGPR pairs
+                if (k0 + SK_GK <= PK) {                                // every stage but a product's last: no vector arithmetic
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        sk_glds16_saddr(lw * ND + d < 8 ? A : B, second ? off[1][d] : off[0][d], lds0 + buf * SK_STAGE_BYTES + (lw * ND + d) * 1024);
+                } else {                                               // depth padding: lanes past the depth read the zero page
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) {
+                        const float *src = (const float *)((const char *)(lw * ND + d < 8 ? A : B) + (second ? off[1][d] : off[0][d]));
+                        if (k0 + koff[d] >= PK) src = a.zero;
+                        sk_glds16(src, lds0 + buf * SK_STAGE_BYTES + (lw * ND + d) * 1024);
+                    }
+                }
+            };
+            // Rhythm (one barrier per stage, B_s at the top of stage s).  The loader arrives at B_s once stages <= s + 1 have
+            // landed, the consumers once they have finished reading stage s - 1.  Behind B_s the loader refills that buffer
+            // with stage s + 2, and the consumers may read stage s AND -- at the end of it, before B_(s+1) -- the first
+            // fragments of stage s + 1: their MFMA stream does not drain at the barrier.
+            __syncthreads();                   // the previous segment's fragment reads are done: the buffers may be refilled
+            issue_all(s_begin, 0);
+            if (s_begin + 1 < s_end) issue_all(s_begin + 1, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // B_(s_begin)
+            int buf = 0;
+            for (int s = s_begin; s < s_end; ++s) {
+                SK_STAMP(0);
+                if (s + 2 < s_end) issue_all(s + 2, buf == 0 ? 2 : buf - 1);
+                SK_STAMP(1);
+                if (s + 1 < s_end) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    SK_STAMP(2);
+                    __builtin_amdgcn_s_barrier();                      // B_(s+1)
+                }
+                SK_STAMP(3);
+                SK_STAMP(4);
+                buf = buf == 2 ? 0 : buf + 1;
+            }
+            u += s_end - s_begin;
+        }
+        return;
+    }
+
+    // ---------------- consumer waves: fragments + MFMAs only ----------------
+    const int wm = wave & 1, wn = wave >> 1;
+    const int g = lane >> 5;
+    const int fa_row = wm * 32 + (lane & 31), fa_swz = (fa_row >> 1) & 7;
+    int fb_row[NT], fb_swz[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        fb_row[t] = wn * 128 + t * 32 + (lane & 31);
+        fb_swz[t] = (fb_row[t] >> 1) & 7;
+    }
+    while (u < u_end) {
+        const int tile = (int)(u / S);
+        const int s_begin = (int)(u - (long long)tile * S);
+        const long long left = u_end - u;
+        const int s_end = (long long)(S - s_begin) <= left ? S : s_begin + (int)left;
+        const int m0 = (tile % a.tiles_m) * SK_TM, n0 = (tile / a.tiles_m) * SK_TN;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        __syncthreads();
+        __builtin_amdgcn_s_barrier();          // B_(s_begin): stages s_begin and s_begin + 1 have landed
+        asm volatile("" ::: "memory");
+        float4 fa[2], fb[NT][2];
+        auto read_pass = [&](int b, int p, int set) {
+            const char *base = smem + b * SK_STAGE_BYTES;
+            const int c = 2 * p + g;
+            fa[set] = *reinterpret_cast<const float4 *>(base + (fa_row * 8 + (c ^ fa_swz)) * 16);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                fb[t][set] = *reinterpret_cast<const float4 *>(base + SK_A_BYTES + (fb_row[t] * 8 + (c ^ fb_swz[t])) * 16);
+        };
+        int buf = 0;
+        read_pass(0, 0, 0);
+        for (int s = s_begin; s < s_end; ++s) {
+            SK_STAMP(0);
+            const bool next = s + 1 < s_end;
+            const int nbuf = buf == 2 ? 0 : buf + 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (p + 1 < 4) read_pass(buf, p + 1, (p + 1) & 1);
+                else if (next) read_pass(nbuf, 0, 0);                  // pass 0 of stage s + 1: landed since B_s
+                __builtin_amdgcn_sched_barrier(0);                     // the next pass's LDS reads are issued above this line
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p & 1].x, fb[t][p & 1].x, acc[t], 0, 0, 0);
+                if (p == 0) SK_STAMP(1);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p & 1].y, fb[t][p & 1].y, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p & 1].z, fb[t][p & 1].z, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p & 1].w, fb[t][p & 1].w, acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            SK_STAMP(2);
+            if (next) {
+                __builtin_amdgcn_s_barrier();                          // B_(s+1)
+                asm volatile("" ::: "memory");
+            }
+            SK_STAMP(3);
+            SK_STAMP(4);
+            buf = nbuf;
+        }
+        // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        const bool complete = s_begin == 0 && s_end == S;
+        if (complete) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = n0 + wn * 128 + t * 32 + (lane & 31);
+                if (n >= a.N) continue;
+                float b = a.bias ? a.bias[n] : 0.0f;
+                asm volatile("" : "+v"(b));      // the bias load is waited for HERE, once (see k_gemm_streamk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < a.M) a.C[(size_t)m * a.ldc + n] = acc[t][r] + b;
+                }
+            }
+        } else {
+            float *dst = a.slab + ((size_t)blockIdx.x * 2 + (s_begin > 0 ? 0 : 1)) * SK_SLAB_FLOATS;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = wn * 128 + t * 32 + (lane & 31);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);

@@ -335,8 +335,9 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
                         int M, int N, const float *bias, float *C, long long ldc, void *slab, size_t slab_bytes, hipStream_t stream,
                         bool *used) {
     *used = false;
-    if (g_gemm_force_tile != 0 && g_gemm_force_tile != 4) return POPE_OK;
-    if (!(g_gemm_force_tile == 4 || streamk_shape_ok(M, K0, K1, N))) return POPE_OK;
+    if (g_gemm_force_tile != 0 && g_gemm_force_tile < 4) return POPE_OK;
+    if (!(g_gemm_force_tile >= 4 || streamk_shape_ok(M, K0, K1, N))) return POPE_OK;
+    if ((long long)M * lda * 4 >= (1ll << 32) || (long long)N * ldb * 4 >= (1ll << 32)) return POPE_OK;   // the loaders' 32-bit byte offsets
     if (!sk_operand_ok(A0, lda, K0) || !sk_operand_ok(B0, ldb, K0) || (K1 > 0 && (!sk_operand_ok(A1, lda, K1) || !sk_operand_ok(B1, ldb, K1))))
         return POPE_OK;
     int cus = 0, rc;
@@ -352,11 +353,33 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
     if (grid > T) grid = T;
     if (!slab || slab_bytes < sk_slab_bytes((int)grid)) return POPE_OK;
     static bool opt_in = false;
+    static const float *zero_page[64];
+    int dev = 0;
+    POPE_HIP(hipGetDevice(&dev));
     if (!opt_in) {
-        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk_ld, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+#ifdef POPE_STAMP
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+#endif
         opt_in = true;
     }
-    hipLaunchKernelGGL(k_gemm_streamk, dim3((unsigned)grid), dim3(SK_THREADS), SK_LDS_BYTES, stream, a);
+    if (!zero_page[dev]) POPE_HIP(hipGetSymbolAddress((void **)&zero_page[dev], HIP_SYMBOL(g_sk_zero)));
+    a.zero = zero_page[dev];
+    if (g_gemm_force_tile == 4)                  // A/B: every wave stages its own share and computes (one wave per SIMD)
+        hipLaunchKernelGGL((k_gemm_streamk<4, 0>), dim3((unsigned)grid), dim3(256), SK_LDS_BYTES, stream, a);
+    else if (g_gemm_force_tile == 5)             // A/B: the same with two waves per SIMD
+        hipLaunchKernelGGL((k_gemm_streamk<8, 0>), dim3((unsigned)grid), dim3(512), SK_LDS_BYTES, stream, a);
+#ifdef POPE_STAMP
+    else if (g_gemm_force_tile == 8)             // diagnostic: no DMA in the loop
+        hipLaunchKernelGGL((k_gemm_streamk<4, 3>), dim3((unsigned)grid), dim3(256), SK_LDS_BYTES, stream, a);
+    else if (g_gemm_force_tile == 9)             // diagnostic: no MFMA
+        hipLaunchKernelGGL((k_gemm_streamk<4, 4>), dim3((unsigned)grid), dim3(256), SK_LDS_BYTES, stream, a);
+#endif
+    else                                         // default: 4 MFMA waves + 4 loader waves
+        hipLaunchKernelGGL(k_gemm_streamk_ld, dim3((unsigned)grid), dim3(SKL_THREADS), SK_LDS_BYTES, stream, a);
     hipLaunchKernelGGL(k_streamk_fixup, dim3(a.tiles_m * a.tiles_n, SK_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
     POPE_HIP(hipGetLastError());
     *used = true;
@@ -368,6 +391,9 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
 using namespace pope;
 
 #ifdef POPE_STAMP
+extern "C" int pope_debug_read_streamk_stamps(unsigned long long *host, int count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sk_stamps), (size_t)count * sizeof(unsigned long long));
+}
 extern "C" int pope_debug_read_gemm_stamps(unsigned long long *host, int count) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamps), (size_t)count * sizeof(unsigned long long));
 }

@@ -75,7 +75,7 @@ int pope_require_device(int32_t *cu_count_host);
 #define POPE_KNOB_LIVE_MODE         0   /* level kernel: -1 auto, 0 no live-bit table, 1 table in LDS, 2 table in global memory */
 #define POPE_KNOB_FINALIZE_VARIANT  1   /* 0 generic finalise kernel, 1 fast path (default), 2 fast path + non-temporal stores   */
 #define POPE_KNOB_FINALIZE_BLOCKS   2   /* grid of the fast finalise kernel (default 2048)                                       */
-#define POPE_KNOB_GEMM_TILE         3   /* SAGE GEMM: 0 auto, 1 64x64, 2 64x128, 3 128x256 tiles, 4 stream-K full-width tile      */
+#define POPE_KNOB_GEMM_TILE         3   /* SAGE GEMM: 0 auto, 1 64x64, 2 64x128, 3 128x256 tiles, 4 / 5 stream-K without loader waves */
 int pope_debug_set(int32_t knob, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ for n_dst, c_in, c_out in shapes:
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     want = xd.double() @ wr.double().t() + b.double()          # agg = 0 for the empty block
     res = {}
-    for name, tile in (("auto", 0), ("64x64", 1), ("64x128", 2), ("streamk", 4)):
+    for name, tile in (("auto", 0), ("64x64", 1), ("64x128", 2), ("sk 4 waves", 4), ("sk 8 waves", 5), ("auto", 0)):
         lib.pope_debug_set(_lib.KNOB_GEMM_TILE, tile)
         def run():
             _lib.check(lib.sage_conv_forward(_lib.ptr(rowptr), _lib.ptr(col), n_dst, n_dst, 0, _lib.ptr(xd), c_in, _lib.ptr(wl), _lib.ptr(b), _lib.ptr(wr),
@@ -42,4 +42,4 @@ for n_dst, c_in, c_out in shapes:
     flops = 4.0 * n_dst * c_in * c_out
     print(f"M={n_dst} K=2x{c_in} N={c_out}  (gather of an empty block included: ~{n_dst*c_in*4/4e6:.0f} us-ish fill)  hipBLASLt {lib_us:.1f} us")
     for k, (us, err) in res.items():
-        print(f"   {k:8s} {us:8.1f} us  {flops/us/1e6:6.1f} TF (whole call)  max err {err:.2e}")
+        print(f"   {k:10s} {us:8.1f} us  {flops/us/1e6:6.1f} TF (whole call)  max err {err:.2e}")

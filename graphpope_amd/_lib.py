@@ -27,6 +27,9 @@ SIGNATURES = {
     "pope_csr_aux_elems": (c_size_t, [c_int64]),
     "pope_csr_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_int32, c_void_p]),
+    "pope_csr_build_canonical": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pope_pagerank_weights": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "pope_pagerank_step": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p]),
     "pope_words": (c_int32, [c_int32]),
     "pope_plane_bytes": (c_size_t, [c_int64, c_int32]),
     "pope_bfs_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
@@ -52,6 +55,8 @@ SIGNATURES = {
     "pope_pairwise_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "pope_pairwise_minmax": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,
                                      c_int32, c_void_p, c_size_t, c_void_p]),
+    "pope_pairwise_features": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,
+                                       c_int32, c_void_p, c_size_t, c_void_p]),
     "pope_concat": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
     "sage_conv_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int32, c_int32]),
     "sage_conv_forward_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),

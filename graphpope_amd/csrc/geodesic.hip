@@ -18,6 +18,7 @@
 #include <vector>
 
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "common.h"
 
@@ -102,6 +103,13 @@ __global__ __launch_bounds__(256) void k_csr_scatter(const long long *__restrict
     }
 }
 
+__global__ __launch_bounds__(256) void k_index_check(const long long *__restrict__ ids, long long count, long long N, int *flag) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
+        bad |= ids[i] < 0 || ids[i] >= N;
+    if (bad) atomicOr(flag, 1);
+}
+
 // mrow[chunk] for a CSR built by the counting path (same format as k_csr_sorted writes): one thread per chunk.
 __global__ __launch_bounds__(256) void k_csr_lists(const int *__restrict__ rowptr, const int *__restrict__ erow,
                                                    int E, int *aux) {
@@ -119,6 +127,16 @@ __global__ __launch_bounds__(256) void k_csr_lists(const int *__restrict__ rowpt
 static size_t scan_temp_bytes(size_t n) {
     size_t bytes = 0;
     (void)rocprim::exclusive_scan(nullptr, bytes, (int *)nullptr, (int *)nullptr, 0, n, rocprim::plus<int>());
+    return bytes;
+}
+
+// Row-wise sort of the scattered targets (general CSR path): k_csr_scatter places the edges of a row in the order its
+// atomic cursor happened to hand out, which differs from run to run; sorted by target the CSR is a pure function of the
+// edge SET (duplicates stay, adjacent), so everything that reads neighbours by position (the fan-out sampler) is repeatable.
+static size_t rowsort_temp_bytes(size_t E, size_t N) {
+    size_t bytes = 0;
+    (void)rocprim::segmented_radix_sort_keys(nullptr, bytes, (const int *)nullptr, (int *)nullptr, (unsigned)E, (unsigned)N,
+                                            (const int *)nullptr, (const int *)nullptr);
     return bytes;
 }
 
@@ -774,23 +792,44 @@ static int aux_cap(int64_t E) { return (int)((E + CHUNK - 1) / CHUNK) + 1; }
 
 extern "C" size_t pope_csr_aux_elems(int64_t E) { return E < 0 ? 0 : (size_t)AUX_HEADER + (size_t)aux_cap(E); }
 
+struct CsrScratch {
+    size_t cnt, scan_tmp, cols, sort_tmp, total;
+};
+
+static CsrScratch csr_scratch_layout(int64_t N, int64_t E) {
+    // cnt[N + 1] | rocPRIM scan temp | unsorted targets [E] | rocPRIM segmented-sort temp   (only used for edge lists that
+    // are not sorted by source)
+    CsrScratch L;
+    size_t o = 0;
+    L.cnt = o;      o += align_up((size_t)(N + 1) * sizeof(int), 256);
+    L.scan_tmp = o; o += align_up(scan_temp_bytes((size_t)N + 1), 256);
+    L.cols = o;     o += align_up((size_t)(E > 0 ? E : 1) * sizeof(int), 256);
+    L.sort_tmp = o; o += align_up(rowsort_temp_bytes((size_t)E, (size_t)N), 256);
+    L.total = o;
+    return L;
+}
+
 extern "C" size_t pope_csr_scratch_bytes(int64_t N, int64_t E) {
-    (void)E;
-    if (N < 0) return 0;
-    // cnt[N + 1] | rocPRIM scan temp      (only used for edge lists that are not sorted by source)
-    return align_up((size_t)(N + 1) * sizeof(int), 256) + align_up(scan_temp_bytes((size_t)N + 1), 256);
+    if (N < 0 || E < 0) return 0;
+    return csr_scratch_layout(N, E).total;
 }
 
 static int csr_fallback(const long long *src, const long long *dst, int E, int N, int *rowptr, int *col, int *erow,
                         int *aux, void *scratch, hipStream_t stream) {
-    int *cnt = (int *)scratch;
-    void *scan_tmp = (char *)scratch + align_up((size_t)(N + 1) * sizeof(int), 256);
-    size_t scan_bytes = scan_temp_bytes((size_t)N + 1);
+    const CsrScratch L = csr_scratch_layout(N, E);
+    int *cnt = (int *)((char *)scratch + L.cnt);
+    void *scan_tmp = (char *)scratch + L.scan_tmp;
+    int *cols_unsorted = (int *)((char *)scratch + L.cols);
+    void *sort_tmp = (char *)scratch + L.sort_tmp;
+    size_t scan_bytes = scan_temp_bytes((size_t)N + 1), sort_bytes = rowsort_temp_bytes((size_t)E, (size_t)N);
     POPE_HIP(hipMemsetAsync(cnt, 0, (size_t)(N + 1) * sizeof(int), stream));
     hipLaunchKernelGGL(k_csr_count, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, E, cnt);
     POPE_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, cnt, rowptr, 0, (size_t)N + 1, rocprim::plus<int>(), stream));
     POPE_HIP(hipMemsetAsync(cnt, 0, (size_t)(N + 1) * sizeof(int), stream));
-    hipLaunchKernelGGL(k_csr_scatter, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, E, rowptr, cnt, col, erow);
+    hipLaunchKernelGGL(k_csr_scatter, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, E, rowptr, cnt, cols_unsorted, erow);
+    // every row's targets in ascending order: the result no longer depends on which edge won which atomic cursor value
+    POPE_HIP(rocprim::segmented_radix_sort_keys(sort_tmp, sort_bytes, (const int *)cols_unsorted, col, (unsigned)E, (unsigned)N,
+                                                (const int *)rowptr, (const int *)rowptr + 1, 0, 32, stream));
     POPE_HIP(hipMemsetAsync(aux, 0, AUX_HEADER * sizeof(int), stream));
     hipLaunchKernelGGL(k_csr_lists, dim3(capped_grid((size_t)aux_cap(E), 256)), dim3(256), 0, stream, rowptr, erow, E, aux);
     POPE_HIP(hipGetLastError());
@@ -813,6 +852,37 @@ extern "C" int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, i
                               void *stream_) {
     clear_error();
     return csr_build(edge_index, E, N, rowptr, col, erow, aux, scratch, scratch_bytes, defer_check, SeedArgs(), (hipStream_t)stream_);
+}
+
+// The canonical form regardless of the input order: counting sort by source, every row's targets ascending (repeated
+// edges adjacent).  What the rankings need (distinct-neighbour counts, SciPy's accumulation order); synchronises once.
+extern "C" int pope_csr_build_canonical(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col, int32_t *erow,
+                                        int32_t *aux, void *scratch, size_t scratch_bytes, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && E >= 0 && E < INT32_MAX, "pope_csr_build_canonical: need 0 < N < 2^31, 0 <= E < 2^31");
+    POPE_REQUIRE(rowptr && aux && scratch && ((edge_index && col && erow) || E == 0), "pope_csr_build_canonical: null pointer");
+    if (scratch_bytes < pope_csr_scratch_bytes(N, E)) {
+        set_error("pope_csr_build_canonical: scratch %zu < %zu bytes", scratch_bytes, pope_csr_scratch_bytes(N, E));
+        return POPE_ERR_WORKSPACE;
+    }
+    if (E == 0) {
+        POPE_HIP(hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * sizeof(int), stream));
+        POPE_HIP(hipMemsetAsync(aux, 0, AUX_HEADER * sizeof(int), stream));
+        return POPE_OK;
+    }
+    // index check first: the counting pass indexes its histogram with the source ids
+    int *flag = (int *)scratch;
+    POPE_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(k_index_check, dim3(capped_grid((size_t)2 * E, 256)), dim3(256), 0, stream, (const long long *)edge_index, 2 * E, (long long)N, flag);
+    int bad = 0;
+    POPE_HIP(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    POPE_HIP(hipStreamSynchronize(stream));
+    if (bad) {
+        set_error("pope_csr_build_canonical: edge_index holds a node id outside [0, %lld)", (long long)N);
+        return POPE_ERR_INDEX;
+    }
+    return csr_fallback((const long long *)edge_index, (const long long *)edge_index + E, (int)E, (int)N, rowptr, col, erow, aux, scratch, stream);
 }
 
 static int csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col, int32_t *erow,

@@ -6,9 +6,16 @@
 //   k_sqnorm          ||x||^2 of every node2vec row and anchor row, accumulated in f64
 //   k_pairwise        dot(X, A^T) with v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate; 64 x 128 tiles on the
 //                     machinery of gemm_tile.h: register double buffering, batched LDS fragment reads), metric
-//                     epilogue, raw values written straight into the [N, F+K] output, per-block column min/max
+//                     epilogue, raw values written straight into the [N, F+K] output, per-block column min/max.
+//                     The blocks also carry the feature copy out[:, :F] = x (utils.py:177 concat_into_features): each
+//                     streams its own rows' share between its tile product and its epilogue, so the copy's HBM time
+//                     (357 MB: 75 us as a pass of its own) hides under the other blocks' MFMAs and epilogue arithmetic.
 //   k_minmax_fold / k_minmax_reduce   column min/max over blocks (two stages) -> scale_ = 1/range (range < 10 eps -> 1), min_ = 0 - min*scale_
 //   k_minmax_apply    y = e * scale_ + min_ in place (two roundings, like NumPy's X *= scale_; X += min_)
+// Measured and rejected (round 2): computing the tile TWICE (statistics pass, then a pass that scales in its epilogue and
+// stores once) instead of raw store + apply pass.  f32 MFMAs issue on the vector ALUs' slots, so the ~25 VALU instructions
+// per output of the metric epilogue do not hide behind them: one tile pass costs ~100 us whether it stores or not, and two
+// of them took 244 us against 161 us for tile + apply (profiles/r02_pairwise_notes.txt).
 // Euclidean: sklearn upcasts f32 inputs to f64 (pairwise.py:582-653).  Here the row norms are accumulated in f64,
 // d2 = xx + aa - 2 dot is one f32 fma on the f32-accumulated MFMA dot (whose own error, ~1e-6 |x||a|, dominates);
 // where d2 is small against the norms (cancellation) the entry is recomputed as a direct sum of squared
@@ -25,6 +32,8 @@ constexpr int PM = 128, PN = 128, PWM = 4, PWN = 1;   // A/B: 4 waves stacked, e
 #else
 constexpr int PM = 64, PN = 128, PWM = 2, PWN = 2;    // rows of X x anchor columns per block: 4 waves as 2 x 2, each 32 x 64 (two MFMA tiles)
 #endif
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // One wave per row: sum of squares in f64 (sklearn row_norms on the upcast chunk).
 __global__ __launch_bounds__(256) void k_sqnorm(const float *__restrict__ m, long long rows, int D, double *__restrict__ out) {
@@ -57,11 +66,17 @@ __device__ __forceinline__ float wave_sqdist(const float *__restrict__ x, const 
 
 // grid = (ceil(N / PM), ceil(K / PN)).  dot(X, A^T) on the shared MFMA tile machinery (gemm_tile.h), then the metric
 // epilogue, the raw values into out[:, c0:], and this block's column min / max.
+// The feature copy a pass carries: float4 columns [c_lo, c_hi) of x [N, F4 * 4] -> out[:, 0 : F4 * 4]; x == nullptr: none.
+struct PwCopy {
+    const float *x;
+    int F4, c_lo, c_hi;
+};
+
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, int N, int D, const float *__restrict__ A,
                                                   int K, int metric, const double *__restrict__ xx, const double *__restrict__ aa,
                                                   float *__restrict__ out, long long out_cols, int c0,
-                                                  float *__restrict__ part_min, float *__restrict__ part_max, int Kpad) {
+                                                  float *__restrict__ part_min, float *__restrict__ part_max, int Kpad, PwCopy cp) {
     constexpr int NT = PN / PWN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *As = reinterpret_cast<float *>(smem);
@@ -76,7 +91,43 @@ __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const Operand Xo{X, D, 1}, Ao{A, D, 1}, none{nullptr, 0, 0};
+    // This block's share of the feature copy: its PM rows, the float4 columns split evenly over the tile columns.  The loads
+    // are issued BEFORE the tile product (up to CPN 16-byte pieces per thread wait in registers while the MFMAs run) and
+    // stored after it: as a load-store loop behind the product the copy added 95 us to the kernel, more than a pass of its own.
+    constexpr int CPN = 16;
+    f32x4v cpv[CPN];
+    int cp_q0 = 0, cp_width = 0, cp_items = 0;
+    if (cp.x) {
+        const int per = (cp.c_hi - cp.c_lo + (int)gridDim.y - 1) / (int)gridDim.y;
+        cp_q0 = cp.c_lo + (int)blockIdx.y * per;
+        cp_width = max(0, min(cp.c_hi, cp_q0 + per) - cp_q0);
+        cp_items = min(PM, N - row0) * cp_width;
+        const f32x4v *src = reinterpret_cast<const f32x4v *>(cp.x) + (size_t)row0 * cp.F4;
+#pragma unroll
+        for (int j = 0; j < CPN; ++j) {
+            const int i = tid + 256 * j;
+            if (i < cp_items) {
+                const int r = i / cp_width;
+                cpv[j] = __builtin_nontemporal_load(src + (size_t)r * cp.F4 + cp_q0 + (i - r * cp_width));
+            }
+        }
+    }
     mfma_accumulate<PM, PN, PWM, PWN, LAYOUT, LAYOUT>(acc, Xo, Ao, 0, D, none, none, 0, 0, row0, col0, N, K, As, Bs);
+    if (cp.x) {
+#pragma unroll
+        for (int j = 0; j < CPN; ++j) {
+            const int i = tid + 256 * j;
+            if (i < cp_items) {
+                const int r = i / cp_width;
+                *reinterpret_cast<f32x4v *>(out + (size_t)(row0 + r) * out_cols + 4 * (cp_q0 + (i - r * cp_width))) = cpv[j];
+            }
+        }
+        const f32x4v *src = reinterpret_cast<const f32x4v *>(cp.x) + (size_t)row0 * cp.F4;
+        for (int i = tid + 256 * CPN; i < cp_items; i += 256) {       // wider shares than CPN pieces per thread (F > 1000 or K <= 128)
+            const int r = i / cp_width, q = cp_q0 + (i - r * cp_width);
+            *reinterpret_cast<f32x4v *>(out + (size_t)(row0 + r) * out_cols + 4 * q) = __builtin_nontemporal_load(src + (size_t)r * cp.F4 + q);
+        }
+    }
 
     // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     // It is instruction-bound (32 outputs per thread), so everything that depends on the row only is hoisted out of the
@@ -263,45 +314,63 @@ extern "C" size_t pope_pairwise_scratch_bytes(int64_t N, int32_t K, int32_t D) {
     return pw_layout(N, K).total;
 }
 
-extern "C" int pope_pairwise_minmax(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric,
-                                    float *out, int64_t out_cols, int32_t c0, void *scratch, size_t scratch_bytes,
-                                    void *stream_) {
-    clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    POPE_REQUIRE(X && A && out && scratch, "pope_pairwise_minmax: null pointer");
-    POPE_REQUIRE(N > 0 && N < INT32_MAX && K > 0 && D > 0 && c0 >= 0 && out_cols >= (int64_t)c0 + K, "pope_pairwise_minmax: bad size");
-    POPE_REQUIRE(metric >= 0 && metric <= 2, "pope_pairwise_minmax: unknown metric %d", metric);
-    const PwLayout L = pw_layout(N, K);
-    if (scratch_bytes < L.total) {
-        set_error("pope_pairwise_minmax: scratch %zu < %zu bytes", scratch_bytes, L.total);
-        return POPE_ERR_WORKSPACE;
-    }
-    char *base = (char *)scratch;
+template <int LAYOUT>
+static int pairwise_passes(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric, const float *x, int32_t F,
+                           float *out, int64_t out_cols, int32_t c0, const PwLayout &L, char *base, hipStream_t stream) {
     double *xx = (double *)(base + L.xx), *aa = (double *)(base + L.aa);
     float *pmin = (float *)(base + L.pmin), *pmax = (float *)(base + L.pmax);
     float *fmin = (float *)(base + L.fmin), *fmax = (float *)(base + L.fmax);
     float *scale = (float *)(base + L.scale), *shift = (float *)(base + L.shift);
-
-    hipLaunchKernelGGL(k_sqnorm, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, X, (long long)N, D, xx);
-    hipLaunchKernelGGL(k_sqnorm, dim3(capped_grid((size_t)K * 64, 256)), dim3(256), 0, stream, A, (long long)K, D, aa);
-    const Operand Xo{X, D, 1}, Ao{A, D, 1};
-    const bool vec = pick_layout(Xo, (int)N, D) == LAYOUT_KC_VEC && pick_layout(Ao, K, D) == LAYOUT_KC_VEC;
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        POPE_HIP(hipFuncSetAttribute((const void *)k_pairwise<LAYOUT_KC_VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pw_lds_bytes()));
-        POPE_HIP(hipFuncSetAttribute((const void *)k_pairwise<LAYOUT_GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pw_lds_bytes()));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_pairwise<LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pw_lds_bytes()));
         lds_opt_in = true;
     }
-    if (vec)
-        hipLaunchKernelGGL(k_pairwise<LAYOUT_KC_VEC>, dim3(L.nblocks, L.Kpad / PN), dim3(256), pw_lds_bytes(), stream, X, (int)N, D, A, K, metric,
-                           xx, aa, out, (long long)out_cols, c0, pmin, pmax, L.Kpad);
-    else
-        hipLaunchKernelGGL(k_pairwise<LAYOUT_GENERIC>, dim3(L.nblocks, L.Kpad / PN), dim3(256), pw_lds_bytes(), stream, X, (int)N, D, A, K, metric,
-                           xx, aa, out, (long long)out_cols, c0, pmin, pmax, L.Kpad);
+    const PwCopy copy{x, F / 4, 0, F / 4};
+    hipLaunchKernelGGL(k_pairwise<LAYOUT>, dim3(L.nblocks, L.Kpad / PN), dim3(256), pw_lds_bytes(), stream, X, (int)N, D, A, K, metric, xx, aa,
+                       out, (long long)out_cols, c0, pmin, pmax, L.Kpad, copy);
     hipLaunchKernelGGL(k_minmax_fold, dim3((K + 63) / 64, RSPLIT), dim3(256), 0, stream, pmin, pmax, L.nblocks, K, L.Kpad, fmin, fmax);
     hipLaunchKernelGGL(k_minmax_reduce, dim3((K + 255) / 256), dim3(256), 0, stream, fmin, fmax, K, L.Kpad, scale, shift);
-    hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K,
-                       (long long)out_cols, c0, scale, shift);
+    hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K, (long long)out_cols, c0,
+                       scale, shift);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
+}
+
+static bool aligned16p(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" int pope_pairwise_features(const float *x, int32_t F, const float *X, int64_t N, int32_t D, const float *A, int32_t K,
+                                      int32_t metric, float *out, int64_t out_cols, int32_t c0, void *scratch, size_t scratch_bytes,
+                                      void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(X && A && out && scratch, "pope_pairwise_features: null pointer");
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && K > 0 && D > 0 && F >= 0 && c0 >= 0 && out_cols >= (int64_t)c0 + K, "pope_pairwise_features: bad size");
+    POPE_REQUIRE(!x || c0 >= F, "pope_pairwise_features: the embedding columns (c0 = %d) overlap the %d feature columns", c0, F);
+    POPE_REQUIRE(metric >= 0 && metric <= 2, "pope_pairwise_features: unknown metric %d", metric);
+    const PwLayout L = pw_layout(N, K);
+    if (scratch_bytes < L.total) {
+        set_error("pope_pairwise_features: scratch %zu < %zu bytes", scratch_bytes, L.total);
+        return POPE_ERR_WORKSPACE;
+    }
+    char *base = (char *)scratch;
+    if (x && F > 0 && !((F & 3) == 0 && (out_cols & 3) == 0 && aligned16p(x) && aligned16p(out))) {
+        // odd widths / unaligned bases: the copy runs as its own pass
+        int rc = pope_concat(x, N, F, out, out_cols, stream_);
+        if (rc) return rc;
+        x = nullptr;
+    }
+    if (F == 0) x = nullptr;
+    hipLaunchKernelGGL(k_sqnorm, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, X, (long long)N, D, (double *)(base + L.xx));
+    hipLaunchKernelGGL(k_sqnorm, dim3(capped_grid((size_t)K * 64, 256)), dim3(256), 0, stream, A, (long long)K, D, (double *)(base + L.aa));
+    const Operand Xo{X, D, 1}, Ao{A, D, 1};
+    const bool vec = pick_layout(Xo, (int)N, D) == LAYOUT_KC_VEC && pick_layout(Ao, K, D) == LAYOUT_KC_VEC;
+    if (vec) return pairwise_passes<LAYOUT_KC_VEC>(X, N, D, A, K, metric, x, F, out, out_cols, c0, L, base, stream);
+    return pairwise_passes<LAYOUT_GENERIC>(X, N, D, A, K, metric, x, F, out, out_cols, c0, L, base, stream);
+}
+
+extern "C" int pope_pairwise_minmax(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric,
+                                    float *out, int64_t out_cols, int32_t c0, void *scratch, size_t scratch_bytes,
+                                    void *stream_) {
+    return pope_pairwise_features(nullptr, 0, X, N, D, A, K, metric, out, out_cols, c0, scratch, scratch_bytes, stream_);
 }

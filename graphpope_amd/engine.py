@@ -282,6 +282,61 @@ def closeness_centrality(edge_index: torch.Tensor, num_nodes: int, batch: int = 
     return out
 
 
+def build_csr_canonical(edge_index: torch.Tensor, num_nodes: int) -> Csr:
+    """Csr with every row's targets ascending (repeated edges adjacent), whatever the order of ``edge_index``."""
+    lib = _lib.load()
+    assert edge_index.is_cuda and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.shape[0] == 2
+    ei = edge_index.contiguous()
+    e, dev = ei.shape[1], ei.device
+    with torch.cuda.device(dev):
+        rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+        padded = (max(e, 1) + 63) // 64 * 64
+        col = torch.empty(padded, dtype=torch.int32, device=dev)
+        erow = torch.empty(padded, dtype=torch.int32, device=dev)
+        aux = torch.empty(lib.pope_csr_aux_elems(e), dtype=torch.int32, device=dev)
+        scratch = _bytes(lib.pope_csr_scratch_bytes(num_nodes, e), dev)
+        check(lib.pope_csr_build_canonical(ptr(ei), e, num_nodes, ptr(rowptr), ptr(col), ptr(erow), ptr(aux), ptr(scratch),
+                                           scratch.numel(), _stream()))
+    return Csr(rowptr, col, erow, aux, num_nodes, e, ei, True)
+
+
+def pagerank(edge_index: torch.Tensor, num_nodes: int, alpha: float = 0.85, max_iter: int = 100, tol: float = 1.0e-6) -> np.ndarray:
+    """nx.pagerank(to_networkx(data)) (utils.py:26-30; NetworkX 3's SciPy power iteration) for every node, float64 [N],
+    bit-identical to NetworkX: the sparse product runs on the GPU in SciPy's accumulation order (pope_pagerank_step); the
+    two scalar reductions of an iteration -- the dangling mass (a Python sum in index order) and the l1 convergence norm
+    (NumPy's pairwise sum) -- are evaluated here on the copied-back vector exactly as the reference's interpreter does.
+
+    Raises RuntimeError if the iteration does not converge within ``max_iter`` (NetworkX: PowerIterationFailedConvergence)."""
+    lib = _lib.load()
+    dev = require_gpu(edge_index.device)
+    n = int(num_nodes)
+    if n == 0:
+        return np.zeros(0, dtype=np.float64)
+    ei = edge_index.to(dev, torch.int64).contiguous()
+    by_source = build_csr_canonical(ei, n)
+    by_target = build_csr_canonical(ei.flip(0).contiguous(), n)          # rows = targets, entries = sources, ascending
+    with torch.cuda.device(dev):
+        w = torch.empty(n, dtype=torch.float64, device=dev)
+        check(lib.pope_pagerank_weights(ptr(by_source.rowptr), ptr(by_source.col), n, ptr(w), _stream()))
+        dangling = np.where(w.cpu().numpy() == 0.0)[0]
+        x_host = np.repeat(1.0 / n, n)
+        bufs = [torch.as_tensor(x_host, device=dev), torch.empty(n, dtype=torch.float64, device=dev)]
+        staging = torch.empty(n, dtype=torch.float64, pin_memory=True)
+        for it in range(max_iter):
+            dsum = float(sum(x_host[dangling]))                            # the reference's Python sum, index order
+            check(lib.pope_pagerank_step(ptr(by_target.rowptr), ptr(by_target.col), n, ptr(bufs[0]), ptr(w), dsum, float(alpha),
+                                         ptr(bufs[1]), _stream()))
+            staging.copy_(bufs[1], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            x_new = staging.numpy().copy()
+            err = np.absolute(x_new - x_host).sum()
+            x_host = x_new
+            bufs.reverse()
+            if err < n * tol:
+                return x_host
+    raise RuntimeError(f"pagerank: power iteration failed to converge within {max_iter} iterations")
+
+
 def hop_matrix(hp: HopPlanes) -> torch.Tensor:
     """int32 [N, K], -1 = unreachable (the integers behind the reference's floats)."""
     lib = _lib.load()
@@ -400,14 +455,24 @@ def pairwise_embedding(emb: torch.Tensor, anchors, distance_function: str, ancho
 
 def pairwise_features(x: torch.Tensor, emb: torch.Tensor, anchors, distance_function: str,
                       anchor_embeddings=None) -> torch.Tensor:
-    """[N, F+K] float32 on the device: the features next to :func:`pairwise_embedding` (device-resident callers)."""
+    """[N, F+K] float32 on the device: the features next to :func:`pairwise_embedding` (device-resident callers); the
+    feature copy rides inside the tile kernel (pope_pairwise_features)."""
     lib = _lib.load()
     dev = require_gpu(x.device)
-    _lib.METRIC[distance_function]
+    metric = _lib.METRIC[distance_function]
     x = x.contiguous()
+    emb = emb.to(dev, torch.float32).contiguous()
     n, f = x.shape
-    k = len(anchor_embeddings) if anchor_embeddings is not None else len(anchors)
+    d = emb.shape[1]
+    if anchor_embeddings is not None:
+        a = torch.as_tensor(anchor_embeddings).to(dev, torch.float32).contiguous()
+        assert a.dim() == 2 and a.shape[1] == d
+    else:
+        a = emb.index_select(0, torch.as_tensor(np.asarray(anchors, dtype=np.int64), device=dev)).contiguous()
+    k = a.shape[0]
     with torch.cuda.device(dev):
         out = torch.empty((n, f + k), dtype=torch.float32, device=dev)
-        check(lib.pope_concat(ptr(x), n, f, ptr(out), f + k, _stream()))
-    return pairwise_embedding(emb, anchors, distance_function, anchor_embeddings, out=out, c0=f)
+        scratch = _bytes(lib.pope_pairwise_scratch_bytes(n, k, d), dev)
+        check(lib.pope_pairwise_features(ptr(x), f, ptr(emb), n, d, ptr(a), k, metric, ptr(out), f + k, f, ptr(scratch),
+                                         scratch.numel(), _stream()))
+    return out

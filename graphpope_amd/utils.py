@@ -34,18 +34,16 @@ from . import engine
 NODE2VEC_DIR = os.environ.get("GRAPHPOPE_DATA_DIR", osp.join(osp.dirname(osp.realpath(__file__)), "data"))
 
 def _host_rankings():
-    """utils.py:26-60: the one-off NetworkX rankings that stay on the host, call for call.
-    nx.pagerank_scipy was folded into nx.pagerank in NetworkX 3 (same SciPy power iteration)."""
+    """utils.py:32-60: the one-off NetworkX rankings that stay on the host, call for call."""
     import networkx as nx
     return {
-        "pagerank": getattr(nx, "pagerank_scipy", nx.pagerank),                  # utils.py:28
         "betweenness_centrality": nx.betweenness_centrality,                      # utils.py:34
         "eigenvector_centrality": nx.eigenvector_centrality_numpy,                # utils.py:46
         "clustering_coefficient": nx.clustering,                                  # utils.py:58
     }
 
 
-_CENTRALITIES = ("pagerank", "betweenness_centrality", "eigenvector_centrality", "clustering_coefficient")
+_CENTRALITIES = ("betweenness_centrality", "eigenvector_centrality", "clustering_coefficient")
 
 
 def _device():
@@ -69,9 +67,11 @@ def sample_anchor_nodes(data, num_anchor_nodes, sampling_method):
     to_networkx builds: repeated edges collapsed, ascending stable sort, last K kept: utils.py:38-42).
     'closeness_centrality' runs the multi-source BFS kernel from every node (engine.closeness_centrality) and
     reproduces NetworkX's scores bit for bit, hence the same anchors (utils.py:50-54).
-    The remaining rankings (pagerank, betweenness, eigenvector, clustering) are the reference's own one-off NetworkX
-    calls, repeated on the host on the DiGraph to_networkx would build (anchor selection is not
-    the accelerated path; the BFS from the chosen anchors is).
+    'pagerank' runs the SciPy power iteration of nx.pagerank as SpMV over the device CSR (engine.pagerank), scores
+    bit-identical to NetworkX (utils.py:26-30).
+    The remaining rankings (betweenness, eigenvector, clustering) are the reference's own one-off NetworkX calls, repeated
+    on the host on the DiGraph to_networkx would build (anchor selection is not the accelerated
+    path; the BFS from the chosen anchors is).
     """
     if sampling_method == "stochastic":
         node_indices = np.arange(data.num_nodes)
@@ -88,6 +88,13 @@ def sample_anchor_nodes(data, num_anchor_nodes, sampling_method):
         # same ascending stable sort, same last-K keys.
         ei = data.edge_index.detach().to(_device(), torch.int64)
         score = engine.closeness_centrality(ei, int(data.num_nodes))
+        order = np.argsort(score, kind="stable")
+        return order[-num_anchor_nodes:].tolist()
+    if sampling_method == "pagerank":
+        # utils.py:26-30 nx.pagerank_scipy (folded into nx.pagerank in NetworkX 3: the same SciPy power iteration), as SpMV
+        # iterations over the device CSR; float64 scores bit-identical to NetworkX, hence the same last-K keys.
+        ei = engine.stage_to_device(data.edge_index.detach(), _device()).to(torch.int64)
+        score = engine.pagerank(ei, int(data.num_nodes))
         order = np.argsort(score, kind="stable")
         return order[-num_anchor_nodes:].tolist()
     if sampling_method in _CENTRALITIES:

@@ -25,8 +25,11 @@
  *                            utils.py:129-135
  *   pope_geodesic_run        utils.py:144-145    get_geodesic_distance_vector + concat_into_features in one call
  *   pope_geodesic_column_stats  utils.py:50-54   the BFS sums behind nx.closeness_centrality (biased anchor selection)
+ *   pope_pagerank_weights /  utils.py:26-30      nx.pagerank_scipy power iteration as SpMV over the device CSR
+ *   pope_pagerank_step                           (biased anchor selection, README's best row)
  *   pope_geodesic_hops       (no counterpart)    the integer hop matrix the floats are made of; parity tests
  *   pope_pairwise_minmax     utils.py:158-176    sklearn cosine/euclidean pairwise + MinMaxScaler
+ *   pope_pairwise_features   utils.py:158-177    the same + concat_into_features inside the tile kernel
  *   pope_concat              utils.py:129-135    torch.cat for the node2vec branch (device-resident callers)
  *   pope_host_copy_2d        utils.py:129-135    torch.cat's feature half on the host cores (host -> host callers)
  *   sage_conv_forward /      main.py:206 and     PyG SAGEConv((x_src, x_dst), adj_t): mean aggregation over the
@@ -93,8 +96,9 @@ size_t pope_csr_aux_elems(int64_t E);          /* int32 elements of `aux` below 
  * Written (all caller-allocated, int32):
  *   rowptr [N + 1], col [E rounded up to a multiple of 4, >= 4], erow [same]: CSR slot p holds the edge erow[p] -> col[p], slots sorted
  *       by erow (erow is the row id of every slot: the edge-parallel BFS kernel streams erow/col instead of
- *       chasing rowptr).  Column order inside a row is unspecified unless edge_index is already sorted by source
- *       (PyG's coalesced order; then it is preserved and no atomics are used).
+ *       chasing rowptr).  Column order inside a row: the edge list's own order if edge_index is already sorted by source
+ *       (PyG's coalesced order: preserved, no atomics); otherwise ascending by target (a row-wise sort follows the
+ *       counting scatter, so the CSR is a pure function of the edge set: repeated builds are identical).
  *   aux [pope_csr_aux_elems(E)]: header (counts, status flags) + the rows that span several 256-slot chunks.
  * defer_check = 0: synchronises `stream` once; returns POPE_ERR_INDEX for an id outside [0, N) and falls back
  *   to a counting sort when edge_index is not sorted by source.
@@ -104,6 +108,28 @@ size_t pope_csr_aux_elems(int64_t E);          /* int32 elements of `aux` below 
  */
 int pope_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col, int32_t *erow,
                    int32_t *aux, void *scratch, size_t scratch_bytes, int32_t defer_check, void *stream);
+
+/*
+ * The same CSR in canonical form whatever the order of edge_index: rows by source, every row's targets ascending
+ * (repeated edges adjacent).  Synchronises `stream` once (index check).  Used by the rankings below.
+ */
+int pope_csr_build_canonical(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr, int32_t *col, int32_t *erow,
+                             int32_t *aux, void *scratch, size_t scratch_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Biased anchor selection: PageRank scores (utils.py:26-30 nx.pagerank_scipy(to_networkx(data)); NetworkX 3: nx.pagerank),
+ * float64, reproduced bit for bit so that the ascending stable sort picks the reference's anchors.
+ *   pope_pagerank_weights  w[j] = 1 / (distinct targets of j), 0 for dangling nodes, from the canonical CSR by source.
+ *   pope_pagerank_step     x_out[i] = alpha * (sum over the in-neighbours j of i, ascending, of w[j] * x[j]
+ *                                               + dangling_sum / N) + (1 - alpha) / N
+ *                          over the canonical CSR of the REVERSED edge list (rows = targets, entries = sources).  One
+ *                          power iteration; the host binding owns the loop (dangling_sum = sum of x over the dangling
+ *                          nodes in index order, convergence on sum |x - xlast| < N * tol, as SciPy / NumPy evaluate them).
+ * Asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------------------ */
+int pope_pagerank_weights(const int32_t *rowptr, const int32_t *col, int64_t N, double *w, void *stream);
+int pope_pagerank_step(const int32_t *rowptr_by_target, const int32_t *sources, int64_t N, const double *x, const double *w,
+                       double dangling_sum, double alpha, double *x_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Geodesic embedding.
@@ -234,6 +260,15 @@ size_t pope_pairwise_scratch_bytes(int64_t N, int32_t K, int32_t D);
 int pope_pairwise_minmax(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric,
                          float *out, int64_t out_cols, int32_t c0, void *scratch, size_t scratch_bytes,
                          void *stream);
+
+/*
+ * The same with the feature half of utils.py:177 concat_into_features fused in: out[v, 0:F] = x[v, :] (x float32 [N, F],
+ * may be NULL) is streamed by the blocks of the tile kernel between their product and their epilogue, next to the embedding
+ * columns out[v, c0 + j], c0 >= F: the copy's HBM time hides under the MFMA work.  Asynchronous on `stream`.
+ */
+int pope_pairwise_features(const float *x, int32_t F, const float *X, int64_t N, int32_t D, const float *A, int32_t K,
+                           int32_t metric, float *out, int64_t out_cols, int32_t c0, void *scratch, size_t scratch_bytes,
+                           void *stream);
 
 /* out[v, 0:F] = x[v, :] for a float32 [N, out_cols] matrix (the feature half of torch.cat). Asynchronous. */
 int pope_concat(const float *x, int64_t N, int32_t F, float *out, int64_t out_cols, void *stream);

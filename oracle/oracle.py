@@ -173,6 +173,41 @@ def geodesic_pairs_networkx_pool(edge_index: np.ndarray, num_nodes: int, anchors
             {"graph_build_s": t1 - t0, "pool_s": t2 - t1})
 
 
+def pagerank_scores(edge_index: np.ndarray, num_nodes: int, alpha=0.85, max_iter=100, tol=1.0e-6) -> np.ndarray:
+    """nx.pagerank_scipy(to_networkx(data)) (utils.py:26-30; NetworkX 3: nx.pagerank -> _pagerank_scipy) restated without
+    NetworkX / SciPy: DiGraph semantics (one edge per distinct pair), x @ A accumulated per target over its sources in
+    ascending order (SciPy's csc_matvec on A^T), Python sum for the dangling mass, NumPy sum for the l1 norm.  Bit-identical
+    to NetworkX 3.4.2 + SciPy 1.15.3 (tests/test_oracle.py).  Pure-Python inner loop: small graphs only."""
+    n = int(num_nodes)
+    ei = np.asarray(edge_index, dtype=np.int64)
+    key = np.unique(ei[0] * n + ei[1])
+    src, dst = key // n, key % n
+    outdeg = np.bincount(src, minlength=n).astype(np.float64)
+    w = np.zeros(n)
+    nz = outdeg != 0
+    w[nz] = 1.0 / outdeg[nz]
+    dangling = np.where(outdeg == 0)[0]
+    order = np.lexsort((src, dst))
+    rsrc = src[order].tolist()
+    rptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))]).tolist()
+    x = np.repeat(1.0 / n, n)
+    p = np.repeat(1.0 / n, n)
+    for _ in range(max_iter):
+        xlast = x
+        xl, wl = x.tolist(), w.tolist()
+        y = np.zeros(n)
+        for i in range(n):
+            acc = 0.0
+            for q in range(rptr[i], rptr[i + 1]):
+                j = rsrc[q]
+                acc += wl[j] * xl[j]
+            y[i] = acc
+        x = alpha * (y + sum(x[dangling]) * p) + (1 - alpha) * p
+        if np.absolute(x - xlast).sum() < n * tol:
+            return x
+    raise RuntimeError("pagerank: power iteration failed to converge")
+
+
 # --------------------------------------------------------------------------------------------
 # node2vec-space pairwise + min-max  (/root/reference/utils.py:149-180)
 # --------------------------------------------------------------------------------------------

@@ -343,3 +343,68 @@ def test_runs_on_a_side_stream(dev, oracle):
     side.synchronize()
     assert np.array_equal(hops.cpu().numpy(), oracle.geodesic_hops(ei, n, anchors))
     assert np.array_equal(out.cpu().numpy().view(np.uint32), oracle.geodesic_features(x.cpu().numpy(), ei, n, anchors).view(np.uint32))
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_pagerank_matches_networkx_bit_for_bit(symmetric, dev):
+    """sampling_method='pagerank' (utils.py:26-30): the SpMV power iteration on the device gives NetworkX's float64 scores
+    bit for bit (shuffled edge list with repeated edges and dangling nodes), hence the reference's anchors."""
+    import networkx as nx
+    from graphpope_amd import engine, synth, utils as gp
+    ei, n = synth.rmat(11, edge_factor=4, seed=21, symmetric=symmetric)
+    ei = np.concatenate([ei, ei[:, :500]], axis=1)
+    ei = ei[:, np.random.RandomState(3).permutation(ei.shape[1])]
+    g = nx.DiGraph()
+    g.add_nodes_from(range(n))
+    g.add_edges_from(zip(ei[0].tolist(), ei[1].tolist()))
+    want = nx.pagerank(g)
+    got = engine.pagerank(torch.as_tensor(ei, device=dev), n)
+    assert np.array_equal(got, np.array([want[v] for v in range(n)]))
+
+    class Data:
+        pass
+    d = Data()
+    d.edge_index, d.num_nodes = torch.as_tensor(ei), n
+    ref = list({k: v for k, v in sorted(want.items(), key=lambda item: item[1])}.keys())[-33:]      # the reference's selection
+    assert gp.sample_anchor_nodes(d, 33, "pagerank") == ref
+
+
+def test_pagerank_anchors_match_reference_golden_and_flickr_size(dev):
+    """tests/golden/anchors_centrality.npz holds the reference's own sample_anchor_nodes(..., 'pagerank'); at Flickr size the
+    GPU scores are compared with NetworkX run here."""
+    import networkx as nx
+    from graphpope_amd import engine, synth, utils as gp
+    g = np.load(os.path.join(GOLDEN, "anchors_centrality.npz"))
+
+    class Data:
+        pass
+    d = Data()
+    d.edge_index, d.num_nodes = torch.as_tensor(g["edge_index"].astype(np.int64)), int(g["num_nodes"])
+    assert gp.sample_anchor_nodes(d, 24, "pagerank") == g["pagerank"].tolist()
+    ei, n = synth.flickr_like()
+    G = nx.DiGraph()
+    G.add_nodes_from(range(n))
+    G.add_edges_from(zip(ei[0].tolist(), ei[1].tolist()))
+    want = nx.pagerank(G)
+    got = engine.pagerank(torch.as_tensor(ei, device=dev), n)
+    assert np.array_equal(got, np.array([want[v] for v in range(n)]))
+
+
+def test_general_csr_build_is_deterministic(dev):
+    """A shuffled edge list goes through the counting path; rows are then sorted by target, so two builds give identical
+    arrays (the atomic cursors alone would not) and the fan-out sampler draws the same batch for the same seed."""
+    from graphpope_amd import engine, synth
+    from graphpope_amd.sampler import NeighborSampler
+    ei, n = synth.rmat(13, edge_factor=8, seed=3)
+    ei = ei[:, np.random.RandomState(0).permutation(ei.shape[1])]
+    eid = torch.as_tensor(ei, device=dev)
+    a, b = engine.build_csr(eid, n), engine.build_csr(eid, n)
+    e = ei.shape[1]
+    assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.col[:e], b.col[:e]) and torch.equal(a.erow[:e], b.erow[:e])
+    col, rowptr = a.col[:e].cpu().numpy(), a.rowptr.cpu().numpy()
+    for v in np.random.RandomState(1).choice(n, 200):
+        assert np.array_equal(col[rowptr[v]:rowptr[v + 1]], np.sort(ei[1][ei[0] == v]))
+    seeds = torch.arange(0, 300, device=dev)
+    s1 = NeighborSampler(a.rowptr, a.col, n, (5, 3)).sample(seeds, seed=9)
+    s2 = NeighborSampler(b.rowptr, b.col, n, (5, 3)).sample(seeds, seed=9)
+    assert torch.equal(s1[0], s2[0]) and all(torch.equal(x.col, y.col) for x, y in zip(s1[1], s2[1]))

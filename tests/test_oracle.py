@@ -109,11 +109,11 @@ def test_sampler_restatement_properties(oracle):
     assert oracle.sample_hop(rowptr, col, seeds, 5, 43, 0)[1].tolist() != cl.tolist()
 
 
-@pytest.mark.parametrize("method", ["pagerank", "betweenness_centrality", "degree_centrality", "eigenvector_centrality",
+@pytest.mark.parametrize("method", ["betweenness_centrality", "degree_centrality", "eigenvector_centrality",
                                     "clustering_coefficient"])
 def test_biased_anchor_selection_matches_reference(method):
-    """utils.py:26-60 (host rankings): same anchors, same order as the reference's own sample_anchor_nodes
-    (tests/golden/anchors_centrality.npz).  closeness_centrality runs on the GPU: tests/test_geodesic_gpu.py."""
+    """utils.py:32-60 (host rankings): same anchors, same order as the reference's own sample_anchor_nodes
+    (tests/golden/anchors_centrality.npz).  closeness_centrality and pagerank run on the GPU: tests/test_geodesic_gpu.py."""
     import torch
     from graphpope_amd import utils as gp
     g = np.load(os.path.join(GOLDEN, "anchors_centrality.npz"))
@@ -135,3 +135,21 @@ def test_pool_restatement_of_the_reference_loop(oracle):
     emb, tm = oracle.geodesic_pairs_networkx_pool(g["edge_index"], n, g["anchors"], nodes, 3)
     assert np.array_equal(emb.view(np.uint32), g["emb"][nodes].view(np.uint32))
     assert tm["pool_s"] > 0 and tm["graph_build_s"] > 0
+
+
+def test_pagerank_restatement_matches_networkx_and_the_reference_golden(oracle):
+    """oracle.pagerank_scores: bit-identical to nx.pagerank (the SciPy iteration the reference calls, utils.py:28) on directed
+    and symmetric graphs with dangling nodes and repeated edges; its last-K selection is the reference's golden."""
+    import networkx as nx
+    from graphpope_amd import synth
+    for seed, sym in ((1, True), (2, False)):
+        ei, n = synth.rmat(8, edge_factor=3, seed=seed, symmetric=sym)
+        ei = np.concatenate([ei, ei[:, :40]], axis=1)                       # repeated edges collapse in the DiGraph
+        g = nx.DiGraph()
+        g.add_nodes_from(range(n))
+        g.add_edges_from(zip(ei[0].tolist(), ei[1].tolist()))
+        want = nx.pagerank(g)
+        assert np.array_equal(oracle.pagerank_scores(ei, n), np.array([want[v] for v in range(n)]))
+    g = np.load(os.path.join(GOLDEN, "anchors_centrality.npz"))
+    score = oracle.pagerank_scores(g["edge_index"].astype(np.int64), int(g["num_nodes"]))
+    assert np.argsort(score, kind="stable")[-24:].tolist() == g["pagerank"].tolist()

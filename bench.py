@@ -22,6 +22,7 @@ Rank 0 prints ONE JSON line.  At N = 1 it also carries
                          cpu_baseline_bfs: one C BFS per anchor (the honest CPU algorithm)
   boundary_host_to_host  SURVEY.md §8(d)'s primary metric: utils.Graphpope() from CPU tensors to the returned CPU tensor,
                          with the PCIe roofline of the bytes that cross the link
+  pagerank               biased anchor selection on the GPU against nx.pagerank (scores bit-identical)
   pairwise               configs[2]: node2vec-euclidean, 256 anchors, with the f32-MFMA roofline and the sklearn baseline
   config3 / config4      configs[3] (1 024 anchors) and configs[4] (R-MAT scale 22, 512 anchors) on this one GPU
   sage                   SAGE nodes/s + per-kernel view of layer 0
@@ -324,6 +325,35 @@ def config4_leg(dev, steps=3):
     del out, hp, ei
     engine._WORKSPACE.clear()
     torch.cuda.empty_cache()
+    return res
+
+
+def pagerank_leg(ei_np, n, ei):
+    """Biased anchor selection: sampling_method='pagerank' on the GPU against nx.pagerank."""
+    t0 = time.perf_counter()
+    got = engine.pagerank(ei, n)
+    torch.cuda.synchronize()
+    first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    got = engine.pagerank(ei, n)
+    torch.cuda.synchronize()
+    gpu = time.perf_counter() - t0
+    res = {"gpu_ms": gpu * 1e3, "gpu_first_call_ms": first * 1e3,
+           "what": "engine.pagerank: two canonical CSR builds + SpMV power iteration (float64, SciPy's accumulation order), "
+                   "edge_index resident; utils.py:26-30"}
+    try:
+        import networkx as nx
+        t0 = time.perf_counter()
+        g = nx.DiGraph()
+        g.add_nodes_from(range(n))
+        g.add_edges_from(zip(ei_np[0].tolist(), ei_np[1].tolist()))
+        want = nx.pagerank(g)
+        cpu = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": cpu, "unit": "s", "cores": 1, "kind": "port",
+                               "sample": "the reference's call on the full graph: DiGraph build + nx.pagerank (SciPy power iteration)"}
+        res["scores_bit_identical_to_networkx"] = bool(np.array_equal(got, np.array([want[v] for v in range(n)])))
+    except Exception as exc:
+        res["cpu_baseline"] = {"error": repr(exc)}
     return res
 
 
@@ -656,6 +686,7 @@ def main():
                     "host_to_host_vs_pool6": result["boundary_host_to_host"]["embeddings_per_s"] / result["cpu_baseline"]["value"],
                     "note": "boundary_host_to_host.embeddings_per_s / cpu_baseline.value: both from host tensors to a host tensor; "
                             "the HBM-resident `value` is not compared with a CPU figure"}
+            result["pagerank"] = pagerank_leg(ei_np, n, ei)
             result["pairwise"] = pairwise_leg(n, anchors, x, dev, steps)
             result["config3"] = config3_leg(x, ei, n, steps)
             del x, ei

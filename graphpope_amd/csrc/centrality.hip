@@ -12,6 +12,11 @@
 //     host binding on the copied-back vector, so the iteration count is the reference's too.
 #include "common.h"
 
+// Every multiply and add in this file is rounded on its own, as SciPy's and NumPy's compiled loops do: hipcc's default
+// -ffp-contract=fast would fuse  acc + w * x  into one fma (HIP's __dmul_rn / __dadd_rn are plain operators and do not
+// prevent it) and the scores would differ from NetworkX's in the last bits.
+#pragma clang fp contract(off)
+
 namespace pope {
 
 // w[j] = 1 / (number of distinct targets of j), 0 for a dangling node.  Rows of the canonical CSR are sorted by target:
@@ -31,17 +36,20 @@ __global__ __launch_bounds__(256) void k_pagerank_pull(const int *__restrict__ r
                                                        const double *__restrict__ x, const double *__restrict__ w, double dsum,
                                                        double alpha, double *__restrict__ x_out) {
     const double p = 1.0 / (double)N;
-    const double dangling = __dmul_rn(dsum, p);                   // sum(x[is_dangling]) * dangling_weights
-    const double teleport = __dmul_rn(1.0 - alpha, p);            // (1 - alpha) * p
+    const double dangling = dsum * p;                             // sum(x[is_dangling]) * dangling_weights
+    const double teleport = (1.0 - alpha) * p;                    // (1 - alpha) * p
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
         const int beg = rowptr_t[i], end = rowptr_t[i + 1];
         double acc = 0.0;
         for (int q = beg; q < end; ++q) {
             const int j = src_t[q];
             if (q > beg && j == src_t[q - 1]) continue;           // a repeated edge: one entry in the DiGraph
-            acc = __dadd_rn(acc, __dmul_rn(w[j], x[j]));
+            const double prod = w[j] * x[j];                       // plain operators: under the pragma above they carry no
+            acc = acc + prod;                                      // 'contract' flag (the __dmul_rn / __dadd_rn wrappers do)
         }
-        x_out[i] = __dadd_rn(__dmul_rn(alpha, __dadd_rn(acc, dangling)), teleport);
+        const double inner = acc + dangling;
+        const double scaled = alpha * inner;
+        x_out[i] = scaled + teleport;
     }
 }
 

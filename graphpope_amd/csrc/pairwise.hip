@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void k_minmax_reduce(const float *__restrict__
     shift[j] = 0.0f - __fmul_rn(mn, sc);
 }
 
-// MinMaxScaler.transform: X *= scale_; X += min_  (two separately rounded operations).
+// MinMaxScaler.transform: X *= scale_; X += min_  (two separately rounded operations: plain operators under contract(off);
+// HIP's __fmul_rn / __fadd_rn wrappers are plain operators too and would let hipcc's default -ffp-contract=fast fuse them).
+#pragma clang fp contract(off)
 __global__ __launch_bounds__(256) void k_minmax_apply(float *__restrict__ out, int N, int K, long long out_cols, int c0,
                                                       const float *__restrict__ scale, const float *__restrict__ shift) {
     const int lane = threadIdx.x & 63;
@@ -276,9 +278,14 @@ __global__ __launch_bounds__(256) void k_minmax_apply(float *__restrict__ out, i
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int v = wave; v < N; v += nwaves) {
         float *row = out + (size_t)v * out_cols + c0;
-        for (int j = lane; j < K; j += 64) row[j] = __fadd_rn(__fmul_rn(row[j], scale[j]), shift[j]);
+        for (int j = lane; j < K; j += 64) {
+            const float scaled = row[j] * scale[j];
+            row[j] = scaled + shift[j];
+        }
     }
 }
+
+#pragma clang fp contract(fast)
 
 static size_t pw_lds_bytes() { return tile_lds_bytes<PM, PN>(); }
 

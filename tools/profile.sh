@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag/trace -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/prof_$tag.trace.log 2>&1 || exit 1
 echo "trace ok"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$tag/fetch -- python3 $R/bench.py --no-cpu-baseline --no-sage --steps 5 --warmup 2 > $R/gpurun_out/prof_$tag.fetch.log 2>&1 || exit 2
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$tag/fetch -- python3 $R/bench.py --no-cpu-baseline --no-sage --no-extra --steps 5 --warmup 2 > $R/gpurun_out/prof_$tag.fetch.log 2>&1 || exit 2
 echo "fetch ok"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$tag/write -- python3 $R/bench.py --no-cpu-baseline --no-sage --steps 5 --warmup 2 > $R/gpurun_out/prof_$tag.write.log 2>&1 || exit 3
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$tag/write -- python3 $R/bench.py --no-cpu-baseline --no-sage --no-extra --steps 5 --warmup 2 > $R/gpurun_out/prof_$tag.write.log 2>&1 || exit 3
 echo "write ok"

@@ -23,6 +23,7 @@ Rank 0 prints ONE JSON line.  At N = 1 it also carries
   boundary_host_to_host  SURVEY.md §8(d)'s primary metric: utils.Graphpope() from CPU tensors to the returned CPU tensor,
                          with the PCIe roofline of the bytes that cross the link
   pagerank               biased anchor selection on the GPU against nx.pagerank (scores bit-identical)
+  kmeans                 K-means anchors of the node2vec branch on the GPU against scikit-learn
   pairwise               configs[2]: node2vec-euclidean, 256 anchors, with the f32-MFMA roofline and the sklearn baseline
   config3 / config4      configs[3] (1 024 anchors) and configs[4] (R-MAT scale 22, 512 anchors) on this one GPU
   sage                   SAGE nodes/s + per-kernel view of layer 0
@@ -352,6 +353,40 @@ def pagerank_leg(ei_np, n, ei):
         res["cpu_baseline"] = {"value": cpu, "unit": "s", "cores": 1, "kind": "port",
                                "sample": "the reference's call on the full graph: DiGraph build + nx.pagerank (SciPy power iteration)"}
         res["scores_bit_identical_to_networkx"] = bool(np.array_equal(got, np.array([want[v] for v in range(n)])))
+    except Exception as exc:
+        res["cpu_baseline"] = {"error": repr(exc)}
+    return res
+
+
+def kmeans_leg(n, dev):
+    """K-means anchors of the node2vec branch (utils.py:168-170) at configs[2]'s size: GPU against the reference's scikit-learn call."""
+    table_cpu = torch.randn((n, 128), generator=torch.Generator().manual_seed(0))
+    table = table_cpu.to(dev)
+    np.random.seed(9)
+    engine.kmeans_centers(table, K_PER_GPU)
+    torch.cuda.synchronize()
+    np.random.seed(9)
+    t0 = time.perf_counter()
+    c = engine.kmeans_centers(table, K_PER_GPU)
+    torch.cuda.synchronize()
+    gpu = time.perf_counter() - t0
+    res = {"gpu_ms": gpu * 1e3, "what": f"engine.kmeans_centers: X [{n}, 128] f32 N(0,1) resident, K = {K_PER_GPU}: k-means++ seeding "
+                                         "(7 local trials) + Lloyd iterations (MFMA tile assignment) until scikit-learn's stopping rule"}
+    try:
+        from sklearn.cluster import KMeans
+        m = 16384                                              # bounded sample of the rows: the full table takes minutes on the host
+        np.random.seed(9)
+        t0 = time.perf_counter()
+        km = KMeans(n_clusters=K_PER_GPU).fit(table_cpu[:m].numpy())
+        cpu = time.perf_counter() - t0
+        np.random.seed(9)
+        t0 = time.perf_counter()
+        engine.kmeans_centers(table[:m].contiguous(), K_PER_GPU)
+        torch.cuda.synchronize()
+        gpu_m = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": cpu, "unit": "s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"the reference's call KMeans(n_clusters={K_PER_GPU}).fit(X[:{m}]) (scikit-learn, {km.n_iter_} Lloyd "
+                                         f"iterations); the GPU path on the same {m} rows: {gpu_m * 1e3:.1f} ms"}
     except Exception as exc:
         res["cpu_baseline"] = {"error": repr(exc)}
     return res
@@ -688,6 +723,7 @@ def main():
                             "the HBM-resident `value` is not compared with a CPU figure"}
             result["pagerank"] = pagerank_leg(ei_np, n, ei)
             result["pairwise"] = pairwise_leg(n, anchors, x, dev, steps)
+            result["kmeans"] = kmeans_leg(n, dev)
             result["config3"] = config3_leg(x, ei, n, steps)
             del x, ei
             engine._WORKSPACE.clear()

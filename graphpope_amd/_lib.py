@@ -30,6 +30,13 @@ SIGNATURES = {
     "pope_csr_build_canonical": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pope_pagerank_weights": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "pope_pagerank_step": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p]),
+    "pope_kmeans_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "pope_column_moments": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pope_shift_columns": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p]),
+    "pope_kmeans_plusplus": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),
+    "pope_kmeans_lloyd_step": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
     "pope_words": (c_int32, [c_int32]),
     "pope_plane_bytes": (c_size_t, [c_int64, c_int32]),
     "pope_bfs_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int32]),

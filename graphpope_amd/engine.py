@@ -453,6 +453,61 @@ def pairwise_embedding(emb: torch.Tensor, anchors, distance_function: str, ancho
     return out
 
 
+def kmeans_centers(emb: torch.Tensor, n_clusters: int, max_iter: int = 300, tol: float = 1e-4):
+    """``KMeans(n_clusters=K).fit(X).cluster_centers_`` (utils.py:168-170, scikit-learn defaults: k-means++ seeding with
+    2 + int(log K) local trials, one run, Lloyd on the mean-centred data) with the distances, reductions and centre updates on
+    the GPU.  The random numbers are drawn HERE from the global legacy NumPy stream, call for call as scikit-learn's
+    ``check_random_state(None)`` would (one ``choice`` for the first seed, ``uniform(size=trials)`` per further seed), so the
+    stream is left where the reference leaves it.  float32 [K, D] on the device.
+
+    Not bit-identical to scikit-learn (whose own result depends on its BLAS chunking); on well-separated data the same
+    points are seeded in the same order and the centres agree to float32 rounding."""
+    lib = _lib.load()
+    dev = require_gpu(emb.device)
+    x = emb.to(dev, torch.float32).contiguous()
+    n, d = x.shape
+    k = int(n_clusters)
+    if not 0 < k <= n:
+        raise ValueError(f"n_samples={n} should be >= n_clusters={k}.")           # scikit-learn's message
+    with torch.cuda.device(dev):
+        scratch = _bytes(max(lib.pope_kmeans_scratch_bytes(n, d, k), 4096 * d * 8), dev)
+        sums = torch.empty((2, d), dtype=torch.float64, device=dev)
+        check(lib.pope_column_moments(ptr(x), n, d, ptr(sums[0]), ptr(sums[1]), ptr(scratch), scratch.numel(), _stream()))
+        s = sums.cpu().numpy()
+        mean64 = s[0] / n
+        tol_abs = float(np.mean(s[1] / n - mean64 * mean64) * tol)          # _tolerance: mean column variance x tol
+        mean = torch.as_tensor(mean64.astype(np.float32), device=dev)
+        xc = torch.empty_like(x)
+        check(lib.pope_shift_columns(ptr(x), ptr(mean), n, d, -1.0, ptr(xc), _stream()))      # KMeans.fit: X -= X.mean(axis=0)
+        # k-means++ seeding (_kmeans_plusplus): the global stream, in scikit-learn's order
+        trials = 2 + int(np.log(k))
+        weights = np.ones(n, dtype=np.float32)
+        first = int(np.random.choice(n, p=weights / weights.sum()))
+        uniforms = np.ascontiguousarray(np.stack([np.random.uniform(size=trials) for _ in range(k - 1)]) if k > 1
+                                        else np.zeros((0, trials)), dtype=np.float64)
+        chosen = torch.empty(k, dtype=torch.int64, device=dev)
+        check(lib.pope_kmeans_plusplus(ptr(xc), n, d, k, first, ctypes.c_void_p(uniforms.ctypes.data), trials, ptr(chosen),
+                                       ptr(scratch), scratch.numel(), _stream()))
+        centers = xc.index_select(0, chosen).contiguous()
+        centers_new = torch.empty_like(centers)
+        labels = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        labels_prev = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        changed = torch.zeros(1, dtype=torch.int32, device=dev)
+        shift = torch.zeros(1, dtype=torch.float64, device=dev)
+        for _ in range(max_iter):                                             # _kmeans_single_lloyd
+            check(lib.pope_kmeans_lloyd_step(ptr(xc), n, d, ptr(centers), k, ptr(centers_new), ptr(labels), ptr(labels_prev),
+                                             ptr(changed), ptr(shift), ptr(scratch), scratch.numel(), _stream()))
+            centers, centers_new = centers_new, centers
+            labels, labels_prev = labels_prev, labels                          # labels_prev now holds this iteration's labels
+            if int(changed.item()) == 0:                                      # strict convergence: the labels did not move
+                break
+            if float(shift.item()) <= tol_abs:
+                break
+        out = torch.empty_like(centers)
+        check(lib.pope_shift_columns(ptr(centers), ptr(mean), k, d, 1.0, ptr(out), _stream()))   # best_centers += X_mean
+    return out
+
+
 def pairwise_features(x: torch.Tensor, emb: torch.Tensor, anchors, distance_function: str,
                       anchor_embeddings=None) -> torch.Tensor:
     """[N, F+K] float32 on the device: the features next to :func:`pairwise_embedding` (device-resident callers); the

@@ -13,7 +13,7 @@ get_geodesic_distance_vector   engine.build_csr + engine.bfs + engine.finalize
 concat_into_features :129      host -> host: data.x copied on the host cores (pope_host_copy_2d), only the K
                                embedding columns cross PCIe; device-resident callers: finalise kernel / pope_concat
 attach_distance_embedding      same prints, sets data.anchor_nodes
-attach_node2vec :149           pairwise MFMA tile + column min-max kernel
+attach_node2vec :149           pairwise MFMA tile + column min-max kernel; K-means anchors: engine.kmeans_centers
 Graphpope :182                 same signature, same process-lifetime cache
 =============================  =============================================================
 
@@ -212,18 +212,16 @@ def attach_node2vec(data, dataset, num_anchor_nodes, sampling_method, distance_f
     if distance_function not in ('distance', 'similarity', 'euclidean'):
         raise KeyError(distance_function)
     anchor_nodes = anchor_embeddings = None
+    dev = _device()
+    table = engine.stage_to_device(node2vec_embeddings.to(torch.float32), dev)
     if sampling_method == 'stochastic':
         anchor_nodes = sample_anchor_nodes(data, num_anchor_nodes, sampling_method='stochastic')
     else:
-        # utils.py:168-170: every other sampling_method means K-means centres as anchors.  The clustering is the
-        # reference's own one-off scikit-learn call on the host (same call, same global NumPy RNG -> same centres);
-        # the N x K distance matrix and the min-max scaling -- the hot part -- run on the GPU.
-        from sklearn.cluster import KMeans
-        kmeans = KMeans(n_clusters=num_anchor_nodes).fit(node2vec_embeddings.numpy())
-        anchor_embeddings = kmeans.cluster_centers_
+        # utils.py:168-170: every other sampling_method means K-means centres as anchors -- scikit-learn's algorithm
+        # (k-means++ seeding from the global NumPy stream, Lloyd iterations) with the arithmetic on the GPU
+        # (engine.kmeans_centers); the N x K distance matrix and the min-max scaling follow on the same device.
+        anchor_embeddings = engine.kmeans_centers(table, num_anchor_nodes)
         print('K means cluster anchor nodes derived!')
-    dev = _device()
-    table = engine.stage_to_device(node2vec_embeddings.to(torch.float32), dev)
     if data.x.is_cuda:
         extended_features = engine.pairwise_features(data.x.detach().to(dev, torch.float32), table, anchor_nodes,
                                                      distance_function, anchor_embeddings=anchor_embeddings).cpu()

@@ -28,6 +28,8 @@
  *   pope_pagerank_weights /  utils.py:26-30      nx.pagerank_scipy power iteration as SpMV over the device CSR
  *   pope_pagerank_step                           (biased anchor selection, README's best row)
  *   pope_geodesic_hops       (no counterpart)    the integer hop matrix the floats are made of; parity tests
+ *   pope_kmeans_plusplus /   utils.py:168-170    KMeans(n_clusters=K).fit(X).cluster_centers_ (k-means++ seeding, Lloyd
+ *   pope_kmeans_lloyd_step                       iterations with the MFMA tile as the assignment step)
  *   pope_pairwise_minmax     utils.py:158-176    sklearn cosine/euclidean pairwise + MinMaxScaler
  *   pope_pairwise_features   utils.py:158-177    the same + concat_into_features inside the tile kernel
  *   pope_concat              utils.py:129-135    torch.cat for the node2vec branch (device-resident callers)
@@ -130,6 +132,31 @@ int pope_csr_build_canonical(const int64_t *edge_index, int64_t E, int64_t N, in
 int pope_pagerank_weights(const int32_t *rowptr, const int32_t *col, int64_t N, double *w, void *stream);
 int pope_pagerank_step(const int32_t *rowptr_by_target, const int32_t *sources, int64_t N, const double *x, const double *w,
                        double dangling_sum, double alpha, double *x_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K-means anchors of the node2vec branch (utils.py:168-170  KMeans(n_clusters=K).fit(X).cluster_centers_, scikit-learn
+ * defaults).  The host binding owns the control flow and the random numbers (the reference's KMeans draws from the global
+ * NumPy stream: one choice() for the first seed, 2 + int(log K) uniforms per further seed); the device does the distances,
+ * the reductions and the centre updates.  X is float32 [N, D], already centred by its column means (KMeans.fit does that).
+ *   pope_column_moments     sum[c], sumsq[c] of every column in float64 (column means; the tolerance 1e-4 x mean variance)
+ *   pope_shift_columns      out = X + sign * shift[c]
+ *   pope_kmeans_plusplus    k-means++ seeding: chosen[K] (device int64) = the seeded rows, in order.  uniforms_host:
+ *                           (K - 1) x n_trials doubles in [0, 1), step-major.  No host synchronisation after the upload.
+ *   pope_kmeans_lloyd_step  one Lloyd iteration: labels (N x K products on the f32 MFMA tile + row argmin, first minimum
+ *                           wins), new centres (mean of the members, float64 sums in index order; an empty cluster keeps
+ *                           its centre), *changed (device int) = some label differs from labels_prev, *shift_total (device
+ *                           double) = sum of squared centre shifts.  Deterministic.  Asynchronous on `stream`.
+ * scratch: pope_kmeans_scratch_bytes(N, D, K) for the two kmeans calls; 4096 * D * 8 bytes for pope_column_moments.
+ * ------------------------------------------------------------------------------------------------ */
+size_t pope_kmeans_scratch_bytes(int64_t N, int32_t D, int32_t K);
+int pope_column_moments(const float *X, int64_t N, int32_t D, double *sum, double *sumsq, void *scratch, size_t scratch_bytes,
+                        void *stream);
+int pope_shift_columns(const float *X, const float *shift, int64_t N, int32_t D, float sign, float *out, void *stream);
+int pope_kmeans_plusplus(const float *X, int64_t N, int32_t D, int32_t K, int64_t first_id, const double *uniforms_host,
+                         int32_t n_trials, int64_t *chosen, void *scratch, size_t scratch_bytes, void *stream);
+int pope_kmeans_lloyd_step(const float *X, int64_t N, int32_t D, const float *centers, int32_t K, float *centers_new,
+                           int32_t *labels, const int32_t *labels_prev, int32_t *changed, double *shift_total,
+                           void *scratch, size_t scratch_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Geodesic embedding.

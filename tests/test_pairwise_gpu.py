@@ -114,3 +114,46 @@ def test_graphpope_node2vec_entry(dev, tmp_path, monkeypatch):
     with pytest.raises(KeyError):
         gp.Graphpope(d, "flickr", "node2vec", "stochastic", 4, "chebyshev")
     gp.clear_cache()
+
+
+def test_kmeans_centers_against_scikit_learn_on_separated_blobs(dev):
+    """engine.kmeans_centers (utils.py:168-170 on the GPU): on well-separated data the k-means++ seeding draws the same points
+    in the same order from the same NumPy stream as scikit-learn, so the centres come out in scikit-learn's order and agree
+    to float32 rounding; the global stream ends where scikit-learn leaves it; two runs are bit-identical."""
+    from sklearn.cluster import KMeans
+    from graphpope_amd import engine
+    rs = np.random.RandomState(5)
+    k, d, n = 48, 32, 20000
+    means = rs.randn(k, d).astype(np.float32) * 12.0
+    x = (means[rs.randint(0, k, n)] + rs.randn(n, d).astype(np.float32)).astype(np.float32)
+    np.random.seed(123)
+    want = KMeans(n_clusters=k).fit(x).cluster_centers_
+    after_sklearn = np.random.random_sample()
+    np.random.seed(123)
+    got = engine.kmeans_centers(torch.as_tensor(x, device=dev), k).cpu().numpy()
+    after_ours = np.random.random_sample()
+    assert after_ours == after_sklearn                                 # same consumption of the global stream
+    assert got.shape == want.shape and got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * float(np.abs(want).max()))
+    np.random.seed(123)
+    again = engine.kmeans_centers(torch.as_tensor(x, device=dev), k).cpu().numpy()
+    assert np.array_equal(got, again)
+
+
+def test_kmeans_overlapping_clusters_reach_a_fixed_point(dev):
+    """Unseparated N(0, 1) data (what an untrained node2vec table is): the result is a Lloyd fixed point -- every point is
+    assigned to its nearest centre and every centre is the mean of its points -- with an inertia in scikit-learn's range."""
+    from sklearn.cluster import KMeans
+    from graphpope_amd import engine
+    x = torch.randn(6000, 24, generator=torch.Generator().manual_seed(0))
+    np.random.seed(7)
+    c = engine.kmeans_centers(x.to(dev), 20).cpu()
+    d2 = torch.cdist(x.double(), c.double()) ** 2
+    lab = d2.argmin(1)
+    inertia = float(d2.gather(1, lab[:, None]).sum())
+    # a near-fixed point: re-estimated centres move by less than the tolerance scikit-learn stops at
+    new = torch.stack([x[lab == j].double().mean(0) if (lab == j).any() else c[j].double() for j in range(20)])
+    assert float(((new - c.double()) ** 2).sum()) <= 1e-4 * float(x.var(0, unbiased=False).mean()) * 4
+    np.random.seed(7)
+    ref = KMeans(n_clusters=20).fit(x.numpy()).inertia_
+    assert abs(inertia - ref) / ref < 0.02

@@ -480,37 +480,28 @@ __global__ __launch_bounds__(256) void k_streamk_fixup(SkArgs a, int G) {
     const int m0 = (tile % a.tiles_m) * SK_TM, n0 = (tile / a.tiles_m) * SK_TN;
     // the partial slabs of this tile (wave-uniform): blocks b_lo .. b_hi, in practice two or three of them; a block with
     // no unit of the tile (possible only when there are fewer units than blocks) contributes nothing
-    const float *part[4];
-    bool has[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int b = b_lo + i;
-        const long long lo = sk_lo(b, T, G), hi = sk_lo(b + 1, T, G);
-        const long long sb = lo > u0 ? lo : u0, se = hi < u1 ? hi : u1;
-        has[i] = b <= b_hi && sb < se;
-        part[i] = a.slab + ((size_t)b * 2 + (sb > u0 ? 0 : 1)) * SK_SLAB_FLOATS;
-    }
-    const bool few = b_hi - b_lo < 4;
     constexpr int PER = SK_TM * SK_TN / 4 / SK_FIX_PARTS;                                 // 16-byte pieces per block
-    for (int q = blockIdx.y * PER + threadIdx.x; q < (blockIdx.y + 1) * PER; q += blockDim.x) {
-        const int m = q / (SK_TN / 4), n = (q % (SK_TN / 4)) * 4;
+    for (int p = blockIdx.y * PER + threadIdx.x; p < (blockIdx.y + 1) * PER; p += blockDim.x) {
+        const int m = p / (SK_TN / 4), n = (p % (SK_TN / 4)) * 4;
         if (m0 + m >= a.M || n0 + n >= a.N) continue;
         const size_t off = (size_t)m * SK_TN + n;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (few) {
+        // the partial slabs of this tile, blocks b_lo .. b_hi in order, FOUR loads in flight at a time (two or three partials
+        // for the forward projection, about eleven per tile for the weight gradients); a block with no unit of the tile
+        // (possible only when there are fewer units than blocks) contributes nothing
+        for (int b0 = b_lo; b0 <= b_hi; b0 += 4) {
             float4 v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = has[i] ? *reinterpret_cast<const float4 *>(part[i] + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
-        } else {                                                                          // a tile cut into many pieces (tiny grids only)
-            for (int b = b_lo; b <= b_hi; ++b) {
+            for (int i = 0; i < 4; ++i) {
+                const int b = b0 + i;
                 const long long lo = sk_lo(b, T, G), hi = sk_lo(b + 1, T, G);
                 const long long sb = lo > u0 ? lo : u0, se = hi < u1 ? hi : u1;
-                if (sb >= se) continue;
-                const float4 v = *reinterpret_cast<const float4 *>(a.slab + ((size_t)b * 2 + (sb > u0 ? 0 : 1)) * SK_SLAB_FLOATS + off);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                const bool has = b <= b_hi && sb < se;
+                v[i] = has ? *reinterpret_cast<const float4 *>(a.slab + ((size_t)b * 2 + (sb > u0 ? 0 : 1)) * SK_SLAB_FLOATS + off)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
         }
         float *c = a.C + (size_t)(m0 + m) * a.ldc + n0 + n;
         const float sv[4] = {s.x, s.y, s.z, s.w};

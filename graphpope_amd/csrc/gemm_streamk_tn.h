@@ -1,0 +1,243 @@
+// Stream-K f32 MFMA GEMM for the SAGEConv weight gradients on MI355X (gfx950): the "TN" twin of gemm_streamk.h.
+//
+//     C_q[M, Nb] = G^T * B_q       q = 0, 1         G [depth, M], B_q [depth, Nb]: both operands row-major over the DEPTH
+//
+// grad_w_l = grad_out^T * agg and grad_w_r = grad_out^T * x_dst (sage_conv_backward): M = c_out = 256, Nb = c_in = 756, the
+// reduction runs over the n_dst ~ 10 000 destination rows.  The two products share G; together they are 24 output tiles of
+// 64 x 256 over a depth of 313 stages of 32 rows -- the same 7 500 units as the forward projection, dealt out the same way
+// (one persistent block per CU, partial tiles to per-block slabs, k_streamk_tn_fixup adds them in block order).
+// Round 1 computed them as whole 64 x 128 tiles with split-K slabs: 324 MB fetched for 70 MB of operands
+// (profiles/r02_sage_counters.json: every tile column re-read grad_out, every tile row re-read agg / x_dst).
+//
+// Here both operands are "k-major" in memory (for one depth row the 64 / 256 outer elements are contiguous), so the LDS
+// image is simply [depth row][outer]: a DMA wave-instruction moves one 1 KiB depth row of B (or four 256-byte depth rows of
+// G), nothing is swizzled, and a fragment read is 32 consecutive dwords per half-wave (ds_read_b32, conflict-free).
+// Roles as in k_gemm_streamk_ld: waves 0-3 read fragments and issue MFMAs (32 x 128 each), waves 4-7 issue the DMAs
+// (SADDR form: no vector arithmetic) and run one stage ahead.
+#pragma once
+
+#include "gemm_streamk.h"
+
+namespace pope {
+
+struct SkTnArgs {
+    const float *G;              // [depth, M]:  A(m, k) = G[k * ldg + m]
+    long long ldg;
+    const float *B[2];           // [depth, Nb]: B_q(n, k) = B[q][k * ldb + n]
+    long long ldb;
+    float *C[2];                 // [M, Nb]
+    long long ldc;
+    int M, Nb, depth;
+    float *slab;                 // [gridDim.x][2][SK_TM][SK_TN]
+    const float *zero;
+    int tiles_m, tiles_nb, S;    // tiles along M, along Nb (per product), depth stages
+};
+
+__device__ __forceinline__ void sk_tn_tile(const SkTnArgs &a, int tile, int &q, int &m0, int &n0) {
+    const int tm = tile % a.tiles_m, rest = tile / a.tiles_m;
+    q = rest / a.tiles_nb;
+    m0 = tm * SK_TM;
+    n0 = (rest - q * a.tiles_nb) * SK_TN;
+}
+
+__global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
+    constexpr int NT = 4;                               // 32 x 32 accumulator tiles per consumer wave: 32 rows x 128 columns
+    constexpr int ND = 40 / SKL_LOADERS;                // DMA wave-instructions per loader wave and stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem);
+    const int S = a.S;
+    const long long T = (long long)a.tiles_m * a.tiles_nb * 2 * S, G = gridDim.x;
+    long long u = sk_lo(blockIdx.x, T, G);
+    const long long u_end = sk_lo(blockIdx.x + 1, T, G);
+
+    if (wave >= SKL_CONSUMERS) {
+        // ---------------- loader waves ----------------
+        __builtin_amdgcn_s_setprio(3);
+        const int lw = wave - SKL_CONSUMERS;
+        while (u < u_end) {
+            const int tile = (int)(u / S);
+            const int s_begin = (int)(u - (long long)tile * S);
+            const long long left = u_end - u;
+            const int s_end = (long long)(S - s_begin) <= left ? S : s_begin + (int)left;
+            int q, m0, n0;
+            sk_tn_tile(a, tile, q, m0, n0);
+            const float *Bq = q ? a.B[1] : a.B[0];
+            // per-lane byte offsets from the stage's first depth row; instruction i < 8: four depth rows of G (16 lanes each),
+            // else depth row i - 8 of B.  Outer indices past the matrix are clamped into it (their products land in output
+            // rows / columns that are never stored); depth rows past the end are handled in the last stage only.
+            unsigned off[ND];
+            int drow[ND];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const int instr = lw * ND + d;
+                if (instr < 8) {
+                    drow[d] = instr * 4 + (lane >> 4);
+                    const int m = min(m0 + (lane & 15) * 4, a.M - 4);
+                    off[d] = (unsigned)(((long long)drow[d] * a.ldg + m) * 4);
+                } else {
+                    drow[d] = instr - 8;
+                    const int n = min(n0 + lane * 4, a.Nb - 4);
+                    off[d] = (unsigned)(((long long)drow[d] * a.ldb + n) * 4);
+                }
+            }
+            auto issue_all = [&](int s, int buf) {
+                const int k0 = s * SK_GK;
+                const float *Ga = a.G + (long long)k0 * a.ldg, *Ba = Bq + (long long)k0 * a.ldb;        // SGPR pairs
+                if (k0 + SK_GK <= a.depth) {
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        sk_glds16_saddr(lw * ND + d < 8 ? Ga : Ba, off[d], lds0 + buf * SK_STAGE_BYTES + (lw * ND + d) * 1024);
+                } else {                                               // the last stage: depth rows past the end
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) {
+                        const bool is_a = lw * ND + d < 8;
+                        const bool past = k0 + drow[d] >= a.depth;
+                        const float *src;
+                        if (is_a) src = past ? a.zero : (const float *)((const char *)Ga + off[d]);           // zero kills the product
+                        else src = (const float *)((const char *)Ba + off[d]) - (past ? (long long)(k0 + drow[d] - (a.depth - 1)) * a.ldb : 0);
+                        sk_glds16(src, lds0 + buf * SK_STAGE_BYTES + (lw * ND + d) * 1024);
+                    }
+                }
+            };
+            __syncthreads();
+            issue_all(s_begin, 0);
+            if (s_begin + 1 < s_end) issue_all(s_begin + 1, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // B_(s_begin)
+            int buf = 0;
+            for (int s = s_begin; s < s_end; ++s) {
+                if (s + 2 < s_end) issue_all(s + 2, buf == 0 ? 2 : buf - 1);
+                if (s + 1 < s_end) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                      // B_(s+1)
+                }
+                buf = buf == 2 ? 0 : buf + 1;
+            }
+            u += s_end - s_begin;
+        }
+        return;
+    }
+
+    // ---------------- consumer waves ----------------
+    const int wm = wave & 1, wn = wave >> 1;
+    const int g = lane >> 5, l31 = lane & 31;
+    while (u < u_end) {
+        const int tile = (int)(u / S);
+        const int s_begin = (int)(u - (long long)tile * S);
+        const long long left = u_end - u;
+        const int s_end = (long long)(S - s_begin) <= left ? S : s_begin + (int)left;
+        int q, m0, n0;
+        sk_tn_tile(a, tile, q, m0, n0);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        __syncthreads();
+        __builtin_amdgcn_s_barrier();          // B_(s_begin): stages s_begin and s_begin + 1 have landed
+        asm volatile("" ::: "memory");
+        // fragments of depth step j: A(m, 2j + g), B(n, 2j + g) -- 32 consecutive dwords per half-wave
+        float fa[2], fb[NT][2];
+        auto read_step = [&](int b, int j, int set) {
+            const float *As = reinterpret_cast<const float *>(smem + b * SK_STAGE_BYTES);
+            const float *Bs = reinterpret_cast<const float *>(smem + b * SK_STAGE_BYTES + SK_A_BYTES);
+            const int k = 2 * j + g;
+            fa[set] = As[k * SK_TM + wm * 32 + l31];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) fb[t][set] = Bs[k * SK_TN + wn * 128 + t * 32 + l31];
+        };
+        int buf = 0;
+        read_step(0, 0, 0);
+        for (int s = s_begin; s < s_end; ++s) {
+            const bool next = s + 1 < s_end;
+            const int nbuf = buf == 2 ? 0 : buf + 1;
+#pragma unroll
+            for (int j = 0; j < SK_GK / 2; ++j) {
+                if (j + 1 < SK_GK / 2) read_step(buf, j + 1, (j + 1) & 1);
+                else if (next) read_step(nbuf, 0, 0);                  // the next stage's first step: landed since B_s
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1], fb[t][j & 1], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (next) {
+                __builtin_amdgcn_s_barrier();                          // B_(s+1)
+                asm volatile("" ::: "memory");
+            }
+            buf = nbuf;
+        }
+        // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        const bool complete = s_begin == 0 && s_end == S;
+        if (complete) {
+            float *C = q ? a.C[1] : a.C[0];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = n0 + wn * 128 + t * 32 + l31;
+                if (n >= a.Nb) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < a.M) C[(size_t)m * a.ldc + n] = acc[t][r];
+                }
+            }
+        } else {
+            float *dst = a.slab + ((size_t)blockIdx.x * 2 + (s_begin > 0 ? 0 : 1)) * SK_SLAB_FLOATS;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = wn * 128 + t * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    dst[(size_t)m * SK_TN + n] = acc[t][r];
+                }
+            }
+        }
+        u += s_end - s_begin;
+    }
+}
+
+// SK_FIX_PARTS blocks per tile, as k_streamk_fixup.
+__global__ __launch_bounds__(256) void k_streamk_tn_fixup(SkTnArgs a, int G) {
+    const int S = a.S;
+    const long long T = (long long)a.tiles_m * a.tiles_nb * 2 * S;
+    const int tile = blockIdx.x;
+    const long long u0 = (long long)tile * S, u1 = u0 + S;
+    const int b_lo = (int)(((u0 + 1) * G - 1) / T), b_hi = (int)((u1 * G - 1) / T);
+    if (b_lo == b_hi) return;
+    int q, m0, n0;
+    sk_tn_tile(a, tile, q, m0, n0);
+    float *C = q ? a.C[1] : a.C[0];
+    constexpr int PER = SK_TM * SK_TN / 4 / SK_FIX_PARTS;                                 // 16-byte pieces per block
+    for (int p = blockIdx.y * PER + threadIdx.x; p < (blockIdx.y + 1) * PER; p += blockDim.x) {
+        const int m = p / (SK_TN / 4), n = (p % (SK_TN / 4)) * 4;
+        if (m0 + m >= a.M || n0 + n >= a.Nb) continue;
+        const size_t off = (size_t)m * SK_TN + n;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        // the partial slabs of this tile, blocks b_lo .. b_hi in order, FOUR loads in flight at a time (two or three partials
+        // for the forward projection, about eleven per tile for the weight gradients); a block with no unit of the tile
+        // (possible only when there are fewer units than blocks) contributes nothing
+        for (int b0 = b_lo; b0 <= b_hi; b0 += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = b0 + i;
+                const long long lo = sk_lo(b, T, G), hi = sk_lo(b + 1, T, G);
+                const long long sb = lo > u0 ? lo : u0, se = hi < u1 ? hi : u1;
+                const bool has = b <= b_hi && sb < se;
+                v[i] = has ? *reinterpret_cast<const float4 *>(a.slab + ((size_t)b * 2 + (sb > u0 ? 0 : 1)) * SK_SLAB_FLOATS + off)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+        }
+        float *c = C + (size_t)(m0 + m) * a.ldc + n0 + n;
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n0 + n + i < a.Nb) c[i] = sv[i];
+    }
+}
+
+}  // namespace pope

@@ -13,7 +13,7 @@
 //                    (reduction over ~40 000 rows), deterministic: no float atomics there.
 //   k_scatter_mean   grad_x[col[p]] += grad_agg[i] / deg(i) (float atomics, whole 16-byte-aligned row segments)
 //   k_colsum_*       grad_bias, two deterministic stages
-#include "gemm_streamk.h"
+#include "gemm_streamk_tn.h"
 
 namespace pope {
 
@@ -386,6 +386,47 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
     return POPE_OK;
 }
 
+// ---- both weight gradients as one stream-K launch (gemm_streamk_tn.h) ----
+static bool streamk_tn_shape_ok(int64_t depth, int32_t M, int32_t Nb) {
+    if ((M & 3) || (Nb & 3) || M < 4 || Nb < 4 || depth <= 0) return false;
+    const long long tiles = 2ll * ((M + SK_TM - 1) / SK_TM) * ((Nb + SK_TN - 1) / SK_TN);
+    return tiles * ((depth + SK_GK - 1) / SK_GK) >= 4ll * SK_MAX_GRID;
+}
+
+// C0 = G^T * B0, C1 = G^T * B1 (G [depth, M], B_q [depth, Nb], C_q [M, Nb]); *used = false if the operands do not qualify.
+static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int64_t depth, int M, int Nb, float *C0, float *C1,
+                           void *slab, size_t slab_bytes, hipStream_t stream, bool *used) {
+    *used = false;
+    if (g_gemm_force_tile != 0 && g_gemm_force_tile < 4) return POPE_OK;
+    if (!streamk_tn_shape_ok(depth, M, Nb)) return POPE_OK;
+    if (!aligned16(G) || !aligned16(B0) || !aligned16(B1) || depth >= INT32_MAX) return POPE_OK;
+    int cus = 0, rc;
+    if ((rc = device_cu_count(&cus))) return rc;
+    SkTnArgs a;
+    a.G = G; a.ldg = M; a.B[0] = B0; a.B[1] = B1; a.ldb = Nb; a.C[0] = C0; a.C[1] = C1; a.ldc = Nb;
+    a.M = M; a.Nb = Nb; a.depth = (int)depth; a.slab = (float *)slab;
+    a.tiles_m = (M + SK_TM - 1) / SK_TM; a.tiles_nb = (Nb + SK_TN - 1) / SK_TN; a.S = (int)((depth + SK_GK - 1) / SK_GK);
+    const long long T = 2ll * a.tiles_m * a.tiles_nb * a.S;
+    long long grid = cus < SK_MAX_GRID ? cus : SK_MAX_GRID;
+    if (grid > T) grid = T;
+    if (!slab || slab_bytes < sk_slab_bytes((int)grid)) return POPE_OK;
+    static bool opt_in = false;
+    static const float *zero_page[64];
+    int dev = 0;
+    POPE_HIP(hipGetDevice(&dev));
+    if (!opt_in) {
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk_tn, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+        opt_in = true;
+    }
+    if (!zero_page[dev]) POPE_HIP(hipGetSymbolAddress((void **)&zero_page[dev], HIP_SYMBOL(g_sk_zero)));
+    a.zero = zero_page[dev];
+    hipLaunchKernelGGL(k_gemm_streamk_tn, dim3((unsigned)grid), dim3(SKL_THREADS), SK_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(k_streamk_tn_fixup, dim3(2 * a.tiles_m * a.tiles_nb, SK_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
+    POPE_HIP(hipGetLastError());
+    *used = true;
+    return POPE_OK;
+}
+
 }  // namespace pope
 
 using namespace pope;
@@ -406,6 +447,7 @@ extern "C" size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t 
     const size_t gagg = align_up((size_t)n_dst * c_in * sizeof(float), 256);
     size_t slabs = 2 * (size_t)weight_grad_splits(n_dst, c_in, c_out) * c_out * c_in * sizeof(float);
     if (slabs < (size_t)COLSUM_SPLITS * c_out * sizeof(float)) slabs = (size_t)COLSUM_SPLITS * c_out * sizeof(float);
+    if (streamk_tn_shape_ok(n_dst, c_out, c_in) && slabs < sk_slab_bytes(SK_MAX_GRID)) slabs = sk_slab_bytes(SK_MAX_GRID);
     slabs = align_up(slabs, 256);
     return gagg + slabs;
 }
@@ -492,10 +534,15 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
     const Operand none{nullptr, 0, 0};
     int rc;
     // grad_w_l[o, c] = sum_i grad_out[i, o] * agg[i, c];  grad_w_r likewise with x_dst   (depth = rows i)
-    const Operand Gt{grad_out, 1, c_out};                       // (outer o, depth i) -> grad_out[i * c_out + o]
-    const Operand AggT{agg, 1, c_in}, XdT{x_src, 1, c_in};      // (outer c, depth i)
-    if ((rc = gemm(Gt, AggT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_l, c_in, splits, slab, stream,
-                   Twin{XdT, grad_w_r, 0}))) return rc;
+    bool used = false;
+    const size_t slab_bytes = scratch_bytes - align_up((size_t)n_dst * c_in * sizeof(float), 256);
+    if ((rc = gemm_streamk_tn(grad_out, agg, x_src, n_dst, c_out, c_in, grad_w_l, grad_w_r, slab, slab_bytes, stream, &used))) return rc;
+    if (!used) {
+        const Operand Gt{grad_out, 1, c_out};                   // (outer o, depth i) -> grad_out[i * c_out + o]
+        const Operand AggT{agg, 1, c_in}, XdT{x_src, 1, c_in};  // (outer c, depth i)
+        if ((rc = gemm(Gt, AggT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_l, c_in, splits, slab, stream,
+                       Twin{XdT, grad_w_r, 0}))) return rc;
+    }
     if (grad_b_l) {                                             // the slab region is free again: stream order
         if ((c_out & 3) == 0 && aligned16(grad_out))
             hipLaunchKernelGGL(k_colsum_partial<true>, dim3((c_out + 255) / 256, COLSUM_SPLITS), dim3(256), 0, stream, grad_out, (int)n_dst, c_out, slab);

@@ -274,15 +274,17 @@ __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words
 // four slots share one row is "transparent" and passes the carry on).  Work per wave is 256 edges whatever the
 // degree distribution (no long rows, no dependent pointer chase: erow/col are coalesced 16-byte streams).
 //   * A row that lies inside this chunk is complete: its words are stored to acc[v] (the next frontier, zeros
-//     included unless the live table makes them unnecessary, so acc needs no clearing) and committed (seen, hop planes) right here -- only this wave ever
-//     touches row v's state.
+//     included unless the live table makes them unnecessary, so acc needs no clearing).
 //   * A row that spans chunks ("multi-chunk": every hub) receives one piece per chunk, OR-ed into acc[v] with a
-//     device-scope atomic (a few thousand per level, distinct addresses).  Its commit is DEFERRED to the next
-//     level's launch: the housekeeping blocks of launch l commit level l-1 for the listed rows and clear their
-//     words in the idle third buffer, which launch l+1 will accumulate into.  Until then the row masks its
-//     candidates with seen[v] | front[v] -- front[v] is exactly what level l-1 added -- so a commit that has or
-//     has not landed yet gives the same result.  One launch per level, no second pass, no inter-block hand-off
-//     inside a launch.
+//     device-scope atomic (a few thousand per level, distinct addresses); the housekeeping blocks clear those words
+//     in the idle third buffer, which launch l+1 will accumulate into.
+//   * Nobody commits level l inside launch l.  The COMMIT (reachability plane, bit-sliced hop planes) of level l-1 is
+//     done by the housekeeping blocks of launch l, one thread per node with a non-zero frontier row, beside the expand
+//     waves; every row masks its candidates with seen[v] | front[v] -- front[v] is exactly what level l-1 added -- so a
+//     commit that has or has not landed yet gives the same result.  The expand waves' dependent chain therefore ends at
+//     the frontier store (round 1 ended it with a plane read-modify-write: ~2.7 of a wave's ~13 us).  The launch after
+//     the last productive level finds nothing and commits that level: the BFS always runs it (it also proves the end).
+//     One launch per level, no second pass, no inter-block hand-off inside a launch.
 // Three frontier buffers rotate: front = level l-1 (read), acc = level l (written), idle = level l+1 (cleared).
 // Beside each goes a "live" table, one BIT per node: set when the node's frontier row is not all zero.  It is N/8
 // bytes (11 KB for Flickr) and every block copies it into LDS first (LIVE = 1; graphs up to LIVE_MAX_NODES), so a lane looks
@@ -295,7 +297,7 @@ __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words
 // WT = words per tile (1, 2 or 4); blockIdx.y selects the tile of a node's W words.
 template <int WT, int LIVE>      // LIVE: 0 no table, 1 table staged in LDS, 2 table read from global memory (big graphs)
 __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
-                                                   int E, int Wp, const u64 *__restrict__ front,
+                                                   int E, int N, int Wp, const u64 *__restrict__ front,
                                                    u64 *__restrict__ seen, u64 *__restrict__ acc,
                                                    u64 *__restrict__ idle, u64 *__restrict__ hop_planes,
                                                    size_t plane_elems, int level, BfsCtl *ctl, const int *aux,
@@ -306,23 +308,36 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
     const int lane = threadIdx.x & 63;
     int woff = blockIdx.y * WT;                                    // housekeeping: tile = blockIdx.y
     if ((int)blockIdx.x >= expand_blocks) {
-        // housekeeping for the rows that span chunks: one thread per (row, tile)
+        // Housekeeping blocks (beside the expand waves, not on their critical path):
+        //  (1) clear, two levels ahead: the live table and the accumulator words of the rows that span chunks;
+        //  (2) COMMIT level - 1 for every node: a node whose frontier row is non-zero gained those anchors at level - 1
+        //      -> reachability plane and hop-bit planes.  The expand waves never commit: they mask with seen[v] | front[v],
+        //      which is the same whether this commit has landed or not (OR is idempotent), and their chain ends at the store
+        //      of the next frontier instead of a plane read-modify-write behind it.
         const int n = (E + CHUNK - 1) >> CHUNK_SHIFT;              // one slot per chunk, -1 = no row continues into it
         const int *mrows = aux + AUX_HEADER;
         const int hb = gridDim.x - expand_blocks;
+        const int t0 = ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x, tstride = hb * blockDim.x;
         if (LIVE && blockIdx.y == 0)
-            for (int i = ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x; i < live_words; i += hb * blockDim.x)
-                live_idle[i] = 0u;
+            for (int i = t0; i < live_words; i += tstride) live_idle[i] = 0u;
         Words<WT> zero;
 #pragma unroll
         for (int i = 0; i < WT; ++i) zero.w[i] = 0;
-        for (int i = ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x; i < n; i += hb * blockDim.x) {
-            const int mv = mrows[i];
-            if (mv < 0) continue;
-            const size_t idx = (size_t)mv * Wp + woff;
-            store_words<WT>(idle + idx, zero);
-            if (level > 1) {
-                const Words<WT> fresh = load_words<WT>(front + idx);       // complete: every piece landed last launch
+        if constexpr (LIVE == 0) {
+            // No live table (A/B mode): the commit below reads EVERY frontier row, so a row that no chunk writes (a node
+            // without out-edges) must not keep what the buffer held three levels ago: the whole buffer is cleared.
+            for (int v = t0; v < N; v += tstride) store_words<WT>(idle + (size_t)v * Wp + woff, zero);
+        } else {
+            for (int i = t0; i < n; i += tstride) {
+                const int mv = mrows[i];
+                if (mv >= 0) store_words<WT>(idle + (size_t)mv * Wp + woff, zero);
+            }
+        }
+        if (level > 1) {
+            for (int v = t0; v < N; v += tstride) {
+                if (LIVE && !((live[v >> 5] >> (v & 31)) & 1u)) continue;              // frontier row all zero: nothing gained
+                const size_t idx = (size_t)v * Wp + woff;
+                const Words<WT> fresh = load_words<WT>(front + idx);
                 if (any_bits<WT>(fresh))
                     commit_words<WT>(fresh, load_words<WT>(seen + idx), idx, seen, hop_planes, plane_elems, level - 1);
             }
@@ -390,29 +405,23 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
         if (g1) c1 = gather_words<WT>(front + (size_t)u1 * Wp + woff);
         if (g2) c2 = gather_words<WT>(front + (size_t)u2 * Wp + woff);
         if (g3) c3 = gather_words<WT>(front + (size_t)u3 * Wp + woff);
-        if (work && v0 >= 0) {
-            s0 = load_words<WT>(seen + (size_t)v0 * Wp + woff);
-            if (x0) {                                                    // deferred commit: level l-1 may not be in seen yet
-                const Words<WT> f = load_words<WT>(front + (size_t)v0 * Wp + woff);
+        // mask of row v: what reached it before this level = seen[v] | front[v].  front[v] (level - 1's gain) is committed to
+        // seen by the housekeeping blocks of THIS launch: either order gives the same mask.  Rows whose live bit is clear
+        // have an all-zero (possibly never written) frontier row: not loaded.
+        auto row_mask = [&](int v) {
+            Words<WT> m = load_words<WT>(seen + (size_t)v * Wp + woff);
+            if (is_live(v)) {
+                const Words<WT> f = load_words<WT>(front + (size_t)v * Wp + woff);
 #pragma unroll
-                for (int i = 0; i < WT; ++i) s0.w[i] |= f.w[i];
+                for (int i = 0; i < WT; ++i) m.w[i] |= f.w[i];
             }
-        }
-        if (work && v3 >= 0) {
-            if (v3 == v0) {
-                s3 = s0;
-            } else {
-                s3 = load_words<WT>(seen + (size_t)v3 * Wp + woff);
-                if (x3) {
-                    const Words<WT> f = load_words<WT>(front + (size_t)v3 * Wp + woff);
-#pragma unroll
-                    for (int i = 0; i < WT; ++i) s3.w[i] |= f.w[i];
-                }
-            }
-        }
-        // an interior row (neither the lane's first nor last row) lies inside the chunk: plain seen is its mask
-        if (work && v1 >= 0) s1 = v1 == v0 ? s0 : (v1 == v3 ? s3 : load_words<WT>(seen + (size_t)v1 * Wp + woff));
-        if (work && v2 >= 0) s2 = v2 == v1 ? s1 : (v2 == v3 ? s3 : load_words<WT>(seen + (size_t)v2 * Wp + woff));
+            return m;
+        };
+        if (work && v0 >= 0) s0 = row_mask(v0);
+        if (work && v3 >= 0) s3 = v3 == v0 ? s0 : row_mask(v3);
+        // an interior row (neither the lane's first nor last row)
+        if (work && v1 >= 0) s1 = v1 == v0 ? s0 : (v1 == v3 ? s3 : row_mask(v1));
+        if (work && v2 >= 0) s2 = v2 == v1 ? s1 : (v2 == v3 ? s3 : row_mask(v2));
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
             c0.w[i] &= ~s0.w[i];
@@ -510,40 +519,6 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
                     if (n2) atomicOr(&live_acc[v2 >> 5], 1u << (v2 & 31));
                     if (n3) atomicOr(&live_acc[v3 >> 5], 1u << (v3 & 31));
                 }
-            }
-        }
-        const bool m0 = n0 && !x0, m1 = n1 && !x1, m2 = n2 && !x2, m3 = n3 && !x3;     // complete rows: commit now
-        if (__any(m0 || m1 || m2 || m3)) {
-#pragma unroll
-            for (int i = 0; i < WT; ++i) {
-                s0.w[i] |= c0.w[i];
-                s1.w[i] |= c1.w[i];
-                s2.w[i] |= c2.w[i];
-                s3.w[i] |= c3.w[i];
-            }
-            if (m0) store_words<WT>(seen + i0, s0);
-            if (m1) store_words<WT>(seen + i1, s1);
-            if (m2) store_words<WT>(seen + i2, s2);
-            if (m3) store_words<WT>(seen + i3, s3);
-            for (int b = 0, l = level; l; ++b, l >>= 1) {               // all four slots side by side per hop bit
-                if (!(l & 1)) continue;
-                u64 *p = hop_planes + (size_t)b * plane_elems;
-                Words<WT> h0 = c0, h1 = c1, h2 = c2, h3 = c3;
-                if (m0) h0 = load_words<WT>(p + i0);
-                if (m1) h1 = load_words<WT>(p + i1);
-                if (m2) h2 = load_words<WT>(p + i2);
-                if (m3) h3 = load_words<WT>(p + i3);
-#pragma unroll
-                for (int i = 0; i < WT; ++i) {
-                    h0.w[i] |= c0.w[i];
-                    h1.w[i] |= c1.w[i];
-                    h2.w[i] |= c2.w[i];
-                    h3.w[i] |= c3.w[i];
-                }
-                if (m0) store_words<WT>(p + i0, h0);
-                if (m1) store_words<WT>(p + i1, h1);
-                if (m2) store_words<WT>(p + i2, h2);
-                if (m3) store_words<WT>(p + i3, h3);
             }
         }
         STAMP(5);
@@ -976,27 +951,27 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
 }
 
 template <int WT>
-static void launch_level(int E, int Wp, const int *col, const int *erow, const int *aux, const u64 *front, u64 *seen,
+static void launch_level(int E, int N, int Wp, const int *col, const int *erow, const int *aux, const u64 *front, u64 *seen,
                          u64 *acc, u64 *idle, u64 *hop_planes, size_t plane_elems, int level, BfsCtl *ctl,
                          const unsigned *live, unsigned *live_acc, unsigned *live_idle, int live_words, hipStream_t stream) {
     const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
     int expand_blocks = (nchunks + 3) / 4;                           // one wave per chunk ...
     if (expand_blocks > 256 * 8) expand_blocks = 256 * 8;            // ... up to 8 blocks per CU, then waves loop
-    int house_blocks = (nchunks + 255) / 256;                        // rows that span chunks: at most one per chunk
-    if (house_blocks > 64) house_blocks = 64;
+    int house_blocks = (N + 255) / 256;                              // the commit of the previous level: one thread per node
+    if (house_blocks > 1024) house_blocks = 1024;                    // (+ the clears: rows that span chunks, the live table)
     profile_mark(stream, level, 0);
     const int mode = g_live_mode >= 0 ? g_live_mode : (live_words <= LIVE_MAX_NODES / 32 ? 1 : 2);
     if (mode == 1 && live_words <= LIVE_MAX_NODES / 32)
         hipLaunchKernelGGL((k_bfs_level<WT, 1>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256),
-                           align_up((size_t)live_words * sizeof(unsigned), 16), stream, erow, col, E, Wp, front, seen, acc, idle, hop_planes,
+                           align_up((size_t)live_words * sizeof(unsigned), 16), stream, erow, col, E, N, Wp, front, seen, acc, idle, hop_planes,
                            plane_elems, level, ctl, aux, expand_blocks, live, live_acc, live_idle, live_words);
     else if (mode == 2)
         hipLaunchKernelGGL((k_bfs_level<WT, 2>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow,
-                           col, E, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
+                           col, E, N, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
                            live_acc, live_idle, live_words);
     else
         hipLaunchKernelGGL((k_bfs_level<WT, 0>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow,
-                           col, E, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
+                           col, E, N, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
                            live_acc, live_idle, live_words);
     profile_mark(stream, level, 1);
 }
@@ -1175,9 +1150,9 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
         u64 *idle = b.front[(level + 1) % 3];                    // next level's accumulator: rows spanning chunks cleared now
         const unsigned *lp = b.live[(level - 1) % 3];
         unsigned *ln = b.live[level % 3], *li = b.live[(level + 1) % 3];
-        if (b.Wp == 1)      launch_level<1>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
-        else if (b.Wp == 2) launch_level<2>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
-        else                launch_level<4>(b.E, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
+        if (b.Wp == 1)      launch_level<1>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
+        else if (b.Wp == 2) launch_level<2>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
+        else                launch_level<4>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
     }
     profile_mark(stream, 0, 1, true);
     if (g_profile.enabled && g_profile.span_only && !g_profile.level.empty())

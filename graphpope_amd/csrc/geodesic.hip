@@ -936,7 +936,7 @@ static void profile_mark(hipStream_t stream, int level, int which, bool span = f
 static int g_live_mode = -1;            // -1: by graph size (LDS table up to LIVE_MAX_NODES, global table beyond)
 static int g_finalize_variant = 1;      // 0: generic kernel, 1: fast path with plain stores, 2: fast path, non-temporal stores
 static int g_finalize_blocks = 256 * 8;
-namespace pope { int g_gemm_force_tile = 0; }
+namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_copy_batches_per_wave = 0; }
 
 extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     clear_error();
@@ -945,6 +945,8 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_FINALIZE_VARIANT: g_finalize_variant = value; break;
     case POPE_KNOB_FINALIZE_BLOCKS:  g_finalize_blocks = value > 0 ? value : 256 * 8; break;
     case POPE_KNOB_GEMM_TILE:        pope::g_gemm_force_tile = value; break;
+    case POPE_KNOB_PAIRWISE_KERNEL:  pope::g_pairwise_kernel = value; break;
+    case POPE_KNOB_COPY_BATCHES:      pope::g_copy_batches_per_wave = value; break;
     default: set_error("pope_debug_set: unknown knob %d", knob); return POPE_ERR_INVALID;
     }
     return POPE_OK;

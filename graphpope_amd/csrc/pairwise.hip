@@ -22,7 +22,12 @@
 // differences, so coincident rows give exactly 0 instead of ~1e-2.  Gate: 1e-5 absolute on the scaled values.
 #include "gemm_tile.h"
 
+#include <mutex>
+#include <type_traits>
+
 namespace pope {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #ifndef PW_TILE
 #define PW_TILE 0
@@ -33,22 +38,56 @@ constexpr int PM = 128, PN = 128, PWM = 4, PWN = 1;   // A/B: 4 waves stacked, e
 constexpr int PM = 64, PN = 128, PWM = 2, PWN = 2;    // rows of X x anchor columns per block: 4 waves as 2 x 2, each 32 x 64 (two MFMA tiles)
 #endif
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));
+extern int g_pairwise_kernel, g_copy_batches_per_wave;   // pope_debug_set(POPE_KNOB_PAIRWISE_KERNEL / _COPY_BATCHES, ...) in geodesic.hip
 
-// One wave per row: sum of squares in f64 (sklearn row_norms on the upcast chunk).
-__global__ __launch_bounds__(256) void k_sqnorm(const float *__restrict__ m, long long rows, int D, double *__restrict__ out) {
+// Sum of squares of every row in f64 (sklearn row_norms on the upcast chunk), handed to the tile kernels' epilogues the
+// way they use it: {(float)|row|^2, 1 / |row|} with 1 for a zero row (sklearn normalize(): zero rows stay zero).
+// VEC: rows of 16-byte pieces (D % 4 == 0, aligned base): 16 lanes per row, four rows per wave and step -- the [N, 128]
+// table at 4-byte loads, one wave per row, read at 2 TB/s.
+// One launch for both matrices: rows [0, rows) of m, then rows [0, rows2) of m2 (same depth).
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_sqnorm(const float *__restrict__ m, long long rows, float2 *__restrict__ out,
+                                                const float *__restrict__ m2, long long rows2, float2 *__restrict__ out2, int D) {
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long r = wave; r < rows; r += nwaves) {
+    const long long total = rows + rows2;
+    if (VEC) {
+        const int sub = lane & 15, D4 = D >> 2;
+        for (long long r = wave * 4 + (lane >> 4); r < (total + 3) / 4 * 4; r += nwaves * 4) {
+            const float *row = r < rows ? m + r * D : m2 + (r - rows) * D;
+            double acc = 0.0;
+            if (r < total)
+                for (int k = sub; k < D4; k += 16) {
+                    const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(row) + k);
+                    acc += (double)v.x * (double)v.x;
+                    acc += (double)v.y * (double)v.y;
+                    acc += (double)v.z * (double)v.z;
+                    acc += (double)v.w * (double)v.w;
+                }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            if (sub == 0 && r < total) (r < rows ? out[r] : out2[r - rows]) = make_float2((float)acc, acc == 0.0 ? 1.0f : 1.0f / sqrtf((float)acc));
+        }
+        return;
+    }
+    for (long long r = wave; r < total; r += nwaves) {
+        const float *row = r < rows ? m + r * D : m2 + (r - rows) * D;
         double acc = 0.0;
         for (int k = lane; k < D; k += 64) {
-            const double v = (double)m[r * D + k];
+            const double v = (double)row[k];
             acc += v * v;
         }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if (lane == 0) out[r] = acc;
+        if (lane == 0) (r < rows ? out[r] : out2[r - rows]) = make_float2((float)acc, acc == 0.0 ? 1.0f : 1.0f / sqrtf((float)acc));
     }
+}
+
+static void launch_sqnorm(const float *X, int64_t N, float2 *xn, const float *A, int64_t K, float2 *an, int32_t D, hipStream_t stream) {
+    if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(A)) & 15u) == 0)
+        hipLaunchKernelGGL(k_sqnorm<true>, dim3(capped_grid((size_t)(N + K) * 16, 256)), dim3(256), 0, stream, X, (long long)N, xn, A, (long long)K, an, D);
+    else
+        hipLaunchKernelGGL(k_sqnorm<false>, dim3(capped_grid((size_t)(N + K) * 64, 256)), dim3(256), 0, stream, X, (long long)N, xn, A, (long long)K, an, D);
 }
 
 // sum_k (x[k] - a[k])^2 by a whole wave: lane l takes k = l, l + 64, ...; fixed shuffle tree, so the value does not
@@ -64,6 +103,10 @@ __device__ __forceinline__ float wave_sqdist(const float *__restrict__ x, const 
     return acc;
 }
 
+}  // namespace pope
+#include "pairwise_persistent.h"
+namespace pope {
+
 // grid = (ceil(N / PM), ceil(K / PN)).  dot(X, A^T) on the shared MFMA tile machinery (gemm_tile.h), then the metric
 // epilogue, the raw values into out[:, c0:], and this block's column min / max.
 // The feature copy a pass carries: float4 columns [c_lo, c_hi) of x [N, F4 * 4] -> out[:, 0 : F4 * 4]; x == nullptr: none.
@@ -74,7 +117,7 @@ struct PwCopy {
 
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, int N, int D, const float *__restrict__ A,
-                                                  int K, int metric, const double *__restrict__ xx, const double *__restrict__ aa,
+                                                  int K, int metric, const float2 *__restrict__ xx, const float2 *__restrict__ aa,
                                                   float *__restrict__ out, long long out_cols, int c0,
                                                   float *__restrict__ part_min, float *__restrict__ part_max, int Kpad, PwCopy cp) {
     constexpr int NT = PN / PWN / 32;
@@ -140,9 +183,9 @@ __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, i
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const double x2 = row < N ? xx[row] : 1.0;
-        x2f[r] = (float)x2;
-        rnx[r] = x2 == 0.0 ? 1.0f : 1.0f / sqrtf((float)x2);        // sklearn normalize(): zero rows stay zero
+        const float2 xn = row < N ? xx[row] : make_float2(1.0f, 1.0f);
+        x2f[r] = xn.x;
+        rnx[r] = xn.y;
         obase[r] = (long long)row * out_cols + c0;
     }
 #pragma unroll
@@ -150,9 +193,8 @@ __global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ X, i
         const int cl = wn * (PN / PWN) + t * 32 + (lane & 31);            // column inside the block
         const int col = col0 + cl;
         const bool col_ok = col < K;
-        const double a2 = col_ok ? aa[col] : 0.0;
-        const float a2f = (float)a2;
-        const float rna = (!col_ok || a2 == 0.0) ? 1.0f : 1.0f / sqrtf(a2f);
+        const float2 an = col_ok ? aa[col] : make_float2(0.0f, 1.0f);
+        const float a2f = an.x, rna = an.y;
         float cmin = inf, cmax = -inf;
         float e[16];
         if (metric == POPE_METRIC_EUCLIDEAN) {
@@ -268,6 +310,38 @@ __global__ __launch_bounds__(256) void k_minmax_reduce(const float *__restrict__
     shift[j] = 0.0f - __fmul_rn(mn, sc);
 }
 
+// Both stages in one launch when there are few partial rows (the persistent kernel leaves one per CU): block = 64 columns,
+// its sixteen waves fold rows wave, wave + 16, ..., then wave 0 finishes as k_minmax_reduce does.
+__global__ __launch_bounds__(1024) void k_minmax_finish(const float *__restrict__ part_min, const float *__restrict__ part_max, int nrows,
+                                                        int K, int Kpad, float *__restrict__ scale, float *__restrict__ shift) {
+    __shared__ float smin[16][64], smax[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
+    if (j < K) {
+#pragma unroll 4
+        for (int b = wave; b < nrows; b += 16) {
+            mn = fminf(mn, part_min[(size_t)b * Kpad + j]);
+            mx = fmaxf(mx, part_max[(size_t)b * Kpad + j]);
+        }
+    }
+    smin[wave][lane] = mn;
+    smax[wave][lane] = mx;
+    __syncthreads();
+    if (wave == 0 && j < K) {
+#pragma unroll
+        for (int w = 1; w < 16; ++w) {
+            mn = fminf(mn, smin[w][lane]);
+            mx = fmaxf(mx, smax[w][lane]);
+        }
+        float range = mx - mn;
+        if (range < 10.0f * 1.1920929e-07f) range = 1.0f;
+        const float sc = 1.0f / range;
+        scale[j] = sc;
+        shift[j] = 0.0f - __fmul_rn(mn, sc);
+    }
+}
+
 // MinMaxScaler.transform: X *= scale_; X += min_  (two separately rounded operations: plain operators under contract(off);
 // HIP's __fmul_rn / __fadd_rn wrappers are plain operators too and would let hipcc's default -ffp-contract=fast fuse them).
 #pragma clang fp contract(off)
@@ -291,18 +365,19 @@ static size_t pw_lds_bytes() { return tile_lds_bytes<PM, PN>(); }
 
 struct PwLayout {
     size_t xx, aa, pmin, pmax, fmin, fmax, scale, shift, total;
-    int nblocks, Kpad;
+    int nblocks, part_rows, Kpad;
 };
 
 static PwLayout pw_layout(int64_t N, int32_t K) {
     PwLayout L;
     L.nblocks = (int)((N + PM - 1) / PM);
+    L.part_rows = std::max<int64_t>(L.nblocks, std::min<int64_t>((N + PP_ROWS - 1) / PP_ROWS, PP_MAX_GRID));   // either tile kernel's partial rows fit
     L.Kpad = (K + PN - 1) / PN * PN;
     size_t o = 0;
-    L.xx = o;    o += align_up((size_t)N * sizeof(double), 256);
-    L.aa = o;    o += align_up((size_t)K * sizeof(double), 256);
-    L.pmin = o;  o += align_up((size_t)L.nblocks * L.Kpad * sizeof(float), 256);
-    L.pmax = o;  o += align_up((size_t)L.nblocks * L.Kpad * sizeof(float), 256);
+    L.xx = o;    o += align_up((size_t)N * sizeof(float2), 256);
+    L.aa = o;    o += align_up((size_t)K * sizeof(float2), 256);
+    L.pmin = o;  o += align_up((size_t)L.part_rows * L.Kpad * sizeof(float), 256);
+    L.pmax = o;  o += align_up((size_t)L.part_rows * L.Kpad * sizeof(float), 256);
     L.fmin = o;  o += align_up((size_t)RSPLIT * L.Kpad * sizeof(float), 256);
     L.fmax = o;  o += align_up((size_t)RSPLIT * L.Kpad * sizeof(float), 256);
     L.scale = o; o += align_up((size_t)K * sizeof(float), 256);
@@ -324,7 +399,7 @@ extern "C" size_t pope_pairwise_scratch_bytes(int64_t N, int32_t K, int32_t D) {
 template <int LAYOUT>
 static int pairwise_passes(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric, const float *x, int32_t F,
                            float *out, int64_t out_cols, int32_t c0, const PwLayout &L, char *base, hipStream_t stream) {
-    double *xx = (double *)(base + L.xx), *aa = (double *)(base + L.aa);
+    const float2 *xx = (const float2 *)(base + L.xx), *aa = (const float2 *)(base + L.aa);
     float *pmin = (float *)(base + L.pmin), *pmax = (float *)(base + L.pmax);
     float *fmin = (float *)(base + L.fmin), *fmax = (float *)(base + L.fmax);
     float *scale = (float *)(base + L.scale), *shift = (float *)(base + L.shift);
@@ -340,6 +415,125 @@ static int pairwise_passes(const float *X, int64_t N, int32_t D, const float *A,
     hipLaunchKernelGGL(k_minmax_reduce, dim3((K + 255) / 256), dim3(256), 0, stream, fmin, fmax, K, L.Kpad, scale, shift);
     hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K, (long long)out_cols, c0,
                        scale, shift);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+// out[:, :F] = x beside the persistent tile kernel: 16-byte pieces, PER per lane and row (F <= 256 PER), 16 / PER rows
+// per wave and batch, all 16 loads issued before the first store.  Two blocks of four waves per CU, at most 80 registers
+// a wave: what fits on a CU next to the tile kernel's six waves of ~170 registers (that kernel owns the CU's whole LDS,
+// this one uses none).  32-bit byte offsets: out is below 4 GB on this path.
+template <int PER>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(80))) void k_copy_features(const float *__restrict__ x, unsigned F4,
+                                                                                            float *__restrict__ out, unsigned out_cols, int N) {
+    constexpr int R = 16 / PER;
+    const int lane = threadIdx.x & 63;
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, W = (gridDim.x * blockDim.x) >> 6;
+    const unsigned xpitch = F4 * 16u, opitch = out_cols * 4u;
+    for (int b = gw; b * R < N; b += W) {
+        f32x4v v[R][PER];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int row = b * R + rr;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const unsigned q = lane + 64 * j;
+                if (row < N && q < F4)
+                    v[rr][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(reinterpret_cast<const char *>(x) + ((unsigned)row * xpitch + q * 16u)));
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int row = b * R + rr;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const unsigned q = lane + 64 * j;
+                if (row < N && q < F4) *reinterpret_cast<f32x4v *>(reinterpret_cast<char *>(out) + ((unsigned)row * opitch + q * 16u)) = v[rr][j];
+            }
+        }
+    }
+}
+
+// The side stream the copy runs on, one per device: forked from the caller's stream before the tile pipeline is enqueued,
+// joined after it.  The mutex is held while a call enqueues (the event pair is shared).
+struct SideStream {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static SideStream g_side[16];
+
+static int side_stream_get(int dev, SideStream **out) {
+    POPE_REQUIRE(dev >= 0 && dev < 16, "pope_pairwise_features: device %d", dev);
+    SideStream &s = g_side[dev];
+    if (!s.stream) {
+        POPE_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        POPE_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        POPE_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+    }
+    *out = &s;
+    return POPE_OK;
+}
+
+static int launch_copy_features(const float *x, int32_t F, float *out, int64_t out_cols, int64_t N, hipStream_t stream) {
+    const unsigned F4 = (unsigned)F / 4;
+    const int per = (int)((F4 + 63) / 64);
+    const int PER = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 16;
+    // Short-lived blocks (one batch of 16 / PER rows per wave by default): the kernel is already running when the tile kernel
+    // is enqueued, and a grid of persistent blocks would hold the wave slots and registers that kernel needs to start.
+    const int64_t batches = (N + 16 / PER - 1) / (16 / PER), per_wave = g_copy_batches_per_wave > 0 ? g_copy_batches_per_wave : 1;
+    const dim3 grid((unsigned)((batches + 4 * per_wave - 1) / (4 * per_wave))), block(256);
+    if (PER == 1) hipLaunchKernelGGL(k_copy_features<1>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
+    else if (PER == 2) hipLaunchKernelGGL(k_copy_features<2>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
+    else if (PER == 4) hipLaunchKernelGGL(k_copy_features<4>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
+    else if (PER == 8) hipLaunchKernelGGL(k_copy_features<8>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
+    else hipLaunchKernelGGL(k_copy_features<16>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+// The persistent kernel (pairwise_persistent.h): depths up to 128 in 16-byte pieces.
+static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric, const float *x, int32_t F,
+                               float *out, int64_t out_cols, int32_t c0, const PwLayout &L, char *base, hipStream_t stream) {
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        POPE_HIP(hipFuncSetAttribute((const void *)k_pairwise_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+        lds_opt_in = true;
+    }
+    int dev = 0, cus = 0;
+    POPE_HIP(hipGetDevice(&dev));
+    POPE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const float *zero = nullptr;
+    POPE_HIP(hipGetSymbolAddress((void **)&zero, HIP_SYMBOL(g_sk_zero)));
+    const int n_tiles = (int)((N + PP_ROWS - 1) / PP_ROWS);
+    const int grid = std::min(std::min(cus, PP_MAX_GRID), n_tiles);
+    float *pmin = (float *)(base + L.pmin), *pmax = (float *)(base + L.pmax);
+    float *scale = (float *)(base + L.scale), *shift = (float *)(base + L.shift);
+    launch_sqnorm(X, N, (float2 *)(base + L.xx), A, K, (float2 *)(base + L.aa), D, stream);
+    // The feature copy: forked onto the side stream here, joined at the end.  Its kernel is enqueued AFTER the tile kernel, so
+    // that one's blocks (one per CU, the whole LDS) are resident first and the copy fills the wave slots they leave; started
+    // first, the copy's blocks kept a quarter of the CUs busy until it ended and the tile kernel ran 139 us instead of 80.
+    SideStream *side = nullptr;
+    std::unique_lock<std::mutex> hold;
+    if (x) {
+        int rc = side_stream_get(dev, &side);
+        if (rc) return rc;
+        hold = std::unique_lock<std::mutex>(side->mu);
+        POPE_HIP(hipEventRecord(side->fork, stream));
+        POPE_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+    }
+    PpArgs a{X, A, (int)N, D, K, metric, (const float2 *)(base + L.xx), (const float2 *)(base + L.aa), out, (unsigned)out_cols, c0,
+             pmin, pmax, L.Kpad, zero};
+    hipLaunchKernelGGL(k_pairwise_persistent, dim3(grid, (K + PP_COLS - 1) / PP_COLS), dim3(PP_THREADS), PP_LDS_BYTES, stream, a);
+    if (x) {
+        int rc = launch_copy_features(x, F, out, out_cols, N, side->stream);
+        if (rc) return rc;
+        POPE_HIP(hipEventRecord(side->join, side->stream));
+    }
+    hipLaunchKernelGGL(k_minmax_finish, dim3((K + 63) / 64), dim3(1024), 0, stream, pmin, pmax, grid, K, L.Kpad, scale, shift);
+    hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K, (long long)out_cols, c0,
+                       scale, shift);
+    if (x) POPE_HIP(hipStreamWaitEvent(stream, side->join, 0));
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
@@ -368,8 +562,15 @@ extern "C" int pope_pairwise_features(const float *x, int32_t F, const float *X,
         x = nullptr;
     }
     if (F == 0) x = nullptr;
-    hipLaunchKernelGGL(k_sqnorm, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, X, (long long)N, D, (double *)(base + L.xx));
-    hipLaunchKernelGGL(k_sqnorm, dim3(capped_grid((size_t)K * 64, 256)), dim3(256), 0, stream, A, (long long)K, D, (double *)(base + L.aa));
+    if (g_pairwise_kernel != 1 && D <= PP_DMAX && (D & 3) == 0 && aligned16p(X) && aligned16p(A) && (uint64_t)N * (uint64_t)out_cols * 4u < (1ull << 32)) {
+        if (x && F > 4096) {                                             // rows wider than k_copy_features' 16 pieces per lane: the copy as its own pass
+            int rc = pope_concat(x, N, F, out, out_cols, stream_);
+            if (rc) return rc;
+            x = nullptr;
+        }
+        return pairwise_persistent(X, N, D, A, K, metric, x, F, out, out_cols, c0, L, base, stream);
+    }
+    launch_sqnorm(X, N, (float2 *)(base + L.xx), A, K, (float2 *)(base + L.aa), D, stream);
     const Operand Xo{X, D, 1}, Ao{A, D, 1};
     const bool vec = pick_layout(Xo, (int)N, D) == LAYOUT_KC_VEC && pick_layout(Ao, K, D) == LAYOUT_KC_VEC;
     if (vec) return pairwise_passes<LAYOUT_KC_VEC>(X, N, D, A, K, metric, x, F, out, out_cols, c0, L, base, stream);
@@ -381,3 +582,9 @@ extern "C" int pope_pairwise_minmax(const float *X, int64_t N, int32_t D, const 
                                     void *stream_) {
     return pope_pairwise_features(nullptr, 0, X, N, D, A, K, metric, out, out_cols, c0, scratch, scratch_bytes, stream_);
 }
+
+#ifdef POPE_STAMP
+extern "C" int pope_debug_read_pairwise_stamps(unsigned long long *host, int count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pp_stamps), (size_t)count * sizeof(unsigned long long));
+}
+#endif

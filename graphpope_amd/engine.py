@@ -522,6 +522,8 @@ def pairwise_features(x: torch.Tensor, emb: torch.Tensor, anchors, distance_func
     if anchor_embeddings is not None:
         a = torch.as_tensor(anchor_embeddings).to(dev, torch.float32).contiguous()
         assert a.dim() == 2 and a.shape[1] == d
+    elif isinstance(anchors, torch.Tensor) and anchors.device == dev and anchors.dtype == torch.int64:
+        a = emb.index_select(0, anchors)                                  # anchor ids already on the device: no host round trip
     else:
         a = emb.index_select(0, torch.as_tensor(np.asarray(anchors, dtype=np.int64), device=dev)).contiguous()
     k = a.shape[0]

@@ -49,6 +49,29 @@ def test_shapes_against_oracle(n, d, k, fn, dev, oracle):
     assert out[:, 3:].min() >= -1e-6 and out[:, 3:].max() <= 1.0 + 1e-6
 
 
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("n,d,k,f", [(5000, 128, 256, 8), (3000, 36, 64, 500), (9000, 128, 200, 1028), (257, 128, 513, 4), (40, 4, 2, 12)])
+def test_both_tile_kernels_with_the_feature_copy_inside(n, d, k, f, kernel, dev, oracle):
+    """The anchor-resident persistent kernel (depth <= 128) and the one-tile-per-block kernel, each carrying the
+    out[:, :F] = x copy: narrow, two-pieces-per-lane and wide rows; ragged last tiles; more than one column group."""
+    from graphpope_amd import _lib, engine
+    rs = np.random.RandomState(n + k + f)
+    emb = rs.randn(n, d).astype(np.float32)
+    emb[n - 1] = emb[0]
+    anchors = rs.choice(n, k)
+    x = rs.rand(n, f).astype(np.float32)
+    lib = _lib.load()
+    lib.pope_debug_set(_lib.KNOB_PAIRWISE_KERNEL, kernel)
+    try:
+        for fn in ("euclidean", "distance"):
+            out = engine.pairwise_features(torch.as_tensor(x, device=dev), torch.as_tensor(emb, device=dev), anchors, fn).cpu().numpy()
+            want = oracle.node2vec_features(x, emb, anchors, fn)
+            assert np.array_equal(out[:, :f], x)
+            np.testing.assert_allclose(out[:, f:], want[:, f:], rtol=0, atol=ATOL)
+    finally:
+        lib.pope_debug_set(_lib.KNOB_PAIRWISE_KERNEL, 0)
+
+
 def test_flickr_size_euclidean_properties(dev, oracle):
     """BASELINE config 3 at full size: every column spans [0, 1]; an anchor's own row is the column minimum."""
     from graphpope_amd import engine, synth

@@ -21,6 +21,7 @@
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "common.h"
+#include "side_copy.h"
 
 namespace pope {
 
@@ -936,7 +937,7 @@ static void profile_mark(hipStream_t stream, int level, int which, bool span = f
 static int g_live_mode = -1;            // -1: by graph size (LDS table up to LIVE_MAX_NODES, global table beyond)
 static int g_finalize_variant = 1;      // 0: generic kernel, 1: fast path with plain stores, 2: fast path, non-temporal stores
 static int g_finalize_blocks = 256 * 8;
-namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_copy_batches_per_wave = 0; }
+namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0; }
 
 extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     clear_error();
@@ -946,7 +947,7 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_FINALIZE_BLOCKS:  g_finalize_blocks = value > 0 ? value : 256 * 8; break;
     case POPE_KNOB_GEMM_TILE:        pope::g_gemm_force_tile = value; break;
     case POPE_KNOB_PAIRWISE_KERNEL:  pope::g_pairwise_kernel = value; break;
-    case POPE_KNOB_COPY_BATCHES:      pope::g_copy_batches_per_wave = value; break;
+    case POPE_KNOB_COPY_BATCHES:     pope::g_copy_batches_per_wave = value; break;
     default: set_error("pope_debug_set: unknown knob %d", knob); return POPE_ERR_INVALID;
     }
     return POPE_OK;
@@ -1403,6 +1404,10 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     // speculative: sorted-CSR fast path, the first LEVEL_BATCH levels and the finalise kernel are all enqueued
     // before the host looks at anything; the finalise kernel reads the depth from the BFS control block.
     int rc;
+    // (Measured and rejected, round 2: out[:, :F] = x on a side stream beside the CSR build and the BFS levels instead of inside
+    //  the finalise kernel.  The finalise kernel drops from 98 to 26 us, but the dense levels are bound by the same L2 / fabric
+    //  the copy streams through: levels 3-4 ran 43 us instead of 19 while it was in flight, and the step stayed at 0.275 ms
+    //  with 2, 4 or 8 resident copy blocks per CU, plain or non-temporal stores.  side_copy.h serves the node2vec path only.)
     Bfs b;
     b.slot = nullptr;
     SlotGuard guard{&b.slot, stream};

@@ -21,8 +21,8 @@
 // where d2 is small against the norms (cancellation) the entry is recomputed as a direct sum of squared
 // differences, so coincident rows give exactly 0 instead of ~1e-2.  Gate: 1e-5 absolute on the scaled values.
 #include "gemm_tile.h"
+#include "side_copy.h"
 
-#include <mutex>
 #include <type_traits>
 
 namespace pope {
@@ -38,7 +38,7 @@ constexpr int PM = 128, PN = 128, PWM = 4, PWN = 1;   // A/B: 4 waves stacked, e
 constexpr int PM = 64, PN = 128, PWM = 2, PWN = 2;    // rows of X x anchor columns per block: 4 waves as 2 x 2, each 32 x 64 (two MFMA tiles)
 #endif
 
-extern int g_pairwise_kernel, g_copy_batches_per_wave;   // pope_debug_set(POPE_KNOB_PAIRWISE_KERNEL / _COPY_BATCHES, ...) in geodesic.hip
+extern int g_pairwise_kernel;          // pope_debug_set(POPE_KNOB_PAIRWISE_KERNEL, ...) in geodesic.hip
 
 // Sum of squares of every row in f64 (sklearn row_norms on the upcast chunk), handed to the tile kernels' epilogues the
 // way they use it: {(float)|row|^2, 1 / |row|} with 1 for a zero row (sklearn normalize(): zero rows stay zero).
@@ -419,79 +419,6 @@ static int pairwise_passes(const float *X, int64_t N, int32_t D, const float *A,
     return POPE_OK;
 }
 
-// out[:, :F] = x beside the persistent tile kernel: 16-byte pieces, PER per lane and row (F <= 256 PER), 16 / PER rows
-// per wave and batch, all 16 loads issued before the first store.  Two blocks of four waves per CU, at most 80 registers
-// a wave: what fits on a CU next to the tile kernel's six waves of ~170 registers (that kernel owns the CU's whole LDS,
-// this one uses none).  32-bit byte offsets: out is below 4 GB on this path.
-template <int PER>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(80))) void k_copy_features(const float *__restrict__ x, unsigned F4,
-                                                                                            float *__restrict__ out, unsigned out_cols, int N) {
-    constexpr int R = 16 / PER;
-    const int lane = threadIdx.x & 63;
-    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, W = (gridDim.x * blockDim.x) >> 6;
-    const unsigned xpitch = F4 * 16u, opitch = out_cols * 4u;
-    for (int b = gw; b * R < N; b += W) {
-        f32x4v v[R][PER];
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            const int row = b * R + rr;
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const unsigned q = lane + 64 * j;
-                if (row < N && q < F4)
-                    v[rr][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(reinterpret_cast<const char *>(x) + ((unsigned)row * xpitch + q * 16u)));
-            }
-        }
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            const int row = b * R + rr;
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const unsigned q = lane + 64 * j;
-                if (row < N && q < F4) *reinterpret_cast<f32x4v *>(reinterpret_cast<char *>(out) + ((unsigned)row * opitch + q * 16u)) = v[rr][j];
-            }
-        }
-    }
-}
-
-// The side stream the copy runs on, one per device: forked from the caller's stream before the tile pipeline is enqueued,
-// joined after it.  The mutex is held while a call enqueues (the event pair is shared).
-struct SideStream {
-    std::mutex mu;
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-static SideStream g_side[16];
-
-static int side_stream_get(int dev, SideStream **out) {
-    POPE_REQUIRE(dev >= 0 && dev < 16, "pope_pairwise_features: device %d", dev);
-    SideStream &s = g_side[dev];
-    if (!s.stream) {
-        POPE_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        POPE_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
-        POPE_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
-    }
-    *out = &s;
-    return POPE_OK;
-}
-
-static int launch_copy_features(const float *x, int32_t F, float *out, int64_t out_cols, int64_t N, hipStream_t stream) {
-    const unsigned F4 = (unsigned)F / 4;
-    const int per = (int)((F4 + 63) / 64);
-    const int PER = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 16;
-    // Short-lived blocks (one batch of 16 / PER rows per wave by default): the kernel is already running when the tile kernel
-    // is enqueued, and a grid of persistent blocks would hold the wave slots and registers that kernel needs to start.
-    const int64_t batches = (N + 16 / PER - 1) / (16 / PER), per_wave = g_copy_batches_per_wave > 0 ? g_copy_batches_per_wave : 1;
-    const dim3 grid((unsigned)((batches + 4 * per_wave - 1) / (4 * per_wave))), block(256);
-    if (PER == 1) hipLaunchKernelGGL(k_copy_features<1>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
-    else if (PER == 2) hipLaunchKernelGGL(k_copy_features<2>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
-    else if (PER == 4) hipLaunchKernelGGL(k_copy_features<4>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
-    else if (PER == 8) hipLaunchKernelGGL(k_copy_features<8>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
-    else hipLaunchKernelGGL(k_copy_features<16>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
-    POPE_HIP(hipGetLastError());
-    return POPE_OK;
-}
-
 // The persistent kernel (pairwise_persistent.h): depths up to 128 in 16-byte pieces.
 static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric, const float *x, int32_t F,
                                float *out, int64_t out_cols, int32_t c0, const PwLayout &L, char *base, hipStream_t stream) {
@@ -513,27 +440,25 @@ static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float
     // The feature copy: forked onto the side stream here, joined at the end.  Its kernel is enqueued AFTER the tile kernel, so
     // that one's blocks (one per CU, the whole LDS) are resident first and the copy fills the wave slots they leave; started
     // first, the copy's blocks kept a quarter of the CUs busy until it ended and the tile kernel ran 139 us instead of 80.
-    SideStream *side = nullptr;
-    std::unique_lock<std::mutex> hold;
+    SideCopy copy;
     if (x) {
-        int rc = side_stream_get(dev, &side);
+        int rc = copy.fork(stream);
         if (rc) return rc;
-        hold = std::unique_lock<std::mutex>(side->mu);
-        POPE_HIP(hipEventRecord(side->fork, stream));
-        POPE_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
     }
     PpArgs a{X, A, (int)N, D, K, metric, (const float2 *)(base + L.xx), (const float2 *)(base + L.aa), out, (unsigned)out_cols, c0,
              pmin, pmax, L.Kpad, zero};
     hipLaunchKernelGGL(k_pairwise_persistent, dim3(grid, (K + PP_COLS - 1) / PP_COLS), dim3(PP_THREADS), PP_LDS_BYTES, stream, a);
     if (x) {
-        int rc = launch_copy_features(x, F, out, out_cols, N, side->stream);
+        int rc = copy.launch(x, F, out, out_cols, N);
         if (rc) return rc;
-        POPE_HIP(hipEventRecord(side->join, side->stream));
     }
     hipLaunchKernelGGL(k_minmax_finish, dim3((K + 63) / 64), dim3(1024), 0, stream, pmin, pmax, grid, K, L.Kpad, scale, shift);
     hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K, (long long)out_cols, c0,
                        scale, shift);
-    if (x) POPE_HIP(hipStreamWaitEvent(stream, side->join, 0));
+    if (x) {
+        int rc = copy.join(stream);
+        if (rc) return rc;
+    }
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
@@ -563,7 +488,7 @@ extern "C" int pope_pairwise_features(const float *x, int32_t F, const float *X,
     }
     if (F == 0) x = nullptr;
     if (g_pairwise_kernel != 1 && D <= PP_DMAX && (D & 3) == 0 && aligned16p(X) && aligned16p(A) && (uint64_t)N * (uint64_t)out_cols * 4u < (1ull << 32)) {
-        if (x && F > 4096) {                                             // rows wider than k_copy_features' 16 pieces per lane: the copy as its own pass
+        if (x && !SideCopy::eligible(x, F, out, out_cols, N)) {          // rows wider than the side copy's 16 pieces per lane: the copy as its own pass
             int rc = pope_concat(x, N, F, out, out_cols, stream_);
             if (rc) return rc;
             x = nullptr;

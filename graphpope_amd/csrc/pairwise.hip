@@ -371,7 +371,7 @@ struct PwLayout {
 static PwLayout pw_layout(int64_t N, int32_t K) {
     PwLayout L;
     L.nblocks = (int)((N + PM - 1) / PM);
-    L.part_rows = std::max<int64_t>(L.nblocks, std::min<int64_t>((N + PP_ROWS - 1) / PP_ROWS, PP_MAX_GRID));   // either tile kernel's partial rows fit
+    L.part_rows = std::max<int64_t>(L.nblocks, 2 * std::min<int64_t>((N + PP_ROWS - 1) / PP_ROWS, PP_MAX_GRID));   // either tile kernel's partial rows fit
     L.Kpad = (K + PN - 1) / PN * PN;
     size_t o = 0;
     L.xx = o;    o += align_up((size_t)N * sizeof(float2), 256);
@@ -452,7 +452,7 @@ static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float
         int rc = copy.launch(x, F, out, out_cols, N);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_minmax_finish, dim3((K + 63) / 64), dim3(1024), 0, stream, pmin, pmax, grid, K, L.Kpad, scale, shift);
+    hipLaunchKernelGGL(k_minmax_finish, dim3((K + 63) / 64), dim3(1024), 0, stream, pmin, pmax, 2 * grid, K, L.Kpad, scale, shift);
     hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K, (long long)out_cols, c0,
                        scale, shift);
     if (x) {

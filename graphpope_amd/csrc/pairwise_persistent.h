@@ -3,12 +3,15 @@
 // One block per CU, for the whole call.  The 256 anchor rows of a column group stay RESIDENT in LDS (256 x 128 floats =
 // 128 KB, loaded once); the node2vec table streams through a 2 x 16 KB double buffer in tiles of 32 rows; the block's
 // LDS is the CU's full 160 KB.  Roles as in the stream-K GEMMs (gemm_streamk.h):
-//   waves 0-3  fragments + MFMAs: wave w owns anchor columns [64 w, 64 w + 64) of every tile (two 32 x 32 accumulators,
-//              128 MFMAs per tile), then the metric epilogue, the raw stores and the running column min / max -- kept in
-//              registers for the whole kernel (a lane always owns the same two columns), written once at the end;
-//   waves 4-5  LDS-DMA of the next tile (8 wave-instructions each).
-// One barrier per tile: the DMA waves arrive once tile i + 1 has landed, the consumers once they have read the last
-// fragment of tile i.
+//   waves 0-7  two sets of four consumer waves; wave w of a set owns anchor columns [64 w, 64 w + 64) of the set's tiles:
+//              fragments + MFMAs (two 32 x 32 accumulators, 128 MFMAs per tile), then the metric epilogue, the raw stores
+//              and the running column min / max -- kept in registers for the whole kernel (a lane always owns the same
+//              two columns), written once at the end.  The sets alternate: while one runs the MFMAs of tile i the other
+//              runs the epilogue of tile i - 1, so the matrix cores do not idle through the epilogues (one set alone:
+//              10 300 cycles of MFMA phase + 5 000 of epilogue and loop top per tile);
+//   waves 8-9  LDS-DMA of the next tile (8 wave-instructions each).
+// One barrier per step (= one tile's MFMA phase): the DMA waves arrive once the next tile has landed, the MFMA set once it
+// has read the last fragment of its tile, the other set once its epilogue is done.
 // The feature copy out[:, :F] = x (utils.py:177) is NOT in this kernel: k_copy_features runs beside it, on a side stream,
 // in the wave slots and registers this kernel leaves free on every CU (pairwise.hip).  Measured first as two and as four
 // extra waves of this block, coupled to the tile cadence by the barrier: 64 KB in flight per CU, 0.9-1.3 TB/s each way,
@@ -32,7 +35,7 @@ namespace pope {
 constexpr int PP_ROWS = 32, PP_COLS = 256, PP_DMAX = 128, PP_CHUNKS = PP_DMAX / 4;
 constexpr int PP_B_BYTES = PP_COLS * PP_DMAX * 4, PP_A_BYTES = PP_ROWS * PP_DMAX * 4;
 constexpr int PP_LDS_BYTES = PP_B_BYTES + 2 * PP_A_BYTES;                 // 160 KB
-constexpr int PP_THREADS = 384, PP_MAX_GRID = 1024;
+constexpr int PP_THREADS = 640, PP_MAX_GRID = 1024;
 
 #ifdef POPE_STAMP
 // Diagnostic build only (make stamp, tools/stamp_pairwise.py): shader-clock stamps of every block's sixth tile: [block][wave][slot].
@@ -40,8 +43,8 @@ __device__ unsigned long long g_pp_stamps[256 * 8 * 8];
 #define PP_STAMP(slot)                                                                                  \
     do {                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                              \
-        if (tile == (int)blockIdx.x + 5 * (int)gridDim.x && lane == 0 && blockIdx.x < 256)             \
-            g_pp_stamps[(blockIdx.x * 8 + wave) * 8 + (slot)] = __builtin_amdgcn_s_memtime();          \
+        if ((tile == (int)blockIdx.x + 5 * (int)gridDim.x || tile == (int)blockIdx.x + 6 * (int)gridDim.x) && lane == 0 && blockIdx.x < 256 && (wave < 4 || wave >= 8) == (tile == (int)blockIdx.x + 6 * (int)gridDim.x)) \
+            g_pp_stamps[(blockIdx.x * 8 + (wave & 7)) * 8 + (slot)] = __builtin_amdgcn_s_memtime();    \
         __builtin_amdgcn_sched_barrier(0);                                                              \
     } while (0)
 #else
@@ -56,7 +59,7 @@ struct PpArgs {
     float *out;                  // [N, out_cols]; embedding columns start at c0; N * out_cols * 4 < 2^32 (32-bit store offsets)
     unsigned out_cols;
     int c0;
-    float *part_min, *part_max;  // [gridDim.x][Kpad]
+    float *part_min, *part_max;  // [2 gridDim.x][Kpad]: one row per block and consumer set
     int Kpad;
     const float *zero;
 };
@@ -85,9 +88,10 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
         sk_glds16(src, lds0 + i * 1024);
     }
 
-    if (wave >= 4) {
-        // ---------------- DMA waves ----------------
-        const int lw = wave - 4;
+    const int my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;     // this block's tiles: steps 0 .. my_tiles
+    if (wave >= 8) {
+        // ---------------- DMA waves: in step s the tile of step s + 1 ----------------
+        const int lw = wave - 8;
         auto issue_tile = [&](int tile, int buf) {
             const int row0 = tile * PP_ROWS;
 #pragma unroll
@@ -104,21 +108,22 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
         if (tile < n_tiles) issue_tile(tile, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the anchor image and the first tile have landed
         __builtin_amdgcn_s_barrier();                                    // B_0
-        for (; tile < n_tiles; tile += gridDim.x) {
+        for (int s = 0; s <= my_tiles; ++s, tile += gridDim.x) {
             const int next = tile + gridDim.x;
             PP_STAMP(0);
-            if (next < n_tiles) issue_tile(next, buf ^ 1);               // buffer of tile i - 1: the consumers left it before B_i
+            if (next < n_tiles) issue_tile(next, buf ^ 1);               // the buffer of the tile of step s - 1: its readers left it before that step's barrier
             PP_STAMP(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the next tile has landed
             PP_STAMP(2);
-            __builtin_amdgcn_s_barrier();                                // B_(i+1)
+            __builtin_amdgcn_s_barrier();                                // end of step s
             PP_STAMP(3);
             buf ^= 1;
         }
         return;
     }
 
-    // ---------------- consumer waves ----------------
+    // ---------------- consumer waves: set 0 (waves 0-3) takes the block's even tiles, set 1 (waves 4-7) the odd ones ----------------
+    const int set = wave >> 2, cw = wave & 3;
     const int g = lane >> 5, l31 = lane & 31;
     const float inf = __builtin_huge_valf();
     // this lane's two columns for the whole kernel
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
     float a2f[2], rna[2], cmin[2], cmax[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        col[t] = col_base + wave * 64 + t * 32 + l31;
+        col[t] = col_base + cw * 64 + t * 32 + l31;
         col_ok[t] = col[t] < K;
         const float2 an_t = col_ok[t] ? an[col[t]] : make_float2(0.0f, 1.0f);
         a2f[t] = an_t.x;
@@ -135,13 +140,13 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
         cmin[t] = inf;
         cmax[t] = -inf;
     }
-    const bool cols_full = col_base + wave * 64 + 64 <= K;
+    const bool cols_full = col_base + cw * 64 + 64 <= K;
     const char *Bimg = smem;
     const int fa_off = (l31 * PP_CHUNKS) * 16, fa_swz = l31 & 15;        // row l31 of the tile
     int fb_off[2], fb_swz[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int brow = wave * 64 + t * 32 + l31;
+        const int brow = cw * 64 + t * 32 + l31;
         fb_off[t] = brow * PP_CHUNKS * 16;
         fb_swz[t] = brow & 15;
     }
@@ -150,16 +155,23 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's share of the anchor image
     __builtin_amdgcn_s_barrier();                                        // B_0
     asm volatile("" ::: "memory");
-    int buf = 0;
-    if (col_base + wave * 64 >= K) {                                     // K <= 192 within this group: nothing to compute, keep the barriers
-        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) __builtin_amdgcn_s_barrier();
+    if (col_base + cw * 64 >= K) {                                       // K <= 192 within this group: nothing to compute, keep the barriers
+        for (int s = 0; s <= my_tiles; ++s) __builtin_amdgcn_s_barrier();
         return;
     }
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // Step s: the set s & 1 runs the MFMAs of the block's s-th tile (LDS buffer s & 1) while the other set runs the epilogue
+    // of tile s - 1 -- the matrix cores never wait for an epilogue.  Every wave passes one barrier per step, my_tiles + 1 in all.
+    int steps_left = my_tiles + 1;
+    if (set == 1) {                                                      // step 0 belongs to set 0
+        __builtin_amdgcn_s_barrier();
+        --steps_left;
+    }
+    const char *const Abuf = smem + PP_B_BYTES + set * PP_A_BYTES;
+    for (int tile = blockIdx.x + set * gridDim.x; tile < n_tiles; tile += 2 * gridDim.x) {
         const int row0 = tile * PP_ROWS;
-        const char *Abuf = smem + PP_B_BYTES + buf * PP_A_BYTES;
         PP_STAMP(0);
         // the norms of the 16 rows this lane holds outputs of: issued ahead of the MFMAs, consumed after them
+        // (one load per tile row and 16 lane permutes in the epilogue instead: the MFMA phase 300 cycles shorter, the epilogue 4 000 longer)
         float xr[16];                                                    // |x|^2 (euclidean) or 1 / |x| (cosine): the component the metric uses
 #pragma unroll
         for (int r = 0; r < 16; ++r) xr[r] = xn_sel[2 * min(row0 + (r & 3) + 8 * (r >> 2) + 4 * g, N - 1)];
@@ -200,12 +212,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // the last fragment of this tile has been read: the DMA waves may refill this buffer after the barrier
+        // the last fragment of this tile has been read: the DMA waves may refill this buffer in the step after next
         PP_STAMP(1);
-        __builtin_amdgcn_s_barrier();                                    // B_(i+1)
+        __builtin_amdgcn_s_barrier();                                    // end of this tile's MFMA step
         PP_STAMP(2);
         asm volatile("" ::: "memory");
-        buf ^= 1;
 
         // ---- metric epilogue (the arithmetic of k_pairwise, see there), raw stores, running column min / max.
         // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  FULL: all 32 rows and this
@@ -268,16 +279,24 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
                 PP_STAMP(3 + t);
             }
         };
+        // The other set's MFMA wave on this SIMD needs one issue slot per 64 cycles, this epilogue ~1 000 of them: ahead of the
+        // MFMA stream in priority it still leaves that stream full.
+        __builtin_amdgcn_s_setprio(3);
         if (cols_full && row0 + PP_ROWS <= N) epilogue(std::true_type{});
         else epilogue(std::false_type{});
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();                                    // end of this tile's epilogue step
+        asm volatile("" ::: "memory");
+        steps_left -= 2;
     }
+    for (; steps_left > 0; --steps_left) __builtin_amdgcn_s_barrier();
     // this block's column minima / maxima: lanes l and l + 32 hold the same column
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const float mn = fminf(cmin[t], __shfl_xor(cmin[t], 32)), mx = fmaxf(cmax[t], __shfl_xor(cmax[t], 32));
         if (lane < 32 && col_ok[t]) {
-            part_min[(size_t)blockIdx.x * Kpad + col[t]] = mn;
-            part_max[(size_t)blockIdx.x * Kpad + col[t]] = mx;
+            part_min[(size_t)(blockIdx.x * 2 + set) * Kpad + col[t]] = mn;
+            part_max[(size_t)(blockIdx.x * 2 + set) * Kpad + col[t]] = mx;
         }
     }
 }

@@ -445,14 +445,17 @@ static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float
         int rc = copy.fork(stream);
         if (rc) return rc;
     }
+    // Two consumer sets keep the matrix cores busy through the epilogues; with the feature copy beside the kernel the call is
+    // HBM-bound and the second set's registers are worth more to the copy's waves (configs[2]: 0.193 ms against 0.205).
+    const int sets = g_pairwise_kernel == 2 ? 1 : g_pairwise_kernel == 3 ? 2 : (x ? 1 : 2);
     PpArgs a{X, A, (int)N, D, K, metric, (const float2 *)(base + L.xx), (const float2 *)(base + L.aa), out, (unsigned)out_cols, c0,
-             pmin, pmax, L.Kpad, zero};
+             pmin, pmax, L.Kpad, zero, sets};
     hipLaunchKernelGGL(k_pairwise_persistent, dim3(grid, (K + PP_COLS - 1) / PP_COLS), dim3(PP_THREADS), PP_LDS_BYTES, stream, a);
     if (x) {
         int rc = copy.launch(x, F, out, out_cols, N);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_minmax_finish, dim3((K + 63) / 64), dim3(1024), 0, stream, pmin, pmax, 2 * grid, K, L.Kpad, scale, shift);
+    hipLaunchKernelGGL(k_minmax_finish, dim3((K + 63) / 64), dim3(1024), 0, stream, pmin, pmax, sets * grid, K, L.Kpad, scale, shift);
     hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K, (long long)out_cols, c0,
                        scale, shift);
     if (x) {

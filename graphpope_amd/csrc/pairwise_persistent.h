@@ -59,9 +59,10 @@ struct PpArgs {
     float *out;                  // [N, out_cols]; embedding columns start at c0; N * out_cols * 4 < 2^32 (32-bit store offsets)
     unsigned out_cols;
     int c0;
-    float *part_min, *part_max;  // [2 gridDim.x][Kpad]: one row per block and consumer set
+    float *part_min, *part_max;  // [sets * gridDim.x][Kpad]: one row per block and consumer set
     int Kpad;
     const float *zero;
+    int sets;                    // consumer sets: 2, or 1 when the feature copy runs beside this kernel (its waves need the registers)
 };
 
 __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args) {
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
     const float2 *const xn = args.xn, *const an = args.an;
     float *const out = args.out, *const part_min = args.part_min, *const part_max = args.part_max;
     const unsigned out_cols = args.out_cols;
+    const int sets = args.sets;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,7 +90,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
         sk_glds16(src, lds0 + i * 1024);
     }
 
-    const int my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;     // this block's tiles: steps 0 .. my_tiles
+    const int my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;     // this block's tiles
+    const int steps = sets == 2 ? my_tiles + 1 : my_tiles;          // barriers every wave passes after the first one
     if (wave >= 8) {
         // ---------------- DMA waves: in step s the tile of step s + 1 ----------------
         const int lw = wave - 8;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
         if (tile < n_tiles) issue_tile(tile, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the anchor image and the first tile have landed
         __builtin_amdgcn_s_barrier();                                    // B_0
-        for (int s = 0; s <= my_tiles; ++s, tile += gridDim.x) {
+        for (int s = 0; s < steps; ++s, tile += gridDim.x) {
             const int next = tile + gridDim.x;
             PP_STAMP(0);
             if (next < n_tiles) issue_tile(next, buf ^ 1);               // the buffer of the tile of step s - 1: its readers left it before that step's barrier
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
 
     // ---------------- consumer waves: set 0 (waves 0-3) takes the block's even tiles, set 1 (waves 4-7) the odd ones ----------------
     const int set = wave >> 2, cw = wave & 3;
+    if (set >= sets) return;                                             // one set only: these waves' registers go to the copy kernel beside this one
     const int g = lane >> 5, l31 = lane & 31;
     const float inf = __builtin_huge_valf();
     // this lane's two columns for the whole kernel
@@ -156,19 +160,22 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
     __builtin_amdgcn_s_barrier();                                        // B_0
     asm volatile("" ::: "memory");
     if (col_base + cw * 64 >= K) {                                       // K <= 192 within this group: nothing to compute, keep the barriers
-        for (int s = 0; s <= my_tiles; ++s) __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < steps; ++s) __builtin_amdgcn_s_barrier();
         return;
     }
     // Step s: the set s & 1 runs the MFMAs of the block's s-th tile (LDS buffer s & 1) while the other set runs the epilogue
     // of tile s - 1 -- the matrix cores never wait for an epilogue.  Every wave passes one barrier per step, my_tiles + 1 in all.
-    int steps_left = my_tiles + 1;
+    // (One set: MFMA phase, barrier, epilogue, tile after tile -- one barrier per tile.)
+    int steps_left = steps;
     if (set == 1) {                                                      // step 0 belongs to set 0
         __builtin_amdgcn_s_barrier();
         --steps_left;
     }
-    const char *const Abuf = smem + PP_B_BYTES + set * PP_A_BYTES;
-    for (int tile = blockIdx.x + set * gridDim.x; tile < n_tiles; tile += 2 * gridDim.x) {
+    int buf = set;
+    for (int tile = blockIdx.x + set * gridDim.x; tile < n_tiles; tile += sets * gridDim.x) {
         const int row0 = tile * PP_ROWS;
+        const char *const Abuf = smem + PP_B_BYTES + buf * PP_A_BYTES;
+        if (sets == 1) buf ^= 1;
         PP_STAMP(0);
         // the norms of the 16 rows this lane holds outputs of: issued ahead of the MFMAs, consumed after them
         // (one load per tile row and 16 lane permutes in the epilogue instead: the MFMA phase 300 cycles shorter, the epilogue 4 000 longer)
@@ -285,9 +292,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
         if (cols_full && row0 + PP_ROWS <= N) epilogue(std::true_type{});
         else epilogue(std::false_type{});
         __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();                                    // end of this tile's epilogue step
+        if (sets == 2) __builtin_amdgcn_s_barrier();                     // end of this tile's epilogue step
         asm volatile("" ::: "memory");
-        steps_left -= 2;
+        steps_left -= sets;
     }
     for (; steps_left > 0; --steps_left) __builtin_amdgcn_s_barrier();
     // this block's column minima / maxima: lanes l and l + 32 hold the same column
@@ -295,8 +302,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
     for (int t = 0; t < 2; ++t) {
         const float mn = fminf(cmin[t], __shfl_xor(cmin[t], 32)), mx = fmaxf(cmax[t], __shfl_xor(cmax[t], 32));
         if (lane < 32 && col_ok[t]) {
-            part_min[(size_t)(blockIdx.x * 2 + set) * Kpad + col[t]] = mn;
-            part_max[(size_t)(blockIdx.x * 2 + set) * Kpad + col[t]] = mx;
+            part_min[(size_t)(blockIdx.x * sets + set) * Kpad + col[t]] = mn;
+            part_max[(size_t)(blockIdx.x * sets + set) * Kpad + col[t]] = mx;
         }
     }
 }

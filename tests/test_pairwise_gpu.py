@@ -49,11 +49,11 @@ def test_shapes_against_oracle(n, d, k, fn, dev, oracle):
     assert out[:, 3:].min() >= -1e-6 and out[:, 3:].max() <= 1.0 + 1e-6
 
 
-@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 @pytest.mark.parametrize("n,d,k,f", [(5000, 128, 256, 8), (3000, 36, 64, 500), (9000, 128, 200, 1028), (257, 128, 513, 4), (40, 4, 2, 12)])
 def test_both_tile_kernels_with_the_feature_copy_inside(n, d, k, f, kernel, dev, oracle):
-    """The anchor-resident persistent kernel (depth <= 128) and the one-tile-per-block kernel, each carrying the
-    out[:, :F] = x copy: narrow, two-pieces-per-lane and wide rows; ragged last tiles; more than one column group."""
+    """The anchor-resident persistent kernel (depth <= 128; automatic choice, one and two consumer sets) and the one-tile-per-block
+    kernel, each with the out[:, :F] = x copy: narrow, two-pieces-per-lane and wide rows; ragged last tiles; more than one column group."""
     from graphpope_amd import _lib, engine
     rs = np.random.RandomState(n + k + f)
     emb = rs.randn(n, d).astype(np.float32)

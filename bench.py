@@ -248,12 +248,17 @@ def pairwise_leg(n, anchors, x, dev, steps):
                     "features [N, 500] resident in HBM -> [N, 756] f32 in HBM (feature copy + pairwise + column min-max)",
         "ms_per_call": call_ms, "embeddings_per_s": n * k / (call_ms * 1e-3),
         "embedding_only_ms": emb_ms,
-        "roofline": {"kernel": "pope_pairwise_minmax (all its launches: norms, MFMA tile passes, min-max)", "bound": "mfma",
+        "hbm_floor": {"bytes": 4.0 * n * (d + 2 * F + 2 * k), "ms_at_6.29TBs": 4.0 * n * (d + 2 * F + 2 * k) / 6.29e12 * 1e3,
+                      "note": "table in, features in and out, embedding out, each once; the call also re-reads and re-writes the embedding "
+                              "in the min-max pass (+8NK bytes) and re-reads the table for the row norms: with the feature copy "
+                              "running beside the MFMA kernel the whole call is HBM-bound, the embedding alone is MFMA-bound"},
+        "roofline": {"kernel": "pope_pairwise_minmax (all its launches: row norms, persistent MFMA tile kernel k_pairwise_persistent, min-max)", "bound": "mfma",
                      "achieved": flops / (emb_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / (emb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
                      "algorithmic_flops": flops,
-                     "note": "2*N*K*D flops of the distance matrix (a tile recomputed in a second pass is not counted twice) over "
-                             "the time of the whole embedding call without the feature copy, HIP events on the launch stream"},
+                     "note": "2*N*K*D flops of the distance matrix over the time of the whole embedding call without the feature "
+                             "copy (norms + tile kernel + min-max fold + scaling pass), HIP events on the launch stream; the tile "
+                             "kernel alone is ~63 us of it (profiles/r02_pairwise_kernel_stats.csv)"},
         "whole_call_frac_of_mfma_peak": flops / (call_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
     }
     # parity on a row sample + CPU baseline (sklearn, the calls of utils.py:174-176, all cores)

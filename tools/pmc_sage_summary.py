@@ -31,6 +31,8 @@ def main(tag, rnd):
         if "pope::" not in name:
             continue
         short = name.split("(")[0].replace("void ", "").replace("pope::", "")
+        if not dur.get(name) or not fetch[name].get("FETCH_SIZE"):
+            continue
         top = sorted(dur[name])[len(dur[name]) // 2:]                      # the larger half: layer 0 launches
         f = sorted(fetch[name]["FETCH_SIZE"])[len(fetch[name]["FETCH_SIZE"]) // 2:]
         w = sorted(write[name]["WRITE_SIZE"])[len(write[name]["WRITE_SIZE"]) // 2:] if name in write else [0.0]

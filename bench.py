@@ -94,17 +94,18 @@ def pope_phases(x, ei, n, anchors, timers):
 
 
 def level_kernel_times(ei, n, anchors, reps):
-    """Average duration of a k_bfs_level launch: HIP events recorded by the library on the launch stream around each
-    enqueued run of level launches (no events between the kernels, so this is what rocprofv3 --stats averages too:
-    every launch of the kernel, the trailing early-exit ones included).  Returns (ms per launch, launches per BFS,
-    levels that did work, HopPlanes)."""
+    """Average duration of a k_bfs_level launch ON THE HOT PATH (pope_geodesic_run, the call the timed steps make): HIP
+    events recorded by the library on the launch stream around each enqueued run of level launches (no events between
+    the kernels, so this is what rocprofv3 --stats averages too: every launch of the kernel, trailing early-exit ones
+    included -- the call sizes its run by the depth the previous call found, so after the first call there are none).
+    Returns (ms per launch, launches per BFS, levels that did work, HopPlanes)."""
     lib = _lib.load()
-    csr = engine.build_csr(ei, n)
-    engine.bfs(csr, anchors)
+    for _ in range(2):
+        engine.geodesic_run(None, ei, n, anchors, want_out=False, reuse_workspace=True)
     torch.cuda.synchronize()
     lib.pope_profile_levels(2)
     for _ in range(reps):
-        hp = engine.bfs(csr, anchors)
+        hp = engine.geodesic_run(None, ei, n, anchors, want_out=False, reuse_workspace=True)[1]
     torch.cuda.synchronize()
     cap = 4096
     lv = (ctypes.c_int32 * cap)()
@@ -680,7 +681,7 @@ def main():
             "algorithmic_bytes_per_launch": exp_bytes, "avg_launch_ms": exp_ms, "launches_per_step": launches,
             "active_levels": active_levels, "algorithmic_bytes_per_active_level": dense_bytes,
             "note": "per GPU; average over EVERY launch of the kernel in a step (what rocprofv3 --stats averages): "
-                    f"{active_levels} levels do work, the other {launches - active_levels} exit at once.  The working set (CSR 7.2 MB + planes of "
+                    f"{active_levels} levels do work, {launches - active_levels} exit at once (the run is sized by the depth of the previous call).  The working set (CSR 7.2 MB + planes of "
                     "2.9 MB) is L2 / Infinity-Cache resident: the dense levels run at the L2 line-fill rate of 32-byte gathers, not at the "
                     "HBM rate (DESIGN.md §5); the live-bit table skips quiet neighbours, so sparse levels move fewer bytes than the model"}
         src_bytes = k_total * (4.0 * e + 4.0 * (n + 1) + 4.0 * n)           # SURVEY.md §8d per-source model, all GPUs

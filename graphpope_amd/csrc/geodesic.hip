@@ -1050,7 +1050,13 @@ static void slot_release(Slot *s, hipStream_t stream) {
 struct SlotGuard {                       // releases the call's slot on every return path
     Slot *const *slot;
     hipStream_t stream;
-    ~SlotGuard() { slot_release(*slot, stream); }
+    // Set once the host has SEEN that the device is through with the slot (the verdict arrived, or the stream was
+    // synchronised): no event then -- an event record at the end of every call put a ~7 us bubble in front of the next
+    // call's first kernel.
+    bool quiescent = false;
+    ~SlotGuard() {
+        if (!quiescent) slot_release(*slot, stream);
+    }
 };
 
 // The BFS verdict (deepest active level, CSR status flags) written straight into pinned host memory.
@@ -1077,6 +1083,33 @@ struct Bfs {
 
 constexpr double POPE_POLL_TIMEOUT_S = 30.0;   // wall-clock bound of the host spin on the verdict word
 constexpr int LEVEL_BATCH = 12;     // levels enqueued between two polls of the device flag (hops <= 10: one poll)
+
+// pope_geodesic_run's speculative window remembers how deep the previous call on the same device and the same sizes went:
+// a level launch that only finds "the BFS is over" still costs 4.5 us (Flickr: two of the twelve).  A wrong guess is not an
+// error: a deeper graph answers "not done" and the call continues on the general path, a shallower one runs spare launches.
+struct DepthHint {
+    std::mutex mu;
+    int64_t N = -1, E = -1;
+    int K = -1, last_active = 0;
+};
+static DepthHint g_depth_hint[16];
+
+static int speculative_window(int64_t N, int64_t E, int K) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LEVEL_BATCH;
+    std::lock_guard<std::mutex> lock(g_depth_hint[dev].mu);
+    const DepthHint &h = g_depth_hint[dev];
+    if (h.N == N && h.E == E && h.K == K) return std::min(LEVEL_BATCH, h.last_active + 1);   // one level past the last one that found something
+    return LEVEL_BATCH;
+}
+
+static void remember_depth(int64_t N, int64_t E, int K, int last_active) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+    std::lock_guard<std::mutex> lock(g_depth_hint[dev].mu);
+    DepthHint &h = g_depth_hint[dev];
+    h.N = N; h.E = E; h.K = K; h.last_active = last_active;
+}
 
 static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
                      int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
@@ -1419,7 +1452,7 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     seed.anchors = b.slot->anchors_dev; seed.K = K; seed.Wp = b.Wp; seed.seen = b.seen; seed.front = b.front[0]; seed.live = b.live[0];
     rc = csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, seed, stream);
     if (rc) return rc;
-    int level = bfs_enqueue_levels(b, 1, 1 + LEVEL_BATCH, stream);
+    int level = bfs_enqueue_levels(b, 1, 1 + speculative_window(N, E, K), stream);
     // The finalise kernel writes the verdict into the pinned report when it starts: no report launch, and the host
     // returns as soon as the BFS is known to be complete -- `out` is finished in stream order.
     int ticket = 0;
@@ -1441,6 +1474,8 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     } else if (rc) {
         return rc;
     } else if (done) {
+        guard.quiescent = true;                           // the seed read the anchors long ago and the verdict has arrived: nobody on the device uses the slot any more
+        remember_depth(N, E, K, last_active);
         if (max_hop_host) *max_hop_host = last_active;
         if (n_hop_bits_host) *n_hop_bits_host = hop_bits(last_active);
         return POPE_OK;
@@ -1450,6 +1485,8 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
         if ((rc = bfs_poll(b, level, &last_active, &done, stream))) return rc;
     }
     if (out && (rc = finalize_enqueue(planes, hop_bits(last_active), nullptr, N, K, x, F, out, out_cols, 0, stream))) return rc;
+    guard.quiescent = true;                               // every poll of this path synchronised the stream; the late finalise kernel does not touch the slot
+    remember_depth(N, E, K, last_active);
     if (max_hop_host) *max_hop_host = last_active;
     if (n_hop_bits_host) *n_hop_bits_host = hop_bits(last_active);
     return POPE_OK;

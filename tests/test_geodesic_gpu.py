@@ -328,6 +328,38 @@ def test_back_to_back_runs_keep_their_outputs(dev, oracle):
         assert np.array_equal(out.cpu().numpy().view(np.uint32), want[id(a)].view(np.uint32))
 
 
+def test_speculative_window_follows_the_previous_depth_and_survives_a_wrong_guess(dev, oracle):
+    """pope_geodesic_run sizes its speculative run of levels by the depth the previous call with the same (N, E, K) found.
+    Three graphs with identical sizes and very different depths, interleaved: every result stays bit-exact whether the guess
+    was right (second call on a graph), too shallow (the deep graphs after the shallow one: the call continues on the general
+    path) or too deep."""
+    from graphpope_amd import engine
+    n = 1500
+    rs = np.random.RandomState(5)
+    path = np.arange(n - 1)
+    deep = np.concatenate([np.stack([path, path + 1]), np.stack([path + 1, path])], axis=1)                 # a path: depth up to 1 499
+    e = deep.shape[1]
+    src = rs.randint(0, n, e // 2); dst = rs.randint(0, n, e // 2)
+    shallow = np.concatenate([np.stack([src, dst]), np.stack([dst, src])], axis=1)                         # random: depth ~ 10
+    comb = np.arange(0, n - 20, 1)
+    medium = np.concatenate([np.stack([comb, comb + 20]), np.stack([comb + 20, comb])], axis=1)            # 20 interleaved paths: depth ~ 74
+    medium = np.concatenate([medium, shallow[:, : e - medium.shape[1]]], axis=1)
+    graphs = []
+    for g in (shallow, deep, medium):
+        assert g.shape[1] == e
+        order = np.lexsort((g[1], g[0]))
+        graphs.append(np.ascontiguousarray(g[:, order]).astype(np.int64))
+    anchors = rs.choice(n, 64, replace=False)
+    x = torch.rand(n, 8, device=dev)
+    want = [oracle.geodesic_features(x.cpu().numpy(), g, n, anchors) for g in graphs]
+    depths = []
+    for which in (0, 0, 1, 1, 0, 2, 2, 1, 0):
+        out, hp = engine.geodesic_run(x, torch.as_tensor(graphs[which], device=dev), n, anchors)
+        depths.append(hp.max_hop)
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want[which].view(np.uint32)), which
+    assert depths[0] == depths[1] == depths[4] == depths[8] and depths[2] == depths[3] == depths[7] and depths[2] > depths[5] == depths[6] > depths[0] > 12
+
+
 def test_runs_on_a_side_stream(dev, oracle):
     """Everything is enqueued on the caller's current stream (also the early verdict read and the asynchronous expansion)."""
     from graphpope_amd import engine, synth

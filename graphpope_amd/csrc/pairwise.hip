@@ -436,7 +436,6 @@ static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float
     const int grid = std::min(std::min(cus, PP_MAX_GRID), n_tiles);
     float *pmin = (float *)(base + L.pmin), *pmax = (float *)(base + L.pmax);
     float *scale = (float *)(base + L.scale), *shift = (float *)(base + L.shift);
-    launch_sqnorm(X, N, (float2 *)(base + L.xx), A, K, (float2 *)(base + L.aa), D, stream);
     // The feature copy: forked onto the side stream here, joined at the end.  Its kernel is enqueued AFTER the tile kernel, so
     // that one's blocks (one per CU, the whole LDS) are resident first and the copy fills the wave slots they leave; started
     // first, the copy's blocks kept a quarter of the CUs busy until it ended and the tile kernel ran 139 us instead of 80.
@@ -448,7 +447,7 @@ static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float
     // Two consumer sets keep the matrix cores busy through the epilogues; with the feature copy beside the kernel the call is
     // HBM-bound and the second set's registers are worth more to the copy's waves (configs[2]: 0.193 ms against 0.205).
     const int sets = g_pairwise_kernel == 2 ? 1 : g_pairwise_kernel == 3 ? 2 : (x ? 1 : 2);
-    PpArgs a{X, A, (int)N, D, K, metric, (const float2 *)(base + L.xx), (const float2 *)(base + L.aa), out, (unsigned)out_cols, c0,
+    PpArgs a{X, A, (int)N, D, K, metric, (float2 *)(base + L.xx), out, (unsigned)out_cols, c0,
              pmin, pmax, L.Kpad, zero, sets};
     hipLaunchKernelGGL(k_pairwise_persistent, dim3(grid, (K + PP_COLS - 1) / PP_COLS), dim3(PP_THREADS), PP_LDS_BYTES, stream, a);
     if (x) {

@@ -16,9 +16,11 @@
 // in the wave slots and registers this kernel leaves free on every CU (pairwise.hip).  Measured first as two and as four
 // extra waves of this block, coupled to the tile cadence by the barrier: 64 KB in flight per CU, 0.9-1.3 TB/s each way,
 // the kernel 208 us instead of 83 -- a copy needs more bytes in flight than a block that is sized for MFMA can hold.
-// Everything a row or a column contributes to the epilogue beyond the dot product -- (float)|x|^2 and 1 / |x| -- comes
-// precomputed from k_sqnorm as one float2 per row: as inline arithmetic (f64 -> f32, IEEE sqrt and division for the 16
-// rows a lane owns, every wave again) it cost as much as the tile's 128 MFMAs (stamps: 8 400 of 17 400 cycles).
+// Everything a row contributes to the epilogue beyond the dot product -- (float)|x|^2 and 1 / |x| -- is computed ONCE per
+// row, by the DMA wave that brought the row in, and handed over as one float2 through global memory (L2) a step ahead; the
+// anchors' norms come from the resident image in the prologue.  As inline arithmetic in the consumers (f64 -> f32, IEEE sqrt
+// and division for the 16 rows a lane owns, every wave again) it cost as much as the tile's 128 MFMAs (stamps: 8 400 of
+// 17 400 cycles); as a kernel of its own (k_sqnorm, still used by the round-1 kernel) a 45 MB pass per call.
 // LDS images are [row][32 chunks of 16 B], chunk index XOR (row & 15): every ds_read_b128 of a fragment is conflict-free
 // (16 lanes of a read group sit in 16 different rows: 16 different low chunk bits).  Rows shorter than 128 floats are
 // padded with zeros from a zero page (DMA source addresses are per lane).
@@ -55,7 +57,7 @@ struct PpArgs {
     const float *X;              // [N, D] node2vec table
     const float *A;              // [K, D] anchor rows
     int N, D, K, metric;
-    const float2 *xn, *an;       // per row: {(float)|row|^2, 1 / |row| (1 for a zero row)}  (k_sqnorm)
+    float2 *xn;                  // [N] scratch: per table row {(float)|row|^2, 1 / |row| (1 for a zero row)}, written by the DMA waves
     float *out;                  // [N, out_cols]; embedding columns start at c0; N * out_cols * 4 < 2^32 (32-bit store offsets)
     unsigned out_cols;
     int c0;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
     // plain locals: a lambda that captured the argument struct by reference would force a copy of it into scratch memory
     const float *const X = args.X, *const A = args.A, *const zero = args.zero;
     const int N = args.N, D = args.D, K = args.K, metric = args.metric, c0 = args.c0, Kpad = args.Kpad;
-    const float2 *const xn = args.xn, *const an = args.an;
+    float2 *const xn = args.xn;
     float *const out = args.out, *const part_min = args.part_min, *const part_max = args.part_max;
     const unsigned out_cols = args.out_cols;
     const int sets = args.sets;
@@ -107,9 +109,31 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
                 sk_glds16(src, lds0 + PP_B_BYTES + buf * PP_A_BYTES + instr * 1024);
             }
         };
+        // The norms of a landed tile's rows (sklearn row_norms on the upcast chunk: f64 accumulation), read back from LDS by the
+        // wave that brought the tile in: 4 lanes per row, 8 chunks each.  A pass of its own over the table (k_sqnorm) was 9 us
+        // and 45 MB per call; here it is ~100 instructions per tile in waves that otherwise wait.
+        auto tile_norms = [&](int tile, int buf) {
+            const int row = lw * 16 + (lane >> 2), sub = lane & 3;
+            const char *base = smem + PP_B_BYTES + buf * PP_A_BYTES + row * (PP_CHUNKS * 16);
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 v = *reinterpret_cast<const float4 *>(base + (((sub * 8 + k) ^ (row & 15)) << 4));
+                acc += (double)v.x * (double)v.x;
+                acc += (double)v.y * (double)v.y;
+                acc += (double)v.z * (double)v.z;
+                acc += (double)v.w * (double)v.w;
+            }
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            const int grow = tile * PP_ROWS + row;
+            if (sub == 0 && grow < N) xn[grow] = make_float2((float)acc, acc == 0.0 ? 1.0f : 1.0f / sqrtf((float)acc));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // in L2 before the barrier that lets a consumer set load them
+        };
         int tile = blockIdx.x, buf = 0;
         if (tile < n_tiles) issue_tile(tile, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the anchor image and the first tile have landed
+        if (tile < n_tiles) tile_norms(tile, 0);
         __builtin_amdgcn_s_barrier();                                    // B_0
         for (int s = 0; s < steps; ++s, tile += gridDim.x) {
             const int next = tile + gridDim.x;
@@ -117,6 +141,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
             if (next < n_tiles) issue_tile(next, buf ^ 1);               // the buffer of the tile of step s - 1: its readers left it before that step's barrier
             PP_STAMP(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the next tile has landed
+            if (next < n_tiles) tile_norms(next, buf ^ 1);
             PP_STAMP(2);
             __builtin_amdgcn_s_barrier();                                // end of step s
             PP_STAMP(3);
@@ -138,9 +163,6 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
     for (int t = 0; t < 2; ++t) {
         col[t] = col_base + cw * 64 + t * 32 + l31;
         col_ok[t] = col[t] < K;
-        const float2 an_t = col_ok[t] ? an[col[t]] : make_float2(0.0f, 1.0f);
-        a2f[t] = an_t.x;
-        rna[t] = an_t.y;
         cmin[t] = inf;
         cmax[t] = -inf;
     }
@@ -155,10 +177,25 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
         fb_swz[t] = brow & 15;
     }
     const unsigned pitch = out_cols * 4u;                                // bytes per output row
-    const float *const xn_sel = reinterpret_cast<const float *>(xn) + (metric == POPE_METRIC_EUCLIDEAN ? 0 : 1);
+    const float *const xn_sel = reinterpret_cast<const float *>(xn) + (metric == POPE_METRIC_EUCLIDEAN ? 0 : 1);   // written by this block's DMA waves one step ahead
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's share of the anchor image
     __builtin_amdgcn_s_barrier();                                        // B_0
     asm volatile("" ::: "memory");
+    // the norms of this lane's two anchor rows, from the resident image: its half of the chunks (the ones its fragments use), f64
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        double acc = 0.0;
+        for (int p = 0; p < passes; ++p) {
+            const float4 v = *reinterpret_cast<const float4 *>(Bimg + fb_off[t] + (((2 * p + g) ^ fb_swz[t]) << 4));
+            acc += (double)v.x * (double)v.x;
+            acc += (double)v.y * (double)v.y;
+            acc += (double)v.z * (double)v.z;
+            acc += (double)v.w * (double)v.w;
+        }
+        acc += __shfl_xor(acc, 32);
+        a2f[t] = (float)acc;
+        rna[t] = acc == 0.0 ? 1.0f : 1.0f / sqrtf((float)acc);     // columns past K are zero rows of the image: (0, 1)
+    }
     if (col_base + cw * 64 >= K) {                                       // K <= 192 within this group: nothing to compute, keep the barriers
         for (int s = 0; s < steps; ++s) __builtin_amdgcn_s_barrier();
         return;

@@ -26,15 +26,18 @@ def main(tag, rnd):
                 agg[i % 12 + 1][k].append(v)
         for lvl in agg:
             levels[lvl].update({k: sum(v) / len(v) for k, v in agg[lvl].items() if k in KEEP})
-    out = {"source": f"rocprofv3 --pmc (one group per pass, --kernel-trace only) on `python bench.py --no-sage --steps 3`, tag {tag}; "
+    out = {"source": f"rocprofv3 --pmc (one group per pass, --kernel-trace only) on tools/bfs_only.py (five BFS of 12 launches each), tag {tag}; "
                      "Flickr-shaped graph, 256 anchors: levels 1-10 active (3-6 dense), 11-12 early-exit launches",
            "levels": {str(l): levels[l] for l in sorted(levels)}}
     d = out["levels"]["5"]
     out["dense_level_5"] = {
         "l1_requests": d.get("TCP_TOTAL_CACHE_ACCESSES_sum"), "l1_to_l2_read_requests": d.get("TCP_TCC_READ_REQ_sum"),
         "l2_requests": d.get("TCC_REQ_sum"), "l2_hit_rate": d.get("TCC_HIT_sum", 0) / max(1.0, d.get("TCC_HIT_sum", 0) + d.get("TCC_MISS_sum", 0)),
-        "note": "900k CSR slots -> ~1.06 M L1->L2 read requests per dense level: about one L2 request per gathered 32-byte frontier row "
-                "(L1 serves the index streams, the seen rows and repeated hub rows); the L2 serves 80 % of them, the rest come from the Infinity Cache"}
+        "note": "900k CSR slots -> %.2f M L1->L2 read requests per dense level: about one L2 request per gathered 32-byte frontier row "
+                "(L1 serves the index streams and repeated hub rows), plus -- from round 2 on -- the housekeeping blocks' own pass over "
+                "front / seen / hop planes of every live node (the commit that round 1 did inside the expand waves: fewer memory "
+                "instructions per level, slightly more line requests); the L2 serves ~80 %% of them, the rest come from the Infinity Cache"
+                % ((d.get("TCP_TCC_READ_REQ_sum") or 0) / 1e6)}
     with open(os.path.join(ROOT, "profiles", f"{rnd}_bfs_level_counters.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out["dense_level_5"], indent=1))

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgraphpope_hip.so")
 OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_HOP_OVERFLOW, ERR_WORKSPACE, ERR_NO_DEVICE, ERR_UNSORTED = 0, -1, -2, -3, -4, -5, -6, -7
 METRIC = {"distance": 0, "similarity": 1, "euclidean": 2}
 KNOB_LIVE_MODE, KNOB_FINALIZE_VARIANT, KNOB_FINALIZE_BLOCKS, KNOB_GEMM_TILE = 0, 1, 2, 3
-KNOB_PAIRWISE_KERNEL, KNOB_COPY_BATCHES = 4, 5
+KNOB_PAIRWISE_KERNEL, KNOB_COPY_BATCHES, KNOB_LEVEL_BLOCKS = 4, 5, 6
 
 # name -> (restype, argtypes); exactly the symbols include/graphpope_hip.h declares
 SIGNATURES = {

@@ -937,6 +937,7 @@ static void profile_mark(hipStream_t stream, int level, int which, bool span = f
 static int g_live_mode = -1;            // -1: by graph size (LDS table up to LIVE_MAX_NODES, global table beyond)
 static int g_finalize_variant = 1;      // 0: generic kernel, 1: fast path with plain stores, 2: fast path, non-temporal stores
 static int g_finalize_blocks = 256 * 8;
+static int g_level_blocks = 0;           // cap on the expand blocks of a level launch (0: one wave per chunk up to 2048 blocks)
 namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0; }
 
 extern "C" int pope_debug_set(int32_t knob, int32_t value) {
@@ -948,6 +949,7 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_GEMM_TILE:        pope::g_gemm_force_tile = value; break;
     case POPE_KNOB_PAIRWISE_KERNEL:  pope::g_pairwise_kernel = value; break;
     case POPE_KNOB_COPY_BATCHES:     pope::g_copy_batches_per_wave = value; break;
+    case POPE_KNOB_LEVEL_BLOCKS:     g_level_blocks = value; break;
     default: set_error("pope_debug_set: unknown knob %d", knob); return POPE_ERR_INVALID;
     }
     return POPE_OK;
@@ -960,6 +962,7 @@ static void launch_level(int E, int N, int Wp, const int *col, const int *erow, 
     const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
     int expand_blocks = (nchunks + 3) / 4;                           // one wave per chunk ...
     if (expand_blocks > 256 * 8) expand_blocks = 256 * 8;            // ... up to 8 blocks per CU, then waves loop
+    if (g_level_blocks > 0 && expand_blocks > g_level_blocks) expand_blocks = g_level_blocks;   // A/B: POPE_KNOB_LEVEL_BLOCKS
     int house_blocks = (N + 255) / 256;                              // the commit of the previous level: one thread per node
     if (house_blocks > 1024) house_blocks = 1024;                    // (+ the clears: rows that span chunks, the live table)
     profile_mark(stream, level, 0);

@@ -1291,34 +1291,30 @@ extern "C" int32_t pope_profile_read(int32_t *levels, float *level_ms, int32_t c
 // The BFS in two halves, so that a caller can put other stream work (an all-gather, the finalise kernel) between the
 // enqueue and the host synchronisation: begin = clears + seed + the first LEVEL_BATCH levels, nothing is waited for;
 // finish = wait, read the verdict, keep going if the graph is deeper.  Both take the same arguments.
-extern "C" int pope_geodesic_bfs_begin(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
-                                       int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
-                                       int32_t plane_capacity, void *scratch, size_t scratch_bytes, void *stream_) {
-    clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
+static int bfs_begin_impl(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                          int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
+                          int32_t plane_capacity, void *scratch, size_t scratch_bytes, int window, hipStream_t stream) {
     Bfs b;
     b.slot = nullptr;
     SlotGuard guard{&b.slot, stream};
     int rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes);
     if (rc) return rc;
     if ((rc = bfs_enqueue_init(b, anchors_host, stream))) return rc;
-    bfs_enqueue_levels(b, 1, 1 + LEVEL_BATCH, stream);
+    bfs_enqueue_levels(b, 1, 1 + window, stream);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
 
-extern "C" int pope_geodesic_bfs_finish(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
-                                        int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
-                                        int32_t plane_capacity, void *scratch, size_t scratch_bytes, int32_t *max_hop_host,
-                                        int32_t *n_hop_bits_host, void *stream_) {
-    clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
+static int bfs_finish_impl(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                           int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
+                           int32_t plane_capacity, void *scratch, size_t scratch_bytes, int32_t *max_hop_host,
+                           int32_t *n_hop_bits_host, int window, hipStream_t stream) {
     Bfs b;
     b.slot = nullptr;
     SlotGuard guard{&b.slot, stream};
     int rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes);
     if (rc) return rc;
-    int level = 1 + LEVEL_BATCH, last_active = 0;                  // what begin enqueued
+    int level = 1 + window, last_active = 0;                       // what begin enqueued
     if (level > b.level_limit) level = (int)b.level_limit;
     if (b.E == 0) level = 1;
     bool done = false;
@@ -1327,20 +1323,45 @@ extern "C" int pope_geodesic_bfs_finish(const int32_t *rowptr, const int32_t *co
         level = bfs_enqueue_levels(b, level, level + LEVEL_BATCH, stream);
         if ((rc = bfs_poll(b, level, &last_active, &done, stream))) return rc;
     }
+    guard.quiescent = true;                                        // every poll synchronised the stream
     if (max_hop_host) *max_hop_host = last_active;
     if (n_hop_bits_host) *n_hop_bits_host = hop_bits(last_active);
     return POPE_OK;
+}
+
+extern "C" int pope_geodesic_bfs_begin(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                                       int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
+                                       int32_t plane_capacity, void *scratch, size_t scratch_bytes, void *stream_) {
+    clear_error();
+    return bfs_begin_impl(rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes, LEVEL_BATCH,
+                          (hipStream_t)stream_);
+}
+
+extern "C" int pope_geodesic_bfs_finish(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
+                                        int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
+                                        int32_t plane_capacity, void *scratch, size_t scratch_bytes, int32_t *max_hop_host,
+                                        int32_t *n_hop_bits_host, void *stream_) {
+    clear_error();
+    return bfs_finish_impl(rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes, max_hop_host,
+                           n_hop_bits_host, LEVEL_BATCH, (hipStream_t)stream_);
 }
 
 extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, const int32_t *erow, const int32_t *aux,
                                  int64_t N, int64_t E, const int64_t *anchors_host, int32_t K, uint64_t *planes,
                                  int32_t plane_capacity, void *scratch, size_t scratch_bytes, int32_t *max_hop_host,
                                  int32_t *n_hop_bits_host, void *stream_) {
-    int rc = pope_geodesic_bfs_begin(rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch,
-                                     scratch_bytes, stream_);
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    const int window = speculative_window(N, E, K);        // both halves in one call: the run of levels can follow the previous depth
+    int rc = bfs_begin_impl(rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes, window, stream);
     if (rc) return rc;
-    return pope_geodesic_bfs_finish(rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch,
-                                    scratch_bytes, max_hop_host, n_hop_bits_host, stream_);
+    int32_t max_hop = 0;
+    rc = bfs_finish_impl(rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes, &max_hop,
+                         n_hop_bits_host, window, stream);
+    if (rc) return rc;
+    remember_depth(N, E, K, max_hop);
+    if (max_hop_host) *max_hop_host = max_hop;
+    return POPE_OK;
 }
 
 static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_hop_dev, int64_t N, int32_t K,

@@ -251,9 +251,9 @@ def pairwise_leg(n, anchors, x, dev, steps):
         "embedding_only_ms": emb_ms,
         "hbm_floor": {"bytes": 4.0 * n * (d + 2 * F + 2 * k), "ms_at_6.29TBs": 4.0 * n * (d + 2 * F + 2 * k) / 6.29e12 * 1e3,
                       "note": "table in, features in and out, embedding out, each once; the call also re-reads and re-writes the embedding "
-                              "in the min-max pass (+8NK bytes) and re-reads the table for the row norms: with the feature copy "
-                              "running beside the MFMA kernel the whole call is HBM-bound, the embedding alone is MFMA-bound"},
-        "roofline": {"kernel": "pope_pairwise_minmax (all its launches: row norms, persistent MFMA tile kernel k_pairwise_persistent, min-max)", "bound": "mfma",
+                              "in the min-max pass (+8NK bytes): with the feature copy running beside the MFMA kernel the whole call "
+                              "is HBM-bound, the embedding alone is MFMA-bound"},
+        "roofline": {"kernel": "pope_pairwise_minmax (all its launches: persistent MFMA tile kernel k_pairwise_persistent, min-max fold, scaling pass)", "bound": "mfma",
                      "achieved": flops / (emb_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / (emb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
                      "algorithmic_flops": flops,

@@ -72,6 +72,46 @@ def test_both_tile_kernels_with_the_feature_copy_inside(n, d, k, f, kernel, dev,
         lib.pope_debug_set(_lib.KNOB_PAIRWISE_KERNEL, 0)
 
 
+def test_concurrent_callers_share_the_side_stream_safely(dev, oracle):
+    """The feature copy of pope_pairwise_features runs on ONE side stream per device with one event pair: two host threads on
+    two streams, several calls each, must each get their own features and embedding back."""
+    import threading
+    from graphpope_amd import engine
+    rs = np.random.RandomState(11)
+    jobs = []
+    for t in range(2):
+        n, d, k, f = 6000 + 500 * t, 128, 256, 500
+        emb = rs.randn(n, d).astype(np.float32)
+        x = rs.rand(n, f).astype(np.float32)
+        anchors = rs.choice(n, k)
+        jobs.append((x, emb, anchors, oracle.node2vec_features(x, emb, anchors, "euclidean")))
+    results, errors = [None, None], []
+
+    def work(t):
+        try:
+            x, emb, anchors, _ = jobs[t]
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                xd, ed = torch.as_tensor(x, device=dev), torch.as_tensor(emb, device=dev)
+                outs = [engine.pairwise_features(xd, ed, anchors, "euclidean") for _ in range(6)]
+                stream.synchronize()
+                results[t] = [o.cpu().numpy() for o in outs]
+        except Exception as exc:                                   # surface it in the main thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(2):
+        x, _, _, want = jobs[t]
+        for out in results[t]:
+            assert np.array_equal(out[:, :x.shape[1]], x)
+            np.testing.assert_allclose(out[:, x.shape[1]:], want[:, x.shape[1]:], rtol=0, atol=ATOL)
+
+
 def test_flickr_size_euclidean_properties(dev, oracle):
     """BASELINE config 3 at full size: every column spans [0, 1]; an anchor's own row is the column minimum."""
     from graphpope_amd import engine, synth

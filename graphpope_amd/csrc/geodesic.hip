@@ -51,6 +51,29 @@ __device__ __forceinline__ void seed_anchor(long long a, int j, int Wp, u64 *see
 // chunk, or -1 -- written here by the thread that owns the chunk's first slot (fixed position: no counter, no atomics).
 // pope_geodesic_run also seeds the BFS from the last block (K > 0): one launch less; the planes were zeroed by the
 // launch before this one.
+__device__ __forceinline__ int csr_sorted_edge(int e, long long s, long long d, long long prev, const long long *__restrict__ src, int E, int N,
+                                               int *__restrict__ rowptr, int *aux) {
+    if (s < 0 || s >= N || d < 0 || d >= N) return CSR_FLAG_BAD_INDEX;
+    int flags = 0;
+    if (prev > s) {
+        flags = CSR_FLAG_UNSORTED;
+    } else if (prev >= -1 && prev < s) {
+        for (long long r = prev + 1; r <= s; ++r) rowptr[r] = e;      // rows prev+1 .. s start here
+    }
+    if (e == E - 1)
+        for (long long r = s + 1; r <= N; ++r) rowptr[r] = E;
+    if ((e & (CHUNK - 1)) == 0) {
+        const int c = e >> CHUNK_SHIFT;
+        // row s runs in from chunk c-1 and its first slot lies there (not further back)
+        const bool first_continuation = c > 0 && prev == s && (c == 1 || src[e - CHUNK - 1] != s);
+        aux[AUX_HEADER + c] = first_continuation ? (int)s : -1;
+    }
+    return flags;
+}
+
+// PAIRS: a thread takes two consecutive edges with 16-byte loads and one 8-byte store per output array (E even, 16-byte
+// aligned halves of edge_index): half the memory instructions of the one-edge form for the same 22 MB.
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict__ src,
                                                     const long long *__restrict__ dst, int E, int N,
                                                     int *__restrict__ rowptr, int *__restrict__ col,
@@ -60,27 +83,27 @@ __global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict_
     if (K > 0 && blockIdx.x == gridDim.x - 1)
         for (int j = threadIdx.x; j < K; j += blockDim.x) seed_anchor(anchors[j], j, Wp, seen, front, live);
     int flags = 0;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
-        const long long s = src[e], d = dst[e];
-        if (s < 0 || s >= N || d < 0 || d >= N) {
-            flags |= CSR_FLAG_BAD_INDEX;
-            continue;
+    if (PAIRS) {
+        typedef long long ll2 __attribute__((ext_vector_type(2)));
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; 2 * t < E; t += gridDim.x * blockDim.x) {
+            const int e = 2 * t;
+            const ll2 s2 = reinterpret_cast<const ll2 *>(src)[t], d2 = reinterpret_cast<const ll2 *>(dst)[t];
+            const long long prev = e > 0 ? src[e - 1] : -1;
+            const int f0 = csr_sorted_edge(e, s2.x, d2.x, prev, src, E, N, rowptr, aux);
+            const int f1 = csr_sorted_edge(e + 1, s2.y, d2.y, s2.x, src, E, N, rowptr, aux);
+            flags |= f0 | f1;
+            // a bad id is flagged and the call fails: what lands in its slot does not matter, the pair is stored as one
+            reinterpret_cast<int2 *>(col)[t] = make_int2((int)d2.x, (int)d2.y);
+            reinterpret_cast<int2 *>(erow)[t] = make_int2((int)s2.x, (int)s2.y);
         }
-        long long prev = e > 0 ? src[e - 1] : -1;
-        if (prev > s) {
-            flags |= CSR_FLAG_UNSORTED;
-        } else if (prev >= -1 && prev < s) {
-            for (long long r = prev + 1; r <= s; ++r) rowptr[r] = e;      // rows prev+1 .. s start here
-        }
-        if (e == E - 1)
-            for (long long r = s + 1; r <= N; ++r) rowptr[r] = E;
-        col[e] = (int)d;
-        erow[e] = (int)s;
-        if ((e & (CHUNK - 1)) == 0) {
-            const int c = e >> CHUNK_SHIFT;
-            // row s runs in from chunk c-1 and its first slot lies there (not further back)
-            const bool first_continuation = c > 0 && prev == s && (c == 1 || src[e - CHUNK - 1] != s);
-            aux[AUX_HEADER + c] = first_continuation ? (int)s : -1;
+    } else {
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+            const long long s = src[e], d = dst[e];
+            const int f = csr_sorted_edge(e, s, d, e > 0 ? src[e - 1] : -1, src, E, N, rowptr, aux);
+            flags |= f;
+            if (f & CSR_FLAG_BAD_INDEX) continue;
+            col[e] = (int)d;
+            erow[e] = (int)s;
         }
     }
     if (flags) atomicOr(&aux[AUX_FLAGS], flags);
@@ -881,8 +904,12 @@ static int csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *r
                                seed.front, seed.live);
         return POPE_OK;
     }
-    hipLaunchKernelGGL(k_csr_sorted, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, aux,
-                       seed.anchors, seed.K, seed.Wp, seed.seen, seed.front, seed.live);
+    if ((E & 1) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(col) | reinterpret_cast<uintptr_t>(erow)) & 15u) == 0)
+        hipLaunchKernelGGL(k_csr_sorted<true>, dim3(capped_grid(E / 2, 256)), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, aux,
+                           seed.anchors, seed.K, seed.Wp, seed.seen, seed.front, seed.live);
+    else
+        hipLaunchKernelGGL(k_csr_sorted<false>, dim3(capped_grid(E, 256)), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, aux,
+                           seed.anchors, seed.K, seed.Wp, seed.seen, seed.front, seed.live);
     POPE_HIP(hipGetLastError());
     if (defer_check) return POPE_OK;                 // pope_geodesic_bfs reports what the speculative pass found
     int flags = 0;

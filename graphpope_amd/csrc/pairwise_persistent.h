@@ -82,6 +82,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
     const int col_base = blockIdx.y * PP_COLS;
     const int n_tiles = (N + PP_ROWS - 1) / PP_ROWS;
     const int passes = (D + 7) / 8;                                   // 8 depth values per pass
+#ifdef POPE_STAMP
+    if (lane == 0 && wave == 0 && blockIdx.x < 256) g_pp_stamps[(blockIdx.x * 8) * 8 + 6] = __builtin_amdgcn_s_memtime();     // kernel entry
+#endif
 
     // ---- the anchor image, once: 256 rows x 32 chunks = 128 DMA wave-instructions ----
     for (int i = wave; i < PP_COLS * PP_CHUNKS / 64; i += PP_THREADS / 64) {
@@ -181,6 +184,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's share of the anchor image
     __builtin_amdgcn_s_barrier();                                        // B_0
     asm volatile("" ::: "memory");
+#ifdef POPE_STAMP
+    if (lane == 0 && wave == 0 && blockIdx.x < 256) g_pp_stamps[(blockIdx.x * 8) * 8 + 7] = __builtin_amdgcn_s_memtime();     // past B_0
+#endif
     // the norms of this lane's two anchor rows, from the resident image: its half of the chunks (the ones its fragments use), f64
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -334,6 +340,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
         steps_left -= sets;
     }
     for (; steps_left > 0; --steps_left) __builtin_amdgcn_s_barrier();
+#ifdef POPE_STAMP
+    if (lane == 0 && wave == 0 && blockIdx.x < 256) g_pp_stamps[(blockIdx.x * 8) * 8 + 5] = __builtin_amdgcn_s_memtime();     // all steps done
+#endif
     // this block's column minima / maxima: lanes l and l + 32 hold the same column
 #pragma unroll
     for (int t = 0; t < 2; ++t) {

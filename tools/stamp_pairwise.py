@@ -35,3 +35,6 @@ for w in range(8):
     rel = st[:, w, :5] - t0
     print(f"wave {w}: median stamps relative to the block's earliest wave: " + "  ".join(f"{np.median(rel[:, i]):7.0f}" for i in range(5)))
 
+e, b0, end = st[:, 0, 6], st[:, 0, 7], st[:, 0, 5]
+print("entry -> past B_0: median %.0f cycles (min %.0f, max %.0f); B_0 -> all steps done: median %.0f; entry spread over blocks: %.0f; last end - first entry: %.0f"
+      % (np.median(b0 - e), (b0 - e).min(), (b0 - e).max(), np.median(end - b0), e.max() - e.min(), end.max() - e.min()))

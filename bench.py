@@ -418,6 +418,7 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
     model = SAGE(c_in, 7, HIDDEN, 3).to(dev)                     # --num_layers 3: two convs execute, logits 256 wide
     opt = Adam(model.parameters(), lr=1e-3)   # torch.optim.Adam rule, one launch per step (the step is launch-bound)
     params = list(model.parameters())
+    one = torch.ones((), device=dev)
 
     def step(i):
         n_id, adjs, y = batches[i % len(batches)]
@@ -425,7 +426,7 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
         for p in params:                                         # opt.zero_grad(set_to_none=True) without its bookkeeping
             p.grad = None
         loss = cross_entropy(model(x, adjs), y)              # main.py:216 F.cross_entropy, two launches
-        loss.backward()
+        loss.backward(gradient=one)                          # the root gradient: torch's default is a ones_like fill launch per step
         opt.step()
         return loss
 

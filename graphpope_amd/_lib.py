@@ -78,7 +78,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),
     "sage_bn_scratch_bytes": (c_size_t, [c_int32]),
-    "sage_bn_relu_dropout_forward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+    "sage_bn_relu_dropout_forward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                              c_int32, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                              c_void_p]),
     "sage_bn_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,

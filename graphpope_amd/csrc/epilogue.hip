@@ -144,7 +144,9 @@ __device__ __forceinline__ void fold_parts(const double *__restrict__ pa, const 
 // training: batch statistics + running-stat update; else: the running statistics.  Launch: 256 threads, C/16 blocks.
 __global__ __launch_bounds__(256) void k_bn_final(const double *__restrict__ pa, const double *__restrict__ pb, int parts, int M, int C, int training,
                            float momentum, float eps, float *__restrict__ running_mean, float *__restrict__ running_var,
-                           float *__restrict__ mean, float *__restrict__ rstd) {
+                           float *__restrict__ mean, float *__restrict__ rstd, long long *num_batches_tracked) {
+    // nn.BatchNorm1d's step counter (`num_batches_tracked += 1` in training mode): as a torch op it is a launch of its own
+    if (training && num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     const int c = blockIdx.x * 16 + (threadIdx.x & 15);
     const bool owner = (threadIdx.x >> 4) == 0 && c < C;
     if (!training) {
@@ -256,7 +258,7 @@ using namespace pope;
 extern "C" size_t sage_bn_scratch_bytes(int32_t C) { return C <= 0 ? 0 : bn_scratch(C); }
 
 extern "C" int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C, const float *gamma, const float *beta,
-                                            float *running_mean, float *running_var, float momentum, float eps,
+                                            float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
                                             int32_t training, float p, uint64_t seed, float *y, float *save_mean,
                                             float *save_rstd, void *scratch, size_t scratch_bytes, void *stream_) {
     clear_error();
@@ -281,7 +283,7 @@ extern "C" int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C
                                nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb);
     }
     hipLaunchKernelGGL(k_bn_final, dim3((C + 15) / 16), dim3(256), 0, stream, pl.pa, pl.pb, pl.parts, (int)M, C, training,
-                       momentum, eps, running_mean, running_var, save_mean, save_rstd);
+                       momentum, eps, running_mean, running_var, save_mean, save_rstd, (long long *)num_batches_tracked);
     const unsigned thr = training ? drop_threshold(p) : 0u;
     const float inv_keep = (training && p > 0.f && p < 1.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
     const size_t total = (size_t)M * C;

@@ -186,7 +186,7 @@ class _BnReluDropoutFn(torch.autograd.Function):
     """BatchNorm1d -> ReLU -> dropout in three launches per direction (csrc/epilogue.hip), main.py:207-209."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, p, seed):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, p, seed, num_batches_tracked=None):
         lib = _lib.load()
         if not x.is_cuda:
             raise RuntimeError("the fused BatchNorm/ReLU/dropout epilogue runs on the GPU only (no CPU fallback)")
@@ -199,7 +199,7 @@ class _BnReluDropoutFn(torch.autograd.Function):
         with on_device(dev):
             scratch = torch.empty(lib.sage_bn_scratch_bytes(c), dtype=torch.uint8, device=dev)
             check(lib.sage_bn_relu_dropout_forward(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                                                   momentum, eps, int(training), p, seed, ptr(y), ptr(mean), ptr(rstd),
+                                                   ptr(num_batches_tracked), momentum, eps, int(training), p, seed, ptr(y), ptr(mean), ptr(rstd),
                                                    ptr(scratch), scratch.numel(), _stream()))
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.cfg = (bool(training), float(p), int(seed))
@@ -221,7 +221,7 @@ class _BnReluDropoutFn(torch.autograd.Function):
             check(lib.sage_bn_relu_dropout_backward(ptr(x), ptr(grad_y), m, c, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                                     int(training), p, seed, ptr(grad_x), ptr(grad_gamma), ptr(grad_beta),
                                                     ptr(scratch), scratch.numel(), _stream()))
-        return grad_x, grad_gamma, grad_beta, None, None, None, None, None, None, None
+        return grad_x, grad_gamma, grad_beta, None, None, None, None, None, None, None, None
 
 
 def bn_relu_dropout(x: torch.Tensor, bn: nn.BatchNorm1d, p: float, training: bool, seed: int | None = None) -> torch.Tensor:
@@ -235,14 +235,16 @@ def bn_relu_dropout(x: torch.Tensor, bn: nn.BatchNorm1d, p: float, training: boo
     if bn.weight is None or bn.momentum is None:
         raise NotImplementedError("fused epilogue: affine BatchNorm1d with a fixed momentum only (the reference's default)")
     use_batch_stats = training or bn.running_mean is None
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    nbt = bn.num_batches_tracked if (training and bn.track_running_stats and bn.num_batches_tracked is not None) else None
+    if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64):
+        nbt.add_(1)                                       # a counter the kernel cannot reach: torch's own op
+        nbt = None
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p > 0) else 0
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     out = _BnReluDropoutFn.apply(x, bn.weight, bn.bias, rm, rv, float(bn.momentum), float(bn.eps), use_batch_stats,
-                                 float(p) if training else 0.0, seed)
+                                 float(p) if training else 0.0, seed, nbt)       # the step counter goes up inside the statistics kernel
     return out
 
 

@@ -413,7 +413,7 @@ int sage_sample_batch(const int32_t *rowptr, const int32_t *col, int64_t N, cons
  * ------------------------------------------------------------------------------------------------ */
 size_t sage_bn_scratch_bytes(int32_t C);
 int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C, const float *gamma, const float *beta,
-                                 float *running_mean, float *running_var, float momentum, float eps, int32_t training,
+                                 float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps, int32_t training,
                                  float p, uint64_t seed, float *y, float *save_mean, float *save_rstd, void *scratch,
                                  size_t scratch_bytes, void *stream);
 int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,

@@ -1117,10 +1117,11 @@ constexpr int LEVEL_BATCH = 12;     // levels enqueued between two polls of the 
 // pope_geodesic_run's speculative window remembers how deep the previous call on the same device and the same sizes went:
 // a level launch that only finds "the BFS is over" still costs 4.5 us (Flickr: two of the twelve).  A wrong guess is not an
 // error: a deeper graph answers "not done" and the call continues on the general path, a shallower one runs spare launches.
+// After a guess that was too shallow the window keeps one spare level for these sizes (anchor sets whose depth wanders by one).
 struct DepthHint {
     std::mutex mu;
     int64_t N = -1, E = -1;
-    int K = -1, last_active = 0;
+    int K = -1, last_active = 0, margin = 1;
 };
 static DepthHint g_depth_hint[16];
 
@@ -1129,15 +1130,17 @@ static int speculative_window(int64_t N, int64_t E, int K) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LEVEL_BATCH;
     std::lock_guard<std::mutex> lock(g_depth_hint[dev].mu);
     const DepthHint &h = g_depth_hint[dev];
-    if (h.N == N && h.E == E && h.K == K) return std::min(LEVEL_BATCH, h.last_active + 1);   // one level past the last one that found something
+    if (h.N == N && h.E == E && h.K == K) return std::min(LEVEL_BATCH, h.last_active + h.margin);   // margin 1: one level past the last one that found something
     return LEVEL_BATCH;
 }
 
-static void remember_depth(int64_t N, int64_t E, int K, int last_active) {
+static void remember_depth(int64_t N, int64_t E, int K, int last_active, bool window_was_too_short = false) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
     std::lock_guard<std::mutex> lock(g_depth_hint[dev].mu);
     DepthHint &h = g_depth_hint[dev];
+    const bool same = h.N == N && h.E == E && h.K == K;
+    h.margin = same ? (window_was_too_short ? 2 : h.margin) : 1;
     h.N = N; h.E = E; h.K = K; h.last_active = last_active;
 }
 
@@ -1386,7 +1389,7 @@ extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, cons
     rc = bfs_finish_impl(rowptr, col, erow, aux, N, E, anchors_host, K, planes, plane_capacity, scratch, scratch_bytes, &max_hop,
                          n_hop_bits_host, window, stream);
     if (rc) return rc;
-    remember_depth(N, E, K, max_hop);
+    remember_depth(N, E, K, max_hop, window < LEVEL_BATCH && max_hop >= window);
     if (max_hop_host) *max_hop_host = max_hop;
     return POPE_OK;
 }
@@ -1503,7 +1506,8 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     seed.anchors = b.slot->anchors_dev; seed.K = K; seed.Wp = b.Wp; seed.seen = b.seen; seed.front = b.front[0]; seed.live = b.live[0];
     rc = csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, seed, stream);
     if (rc) return rc;
-    int level = bfs_enqueue_levels(b, 1, 1 + speculative_window(N, E, K), stream);
+    const int window = speculative_window(N, E, K);
+    int level = bfs_enqueue_levels(b, 1, 1 + window, stream);
     // The finalise kernel writes the verdict into the pinned report when it starts: no report launch, and the host
     // returns as soon as the BFS is known to be complete -- `out` is finished in stream order.
     int ticket = 0;
@@ -1537,7 +1541,7 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     }
     if (out && (rc = finalize_enqueue(planes, hop_bits(last_active), nullptr, N, K, x, F, out, out_cols, 0, stream))) return rc;
     guard.quiescent = true;                               // every poll of this path synchronised the stream; the late finalise kernel does not touch the slot
-    remember_depth(N, E, K, last_active);
+    remember_depth(N, E, K, last_active, window < LEVEL_BATCH);
     if (max_hop_host) *max_hop_host = last_active;
     if (n_hop_bits_host) *n_hop_bits_host = hop_bits(last_active);
     return POPE_OK;

@@ -740,6 +740,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        barrier()                              # rank 0 measured its level kernel alone meanwhile: leave the group together
         dist.destroy_process_group()
 
 

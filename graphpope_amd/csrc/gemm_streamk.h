@@ -447,7 +447,7 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_ld(SkArgs a) {
 
 // SK_FIX_PARTS blocks per tile: a tile whose units went to several blocks is the sum of their partial slabs, in block
 // order.  Each thread owns two 16-byte pieces and has the loads of all partials in flight together.
-constexpr int SK_FIX_PARTS = 8;
+constexpr int SK_FIX_PARTS = 8;       // (16 parts, one piece per thread: 10.7 us against 9.7)
 
 __global__ __launch_bounds__(256) void k_streamk_fixup(SkArgs a, int G) {
     const int S = a.S0 + a.S1;

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
     }
 }
 
-// SK_FIX_PARTS blocks per tile, as k_streamk_fixup.
+// SK_TN_FIX_PARTS blocks per tile, as k_streamk_fixup: 24 tiles only, so more parts per tile (384 blocks, one piece per thread).
+constexpr int SK_TN_FIX_PARTS = 16;
 __global__ __launch_bounds__(256) void k_streamk_tn_fixup(SkTnArgs a, int G) {
     const int S = a.S;
     const long long T = (long long)a.tiles_m * a.tiles_nb * 2 * S;
@@ -209,19 +210,21 @@ __global__ __launch_bounds__(256) void k_streamk_tn_fixup(SkTnArgs a, int G) {
     int q, m0, n0;
     sk_tn_tile(a, tile, q, m0, n0);
     float *C = q ? a.C[1] : a.C[0];
-    constexpr int PER = SK_TM * SK_TN / 4 / SK_FIX_PARTS;                                 // 16-byte pieces per block
+    constexpr int PER = SK_TM * SK_TN / 4 / SK_TN_FIX_PARTS;                              // 16-byte pieces per block
     for (int p = blockIdx.y * PER + threadIdx.x; p < (blockIdx.y + 1) * PER; p += blockDim.x) {
         const int m = p / (SK_TN / 4), n = (p % (SK_TN / 4)) * 4;
         if (m0 + m >= a.M || n0 + n >= a.Nb) continue;
         const size_t off = (size_t)m * SK_TN + n;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        // the partial slabs of this tile, blocks b_lo .. b_hi in order, FOUR loads in flight at a time (two or three partials
-        // for the forward projection, about eleven per tile for the weight gradients); a block with no unit of the tile
-        // (possible only when there are fewer units than blocks) contributes nothing
-        for (int b0 = b_lo; b0 <= b_hi; b0 += 4) {
-            float4 v[4];
+        // the partial slabs of this tile, blocks b_lo .. b_hi in order, TWELVE loads in flight at a time: a tile of the weight
+        // gradients has about eleven partials, and with four in flight and two pieces per thread the kernel was six load
+        // latencies deep (9.4 us for 18 MB); a block with no unit of the tile (possible only when there are fewer units than
+        // blocks) contributes nothing
+        constexpr int INFLIGHT = 12;
+        for (int b0 = b_lo; b0 <= b_hi; b0 += INFLIGHT) {
+            float4 v[INFLIGHT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < INFLIGHT; ++i) {
                 const int b = b0 + i;
                 const long long lo = sk_lo(b, T, G), hi = sk_lo(b + 1, T, G);
                 const long long sb = lo > u0 ? lo : u0, se = hi < u1 ? hi : u1;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void k_streamk_tn_fixup(SkTnArgs a, int G) {
                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+            for (int i = 0; i < INFLIGHT; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
         }
         float *c = C + (size_t)(m0 + m) * a.ldc + n0 + n;
         const float sv[4] = {s.x, s.y, s.z, s.w};

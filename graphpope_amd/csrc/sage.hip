@@ -421,7 +421,7 @@ static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int
     if (!zero_page[dev]) POPE_HIP(hipGetSymbolAddress((void **)&zero_page[dev], HIP_SYMBOL(g_sk_zero)));
     a.zero = zero_page[dev];
     hipLaunchKernelGGL(k_gemm_streamk_tn, dim3((unsigned)grid), dim3(SKL_THREADS), SK_LDS_BYTES, stream, a);
-    hipLaunchKernelGGL(k_streamk_tn_fixup, dim3(2 * a.tiles_m * a.tiles_nb, SK_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
+    hipLaunchKernelGGL(k_streamk_tn_fixup, dim3(2 * a.tiles_m * a.tiles_nb, SK_TN_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
     POPE_HIP(hipGetLastError());
     *used = true;
     return POPE_OK;

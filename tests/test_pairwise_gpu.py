@@ -112,6 +112,34 @@ def test_concurrent_callers_share_the_side_stream_safely(dev, oracle):
             np.testing.assert_allclose(out[:, x.shape[1]:], want[:, x.shape[1]:], rtol=0, atol=ATOL)
 
 
+def test_the_call_survives_stream_capture_and_replay(dev, oracle):
+    """pope_pairwise_features forks the feature copy onto its side stream and joins it through events -- the pattern stream
+    capture supports: captured once into a HIP graph, replayed on new table contents, it must give the new result."""
+    from graphpope_amd import engine
+    n = 6000
+    rs = np.random.RandomState(21)
+    x = torch.as_tensor(rs.rand(n, 500).astype(np.float32), device=dev)
+    emb = torch.as_tensor(rs.randn(n, 128).astype(np.float32), device=dev)
+    anchors = torch.as_tensor(rs.choice(n, 256).astype(np.int64), device=dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):                          # warm up outside the capture: one-time allocations and attributes
+        for _ in range(2):
+            engine.pairwise_features(x, emb, anchors, "euclidean")
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = engine.pairwise_features(x, emb, anchors, "euclidean")
+    emb2 = rs.randn(n, 128).astype(np.float32)
+    emb.copy_(torch.as_tensor(emb2, device=dev))
+    graph.replay()
+    torch.cuda.synchronize()
+    want = oracle.node2vec_features(x.cpu().numpy(), emb2, anchors.cpu().numpy(), "euclidean")
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :500], x.cpu().numpy())
+    np.testing.assert_allclose(got[:, 500:], want[:, 500:], rtol=0, atol=ATOL)
+
+
 def test_flickr_size_euclidean_properties(dev, oracle):
     """BASELINE config 3 at full size: every column spans [0, 1]; an anchor's own row is the column minimum."""
     from graphpope_amd import engine, synth

@@ -2,20 +2,24 @@
 // exact-f32 MFMA tile, then per-column min-max scaling.
 //
 // Replaces /root/reference/utils.py:158-176 (sklearn cosine_similarity / cosine_distances / euclidean_distances
-// followed by MinMaxScaler().fit/transform).  Pipeline:
-//   k_sqnorm          ||x||^2 of every node2vec row and anchor row, accumulated in f64
+// followed by MinMaxScaler().fit/transform).  Two pipelines:
+//  (A) depth <= 128 in 16-byte pieces, out below 4 GB -- the node2vec table is [N, 128]:
+//   k_pairwise_persistent  (pairwise_persistent.h) one block per CU, the anchor rows resident in LDS, the table streamed
+//                     through by LDS-DMA; row norms, metric epilogue, raw values into out[:, F:], per-block column min / max
+//   k_copy_features   (side_copy.hip) out[:, :F] = x on a side stream, beside that kernel
+//   k_minmax_finish   column min / max over the partial rows -> scale_ = 1/range (range < 10 eps -> 1), min_ = 0 - min*scale_
+//   k_minmax_apply    y = e * scale_ + min_ in place (two roundings, like NumPy's X *= scale_; X += min_)
+//  (B) everything else -- round 1's pipeline:
+//   k_sqnorm          ||x||^2 of every node2vec row and anchor row, accumulated in f64, as {(float)|r|^2, 1/|r|}
 //   k_pairwise        dot(X, A^T) with v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate; 64 x 128 tiles on the
 //                     machinery of gemm_tile.h: register double buffering, batched LDS fragment reads), metric
 //                     epilogue, raw values written straight into the [N, F+K] output, per-block column min/max.
 //                     The blocks also carry the feature copy out[:, :F] = x (utils.py:177 concat_into_features): each
-//                     streams its own rows' share between its tile product and its epilogue, so the copy's HBM time
-//                     (357 MB: 75 us as a pass of its own) hides under the other blocks' MFMAs and epilogue arithmetic.
-//   k_minmax_fold / k_minmax_reduce   column min/max over blocks (two stages) -> scale_ = 1/range (range < 10 eps -> 1), min_ = 0 - min*scale_
-//   k_minmax_apply    y = e * scale_ + min_ in place (two roundings, like NumPy's X *= scale_; X += min_)
+//                     streams its own rows' share between its tile product and its epilogue.
+//   k_minmax_fold / k_minmax_reduce   column min/max over blocks (two stages), then k_minmax_apply
 // Measured and rejected (round 2): computing the tile TWICE (statistics pass, then a pass that scales in its epilogue and
-// stores once) instead of raw store + apply pass.  f32 MFMAs issue on the vector ALUs' slots, so the ~25 VALU instructions
-// per output of the metric epilogue do not hide behind them: one tile pass costs ~100 us whether it stores or not, and two
-// of them took 244 us against 161 us for tile + apply (profiles/r02_pairwise_notes.txt).
+// stores once) instead of raw store + apply pass: with kernel (B) two tile passes took 244 us against 161 us for tile +
+// apply; with kernel (A) the second pass would cost more than the 35 us scaling pass it removes.
 // Euclidean: sklearn upcasts f32 inputs to f64 (pairwise.py:582-653).  Here the row norms are accumulated in f64,
 // d2 = xx + aa - 2 dot is one f32 fma on the f32-accumulated MFMA dot (whose own error, ~1e-6 |x||a|, dominates);
 // where d2 is small against the norms (cancellation) the entry is recomputed as a direct sum of squared

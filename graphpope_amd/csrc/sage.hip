@@ -11,6 +11,10 @@
 //                    that never materialises either product.  Arbitrary strides cover NT / NN / TN shapes;
 //                    split-K (grid.z) with partial slabs + k_slab_reduce for the weight gradients
 //                    (reduction over ~40 000 rows), deterministic: no float atomics there.
+//   k_gemm_streamk_ld / k_gemm_streamk_tn   (gemm_streamk.h, gemm_streamk_tn.h) the two big products of a layer -- the forward
+//                    projection and the weight-gradient twin -- as stream-K over one persistent block per CU: LDS-DMA staging by
+//                    loader waves, MFMA-only consumer waves, partial tiles to slabs + a fix-up launch that sums them in block
+//                    order; shapes they do not take (depth % 4, alignment, offsets beyond 32 bits, too few units) stay on k_gemm.
 //   k_scatter_mean   grad_x[col[p]] += grad_agg[i] / deg(i) (float atomics, whole 16-byte-aligned row segments)
 //   k_colsum_*       grad_bias, two deterministic stages
 #include "gemm_streamk_tn.h"

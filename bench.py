@@ -244,6 +244,14 @@ def pairwise_leg(n, anchors, x, dev, steps):
     torch.cuda.synchronize()
     emb_ms = ev[0].elapsed_time(ev[1]) / steps
     flops = 2.0 * n * k * d
+    tile_traffic, tile_traffic_src = None, None
+    try:                                                         # HBM bytes of the tile kernel from the committed counter passes
+        with open(os.path.join(ROOT, "profiles", "r02_pairwise_pmc.json")) as fh:
+            kk = json.load(fh)["kernels"]["k_pairwise_persistent"]
+        tile_traffic = kk["hbm_read_bytes"] + kk["hbm_write_bytes"]
+        tile_traffic_src = "profiles/r02_pairwise_pmc.json (rocprofv3 --pmc passes of tools/pairwise_time.py, a separate run: k_pairwise_persistent only)"
+    except (OSError, ValueError, KeyError):
+        pass
     res = {
         "workload": f"configs[2]: node2vec-euclidean, X [{n}, {d}] f32 N(0,1) (torch seed 0), {k} anchors (np seed 42), "
                     "features [N, 500] resident in HBM -> [N, 756] f32 in HBM (feature copy + pairwise + column min-max)",
@@ -255,7 +263,7 @@ def pairwise_leg(n, anchors, x, dev, steps):
                               "is HBM-bound, the embedding alone is MFMA-bound"},
         "roofline": {"kernel": "pope_pairwise_minmax (all its launches: persistent MFMA tile kernel k_pairwise_persistent, min-max fold, scaling pass)", "bound": "mfma",
                      "achieved": flops / (emb_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": flops / (emb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                     "frac": flops / (emb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": tile_traffic, "traffic_source": tile_traffic_src,
                      "algorithmic_flops": flops,
                      "note": "2*N*K*D flops of the distance matrix over the time of the whole embedding call without the feature "
                              "copy (norms + tile kernel + min-max fold + scaling pass), HIP events on the launch stream; the tile "

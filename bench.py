@@ -407,10 +407,66 @@ def kmeans_leg(n, dev):
     return res
 
 
+def _torch_sage_step_baseline(feats, batches, c_in, dev, steps):
+    """SURVEY.md 8(d) "SAGE baseline ... on the same GPU": the step in stock torch ops (index_select + index_add_ segment
+    mean + F.linear, nn.BatchNorm1d, relu_, F.dropout, F.cross_entropy, torch.optim.Adam), the same pre-sampled batches,
+    the same model shape (main.py:182-222).  What the reference's stack does minus PyG's fused SpMM."""
+    import torch.nn.functional as Fn
+
+    class Conv(torch.nn.Module):
+        def __init__(self, ci, co):
+            super().__init__()
+            self.lin_l, self.lin_r = torch.nn.Linear(ci, co), torch.nn.Linear(ci, co, bias=False)
+
+        def forward(self, x_src, seg, col64, n_dst, inv_deg):
+            agg = torch.zeros(n_dst, x_src.shape[1], dtype=x_src.dtype, device=x_src.device)
+            agg.index_add_(0, seg, x_src.index_select(0, col64))
+            return self.lin_l(agg * inv_deg) + self.lin_r(x_src[:n_dst])
+
+    torch.manual_seed(0)
+    convs = torch.nn.ModuleList([Conv(c_in, HIDDEN), Conv(HIDDEN, HIDDEN)]).to(dev)
+    bn = torch.nn.BatchNorm1d(HIDDEN).to(dev)
+    params = list(convs.parameters()) + list(bn.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3)
+    prepared = []
+    for n_id, adjs, y in batches:                                   # index lists a stock pipeline would hold per batch
+        blocks = []
+        for a in adjs:
+            deg = (a.rowptr[1:] - a.rowptr[:-1]).to(torch.int64)
+            blocks.append((torch.repeat_interleave(torch.arange(a.n_dst, device=dev), deg), a.col.to(torch.int64), a.n_dst,
+                           (1.0 / deg.clamp(min=1).to(torch.float32))[:, None]))
+        prepared.append((n_id, blocks, y))
+
+    def step(i):
+        n_id, blocks, y = prepared[i % len(prepared)]
+        x = feats.index_select(0, n_id)                             # convert_batch: x = data.x[n_id] (main.py:118-123)
+        x = convs[0](x, *blocks[0])
+        x = Fn.dropout(bn(x).relu_(), 0.5, True)
+        x = convs[1](x, *blocks[1])
+        loss = Fn.cross_entropy(x, y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": BATCH / dt, "unit": "seed nodes/s", "ms_per_step": dt * 1e3, "kind": "port",
+            "what": "the same step in stock torch ops on the same GPU: index_select + index_add_ segment mean + F.linear (hipBLASLt), "
+                    "nn.BatchNorm1d, relu_, F.dropout, F.cross_entropy, torch.optim.Adam; same pre-sampled batches, x = data.x[n_id] gathered per step"}
+
+
 def sage_leg(feats, ei_np, n, dev, steps, warmup):
     """SAGE nodes/s: fwd + bwd + Adam on pre-sampled Flickr-shaped batches over the features + POPE matrix."""
     from graphpope_amd.sage import SAGE, IndexedFeatures, cross_entropy, sample_batch
     from graphpope_amd.optim import Adam
+    from graphpope_amd.sampler import DeviceBatch
+    from graphpope_amd.train import SageTrainStep
     from oracle import oracle
     rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei_np[0], minlength=n))])
     col = ei_np[1]                                               # synthetic edge list is sorted by source
@@ -427,6 +483,33 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
     opt = Adam(model.parameters(), lr=1e-3)   # torch.optim.Adam rule, one launch per step (the step is launch-bound)
     params = list(model.parameters())
     one = torch.ones((), device=dev)
+
+    # (1) the step as the product runs it (graphpope_amd.train.SageTrainStep): captured once into a HIP graph and replayed;
+    #     the pre-sampled batch is loaded into the graph's fixed buffers by one launch, its sizes stay in device words
+    pool = []
+    for n_id, adjs, y in batches:
+        db = DeviceBatch(BATCH, (25, 10), dev)
+        db.load(n_id, adjs)
+        pool.append((db, y))
+    trainer = SageTrainStep(model, opt, feats, BATCH, (25, 10), sampler=None, graph=True)
+
+    def gstep(i):
+        db, y = pool[i % len(pool)]
+        trainer.load_batch(db, y)
+        return trainer.run()
+
+    for i in range(max(warmup, 4)):                              # two eager calls, the capture, one replay
+        gstep(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        gstep(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+
+    # (2) the same step enqueued eagerly through autograd on host-sized batches (rounds 1-2's figure)
+    model.dropout_seed_dev = None
+    opt.use_device_step(None)
 
     def step(i):
         n_id, adjs, y = batches[i % len(batches)]
@@ -449,8 +532,12 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
     for i in range(steps):
         step(i)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    eager_dt = (time.perf_counter() - t0) / steps
     shapes = [(a.n_dst, a.n_src, int(a.col.numel())) for a in batches[0][1]]
+    try:
+        torch_gpu = _torch_sage_step_baseline(feats, batches, c_in, dev, steps)
+    except Exception as exc:                                     # never take the bench down
+        torch_gpu = {"error": repr(exc)}
 
     # per-kernel view of layer 0 forward: gather (HBM/L2 bound) and projection (f32 MFMA bound)
     n_id, adjs, _ = batches[0]
@@ -501,26 +588,24 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
     lib_ms = ev[0].elapsed_time(ev[1]) / 10
     del xcat, wcat
 
-    # the same step with the batch sampled ON THE DEVICE each step (graphpope_amd.sampler: SURVEY §8f rank 1) instead of
-    # taken from the pre-sampled pool: what an epoch actually costs when nothing is prepared on the host
+    # the same step with the batch sampled ON THE DEVICE each step (graphpope_amd.sampler: SURVEY 8f rank 1) instead of
+    # taken from the pre-sampled pool: what an epoch actually costs when nothing is prepared on the host.  The sampler runs
+    # inside the replayed graph (device extents: no size ever comes back to the host).
     sampled = {}
     try:
         from graphpope_amd.sampler import NeighborSampler
         csr = engine.build_csr(torch.as_tensor(ei_np, device=dev), n)
         sampler = NeighborSampler(csr.rowptr, csr.col, n, (25, 10))
         perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        labels = torch.randint(0, 7, (n,), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+        strainer = SageTrainStep(model, opt, feats, BATCH, sampler=sampler, graph=True)
 
         def sstep(i):
-            seeds = perm[(i * BATCH) % (n - BATCH): (i * BATCH) % (n - BATCH) + BATCH]
-            n_id_s, adjs_s = sampler.sample(seeds, seed=i)
-            xs = IndexedFeatures(feats, n_id_s)
-            for p in params:
-                p.grad = None
-            loss = cross_entropy(model(xs, adjs_s), batches[0][2])
-            loss.backward()
-            opt.step()
+            lo = (i * BATCH) % (n - BATCH)
+            seeds = perm[lo: lo + BATCH]
+            return strainer.step(seeds, labels[seeds])            # main.py:122 y = data.y[n_id[:batch_size]]: one small gather outside the graph
 
-        for i in range(warmup):
+        for i in range(max(warmup, 4)):
             sstep(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -529,7 +614,30 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
         torch.cuda.synchronize()
         sdt = (time.perf_counter() - t0) / steps
         sampled = {"nodes_per_s": BATCH / sdt, "ms_per_step": sdt * 1e3,
-                   "note": "fan-out [25, 10] sampled on the GPU inside the step, features gathered from the HBM-resident matrix"}
+                   "note": "fan-out [25, 10] sampled on the GPU inside the replayed step (device-extent sampler, no host synchronisation), "
+                           "features gathered from the HBM-resident matrix"}
+        # and as rounds 1-2 ran it: eager launches, sizes read back by the host every hop
+        model.dropout_seed_dev = None
+        opt.use_device_step(None)
+
+        def estep(i):
+            lo = (i * BATCH) % (n - BATCH)
+            seeds = perm[lo: lo + BATCH]
+            n_id_s, adjs_s = sampler.sample(seeds, seed=i)
+            for p in params:
+                p.grad = None
+            loss = cross_entropy(model(IndexedFeatures(feats, n_id_s), adjs_s), labels[seeds])
+            loss.backward()
+            opt.step()
+
+        for i in range(warmup):
+            estep(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            estep(i)
+        torch.cuda.synchronize()
+        sampled["eager_host_sized_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
     except Exception as exc:
         sampled = {"error": repr(exc)}
 
@@ -558,6 +666,10 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
     proj_ms = l0_ms - g_ms
     return {
         "nodes_per_s": BATCH / dt, "ms_per_step": dt * 1e3, "steps": steps, "batch_seed_nodes": BATCH,
+        "how": "graphpope_amd.train.SageTrainStep: the step (fwd + cross-entropy + bwd + Adam) captured once into a HIP graph and replayed; "
+               "each pre-sampled batch is loaded into the graph's fixed buffers by one launch, its sizes stay on the device",
+        "eager_ms_per_step": eager_dt * 1e3,
+        "torch_gpu_baseline": torch_gpu,
         "model": f"SAGE {c_in}->{HIDDEN}->{HIDDEN} (num_layers 3, 2 executed), fan-out [25, 10], fp32, fused BN+ReLU+dropout epilogue, one-launch Adam",
         "block_shapes_n_dst_n_src_nnz": shapes,
         "layer0_forward_ms": l0_ms,

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgraphpope_hip.so")
 OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_HOP_OVERFLOW, ERR_WORKSPACE, ERR_NO_DEVICE, ERR_UNSORTED = 0, -1, -2, -3, -4, -5, -6, -7
 METRIC = {"distance": 0, "similarity": 1, "euclidean": 2}
 KNOB_LIVE_MODE, KNOB_FINALIZE_VARIANT, KNOB_FINALIZE_BLOCKS, KNOB_GEMM_TILE = 0, 1, 2, 3
-KNOB_PAIRWISE_KERNEL, KNOB_COPY_BATCHES, KNOB_LEVEL_BLOCKS = 4, 5, 6
+KNOB_PAIRWISE_KERNEL, KNOB_COPY_BATCHES, KNOB_LEVEL_BLOCKS, KNOB_FAIL_HOST_REGISTER, KNOB_SAGE_LANES = 4, 5, 6, 7, 8
 
 # name -> (restype, argtypes); exactly the symbols include/graphpope_hip.h declares
 SIGNATURES = {
@@ -24,6 +24,11 @@ SIGNATURES = {
     "pope_debug_set": (c_int, [c_int32, c_int32]),
     "pope_host_copy_2d": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32]),
     "pope_copy_2d_to_host": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "pope_assemble_host_result": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32,
+                                          c_int32, c_void_p]),
+    "pope_host_pin": (c_int, [c_void_p, c_size_t]),
+    "pope_host_unpin": (c_int, [c_void_p]),
+    "pope_copy_to_device": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "pope_csr_scratch_bytes": (c_size_t, [c_int64, c_int64]),
     "pope_csr_aux_elems": (c_size_t, [c_int64]),
     "pope_csr_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
@@ -69,26 +74,30 @@ SIGNATURES = {
     "sage_conv_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int32, c_int32]),
     "sage_conv_forward_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "sage_conv_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p,
-                                  c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                  c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "sage_gather_mean": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     "sage_conv_forward_indexed": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32,
                                           c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                                          c_void_p]),
+                                          c_void_p, c_void_p]),
     "sage_conv_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int32,
                                    c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_size_t, c_void_p]),
+                                   c_void_p, c_size_t, c_void_p, c_void_p]),
     "sage_bn_scratch_bytes": (c_size_t, [c_int32]),
     "sage_bn_relu_dropout_forward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                              c_int32, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                                             c_void_p]),
+                                             c_void_p, c_void_p, c_void_p]),
     "sage_bn_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_int32, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                                              c_void_p]),
+                                              c_void_p, c_void_p, c_void_p]),
     "sage_cross_entropy_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p]),
     "sage_cross_entropy_backward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sage_adam_step": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
-                               c_double, c_int64, c_void_p]),
+                               c_double, c_int64, c_void_p, c_void_p]),
+    "sage_advance_counters": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "sage_copy_segments": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sage_sample_batch_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_uint64, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sage_sample_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "sage_sample_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_uint64, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -59,11 +59,17 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
                                                     const float *__restrict__ rstd, const float *__restrict__ gamma,
                                                     const float *__restrict__ beta, unsigned long long seed,
                                                     unsigned threshold, float inv_keep, double *__restrict__ pa,
-                                                    double *__restrict__ pb) {
+                                                    double *__restrict__ pb, const int *__restrict__ m_dev,
+                                                    const unsigned long long *__restrict__ seed_dev) {
     __shared__ double sh[2][4][64 * VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = (blockIdx.y * 64 + lane) * VEC;
     const bool valid = c0 < C;
+    if (m_dev) {                                                   // device extent: the grid was sized for the capacity M
+        M = dyn_extent(m_dev, M);
+        rows_per_part = (M + (int)gridDim.x - 1) / (int)gridDim.x;
+    }
+    if (seed_dev) seed += *seed_dev;
     const int r0 = blockIdx.x * rows_per_part, r1 = min(M, r0 + rows_per_part);
     double a[VEC], b[VEC];
     float mu[VEC], rs[VEC], ga[VEC], be[VEC];
@@ -144,7 +150,9 @@ __device__ __forceinline__ void fold_parts(const double *__restrict__ pa, const 
 // training: batch statistics + running-stat update; else: the running statistics.  Launch: 256 threads, C/16 blocks.
 __global__ __launch_bounds__(256) void k_bn_final(const double *__restrict__ pa, const double *__restrict__ pb, int parts, int M, int C, int training,
                            float momentum, float eps, float *__restrict__ running_mean, float *__restrict__ running_var,
-                           float *__restrict__ mean, float *__restrict__ rstd, long long *num_batches_tracked) {
+                           float *__restrict__ mean, float *__restrict__ rstd, long long *num_batches_tracked,
+                           const int *__restrict__ m_dev) {
+    M = dyn_extent(m_dev, M);
     // nn.BatchNorm1d's step counter (`num_batches_tracked += 1` in training mode): as a torch op it is a launch of its own
     if (training && num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     const int c = blockIdx.x * 16 + (threadIdx.x & 15);
@@ -173,7 +181,8 @@ __global__ __launch_bounds__(256) void k_bn_final(const double *__restrict__ pa,
 
 __global__ __launch_bounds__(256) void k_bn_bwd_final(const double *__restrict__ pa, const double *__restrict__ pb, int parts, int M, int C,
                                int training, float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ c1,
-                               float *__restrict__ c2) {
+                               float *__restrict__ c2, const int *__restrict__ m_dev) {
+    M = dyn_extent(m_dev, M);
     const int c = blockIdx.x * 16 + (threadIdx.x & 15);
     double s, q;
     fold_parts(pa, pb, parts, C, c, s, q);
@@ -191,7 +200,10 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, c
                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
                                                   const float *__restrict__ c1, const float *__restrict__ c2,
                                                   unsigned long long seed, unsigned threshold, float inv_keep,
-                                                  float *__restrict__ out) {
+                                                  float *__restrict__ out, const int *__restrict__ m_dev,
+                                                  const unsigned long long *__restrict__ seed_dev) {
+    if (m_dev) total = (size_t)dyn_extent(m_dev, (int)(total / C)) * C;
+    if (seed_dev) seed += *seed_dev;
     const size_t stride = (size_t)gridDim.x * blockDim.x * VEC;
     for (size_t off = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; off < total; off += stride) {
         const int c0 = (int)(off % C);                             // VEC == 4 only when C % 4 == 0: one row per pack
@@ -260,7 +272,8 @@ extern "C" size_t sage_bn_scratch_bytes(int32_t C) { return C <= 0 ? 0 : bn_scra
 extern "C" int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C, const float *gamma, const float *beta,
                                             float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
                                             int32_t training, float p, uint64_t seed, float *y, float *save_mean,
-                                            float *save_rstd, void *scratch, size_t scratch_bytes, void *stream_) {
+                                            float *save_rstd, void *scratch, size_t scratch_bytes, const int32_t *rows_dev,
+                                            const uint64_t *seed_dev_, void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && scratch, "sage_bn_relu_dropout_forward: null pointer");
@@ -273,27 +286,28 @@ extern "C" int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C
         return POPE_ERR_WORKSPACE;
     }
     const BnPlan pl = bn_plan(M, C, scratch, x, y, nullptr, gamma, beta, save_mean, save_rstd);
+    const unsigned long long *seed_dev = (const unsigned long long *)seed_dev_;
     if (training) {
         const dim3 grid(pl.parts, (C + 64 * pl.vec - 1) / (64 * pl.vec));
         if (pl.vec == 4)
             hipLaunchKernelGGL((k_bn_partial<4, false>), grid, dim3(256), 0, stream, x, nullptr, (int)M, C, pl.rows_per_part,
-                               nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb);
+                               nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb, rows_dev, nullptr);
         else
             hipLaunchKernelGGL((k_bn_partial<1, false>), grid, dim3(256), 0, stream, x, nullptr, (int)M, C, pl.rows_per_part,
-                               nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb);
+                               nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb, rows_dev, nullptr);
     }
     hipLaunchKernelGGL(k_bn_final, dim3((C + 15) / 16), dim3(256), 0, stream, pl.pa, pl.pb, pl.parts, (int)M, C, training,
-                       momentum, eps, running_mean, running_var, save_mean, save_rstd, (long long *)num_batches_tracked);
+                       momentum, eps, running_mean, running_var, save_mean, save_rstd, (long long *)num_batches_tracked, rows_dev);
     const unsigned thr = training ? drop_threshold(p) : 0u;
     const float inv_keep = (training && p > 0.f && p < 1.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
     const size_t total = (size_t)M * C;
     const unsigned blocks = capped_grid(total / pl.vec, 256);
     if (pl.vec == 4)
         hipLaunchKernelGGL((k_bn_apply<4, false>), dim3(blocks), dim3(256), 0, stream, x, nullptr, total, C, save_mean, save_rstd,
-                           gamma, beta, nullptr, nullptr, (unsigned long long)seed, thr, inv_keep, y);
+                           gamma, beta, nullptr, nullptr, (unsigned long long)seed, thr, inv_keep, y, rows_dev, seed_dev);
     else
         hipLaunchKernelGGL((k_bn_apply<1, false>), dim3(blocks), dim3(256), 0, stream, x, nullptr, total, C, save_mean, save_rstd,
-                           gamma, beta, nullptr, nullptr, (unsigned long long)seed, thr, inv_keep, y);
+                           gamma, beta, nullptr, nullptr, (unsigned long long)seed, thr, inv_keep, y, rows_dev, seed_dev);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
@@ -301,7 +315,8 @@ extern "C" int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C
 extern "C" int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,
                                              const float *beta, const float *save_mean, const float *save_rstd,
                                              int32_t training, float p, uint64_t seed, float *grad_x, float *grad_gamma,
-                                             float *grad_beta, void *scratch, size_t scratch_bytes, void *stream_) {
+                                             float *grad_beta, void *scratch, size_t scratch_bytes, const int32_t *rows_dev,
+                                             const uint64_t *seed_dev_, void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(x && grad_y && gamma && beta && save_mean && save_rstd && grad_x && scratch,
@@ -313,25 +328,26 @@ extern "C" int sage_bn_relu_dropout_backward(const float *x, const float *grad_y
         return POPE_ERR_WORKSPACE;
     }
     const BnPlan pl = bn_plan(M, C, scratch, x, grad_y, grad_x, gamma, beta, save_mean, save_rstd);
+    const unsigned long long *seed_dev = (const unsigned long long *)seed_dev_;
     const unsigned thr = training ? drop_threshold(p) : 0u;
     const float inv_keep = (training && p > 0.f && p < 1.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
     const dim3 grid(pl.parts, (C + 64 * pl.vec - 1) / (64 * pl.vec));
     if (pl.vec == 4)
         hipLaunchKernelGGL((k_bn_partial<4, true>), grid, dim3(256), 0, stream, x, grad_y, (int)M, C, pl.rows_per_part, save_mean,
-                           save_rstd, gamma, beta, (unsigned long long)seed, thr, inv_keep, pl.pa, pl.pb);
+                           save_rstd, gamma, beta, (unsigned long long)seed, thr, inv_keep, pl.pa, pl.pb, rows_dev, seed_dev);
     else
         hipLaunchKernelGGL((k_bn_partial<1, true>), grid, dim3(256), 0, stream, x, grad_y, (int)M, C, pl.rows_per_part, save_mean,
-                           save_rstd, gamma, beta, (unsigned long long)seed, thr, inv_keep, pl.pa, pl.pb);
+                           save_rstd, gamma, beta, (unsigned long long)seed, thr, inv_keep, pl.pa, pl.pb, rows_dev, seed_dev);
     hipLaunchKernelGGL(k_bn_bwd_final, dim3((C + 15) / 16), dim3(256), 0, stream, pl.pa, pl.pb, pl.parts, (int)M, C, training,
-                       grad_gamma, grad_beta, pl.c1, pl.c2);
+                       grad_gamma, grad_beta, pl.c1, pl.c2, rows_dev);
     const size_t total = (size_t)M * C;
     const unsigned blocks = capped_grid(total / pl.vec, 256);
     if (pl.vec == 4)
         hipLaunchKernelGGL((k_bn_apply<4, true>), dim3(blocks), dim3(256), 0, stream, x, grad_y, total, C, save_mean, save_rstd,
-                           gamma, beta, pl.c1, pl.c2, (unsigned long long)seed, thr, inv_keep, grad_x);
+                           gamma, beta, pl.c1, pl.c2, (unsigned long long)seed, thr, inv_keep, grad_x, rows_dev, seed_dev);
     else
         hipLaunchKernelGGL((k_bn_apply<1, true>), dim3(blocks), dim3(256), 0, stream, x, grad_y, total, C, save_mean, save_rstd,
-                           gamma, beta, pl.c1, pl.c2, (unsigned long long)seed, thr, inv_keep, grad_x);
+                           gamma, beta, pl.c1, pl.c2, (unsigned long long)seed, thr, inv_keep, grad_x, rows_dev, seed_dev);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
@@ -360,8 +376,16 @@ struct AdamTable {
 };
 
 // one_minus_b1 / one_minus_b2 are formed in double on the host, as Python does for torch (1 - 0.999f != float(1 - 0.999)).
+// step_dev != nullptr: the 1-based step count lives on the device (a replayed HIP graph cannot take it as an argument);
+// lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t) are then formed here, in double like on the host.
 __global__ __launch_bounds__(256) void k_adam(AdamTable t, float step_size, float one_minus_b1, float beta2, float one_minus_b2,
-                                              float eps, float weight_decay, float inv_bc2_sqrt) {
+                                              float eps, float weight_decay, float inv_bc2_sqrt, const long long *__restrict__ step_dev,
+                                              double lr, double beta1_d, double beta2_d) {
+    if (step_dev) {
+        const double step = (double)*step_dev;
+        step_size = (float)(lr / (1.0 - pow(beta1_d, step)));
+        inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow(beta2_d, step)));
+    }
     int k = 0;
     while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
     const long long base = (long long)((int)blockIdx.x - t.first_block[k]) * ADAM_CHUNK;
@@ -407,10 +431,11 @@ __global__ __launch_bounds__(256) void k_adam(AdamTable t, float step_size, floa
 
 extern "C" int sage_adam_step(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                               float *const *exp_avg_sq, const int64_t *numel, double lr, double beta1, double beta2, double eps,
-                              double weight_decay, int64_t step, void *stream_) {
+                              double weight_decay, int64_t step, const int64_t *step_dev, void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (params && grads && exp_avg && exp_avg_sq && numel)), "sage_adam_step: null pointer");
+    if (step_dev) step = 1;                                         // the device word is the step count; `step` is ignored
     POPE_REQUIRE(step >= 1 && lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0,
                  "sage_adam_step: need step >= 1, lr >= 0, 0 <= beta < 1, eps >= 0");
     // scalars are formed in double, as Python does for torch.optim.Adam, and rounded to float once
@@ -432,7 +457,7 @@ extern "C" int sage_adam_step(int32_t n_tensors, float *const *params, const flo
         if (tab.count == 0) continue;
         tab.first_block[tab.count] = blocks;
         hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, stream, tab, step_size, (float)(1.0 - beta1), (float)beta2,
-                           (float)(1.0 - beta2), (float)eps, (float)weight_decay, inv_bc2_sqrt);
+                           (float)(1.0 - beta2), (float)eps, (float)weight_decay, inv_bc2_sqrt, (const long long *)step_dev, lr, beta1, beta2);
     }
     POPE_HIP(hipGetLastError());
     return POPE_OK;
@@ -530,6 +555,80 @@ extern "C" int sage_cross_entropy_backward(const float *grad_unscaled, int64_t N
     POPE_REQUIRE(N > 0 && C > 0, "sage_cross_entropy_backward: bad size");
     hipLaunchKernelGGL(k_xent_scale, dim3(capped_grid((size_t)N * C, 256)), dim3(256), 0, (hipStream_t)stream_, grad_unscaled,
                        (size_t)N * C, grad_loss, inv_count, grad_logits);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Plumbing of a training step that is replayed as a HIP graph (no host in the loop): the step's seeds and the optimiser's
+// step count live in device words that one tiny launch advances, and a batch taken from a pre-sampled pool is loaded
+// into the step's fixed buffers by ONE launch.
+// ------------------------------------------------------------------------------------------------
+namespace pope {
+
+constexpr int COUNTERS_MAX = 8, SEGMENTS_MAX = 12;
+struct CounterIncs { long long v[COUNTERS_MAX]; };
+__global__ void k_advance_counters(long long *__restrict__ c, CounterIncs inc, int n) {
+    if ((int)threadIdx.x < n) c[threadIdx.x] += inc.v[threadIdx.x];
+}
+
+struct SegmentTable {
+    char *dst[SEGMENTS_MAX];
+    const char *src[SEGMENTS_MAX];
+    long long bytes[SEGMENTS_MAX];
+    int first_block[SEGMENTS_MAX + 1];
+    int count;
+};
+constexpr int SEG_CHUNK = 64 * 1024;          // bytes per block
+
+__global__ __launch_bounds__(256) void k_copy_segments(SegmentTable t) {
+    int k = 0;
+    while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
+    const long long base = (long long)((int)blockIdx.x - t.first_block[k]) * SEG_CHUNK;
+    const long long end = min(t.bytes[k], base + SEG_CHUNK);
+    char *__restrict__ d = t.dst[k];
+    const char *__restrict__ s = t.src[k];
+    if (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15) == 0) {
+        const long long end16 = base + ((end - base) & ~15ll);
+        for (long long q = base + 16ll * threadIdx.x; q < end16; q += 16ll * blockDim.x)
+            *reinterpret_cast<float4 *>(d + q) = *reinterpret_cast<const float4 *>(s + q);
+        for (long long q = end16 + threadIdx.x; q < end; q += blockDim.x) d[q] = s[q];
+    } else {
+        for (long long q = base + threadIdx.x; q < end; q += blockDim.x) d[q] = s[q];
+    }
+}
+
+}  // namespace pope
+
+extern "C" int sage_advance_counters(int64_t *counters, const int64_t *increments_host, int32_t n, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(counters && increments_host && n > 0 && n <= COUNTERS_MAX, "sage_advance_counters: null pointer or more than %d counters", COUNTERS_MAX);
+    CounterIncs inc;
+    for (int i = 0; i < COUNTERS_MAX; ++i) inc.v[i] = i < n ? (long long)increments_host[i] : 0;
+    hipLaunchKernelGGL(k_advance_counters, dim3(1), dim3(64), 0, (hipStream_t)stream_, (long long *)counters, inc, n);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+extern "C" int sage_copy_segments(int32_t n, void *const *dst, const void *const *src, const int64_t *bytes, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(n >= 0 && (n == 0 || (dst && src && bytes)), "sage_copy_segments: null pointer");
+    for (int t0 = 0; t0 < n; t0 += SEGMENTS_MAX) {
+        SegmentTable tab;
+        tab.count = 0;
+        int blocks = 0;
+        for (int t = t0; t < n && tab.count < SEGMENTS_MAX; ++t) {
+            POPE_REQUIRE(bytes[t] >= 0 && (bytes[t] == 0 || (dst[t] && src[t])), "sage_copy_segments: segment %d has a null pointer", t);
+            if (bytes[t] == 0) continue;
+            const int c = tab.count++;
+            tab.dst[c] = (char *)dst[t]; tab.src[c] = (const char *)src[t]; tab.bytes[c] = bytes[t];
+            tab.first_block[c] = blocks;
+            blocks += (int)((bytes[t] + SEG_CHUNK - 1) / SEG_CHUNK);
+        }
+        if (tab.count == 0) continue;
+        tab.first_block[tab.count] = blocks;
+        hipLaunchKernelGGL(k_copy_segments, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, tab);
+    }
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }

@@ -61,7 +61,16 @@ struct SkArgs {
     float *slab;                 // [gridDim.x][2][SK_TM][SK_TN]
     int tiles_m, tiles_n, S0, S1;
     const float *zero;           // 16 zero bytes in device memory (&g_sk_zero): as an argument it sits in SGPRs from the start
+    const int *m_dev;            // device extent: the true M (<= M, which then is the capacity the launch was sized for), or null
 };
+
+// Device extents: a kernel's first statement.  M and tiles_m become the true values; every block derives the same unit range.
+__device__ __forceinline__ void sk_resolve(SkArgs &a) {
+    if (a.m_dev) {
+        a.M = dyn_extent(a.m_dev, a.M);
+        a.tiles_m = (a.M + SK_TM - 1) / SK_TM;
+    }
+}
 
 // First unit of block b when T units are dealt to G blocks: block b owns [sk_lo(b), sk_lo(b + 1)).
 __host__ __device__ __forceinline__ long long sk_lo(long long b, long long T, long long G) { return b * T / G; }
@@ -72,6 +81,7 @@ __host__ __device__ __forceinline__ long long sk_lo(long long b, long long T, lo
 //  read / a few VALU, one DMA per MFMA group instead of two or three per pass: 5 600-5 850 cycles per stage every time.)
 template <int WAVES, int SCHED>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_streamk(SkArgs a) {
+    sk_resolve(a);
     constexpr int WN = WAVES / 2;                       // waves along N (2 along M)
     constexpr int NT = SK_TN / WN / 32;                 // 32 x 32 accumulator tiles per wave
     constexpr int NA = 8 / WAVES, NB = 32 / WAVES;      // DMA wave-instructions per wave and stage: A rows, B rows
@@ -265,6 +275,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_streamk(SkArgs a) {
 constexpr int SKL_CONSUMERS = 4, SKL_LOADERS = 4, SKL_THREADS = (SKL_CONSUMERS + SKL_LOADERS) * 64;
 
 __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_ld(SkArgs a) {
+    sk_resolve(a);
     constexpr int NT = 4;                               // 32 x 32 accumulator tiles per consumer wave: 32 rows x 128 columns
     constexpr int ND = 40 / SKL_LOADERS;                // DMA wave-instructions per loader wave and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -450,9 +461,11 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_ld(SkArgs a) {
 constexpr int SK_FIX_PARTS = 8;       // (16 parts, one piece per thread: 10.7 us against 9.7)
 
 __global__ __launch_bounds__(256) void k_streamk_fixup(SkArgs a, int G) {
+    sk_resolve(a);
     const int S = a.S0 + a.S1;
     const long long T = (long long)a.tiles_m * a.tiles_n * S;
     const int tile = blockIdx.x;
+    if (tile >= a.tiles_m * a.tiles_n || T <= 0) return;                                  // device extents: the grid covers the capacity
     const long long u0 = (long long)tile * S, u1 = u0 + S;
     const int b_lo = (int)(((u0 + 1) * G - 1) / T), b_hi = (int)((u1 * G - 1) / T);       // owners of the first and the last unit
     if (b_lo == b_hi) return;                                                             // written whole by its one block

@@ -31,7 +31,15 @@ struct SkTnArgs {
     float *slab;                 // [gridDim.x][2][SK_TM][SK_TN]
     const float *zero;
     int tiles_m, tiles_nb, S;    // tiles along M, along Nb (per product), depth stages
+    const int *depth_dev;        // device extent: the true depth (<= depth, which then is the capacity), or null
 };
+
+__device__ __forceinline__ void sk_tn_resolve(SkTnArgs &a) {
+    if (a.depth_dev) {
+        a.depth = dyn_extent(a.depth_dev, a.depth);
+        a.S = (a.depth + SK_GK - 1) / SK_GK;
+    }
+}
 
 __device__ __forceinline__ void sk_tn_tile(const SkTnArgs &a, int tile, int &q, int &m0, int &n0) {
     const int tm = tile % a.tiles_m, rest = tile / a.tiles_m;
@@ -41,6 +49,7 @@ __device__ __forceinline__ void sk_tn_tile(const SkTnArgs &a, int tile, int &q, 
 }
 
 __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
+    sk_tn_resolve(a);
     constexpr int NT = 4;                               // 32 x 32 accumulator tiles per consumer wave: 32 rows x 128 columns
     constexpr int ND = 40 / SKL_LOADERS;                // DMA wave-instructions per loader wave and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -201,8 +210,10 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
 // SK_TN_FIX_PARTS blocks per tile, as k_streamk_fixup: 24 tiles only, so more parts per tile (384 blocks, one piece per thread).
 constexpr int SK_TN_FIX_PARTS = 16;
 __global__ __launch_bounds__(256) void k_streamk_tn_fixup(SkTnArgs a, int G) {
+    sk_tn_resolve(a);
     const int S = a.S;
     const long long T = (long long)a.tiles_m * a.tiles_nb * 2 * S;
+    if (T <= 0) return;                                                                   // (a device extent of 0 rows: nothing was computed)
     const int tile = blockIdx.x;
     const long long u0 = (long long)tile * S, u1 = u0 + S;
     const int b_lo = (int)(((u0 + 1) * G - 1) / T), b_hi = (int)((u1 * G - 1) / T);

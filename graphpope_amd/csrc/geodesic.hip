@@ -965,7 +965,7 @@ static int g_live_mode = -1;            // -1: by graph size (LDS table up to LI
 static int g_finalize_variant = 1;      // 0: generic kernel, 1: fast path with plain stores, 2: fast path, non-temporal stores
 static int g_finalize_blocks = 256 * 8;
 static int g_level_blocks = 0;           // cap on the expand blocks of a level launch (0: one wave per chunk up to 2048 blocks)
-namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0; }
+namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0; extern int g_sage_lanes; }
 
 extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     clear_error();
@@ -977,6 +977,8 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_PAIRWISE_KERNEL:  pope::g_pairwise_kernel = value; break;
     case POPE_KNOB_COPY_BATCHES:     pope::g_copy_batches_per_wave = value; break;
     case POPE_KNOB_LEVEL_BLOCKS:     g_level_blocks = value; break;
+    case POPE_KNOB_FAIL_HOST_REGISTER: pope::g_fail_host_register = value; break;
+    case POPE_KNOB_SAGE_LANES:       pope::g_sage_lanes = value; break;
     default: set_error("pope_debug_set: unknown knob %d", knob); return POPE_ERR_INVALID;
     }
     return POPE_OK;
@@ -1123,11 +1125,12 @@ struct DepthHint {
     int64_t N = -1, E = -1;
     int K = -1, last_active = 0, margin = 1;
 };
-static DepthHint g_depth_hint[16];
+constexpr int MAX_DEVICES = 64;        // like g_ctx: device indices beyond it simply get no hint
+static DepthHint g_depth_hint[MAX_DEVICES];
 
 static int speculative_window(int64_t N, int64_t E, int K) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LEVEL_BATCH;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return LEVEL_BATCH;
     std::lock_guard<std::mutex> lock(g_depth_hint[dev].mu);
     const DepthHint &h = g_depth_hint[dev];
     if (h.N == N && h.E == E && h.K == K) return std::min(LEVEL_BATCH, h.last_active + h.margin);   // margin 1: one level past the last one that found something
@@ -1136,7 +1139,7 @@ static int speculative_window(int64_t N, int64_t E, int K) {
 
 static void remember_depth(int64_t N, int64_t E, int K, int last_active, bool window_was_too_short = false) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return;
     std::lock_guard<std::mutex> lock(g_depth_hint[dev].mu);
     DepthHint &h = g_depth_hint[dev];
     const bool same = h.N == N && h.E == E && h.K == K;

@@ -410,11 +410,11 @@ extern "C" int pope_kmeans_lloyd_step(const float *X, int64_t N, int32_t D, cons
     const Operand Xo{X, D, 1}, Co{centers, D, 1};
     const bool vec = pick_layout(Xo, (int)N, D) == LAYOUT_KC_VEC && pick_layout(Co, K, D) == LAYOUT_KC_VEC;
     const size_t lds = tile_lds_bytes<KM_TM, KM_TN>();
-    static bool opt_in = false;
-    if (!opt_in) {
+    static LdsOptIn opt_in;
+    if (!opt_in.done()) {
         POPE_HIP(hipFuncSetAttribute((const void *)k_assign<LAYOUT_KC_VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         POPE_HIP(hipFuncSetAttribute((const void *)k_assign<LAYOUT_GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        opt_in = true;
+        opt_in.mark();
     }
     const dim3 grid((unsigned)((N + KM_TM - 1) / KM_TM), (unsigned)((K + KM_TN - 1) / KM_TN));
     if (vec) hipLaunchKernelGGL(k_assign<LAYOUT_KC_VEC>, grid, dim3(256), lds, stream, X, (int)N, D, centers, K, (const float *)c2, keys);

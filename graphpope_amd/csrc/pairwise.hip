@@ -407,10 +407,10 @@ static int pairwise_passes(const float *X, int64_t N, int32_t D, const float *A,
     float *pmin = (float *)(base + L.pmin), *pmax = (float *)(base + L.pmax);
     float *fmin = (float *)(base + L.fmin), *fmax = (float *)(base + L.fmax);
     float *scale = (float *)(base + L.scale), *shift = (float *)(base + L.shift);
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
+    static LdsOptIn lds_opt_in;
+    if (!lds_opt_in.done()) {
         POPE_HIP(hipFuncSetAttribute((const void *)k_pairwise<LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pw_lds_bytes()));
-        lds_opt_in = true;
+        lds_opt_in.mark();
     }
     const PwCopy copy{x, F / 4, 0, F / 4};
     hipLaunchKernelGGL(k_pairwise<LAYOUT>, dim3(L.nblocks, L.Kpad / PN), dim3(256), pw_lds_bytes(), stream, X, (int)N, D, A, K, metric, xx, aa,
@@ -426,10 +426,10 @@ static int pairwise_passes(const float *X, int64_t N, int32_t D, const float *A,
 // The persistent kernel (pairwise_persistent.h): depths up to 128 in 16-byte pieces.
 static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric, const float *x, int32_t F,
                                float *out, int64_t out_cols, int32_t c0, const PwLayout &L, char *base, hipStream_t stream) {
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
+    static LdsOptIn lds_opt_in;
+    if (!lds_opt_in.done()) {
         POPE_HIP(hipFuncSetAttribute((const void *)k_pairwise_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
-        lds_opt_in = true;
+        lds_opt_in.mark();
     }
     int dev = 0, cus = 0;
     POPE_HIP(hipGetDevice(&dev));

@@ -18,6 +18,7 @@
 //   k_scatter_mean   grad_x[col[p]] += grad_agg[i] / deg(i) (float atomics, whole 16-byte-aligned row segments)
 //   k_colsum_*       grad_bias, two deterministic stages
 #include "gemm_streamk_tn.h"
+#include "side_copy.h"
 
 namespace pope {
 
@@ -32,10 +33,11 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void k_gather_mean(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                      int n_dst, const float *__restrict__ x, int C,
                                                      float *__restrict__ agg, const long long *__restrict__ n_id,
-                                                     float *__restrict__ x_dst) {
+                                                     float *__restrict__ x_dst, const int *__restrict__ n_dst_dev) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    n_dst = dyn_extent(n_dst_dev, n_dst);
     for (int i = wave; i < n_dst; i += nwaves) {
         const int beg = rowptr[i], end = rowptr[i + 1];
         const float inv = end > beg ? 1.0f / (float)(end - beg) : 0.0f;
@@ -80,11 +82,12 @@ __global__ __launch_bounds__(256) void k_gather_mean(const int *__restrict__ row
 // instruction), instead of a dependent col[p] load in front of every one (38 us -> see DESIGN.md §7).
 __global__ __launch_bounds__(256) void k_scatter_mean(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                       int n_dst, const float *__restrict__ gagg, int C,
-                                                      float *__restrict__ gx) {
+                                                      float *__restrict__ gx, const int *__restrict__ n_dst_dev) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int slabs = (C + 255) / 256;
+    n_dst = dyn_extent(n_dst_dev, n_dst);
     for (int w = wave; w < n_dst * slabs; w += nwaves) {
         const int i = w / slabs, c0 = (w - i * slabs) * 256;
         const int beg = rowptr[i], end = rowptr[i + 1];
@@ -111,13 +114,34 @@ __global__ __launch_bounds__(256) void k_scatter_mean(const int *__restrict__ ro
     }
 }
 
+// x[r, :] = 0 for r in [r0, r1): the rows of grad_x that only the scatter adds to.  Both bounds may live on the device.
+__global__ __launch_bounds__(256) void k_zero_rows(float *__restrict__ x, int C, int r0, int r1, const int *__restrict__ r0_dev,
+                                                   const int *__restrict__ r1_dev) {
+    r0 = dyn_extent(r0_dev, r0);
+    r1 = dyn_extent(r1_dev, r1);
+    if (r1 <= r0) return;
+    const size_t lo = (size_t)r0 * C, n = (size_t)(r1 - r0) * C;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float *base = x + lo;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(base)) & 15) == 0) {
+        const size_t n4 = n >> 2;
+        for (size_t q = i; q < n4; q += stride) reinterpret_cast<float4 *>(base)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t q = (n4 << 2) + i; q < n; q += stride) base[q] = 0.f;
+    } else {
+        for (size_t q = i; q < n; q += stride) base[q] = 0.f;
+    }
+}
+
 // Column sums in two deterministic stages: part[s][c] = sum over row slice s, then out[c] = sum_s part[s][c].
 constexpr int COLSUM_SPLITS = 256;
 
 // VEC: lane l owns 4 adjacent columns (16-byte loads, a wave covers 256 columns of a row); else one column per lane.
 template <bool VEC>
-__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ g, int rows, int C, float *__restrict__ part) {
+__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ g, int rows, int C, float *__restrict__ part,
+                                                        const int *__restrict__ rows_dev) {
     constexpr int W = VEC ? 4 : 1;
+    rows = dyn_extent(rows_dev, rows);
     __shared__ float red[4][64 * W];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = (blockIdx.x * 64 + lane) * W;
@@ -181,11 +205,23 @@ struct Twin {
     int tiles_n;               // tile columns of the first result; 0 = plain GEMM
 };
 
+// Device extents of a k_gemm launch (null: the host-side size is the size): the true M, the true depth of product 0.
+struct GemmDyn {
+    const int *m = nullptr, *k0 = nullptr;
+};
+
 template <int TM, int TN, int WM, int WN, int LA, int LB>
 __global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Operand A1, Operand B1, int K1, int M, int N,
                                               const float *__restrict__ bias, float *__restrict__ C, long long ldc,
-                                              float *__restrict__ slab, Twin twin) {
+                                              float *__restrict__ slab, Twin twin, const int *__restrict__ m_dev,
+                                              const int *__restrict__ k0_dev) {
     constexpr int NT = TN / WN / 32;
+    // device extents: the true row count / the true depth of product 0 (the launch covers the capacities).  The slab
+    // stride stays the capacity M: k_slab_reduce is given the same.
+    const int M_cap = M;
+    M = dyn_extent(m_dev, M);
+    K0 = dyn_extent(k0_dev, K0);
+    if ((int)blockIdx.x * TM >= M) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *As = reinterpret_cast<float *>(smem);
     float *Bs = As + Tile<TM>::FLOATS;
@@ -197,7 +233,7 @@ __global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Op
         by -= twin.tiles_n;
         B0 = twin.B;
         C = twin.C;
-        slab += (size_t)splits * M * N;
+        slab += (size_t)splits * M_cap * N;
     }
     const int m0 = blockIdx.x * TM, n0 = by * TN;
     f32x16 acc[NT];
@@ -211,7 +247,7 @@ __global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Op
     const int kb0 = z * per0, ke0 = min(K0, kb0 + per0), kb1 = z * per1, ke1 = min(K1, kb1 + per1);
     mfma_accumulate<TM, TN, WM, WN, LA, LB>(acc, A0, B0, kb0, ke0, A1, B1, kb1, ke1, m0, n0, M, N, As, Bs);
     // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float *dst = splits > 1 ? slab + (size_t)z * M * N : C;
+    float *dst = splits > 1 ? slab + (size_t)z * M_cap * N : C;
     const long long ld = splits > 1 ? (long long)N : ldc;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -243,18 +279,19 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float *__restrict__ s
 template <int TM, int TN, int WM, int WN, int LA, int LB>
 static int launch_gemm_layout(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1,
                               int M, int N, const float *bias, float *C, long long ldc, int splits, float *slab,
-                              const Twin &twin, hipStream_t stream) {
+                              const Twin &twin, hipStream_t stream, const GemmDyn &dyn) {
     const size_t lds = tile_lds_bytes<TM, TN>();
-    static bool opt_in = false;
-    if (!opt_in) {
+    static LdsOptIn opt_in;
+    if (!opt_in.done()) {
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm<TM, TN, WM, WN, LA, LB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        opt_in = true;
+        opt_in.mark();
     }
     Twin tw = twin;
     const int tiles_n = (N + TN - 1) / TN;
     if (tw.C) tw.tiles_n = tiles_n;
     dim3 grid((M + TM - 1) / TM, tw.C ? 2 * tiles_n : tiles_n, splits);
-    hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN, LA, LB>), grid, dim3(256), lds, stream, A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, slab, tw);
+    hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN, LA, LB>), grid, dim3(256), lds, stream, A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, slab, tw,
+                       dyn.m, dyn.k0);
     return POPE_OK;
 }
 
@@ -263,17 +300,17 @@ static int launch_gemm_layout(const Operand &A0, const Operand &B0, int K0, cons
 template <int TM, int TN, int WM, int WN>
 static int launch_gemm(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1, int M,
                        int N, const float *bias, float *C, long long ldc, int splits, float *slab, const Twin &twin,
-                       hipStream_t stream) {
+                       hipStream_t stream, const GemmDyn &dyn) {
     Layout la = pick_layout(A0, M, K0), lb = pick_layout(B0, N, K0);
     if (K1 > 0 && (pick_layout(A1, M, K1) != la || pick_layout(B1, N, K1) != lb)) la = lb = LAYOUT_GENERIC;
     if (twin.C && pick_layout(twin.B, N, K0) != lb) la = lb = LAYOUT_GENERIC;
     if (la == LAYOUT_KC_VEC && lb == LAYOUT_KC_VEC)
-        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_KC_VEC, LAYOUT_KC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
+        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_KC_VEC, LAYOUT_KC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream, dyn);
     if (la == LAYOUT_OC_VEC && lb == LAYOUT_OC_VEC)
-        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_OC_VEC, LAYOUT_OC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
+        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_OC_VEC, LAYOUT_OC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream, dyn);
     if (la == LAYOUT_KC_VEC && lb == LAYOUT_OC_VEC)
-        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_KC_VEC, LAYOUT_OC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
-    return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_GENERIC, LAYOUT_GENERIC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
+        return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_KC_VEC, LAYOUT_OC_VEC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream, dyn);
+    return launch_gemm_layout<TM, TN, WM, WN, LAYOUT_GENERIC, LAYOUT_GENERIC>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream, dyn);
 }
 
 extern int g_gemm_force_tile;          // pope_debug_set(POPE_KNOB_GEMM_TILE, ...) in geodesic.hip: 0 = automatic choice
@@ -284,15 +321,15 @@ static long long tiles(int M, int N, int tm, int tn) { return (long long)((M + t
 // one block's staging waits with another's MFMAs, and many small blocks balance better over 256 CUs than 1.2 per CU.
 static int gemm(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1, int M, int N,
                 const float *bias, float *C, long long ldc, int splits, float *slab, hipStream_t stream,
-                const Twin &twin = Twin{Operand{nullptr, 0, 0}, nullptr, 0}) {
+                const Twin &twin = Twin{Operand{nullptr, 0, 0}, nullptr, 0}, const GemmDyn &dyn = GemmDyn{}) {
     int rc;
     const int results = twin.C ? 2 : 1;
     if (g_gemm_force_tile == 3 || (g_gemm_force_tile == 0 && tiles(M, N, 128, 256) * splits * results >= 512))
-        rc = launch_gemm<128, 256, 4, 1>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
+        rc = launch_gemm<128, 256, 4, 1>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream, dyn);
     else if (g_gemm_force_tile == 2 || (g_gemm_force_tile == 0 && tiles(M, N, 64, 128) * splits * results >= 384))
-        rc = launch_gemm<64, 128, 2, 2>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
+        rc = launch_gemm<64, 128, 2, 2>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream, dyn);
     else
-        rc = launch_gemm<64, 64, 2, 2>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream);
+        rc = launch_gemm<64, 64, 2, 2>(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, stream, dyn);
     if (rc) return rc;
     if (splits > 1)
         hipLaunchKernelGGL(k_slab_reduce, dim3(capped_grid((size_t)M * N * results, 256)), dim3(256), 0, stream, slab, splits,
@@ -337,7 +374,7 @@ static int device_cu_count(int *out) {
 // qualify (alignment, size, slab too small) and nothing was launched.
 static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A1, const float *B1, int K1, long long lda, long long ldb,
                         int M, int N, const float *bias, float *C, long long ldc, void *slab, size_t slab_bytes, hipStream_t stream,
-                        bool *used) {
+                        bool *used, const int *m_dev = nullptr) {
     *used = false;
     if (g_gemm_force_tile != 0 && g_gemm_force_tile < 4) return POPE_OK;
     if (!(g_gemm_force_tile >= 4 || streamk_shape_ok(M, K0, K1, N))) return POPE_OK;
@@ -352,15 +389,16 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
     a.M = M; a.N = N; a.bias = bias; a.C = C; a.ldc = ldc; a.slab = (float *)slab;
     a.tiles_m = (M + SK_TM - 1) / SK_TM; a.tiles_n = (N + SK_TN - 1) / SK_TN;
     a.S0 = (K0 + SK_GK - 1) / SK_GK; a.S1 = (K1 + SK_GK - 1) / SK_GK;
+    a.m_dev = m_dev;
     const long long T = (long long)a.tiles_m * a.tiles_n * (a.S0 + a.S1);
     long long grid = cus < SK_MAX_GRID ? cus : SK_MAX_GRID;
     if (grid > T) grid = T;
     if (!slab || slab_bytes < sk_slab_bytes((int)grid)) return POPE_OK;
-    static bool opt_in = false;
+    static LdsOptIn opt_in;
     static const float *zero_page[64];
     int dev = 0;
     POPE_HIP(hipGetDevice(&dev));
-    if (!opt_in) {
+    if (!opt_in.done()) {
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk_ld, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
@@ -368,7 +406,7 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
 #endif
-        opt_in = true;
+        opt_in.mark();
     }
     if (!zero_page[dev]) POPE_HIP(hipGetSymbolAddress((void **)&zero_page[dev], HIP_SYMBOL(g_sk_zero)));
     a.zero = zero_page[dev];
@@ -399,7 +437,7 @@ static bool streamk_tn_shape_ok(int64_t depth, int32_t M, int32_t Nb) {
 
 // C0 = G^T * B0, C1 = G^T * B1 (G [depth, M], B_q [depth, Nb], C_q [M, Nb]); *used = false if the operands do not qualify.
 static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int64_t depth, int M, int Nb, float *C0, float *C1,
-                           void *slab, size_t slab_bytes, hipStream_t stream, bool *used) {
+                           void *slab, size_t slab_bytes, hipStream_t stream, bool *used, const int *depth_dev = nullptr) {
     *used = false;
     if (g_gemm_force_tile != 0 && g_gemm_force_tile < 4) return POPE_OK;
     if (!streamk_tn_shape_ok(depth, M, Nb)) return POPE_OK;
@@ -410,17 +448,18 @@ static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int
     a.G = G; a.ldg = M; a.B[0] = B0; a.B[1] = B1; a.ldb = Nb; a.C[0] = C0; a.C[1] = C1; a.ldc = Nb;
     a.M = M; a.Nb = Nb; a.depth = (int)depth; a.slab = (float *)slab;
     a.tiles_m = (M + SK_TM - 1) / SK_TM; a.tiles_nb = (Nb + SK_TN - 1) / SK_TN; a.S = (int)((depth + SK_GK - 1) / SK_GK);
+    a.depth_dev = depth_dev;
     const long long T = 2ll * a.tiles_m * a.tiles_nb * a.S;
     long long grid = cus < SK_MAX_GRID ? cus : SK_MAX_GRID;
     if (grid > T) grid = T;
     if (!slab || slab_bytes < sk_slab_bytes((int)grid)) return POPE_OK;
-    static bool opt_in = false;
+    static LdsOptIn opt_in;
     static const float *zero_page[64];
     int dev = 0;
     POPE_HIP(hipGetDevice(&dev));
-    if (!opt_in) {
+    if (!opt_in.done()) {
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk_tn, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
-        opt_in = true;
+        opt_in.mark();
     }
     if (!zero_page[dev]) POPE_HIP(hipGetSymbolAddress((void **)&zero_page[dev], HIP_SYMBOL(g_sk_zero)));
     a.zero = zero_page[dev];
@@ -447,13 +486,14 @@ extern "C" int pope_debug_read_gemm_stamps(unsigned long long *host, int count) 
 extern "C" size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t nnz, int32_t c_in, int32_t c_out) {
     (void)n_src; (void)nnz;
     if (n_dst <= 0 || c_in <= 0 || c_out <= 0) return 0;
-    // backward: grad_agg [n_dst, c_in] | split-K slabs of the two weight gradients (one twin launch)
+    // backward: grad_agg [n_dst, c_in] | split-K / stream-K slabs of the two weight gradients (one twin launch) | the partial
+    // column sums of the bias gradient (a region of its own: they are computed beside the weight gradients)
     const size_t gagg = align_up((size_t)n_dst * c_in * sizeof(float), 256);
     size_t slabs = 2 * (size_t)weight_grad_splits(n_dst, c_in, c_out) * c_out * c_in * sizeof(float);
-    if (slabs < (size_t)COLSUM_SPLITS * c_out * sizeof(float)) slabs = (size_t)COLSUM_SPLITS * c_out * sizeof(float);
     if (streamk_tn_shape_ok(n_dst, c_out, c_in) && slabs < sk_slab_bytes(SK_MAX_GRID)) slabs = sk_slab_bytes(SK_MAX_GRID);
     slabs = align_up(slabs, 256);
-    return gagg + slabs;
+    const size_t colsum = align_up((size_t)COLSUM_SPLITS * c_out * sizeof(float), 256);
+    return gagg + slabs + colsum;
 }
 
 extern "C" size_t sage_conv_forward_scratch_bytes(int64_t n_dst, int32_t c_in, int32_t c_out) {
@@ -462,14 +502,15 @@ extern "C" size_t sage_conv_forward_scratch_bytes(int64_t n_dst, int32_t c_in, i
 }
 
 static void enqueue_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_dst, const float *x_src, int32_t c_in,
-                                float *agg, hipStream_t stream, const int64_t *n_id = nullptr, float *x_dst = nullptr) {
+                                float *agg, hipStream_t stream, const int64_t *n_id = nullptr, float *x_dst = nullptr,
+                                const int32_t *n_dst_dev = nullptr) {
     dim3 grid(capped_grid((size_t)n_dst * 64, 256));
     if ((c_in & 3) == 0 && aligned16(x_src) && aligned16(agg) && (!x_dst || aligned16(x_dst)))
         hipLaunchKernelGGL(k_gather_mean<true>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
-                           (const long long *)n_id, x_dst);
+                           (const long long *)n_id, x_dst, n_dst_dev);
     else
         hipLaunchKernelGGL(k_gather_mean<false>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
-                           (const long long *)n_id, x_dst);
+                           (const long long *)n_id, x_dst, n_dst_dev);
 }
 
 extern "C" int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
@@ -482,21 +523,25 @@ extern "C" int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64
     return POPE_OK;
 }
 
+// `dims` (device int32 [4] = {n_dst, n_src, nnz, 0}, or NULL): see include/graphpope_hip.h, "Device extents".
 extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
                                  const float *x_src, int32_t c_in, const float *w_l, const float *b_l, const float *w_r,
-                                 int32_t c_out, float *agg, float *out, void *scratch, size_t scratch_bytes, void *stream_) {
+                                 int32_t c_out, float *agg, float *out, void *scratch, size_t scratch_bytes, const int32_t *dims,
+                                 void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(rowptr && (col || nnz == 0) && x_src && w_l && w_r && agg && out, "sage_conv_forward: null pointer");
     POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && nnz >= 0 && nnz < INT32_MAX && c_in > 0 && c_out > 0,
                  "sage_conv_forward: bad size (destinations must be the first n_dst sources)");
-    enqueue_gather_mean(rowptr, col, n_dst, x_src, c_in, agg, stream);
+    enqueue_gather_mean(rowptr, col, n_dst, x_src, c_in, agg, stream, nullptr, nullptr, dims);
     // out = agg * w_l^T + b_l + x_dst * w_r^T in one pass
     bool used = false;
-    int rc = gemm_streamk(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used);
+    int rc = gemm_streamk(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);
     if (rc || used) return rc;
     const Operand A0{agg, c_in, 1}, B0{w_l, c_in, 1}, A1{x_src, c_in, 1}, B1{w_r, c_in, 1};
-    return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream);
+    GemmDyn dyn;
+    dyn.m = dims;
+    return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream, Twin{Operand{nullptr, 0, 0}, nullptr, 0}, dyn);
 }
 
 // The same layer on rows of the resident feature matrix: source j of the block is feats[n_id[j]].  Replaces
@@ -505,24 +550,31 @@ extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int6
 extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
                                          int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l,
                                          const float *b_l, const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out,
-                                         void *scratch, size_t scratch_bytes, void *stream_) {
+                                         void *scratch, size_t scratch_bytes, const int32_t *dims, void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(rowptr && (col || nnz == 0) && n_id && feats && w_l && w_r && agg && x_dst && out, "sage_conv_forward_indexed: null pointer");
     POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && n_rows > 0 && nnz >= 0 && nnz < INT32_MAX && c_in > 0 && c_out > 0,
                  "sage_conv_forward_indexed: bad size (destinations must be the first n_dst entries of n_id)");
-    enqueue_gather_mean(rowptr, col, n_dst, feats, c_in, agg, stream, n_id, x_dst);
+    enqueue_gather_mean(rowptr, col, n_dst, feats, c_in, agg, stream, n_id, x_dst, dims);
     bool used = false;
-    int rc = gemm_streamk(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used);
+    int rc = gemm_streamk(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);
     if (rc || used) return rc;
     const Operand A0{agg, c_in, 1}, B0{w_l, c_in, 1}, A1{x_dst, c_in, 1}, B1{w_r, c_in, 1};
-    return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream);
+    GemmDyn dyn;
+    dyn.m = dims;
+    return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream, Twin{Operand{nullptr, 0, 0}, nullptr, 0}, dyn);
 }
 
+namespace pope { int g_sage_lanes = 1; }     // pope_debug_set(POPE_KNOB_SAGE_LANES): 0 = every launch of the backward pass on the caller's stream
+
+// The three results of the backward pass only share grad_out: the weight gradients (the big GEMM) stay on the caller's
+// stream, the bias gradient (two short launches) and the grad_x chain (zero the scatter-only rows, grad_out * [W_r | W_l],
+// scatter) run beside them on side streams, forked and joined inside the call.
 extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
                                   const float *x_src, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
                                   int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l,
-                                  float *grad_w_r, void *scratch, size_t scratch_bytes, void *stream_) {
+                                  float *grad_w_r, void *scratch, size_t scratch_bytes, const int32_t *dims, void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(rowptr && (col || nnz == 0) && x_src && agg && w_l && w_r && grad_out && grad_w_l && grad_w_r && scratch,
@@ -532,39 +584,56 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
         set_error("sage_conv_backward: scratch %zu < %zu bytes", scratch_bytes, sage_conv_scratch_bytes(n_src, n_dst, nnz, c_in, c_out));
         return POPE_ERR_WORKSPACE;
     }
+    const size_t gagg_bytes = align_up((size_t)n_dst * c_in * sizeof(float), 256);
+    const size_t colsum_bytes = align_up((size_t)COLSUM_SPLITS * c_out * sizeof(float), 256);
     float *gagg = (float *)scratch;
-    float *slab = (float *)((char *)scratch + align_up((size_t)n_dst * c_in * sizeof(float), 256));
+    float *slab = (float *)((char *)scratch + gagg_bytes);
+    const size_t slab_bytes = scratch_bytes - gagg_bytes - colsum_bytes;
+    float *colsum = (float *)((char *)scratch + scratch_bytes - colsum_bytes);
+    const int32_t *n_dst_dev = dims, *n_src_dev = dims ? dims + 1 : nullptr;
     const int splits = weight_grad_splits(n_dst, c_in, c_out);
     const Operand none{nullptr, 0, 0};
     int rc;
+
+    SideLanes lanes;
+    const bool side = g_sage_lanes != 0 && (grad_b_l || grad_x);
+    if (side && (rc = lanes.fork(stream, SIDE_LANES))) return rc;
+    hipStream_t s_bias = side ? lanes.lane(0) : stream, s_x = side ? lanes.lane(1) : stream;
+
     // grad_w_l[o, c] = sum_i grad_out[i, o] * agg[i, c];  grad_w_r likewise with x_dst   (depth = rows i)
     bool used = false;
-    const size_t slab_bytes = scratch_bytes - align_up((size_t)n_dst * c_in * sizeof(float), 256);
-    if ((rc = gemm_streamk_tn(grad_out, agg, x_src, n_dst, c_out, c_in, grad_w_l, grad_w_r, slab, slab_bytes, stream, &used))) return rc;
+    if ((rc = gemm_streamk_tn(grad_out, agg, x_src, n_dst, c_out, c_in, grad_w_l, grad_w_r, slab, slab_bytes, stream, &used, n_dst_dev))) return rc;
     if (!used) {
         const Operand Gt{grad_out, 1, c_out};                   // (outer o, depth i) -> grad_out[i * c_out + o]
         const Operand AggT{agg, 1, c_in}, XdT{x_src, 1, c_in};  // (outer c, depth i)
+        GemmDyn dyn;
+        dyn.k0 = n_dst_dev;
         if ((rc = gemm(Gt, AggT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_l, c_in, splits, slab, stream,
-                       Twin{XdT, grad_w_r, 0}))) return rc;
+                       Twin{XdT, grad_w_r, 0}, dyn))) return rc;
     }
-    if (grad_b_l) {                                             // the slab region is free again: stream order
+    if (grad_b_l) {
         if ((c_out & 3) == 0 && aligned16(grad_out))
-            hipLaunchKernelGGL(k_colsum_partial<true>, dim3((c_out + 255) / 256, COLSUM_SPLITS), dim3(256), 0, stream, grad_out, (int)n_dst, c_out, slab);
+            hipLaunchKernelGGL(k_colsum_partial<true>, dim3((c_out + 255) / 256, COLSUM_SPLITS), dim3(256), 0, s_bias, grad_out, (int)n_dst, c_out, colsum, n_dst_dev);
         else
-            hipLaunchKernelGGL(k_colsum_partial<false>, dim3((c_out + 63) / 64, COLSUM_SPLITS), dim3(256), 0, stream, grad_out, (int)n_dst, c_out, slab);
-        hipLaunchKernelGGL(k_colsum_final, dim3((c_out + 15) / 16), dim3(256), 0, stream, slab, COLSUM_SPLITS, c_out, grad_b_l);
+            hipLaunchKernelGGL(k_colsum_partial<false>, dim3((c_out + 63) / 64, COLSUM_SPLITS), dim3(256), 0, s_bias, grad_out, (int)n_dst, c_out, colsum, n_dst_dev);
+        hipLaunchKernelGGL(k_colsum_final, dim3((c_out + 15) / 16), dim3(256), 0, s_bias, colsum, COLSUM_SPLITS, c_out, grad_b_l);
     }
     if (grad_x) {
         // grad_x[:n_dst] = grad_out * w_r ; rows >= n_dst start at zero; then scatter grad_agg = grad_out * w_l
-        POPE_HIP(hipMemsetAsync(grad_x + (size_t)n_dst * c_in, 0, (size_t)(n_src - n_dst) * c_in * sizeof(float), stream));
+        if (n_src > n_dst)
+            hipLaunchKernelGGL(k_zero_rows, dim3(capped_grid((size_t)(n_src - (dims ? 0 : n_dst)) * c_in / 4 + 1, 256)), dim3(256), 0, s_x, grad_x, c_in,
+                               (int)n_dst, (int)n_src, n_dst_dev, n_src_dev);
         const Operand G{grad_out, c_out, 1};                    // (outer i, depth o)
         const Operand WrT{w_r, 1, c_in}, WlT{w_l, 1, c_in};     // (outer c, depth o) -> w[o * c_in + c]
-        if ((rc = gemm(G, WrT, c_out, none, none, 0, (int)n_dst, c_in, nullptr, grad_x, c_in, 1, nullptr, stream,
-                       Twin{WlT, gagg, 0}))) return rc;
+        GemmDyn dyn;
+        dyn.m = n_dst_dev;
+        if ((rc = gemm(G, WrT, c_out, none, none, 0, (int)n_dst, c_in, nullptr, grad_x, c_in, 1, nullptr, s_x,
+                       Twin{WlT, gagg, 0}, dyn))) return rc;
         if (nnz > 0)
-            hipLaunchKernelGGL(k_scatter_mean, dim3(capped_grid((size_t)n_dst * ((c_in + 255) / 256) * 64, 256)), dim3(256), 0, stream, rowptr, col,
-                               (int)n_dst, gagg, c_in, grad_x);
+            hipLaunchKernelGGL(k_scatter_mean, dim3(capped_grid((size_t)n_dst * ((c_in + 255) / 256) * 64, 256)), dim3(256), 0, s_x, rowptr, col,
+                               (int)n_dst, gagg, c_in, grad_x, n_dst_dev);
     }
+    if (side && (rc = lanes.join(stream))) return rc;
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }

@@ -52,11 +52,22 @@ __host__ __device__ __forceinline__ int feistel_perm(int i, int d, unsigned key)
     return (int)x;
 }
 
+// t_dev != nullptr (device-extent mode, sage_sample_batch_device): the launch covers the CAPACITY T and the true number
+// of targets is read on the device; slots past it count zero neighbours, so the scan over the capacity still ends in nnz.
+__device__ __forceinline__ int true_count(const int *t_dev, int cap) {
+    if (!t_dev) return cap;
+    const int v = *t_dev;
+    return v < cap ? v : cap;
+}
+
 __global__ __launch_bounds__(256) void k_sample_count(const int *__restrict__ rowptr, const long long *__restrict__ targets,
-                                                      int T, int fanout, int *__restrict__ cnt, int *__restrict__ map,
-                                                      long long *__restrict__ out_n_id) {
+                                                      int T_cap, int fanout, int *__restrict__ cnt, int *__restrict__ map,
+                                                      long long *__restrict__ out_n_id, const int *__restrict__ t_dev,
+                                                      int *__restrict__ dims) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > T) return;
+    const int T = true_count(t_dev, T_cap);
+    if (i == 0 && dims) dims[0] = T;                               // n_dst of this block
+    if (i > T_cap) return;
     int c = 0;
     if (i < T) {
         const long long g = targets[i];
@@ -70,9 +81,12 @@ __global__ __launch_bounds__(256) void k_sample_count(const int *__restrict__ ro
 
 // map[g] = smallest "position key" at which node g occurs: targets occupy keys [0, T) (k_sample_count), sampled slot p key T + p.
 __global__ __launch_bounds__(256) void k_sample_pick(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                     const long long *__restrict__ targets, int T, int fanout,
+                                                     const long long *__restrict__ targets, int T_cap, int fanout,
                                                      unsigned long long seed, int hop, const int *__restrict__ out_rowptr,
-                                                     int *__restrict__ picked, int *__restrict__ map) {
+                                                     int *__restrict__ picked, int *__restrict__ map, const int *__restrict__ t_dev,
+                                                     const unsigned long long *__restrict__ seed_dev) {
+    const int T = true_count(t_dev, T_cap);
+    if (seed_dev) seed += *seed_dev;                               // replayed launches (HIP graph): the seed lives on the device
     const int stride = fanout < 0 ? 1 : fanout;
     const long long total = (long long)T * stride;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
@@ -108,8 +122,10 @@ __global__ __launch_bounds__(256) void k_sample_all(const int *__restrict__ rowp
 // The passes after the pick run over the CAPACITY (known on the host) and read the true edge count from out_rowptr[T],
 // so the host needs no readback until the very end.
 __global__ __launch_bounds__(256) void k_sample_flag(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int cap,
-                                                     int T, const int *__restrict__ map, int *__restrict__ first) {
+                                                     int T_cap, const int *__restrict__ map, int *__restrict__ first,
+                                                     const int *__restrict__ t_dev) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = true_count(t_dev, T_cap);
     if (p > cap) return;
     const int nnz = out_rowptr[T];
     first[p] = (p < nnz && map[picked[p]] == T + p) ? 1 : 0;      // zeros from nnz on: rank[nnz] = number of new nodes
@@ -118,16 +134,25 @@ __global__ __launch_bounds__(256) void k_sample_flag(const int *__restrict__ pic
 // Local ids.  A node's position key tells everything: a target keeps its index; a new node first seen at slot p0 = key - T
 // gets T + rank[p0] (rank = exclusive scan of the first-occurrence flags), and the thread that owns p0 also writes it into
 // n_id.  One pass, no per-node id table; thread 0 reports the two counts into pinned host memory.
-__global__ __launch_bounds__(256) void k_sample_relabel(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int T,
+__global__ __launch_bounds__(256) void k_sample_relabel(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int T_cap,
                                                         const int *__restrict__ map, const int *__restrict__ rank,
                                                         int *__restrict__ out_col, long long *__restrict__ n_id,
-                                                        long long *__restrict__ report) {
+                                                        long long *__restrict__ report, const int *__restrict__ t_dev,
+                                                        int *__restrict__ dims) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = true_count(t_dev, T_cap);
     const int nnz = out_rowptr[T];
     if (p == 0) {
-        report[0] = nnz;
-        report[1] = T + rank[nnz];                                 // n_src: targets + distinct new nodes
-        __threadfence_system();                                    // `report` is pinned host memory: no copy kernel
+        if (dims) {                                                // device-extent mode: the sizes stay on the device
+            dims[1] = T + rank[nnz];                               // n_src: targets + distinct new nodes
+            dims[2] = nnz;
+            dims[3] = 0;
+        }
+        if (report) {
+            report[0] = nnz;
+            report[1] = T + rank[nnz];
+            __threadfence_system();                                // `report` is pinned host memory: no copy kernel
+        }
     }
     if (p >= nnz) return;
     const int u = picked[p], k = map[u];
@@ -191,6 +216,44 @@ extern "C" size_t sage_sample_scratch_bytes(int64_t N, int64_t n_targets, int64_
     return sample_layout(N, n_targets, nnz_capacity).total;
 }
 
+// One hop, enqueued without waiting.  t_dev / dims / seed_dev: device-extent mode (see sage_sample_batch_device); report:
+// pinned host words for the host-sized mode.
+static int enqueue_hop(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *targets, int64_t n_targets, int32_t fanout,
+                       uint64_t seed, int32_t hop, int32_t *out_rowptr, int32_t *out_col, int64_t nnz_capacity, int64_t *out_n_id,
+                       void *scratch, size_t scratch_bytes, const int *t_dev, int *dims, const unsigned long long *seed_dev,
+                       long long *report_dev, hipStream_t stream, const char *who) {
+    const SampleLayout L = sample_layout(N, n_targets, nnz_capacity);
+    if (scratch_bytes < L.total) {
+        set_error("%s: scratch %zu < %zu bytes", who, scratch_bytes, L.total);
+        return POPE_ERR_WORKSPACE;
+    }
+    char *base = (char *)scratch;
+    int *cnt = (int *)(base + L.cnt), *picked = (int *)(base + L.picked), *first = (int *)(base + L.first);
+    int *rank = (int *)(base + L.rank), *map = (int *)(base + L.map);
+    void *scan_tmp = base + L.scan;
+    size_t sb = L.total - L.scan;
+    const int T = (int)n_targets;
+
+    POPE_HIP(hipMemsetAsync(map, 0x7F, (size_t)N * 4, stream));                       // 0x7F7F7F7F: larger than any key
+    hipLaunchKernelGGL(k_sample_count, dim3((T + 256) / 256), dim3(256), 0, stream, rowptr, (const long long *)targets, T, fanout, cnt,
+                       map, (long long *)out_n_id, t_dev, dims);
+    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, cnt, out_rowptr, 0, (size_t)T + 1, rocprim::plus<int>(), stream));
+    if (fanout < 0) {
+        // all neighbours: the total is only known on the device; the caller sized nnz_capacity for it
+        hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, (int)nnz_capacity, picked, map);
+    } else {
+        hipLaunchKernelGGL(k_sample_pick, dim3(capped_grid((size_t)T * fanout, 256)), dim3(256), 0, stream, rowptr, col,
+                           (const long long *)targets, T, fanout, (unsigned long long)seed, hop, out_rowptr, picked, map, t_dev, seed_dev);
+    }
+    const int cap = (int)nnz_capacity;
+    hipLaunchKernelGGL(k_sample_flag, dim3((cap + 256) / 256), dim3(256), 0, stream, picked, out_rowptr, cap, T, map, first, t_dev);
+    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, first, rank, 0, (size_t)cap + 1, rocprim::plus<int>(), stream));
+    hipLaunchKernelGGL(k_sample_relabel, dim3((cap + 256) / 256), dim3(256), 0, stream, picked, out_rowptr, T, map, rank, out_col,
+                       (long long *)out_n_id, report_dev, t_dev, dims);   // at least one block: thread 0 also reports the counts
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
 extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *targets, int64_t n_targets,
                                int32_t fanout, uint64_t seed, int32_t hop, int32_t *out_rowptr, int32_t *out_col,
                                int64_t nnz_capacity, int64_t *out_n_id, int64_t *nnz_host, int64_t *n_src_host, void *scratch,
@@ -204,40 +267,12 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
     POPE_REQUIRE(fanout != 0, "sage_sample_hop: fanout must be > 0, or < 0 for all neighbours");
     POPE_REQUIRE(fanout < 0 || nnz_capacity >= n_targets * (int64_t)fanout, "sage_sample_hop: nnz_capacity %lld < n_targets * fanout",
                  (long long)nnz_capacity);
-    const SampleLayout L = sample_layout(N, n_targets, nnz_capacity);
-    if (scratch_bytes < L.total) {
-        set_error("sage_sample_hop: scratch %zu < %zu bytes", scratch_bytes, L.total);
-        return POPE_ERR_WORKSPACE;
-    }
-    char *base = (char *)scratch;
-    int *cnt = (int *)(base + L.cnt), *picked = (int *)(base + L.picked), *first = (int *)(base + L.first);
-    int *rank = (int *)(base + L.rank), *map = (int *)(base + L.map), *newid = (int *)(base + L.newid);
-    long long *report = (long long *)(base + L.report);
-    void *scan_tmp = base + L.scan;
-    size_t sb = L.total - L.scan;
-    const int T = (int)n_targets;
-
-    POPE_HIP(hipMemsetAsync(map, 0x7F, (size_t)N * 4, stream));                       // 0x7F7F7F7F: larger than any key
-    hipLaunchKernelGGL(k_sample_count, dim3((T + 256) / 256), dim3(256), 0, stream, rowptr, (const long long *)targets, T, fanout, cnt,
-                       map, (long long *)out_n_id);
-    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, cnt, out_rowptr, 0, (size_t)T + 1, rocprim::plus<int>(), stream));
-    if (fanout < 0) {
-        // all neighbours: the total is only known on the device; the caller sized nnz_capacity for it
-        hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, (int)nnz_capacity, picked, map);
-    } else {
-        hipLaunchKernelGGL(k_sample_pick, dim3(capped_grid((size_t)T * fanout, 256)), dim3(256), 0, stream, rowptr, col,
-                           (const long long *)targets, T, fanout, (unsigned long long)seed, hop, out_rowptr, picked, map);
-    }
-    const int cap = (int)nnz_capacity;
     long long *rep = nullptr, *rep_dev = nullptr;                 // the two counts come back through pinned, device-mapped memory
-    int rc_pin = pinned_report(&rep, &rep_dev);
-    if (rc_pin) return rc_pin;
-    hipLaunchKernelGGL(k_sample_flag, dim3((cap + 256) / 256), dim3(256), 0, stream, picked, out_rowptr, cap, T, map, first);
-    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, first, rank, 0, (size_t)cap + 1, rocprim::plus<int>(), stream));
-    (void)report;
-    (void)newid;
-    hipLaunchKernelGGL(k_sample_relabel, dim3((cap + 256) / 256), dim3(256), 0, stream, picked, out_rowptr, T, map, rank, out_col,
-                       (long long *)out_n_id, rep_dev);        // at least one block: thread 0 also reports the counts
+    int rc = pinned_report(&rep, &rep_dev);
+    if (rc) return rc;
+    rc = enqueue_hop(rowptr, col, N, targets, n_targets, fanout, seed, hop, out_rowptr, out_col, nnz_capacity, out_n_id, scratch,
+                     scratch_bytes, nullptr, nullptr, nullptr, rep_dev, stream, "sage_sample_hop");
+    if (rc) return rc;
     POPE_HIP(hipStreamSynchronize(stream));
     POPE_HIP(hipGetLastError());
     if (rep[0] > nnz_capacity) {
@@ -246,6 +281,35 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
     }
     *nnz_host = rep[0];
     *n_src_host = rep[1];
+    return POPE_OK;
+}
+
+// Device-extent form of sage_sample_batch: NO host synchronisation.  Every hop runs over its capacity (hop h may meet up to
+// t_cap[h] targets) and reads the true target count of hop h - 1 on the device; dims[h] = {n_dst, n_src, nnz, 0} (int32,
+// device) is what the SAGE entry points take as their `dims` argument.  Capturable into a HIP graph: with seed_dev the
+// draw follows a device word (sage_step_state_advance bumps it between replays).
+extern "C" int sage_sample_batch_device(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *seeds, int64_t n_seeds,
+                                        const int32_t *fanouts_host, int32_t n_hops, uint64_t seed, const uint64_t *seed_dev,
+                                        int32_t *const *out_rowptr, int32_t *const *out_col, int64_t *const *out_n_id, int32_t *dims,
+                                        void *scratch, size_t scratch_bytes, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(rowptr && col && seeds && fanouts_host && out_rowptr && out_col && out_n_id && dims && scratch && n_hops > 0 && n_hops <= 16,
+                 "sage_sample_batch_device: null pointer or bad hop count");
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && n_seeds > 0, "sage_sample_batch_device: bad size");
+    const int64_t *targets = seeds;
+    int64_t t_cap = n_seeds;
+    for (int h = 0; h < n_hops; ++h) {
+        POPE_REQUIRE(fanouts_host[h] > 0, "sage_sample_batch_device: fan-outs must be positive");
+        const int64_t cap = t_cap * (int64_t)fanouts_host[h];
+        POPE_REQUIRE(t_cap + cap < INT32_MAX, "sage_sample_batch_device: capacity of hop %d exceeds 31 bits", h);
+        const int rc = enqueue_hop(rowptr, col, N, targets, t_cap, fanouts_host[h], seed, h, out_rowptr[h], out_col[h], cap, out_n_id[h],
+                                   scratch, scratch_bytes, h == 0 ? nullptr : dims + 4 * (h - 1) + 1, dims + 4 * h,
+                                   (const unsigned long long *)seed_dev, nullptr, stream, "sage_sample_batch_device");
+        if (rc) return rc;
+        targets = out_n_id[h];
+        t_cap = t_cap + cap;
+    }
     return POPE_OK;
 }
 

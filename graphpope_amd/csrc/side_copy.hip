@@ -46,10 +46,13 @@ struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
-static SideStream g_side[16];
+constexpr int SIDE_MAX_DEVICES = 64;
+static SideStream g_side[SIDE_MAX_DEVICES];
 static std::mutex g_side_create;
 
 bool SideCopy::eligible(const float *x, int32_t F, const float *out, int64_t out_cols, int64_t N) {
+    int dev = 0;                                               // a device without a side-stream slot takes the serial pope_concat path
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SIDE_MAX_DEVICES) return false;
     return x && out && F > 0 && (F & 3) == 0 && F <= 4096 && (out_cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0 &&
            (uint64_t)N * (uint64_t)out_cols * 4u < (1ull << 32);
 }
@@ -57,7 +60,7 @@ bool SideCopy::eligible(const float *x, int32_t F, const float *out, int64_t out
 int SideCopy::fork(hipStream_t main) {
     int dev = 0;
     POPE_HIP(hipGetDevice(&dev));
-    POPE_REQUIRE(dev >= 0 && dev < 16, "feature copy: device %d", dev);
+    POPE_REQUIRE(dev >= 0 && dev < SIDE_MAX_DEVICES, "feature copy: device %d", dev);
     SideStream &s = g_side[dev];
     {
         std::lock_guard<std::mutex> once(g_side_create);
@@ -98,6 +101,47 @@ int SideCopy::launch(const float *x, int32_t F, float *out, int64_t out_cols, in
 int SideCopy::join(hipStream_t main) {
     POPE_REQUIRE(side_, "feature copy: join before fork");
     POPE_HIP(hipStreamWaitEvent(main, side_->join, 0));
+    return POPE_OK;
+}
+
+struct LaneSet {
+    std::mutex mu;
+    hipStream_t stream[SIDE_LANES] = {};
+    hipEvent_t fork = nullptr, join[SIDE_LANES] = {};
+};
+static LaneSet g_lanes[SIDE_MAX_DEVICES];
+
+int SideLanes::fork(hipStream_t main, int lanes) {
+    int dev = 0;
+    POPE_HIP(hipGetDevice(&dev));
+    POPE_REQUIRE(dev >= 0 && dev < SIDE_MAX_DEVICES && lanes >= 1 && lanes <= SIDE_LANES, "side lanes: device %d, %d lanes", dev, lanes);
+    LaneSet &s = g_lanes[dev];
+    {
+        std::lock_guard<std::mutex> once(g_side_create);
+        if (!s.fork) {
+            for (int i = 0; i < SIDE_LANES; ++i) {
+                POPE_HIP(hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking));
+                POPE_HIP(hipEventCreateWithFlags(&s.join[i], hipEventDisableTiming));
+            }
+            POPE_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        }
+    }
+    hold_ = std::unique_lock<std::mutex>(s.mu);
+    set_ = &s;
+    lanes_ = lanes;
+    POPE_HIP(hipEventRecord(s.fork, main));
+    for (int i = 0; i < lanes; ++i) POPE_HIP(hipStreamWaitEvent(s.stream[i], s.fork, 0));
+    return POPE_OK;
+}
+
+hipStream_t SideLanes::lane(int i) const { return set_->stream[i]; }
+
+int SideLanes::join(hipStream_t main) {
+    POPE_REQUIRE(set_, "side lanes: join before fork");
+    for (int i = 0; i < lanes_; ++i) {
+        POPE_HIP(hipEventRecord(set_->join[i], set_->stream[i]));
+        POPE_HIP(hipStreamWaitEvent(main, set_->join[i], 0));
+    }
     return POPE_OK;
 }
 

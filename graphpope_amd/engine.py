@@ -67,16 +67,81 @@ def host_copy_2d(src: torch.Tensor, dst: torch.Tensor, threads: int = 0) -> None
 
 
 def stage_to_device(t: torch.Tensor, device) -> torch.Tensor:
-    """A pageable host tensor -> device through pinned staging memory (threaded host copy + one asynchronous DMA).
-    torch's pinned allocator keeps the staging block alive until the DMA has run and caches it for the next call."""
+    """A pageable host tensor -> device, asynchronously on the current stream.
+
+    The caller's pages are registered with the HIP runtime for the length of the copy (pope_host_pin: microseconds per
+    MB, no staging copy, no pinned allocation that outlives the call) and the DMA reads them in place; the registration
+    is dropped once the copy has completed.  If the runtime refuses the registration the tensor goes through pinned
+    staging memory instead (threaded host copy + one DMA)."""
     if t.is_cuda:
         return t.to(device)
     t = t.contiguous()
     if t.is_pinned() or t.numel() == 0:
         return t.to(device, non_blocking=True)
+    lib = _lib.load()
+    nbytes = t.numel() * t.element_size()
+    if nbytes >= (1 << 20) and lib.pope_host_pin(ptr(t), nbytes) == _lib.OK:
+        try:
+            with torch.cuda.device(device):
+                out = torch.empty(t.shape, dtype=t.dtype, device=device)
+                check(lib.pope_copy_to_device(ptr(t), ptr(out), nbytes, _stream()))
+                torch.cuda.current_stream().synchronize()          # the pages stay registered exactly as long as the DMA reads them
+        finally:
+            lib.pope_host_unpin(ptr(t))
+        return out
     staged = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host_copy_2d(t.view(1, -1), staged.view(1, -1))
     return staged.to(device, non_blocking=True)
+
+
+class staged:
+    """``with staged(t, device) as t_dev:`` -- stage_to_device without the wait: the copy is enqueued, the body runs
+    (enqueueing the GPU work that consumes t_dev), and the caller's pages are released on exit, once the event recorded
+    behind the copy has completed (normally long before: the body has waited for results that depend on it)."""
+
+    def __init__(self, t: torch.Tensor, device):
+        self.t, self.device, self.pinned, self.event = t, device, False, None
+
+    def __enter__(self) -> torch.Tensor:
+        t = self.t
+        if t.is_cuda or t.numel() == 0 or t.is_pinned():
+            return stage_to_device(t, self.device)
+        lib = _lib.load()
+        self.t = t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        if nbytes < (1 << 20) or lib.pope_host_pin(ptr(t), nbytes) != _lib.OK:
+            return stage_to_device(t, self.device)
+        self.pinned = True
+        try:
+            with torch.cuda.device(self.device):
+                out = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+                check(lib.pope_copy_to_device(ptr(t), ptr(out), nbytes, _stream()))
+                self.event = torch.cuda.Event()
+                self.event.record()
+        except BaseException:
+            self.__exit__(None, None, None)
+            raise
+        return out
+
+    def __exit__(self, *exc):
+        if self.pinned:
+            if self.event is not None:
+                self.event.synchronize()
+            _lib.load().pope_host_unpin(ptr(self.t))
+            self.pinned = False
+        return False
+
+
+def assemble_host_result(x: torch.Tensor | None, emb: torch.Tensor, out: torch.Tensor, f: int, threads: int = 0, chunks: int = 0) -> None:
+    """out[:, :f] = x (HOST, threads) and out[:, f:] = emb (DEVICE [N, K], DMA on the current stream) for a pageable
+    HOST result `out` [N, f + K]; returns when `out` is complete (pope_assemble_host_result)."""
+    lib = _lib.load()
+    assert not out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and emb.is_cuda and emb.is_contiguous()
+    n, k = emb.shape
+    assert out.shape == (n, f + k) and (f == 0 or (x is not None and not x.is_cuda and x.shape == (n, f) and x.stride(1) == 1))
+    with torch.cuda.device(emb.device):
+        check(lib.pope_assemble_host_result(ptr(x) if f else None, (x.stride(0) * 4) if f else 0, f * 4, ptr(emb), k * 4, k * 4,
+                                            ptr(out), (f + k) * 4, n, threads or host_threads(), chunks, _stream()))
 
 
 def copy_columns_to_host(src: torch.Tensor, dst: torch.Tensor) -> None:

@@ -22,6 +22,14 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self._tables = {}            # per group: cached ctypes pointer arrays, rebuilt when the set of tensors changes
+        self.step_dev = None         # device int64 scalar holding the 1-based step count (use_device_step)
+
+    def use_device_step(self, word: torch.Tensor | None) -> None:
+        """Read the step count of the bias corrections from a device word instead of the host counter: a training step that
+        is replayed as a HIP graph cannot take it as a launch argument.  The word must hold the number of the step being
+        taken (the caller advances it, sage_advance_counters); the host-side counters keep counting the calls made here."""
+        assert word is None or (word.is_cuda and word.dtype == torch.int64 and word.numel() == 1)
+        self.step_dev = word
 
     def _build(self, group, live):
         """Slow path, taken when the set of parameters with gradients changes: checks, state creation, pointer tables."""
@@ -76,6 +84,7 @@ class Adam(torch.optim.Optimizer):
             with on_device(tab["dev"]):
                 check(lib.sage_adam_step(tab["n"], tab["pp"], gg, tab["mm"], tab["vv"], tab["nn"], float(group["lr"]), float(b1),
                                          float(b2), float(group["eps"]), float(group["weight_decay"]), step,
+                                         ctypes.c_void_p(0 if self.step_dev is None else self.step_dev.data_ptr()),
                                          ctypes.c_void_p(torch.cuda.current_stream(tab["dev"]).cuda_stream)))
             for st in tab["states"]:
                 st["step"] = step

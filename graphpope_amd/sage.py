@@ -29,19 +29,34 @@ class SampledAdj:
 
     Stands in for the ``torch_sparse.SparseTensor`` ``adj_t`` PyG's NeighborSampler yields
     (main.py:59-63, 118-123): ``size(0)`` = n_dst, ``size(1)`` = n_src, values dropped.
+
+    ``dims`` (device int32 [4] = {n_dst, n_src, nnz, 0}, written by the device-extent sampler) makes the block one of
+    DEVICE extents: ``n_dst`` / ``n_src`` / the lengths of ``rowptr`` and ``col`` are then capacities, the kernels read the
+    true sizes from ``dims`` and nothing is ever read back to the host (include/graphpope_hip.h, "Device extents").
     """
 
-    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, n_src: int):
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, n_src: int, dims: torch.Tensor | None = None):
         self.rowptr = rowptr.to(torch.int32).contiguous()
         self.col = col.to(torch.int32).contiguous()
         self.n_dst = int(rowptr.numel() - 1)
         self.n_src = int(n_src)
+        if dims is not None:
+            assert dims.is_cuda and dims.dtype == torch.int32 and dims.numel() >= 3 and dims.is_contiguous()
+        self.dims = dims
 
     def size(self, dim: int) -> int:
         return (self.n_dst, self.n_src)[dim]
 
     def to(self, device):
-        return SampledAdj(self.rowptr.to(device), self.col.to(device), self.n_src)
+        return SampledAdj(self.rowptr.to(device), self.col.to(device), self.n_src, None if self.dims is None else self.dims.to(device))
+
+    def device_extents(self) -> "SampledAdj":
+        """The same block with its sizes in a device word triple (for blocks sampled on the host: pools of pre-sampled
+        batches that feed a replayed step)."""
+        if self.dims is not None:
+            return self
+        dims = torch.tensor([self.n_dst, self.n_src, int(self.col.numel()), 0], dtype=torch.int32, device=self.rowptr.device)
+        return SampledAdj(self.rowptr, self.col, self.n_src, dims)
 
 
 def _forward_scratch(lib, n_dst, c_in, c_out, dev):
@@ -55,7 +70,7 @@ def _forward_scratch(lib, n_dst, c_in, c_out, dev):
 
 class _SageConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_src, w_l, b_l, w_r, rowptr, col, n_dst):
+    def forward(ctx, x_src, w_l, b_l, w_r, rowptr, col, n_dst, dims=None):
         lib = _lib.load()
         if not x_src.is_cuda:
             raise RuntimeError("SAGEConv runs on the GPU only (no CPU fallback)")
@@ -68,10 +83,11 @@ class _SageConvFn(torch.autograd.Function):
         with on_device(x_src.device):
             scratch, nbytes = _forward_scratch(lib, n_dst, c_in, c_out, x_src.device)
             check(lib.sage_conv_forward(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), c_in, ptr(w_l),
-                                        ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(out), ptr(scratch), nbytes, _stream()))
+                                        ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(out), ptr(scratch), nbytes, ptr(dims), _stream()))
         ctx.save_for_backward(x_src, agg, w_l, w_r, rowptr, col)
         ctx.has_bias = b_l is not None
         ctx.n_dst = n_dst
+        ctx.dims = dims
         return out
 
     @staticmethod
@@ -92,8 +108,8 @@ class _SageConvFn(torch.autograd.Function):
                                   dtype=torch.uint8, device=dev)
             check(lib.sage_conv_backward(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), ptr(agg), c_in,
                                          ptr(w_l), ptr(w_r), c_out, ptr(grad_out), ptr(grad_x), ptr(grad_w_l), ptr(grad_b),
-                                         ptr(grad_w_r), ptr(scratch), scratch.numel(), _stream()))
-        return grad_x, grad_w_l, grad_b, grad_w_r, None, None, None
+                                         ptr(grad_w_r), ptr(scratch), scratch.numel(), ptr(ctx.dims), _stream()))
+        return grad_x, grad_w_l, grad_b, grad_w_r, None, None, None, None
 
 
 class IndexedFeatures:
@@ -112,7 +128,7 @@ class IndexedFeatures:
 
 class _SageConvIndexedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, w_l, b_l, w_r, feats, n_id, rowptr, col, n_dst):
+    def forward(ctx, w_l, b_l, w_r, feats, n_id, rowptr, col, n_dst, dims=None):
         lib = _lib.load()
         if not feats.is_cuda:
             raise RuntimeError("SAGEConv runs on the GPU only (no CPU fallback)")
@@ -126,9 +142,10 @@ class _SageConvIndexedFn(torch.autograd.Function):
             scratch, nbytes = _forward_scratch(lib, n_dst, c_in, c_out, dev)
             check(lib.sage_conv_forward_indexed(ptr(rowptr), ptr(col), ptr(n_id), n_id.numel(), n_dst, col.numel(), ptr(feats),
                                                 feats.shape[0], c_in, ptr(w_l), ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(x_dst),
-                                                ptr(out), ptr(scratch), nbytes, _stream()))
+                                                ptr(out), ptr(scratch), nbytes, ptr(dims), _stream()))
         ctx.save_for_backward(x_dst, agg, w_l, w_r, rowptr, col)
         ctx.has_bias = b_l is not None
+        ctx.dims = dims
         return out
 
     @staticmethod
@@ -144,8 +161,8 @@ class _SageConvIndexedFn(torch.autograd.Function):
             scratch = torch.empty(max(lib.sage_conv_scratch_bytes(n_dst, n_dst, col.numel(), c_in, c_out), 16), dtype=torch.uint8, device=dev)
             check(lib.sage_conv_backward(ptr(rowptr), ptr(col), n_dst, n_dst, col.numel(), ptr(x_dst), ptr(agg), c_in, ptr(w_l),
                                          ptr(w_r), c_out, ptr(grad_out), None, ptr(grad_w_l), ptr(grad_b), ptr(grad_w_r),
-                                         ptr(scratch), scratch.numel(), _stream()))
-        return grad_w_l, grad_b, grad_w_r, None, None, None, None, None
+                                         ptr(scratch), scratch.numel(), ptr(ctx.dims), _stream()))
+        return grad_w_l, grad_b, grad_w_r, None, None, None, None, None, None
 
 
 class _Linear(nn.Module):
@@ -176,17 +193,18 @@ class SAGEConv(nn.Module):
     def forward(self, x, adj_t: SampledAdj):
         if isinstance(x, IndexedFeatures):                        # neighbours read straight from the resident feature matrix
             return _SageConvIndexedFn.apply(self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, x.feats, x.n_id, adj_t.rowptr,
-                                            adj_t.col, adj_t.size(0))
+                                            adj_t.col, adj_t.size(0), adj_t.dims)
         x_src = x[0] if isinstance(x, (tuple, list)) else x       # x_dst = x_src[:n_dst] by construction (main.py:206)
         return _SageConvFn.apply(x_src, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, adj_t.rowptr, adj_t.col,
-                                 adj_t.size(0))
+                                 adj_t.size(0), adj_t.dims)
 
 
 class _BnReluDropoutFn(torch.autograd.Function):
     """BatchNorm1d -> ReLU -> dropout in three launches per direction (csrc/epilogue.hip), main.py:207-209."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, p, seed, num_batches_tracked=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, p, seed, num_batches_tracked=None,
+                rows=None, seed_dev=None):
         lib = _lib.load()
         if not x.is_cuda:
             raise RuntimeError("the fused BatchNorm/ReLU/dropout epilogue runs on the GPU only (no CPU fallback)")
@@ -200,9 +218,10 @@ class _BnReluDropoutFn(torch.autograd.Function):
             scratch = torch.empty(lib.sage_bn_scratch_bytes(c), dtype=torch.uint8, device=dev)
             check(lib.sage_bn_relu_dropout_forward(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                                    ptr(num_batches_tracked), momentum, eps, int(training), p, seed, ptr(y), ptr(mean), ptr(rstd),
-                                                   ptr(scratch), scratch.numel(), _stream()))
+                                                   ptr(scratch), scratch.numel(), ptr(rows), ptr(seed_dev), _stream()))
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.cfg = (bool(training), float(p), int(seed))
+        ctx.dev_words = (rows, seed_dev)
         return y
 
     @staticmethod
@@ -220,17 +239,22 @@ class _BnReluDropoutFn(torch.autograd.Function):
             scratch = torch.empty(lib.sage_bn_scratch_bytes(c), dtype=torch.uint8, device=dev)
             check(lib.sage_bn_relu_dropout_backward(ptr(x), ptr(grad_y), m, c, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                                     int(training), p, seed, ptr(grad_x), ptr(grad_gamma), ptr(grad_beta),
-                                                    ptr(scratch), scratch.numel(), _stream()))
-        return grad_x, grad_gamma, grad_beta, None, None, None, None, None, None, None, None
+                                                    ptr(scratch), scratch.numel(), ptr(ctx.dev_words[0]), ptr(ctx.dev_words[1]), _stream()))
+        return grad_x, grad_gamma, grad_beta, None, None, None, None, None, None, None, None, None, None
 
 
-def bn_relu_dropout(x: torch.Tensor, bn: nn.BatchNorm1d, p: float, training: bool, seed: int | None = None) -> torch.Tensor:
+def bn_relu_dropout(x: torch.Tensor, bn: nn.BatchNorm1d, p: float, training: bool, seed: int | None = None,
+                    rows: torch.Tensor | None = None, seed_dev: torch.Tensor | None = None) -> torch.Tensor:
     """``F.dropout(bn(x).relu_(), p, training)`` (main.py:207-209) on the fused HIP epilogue.
 
     `bn` stays an ordinary ``nn.BatchNorm1d`` (same state-dict keys as the reference's checkpoints); its running
     statistics and ``num_batches_tracked`` are updated as torch does.  The dropout mask is a counter hash of
     (seed, element): `seed` defaults to a draw from torch's global generator, so ``torch.manual_seed`` makes runs
     repeatable; the mask itself is not torch's Philox stream.
+
+    ``rows`` (device int32 scalar): the true row count of ``x`` when its first dimension is a capacity (device-extent
+    batches).  ``seed_dev`` (device int64 scalar): added to ``seed`` on the device, so that a replayed HIP graph draws a
+    new mask every replay; with it ``seed`` defaults to 0 instead of a draw from torch's generator (which is a host read).
     """
     if bn.weight is None or bn.momentum is None:
         raise NotImplementedError("fused epilogue: affine BatchNorm1d with a fixed momentum only (the reference's default)")
@@ -240,11 +264,11 @@ def bn_relu_dropout(x: torch.Tensor, bn: nn.BatchNorm1d, p: float, training: boo
         nbt.add_(1)                                       # a counter the kernel cannot reach: torch's own op
         nbt = None
     if seed is None:
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p > 0) else 0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p > 0 and seed_dev is None) else 0
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     out = _BnReluDropoutFn.apply(x, bn.weight, bn.bias, rm, rv, float(bn.momentum), float(bn.eps), use_batch_stats,
-                                 float(p) if training else 0.0, seed, nbt)       # the step counter goes up inside the statistics kernel
+                                 float(p) if training else 0.0, seed, nbt, rows, seed_dev)       # the step counter goes up inside the statistics kernel
     return out
 
 
@@ -316,12 +340,18 @@ class SAGE(nn.Module):
         self.bns = nn.ModuleList()
         for _ in range(num_layers - 1):
             self.bns.append(nn.BatchNorm1d(hidden_channels))
+        self.dropout_seed_dev = None     # device int64 scalar the dropout seeds follow (train.SageTrainStep sets it: graph replay)
 
     def forward(self, x, adjs):
         for i, adj_t in enumerate(adjs):
             x = self.convs[i](x if isinstance(x, IndexedFeatures) else (x, x[:adj_t.size(0)]), adj_t)
             if i < len(adjs) - 1:
-                x = bn_relu_dropout(x, self.bns[i], self.dropout, self.training)
+                rows = None if adj_t.dims is None else adj_t.dims[0:1]
+                if self.dropout_seed_dev is not None:
+                    x = bn_relu_dropout(x, self.bns[i], self.dropout, self.training, seed=0x9E3779B97F4A7C15 * (i + 1) % (1 << 63),
+                                        rows=rows, seed_dev=self.dropout_seed_dev)
+                else:
+                    x = bn_relu_dropout(x, self.bns[i], self.dropout, self.training, rows=rows)
         return x
 
 

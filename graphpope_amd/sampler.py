@@ -24,11 +24,78 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class DeviceBatch:
+    """Fixed buffers for mini-batches of `n_seeds` seeds and fan-outs `sizes`, sized by CAPACITY (hop h may meet up to
+    t_cap[h] = t_cap[h-1] * (1 + sizes[h-1]) targets): the device-extent sampler fills them without ever telling the host
+    how large the batch came out -- ``dims[h]`` = {n_dst, n_src, nnz, 0} stays on the device and every SAGE kernel reads
+    its sizes there.  The same buffers are filled again for the next batch (a captured HIP graph replays on them)."""
+
+    def __init__(self, n_seeds: int, sizes, device):
+        self.n_seeds, self.sizes = int(n_seeds), [int(f) for f in sizes]
+        assert all(f > 0 for f in self.sizes), "device-extent batches need positive fan-outs"
+        h = len(self.sizes)
+        self.t_cap, self.caps = [], []
+        t = self.n_seeds
+        for f in self.sizes:
+            self.t_cap.append(t)
+            self.caps.append(t * f)
+            t = t + t * f
+        self.rowptrs = [torch.zeros(tc + 1, dtype=torch.int32, device=device) for tc in self.t_cap]
+        self.cols = [torch.zeros(max(c, 1), dtype=torch.int32, device=device) for c in self.caps]
+        self.n_ids = [torch.zeros(tc + c, dtype=torch.int64, device=device) for tc, c in zip(self.t_cap, self.caps)]
+        self.dims = torch.zeros((h, 4), dtype=torch.int32, device=device)
+        self.n_id = self.n_ids[-1]                                   # [capacity]: the true length is dims[-1, 1]
+        # outermost block first, like NeighborSampler's adjs (main.py:118-123)
+        self.adjs = [SampledAdj(self.rowptrs[i], self.cols[i], self.t_cap[i] + self.caps[i], self.dims[i]) for i in range(h)][::-1]
+
+    def segments(self):
+        """Every buffer a batch consists of (same order for every DeviceBatch of the same shape): for sage_copy_segments."""
+        return self.rowptrs + self.cols + [self.n_id, self.dims]
+
+    def load(self, n_id: torch.Tensor, adjs) -> None:
+        """Fill the buffers from a batch sampled elsewhere (host-sized SampledAdjs, outermost first): plain copies; the
+        sizes travel as four device words per hop."""
+        h = len(self.sizes)
+        assert len(adjs) == h
+        self.n_id[: n_id.numel()].copy_(n_id)
+        host_dims = []
+        for i, adj in enumerate(adjs[::-1]):                       # hop order
+            self.rowptrs[i].fill_(int(adj.col.numel()))            # rows past n_dst are empty
+            self.rowptrs[i][: adj.n_dst + 1].copy_(adj.rowptr)
+            self.cols[i][: adj.col.numel()].copy_(adj.col)
+            host_dims.append([adj.n_dst, adj.n_src, int(adj.col.numel()), 0])
+        self.dims.copy_(torch.tensor(host_dims, dtype=torch.int32))
+
+
 class NeighborSampler:
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int, sizes=(25, 10)):
         assert rowptr.is_cuda and rowptr.dtype == torch.int32 and col.dtype == torch.int32
         self.rowptr, self.col, self.num_nodes, self.sizes = rowptr, col, int(num_nodes), list(sizes)
         self._scratch = None
+
+    def sample_device(self, seeds: torch.Tensor, seed: int = 0, out: DeviceBatch | None = None,
+                      seed_dev: torch.Tensor | None = None) -> DeviceBatch:
+        """The batch around `seeds` (int64 on the device, out.n_seeds of them) WITHOUT any host synchronisation
+        (sage_sample_batch_device): `out`'s buffers are filled, the sizes stay in out.dims.  The draw equals
+        ``sample(seeds, seed + int(seed_dev))``; capturable into a HIP graph (seed_dev: device int64 scalar)."""
+        lib = _lib.load()
+        dev = self.rowptr.device
+        if out is None:
+            out = DeviceBatch(seeds.numel(), self.sizes, dev)
+        assert seeds.is_cuda and seeds.dtype == torch.int64 and seeds.is_contiguous() and seeds.numel() == out.n_seeds
+        assert out.sizes == [int(f) for f in self.sizes]
+        h = len(out.sizes)
+        need = lib.sage_sample_scratch_bytes(self.num_nodes, out.t_cap[-1], out.caps[-1])
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+        arr = ctypes.c_void_p * h
+        with on_device(dev):
+            check(lib.sage_sample_batch_device(ptr(self.rowptr), ptr(self.col), self.num_nodes, ptr(seeds), seeds.numel(),
+                                               (ctypes.c_int32 * h)(*out.sizes), h, int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(seed_dev),
+                                               arr(*[r.data_ptr() for r in out.rowptrs]), arr(*[c.data_ptr() for c in out.cols]),
+                                               arr(*[n.data_ptr() for n in out.n_ids]), ptr(out.dims), ptr(self._scratch),
+                                               self._scratch.numel(), _stream()))
+        return out
 
     def _hop(self, targets: torch.Tensor, fanout: int, seed: int, hop: int):
         lib = _lib.load()

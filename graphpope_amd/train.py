@@ -1,0 +1,160 @@
+"""One GraphSAGE training step with no host in the loop: sampled, run and optimised entirely by kernels that read their
+sizes on the device, captured once into a HIP graph and replayed.
+
+What the reference does per step (/root/reference/main.py): a DataLoader worker samples the batch
+(NeighborSampler(sizes=[25, 10]), main.py:100-116) and gathers ``data.x[n_id]`` (convert_batch, main.py:118-123);
+Lightning moves it to the GPU, calls ``training_step`` (main.py:213-222: forward + ``F.cross_entropy``), backward,
+clips the gradient norm to 0.5 (main.py:286) and steps Adam (main.py:244).  Here the same step is
+
+    sample (device-extent sampler, no read-back)  ->  SAGE forward on IndexedFeatures  ->  cross-entropy
+    ->  backward  ->  [clip]  ->  one-launch Adam  ->  advance the device-side seeds / step count
+
+enqueued once through the ordinary autograd path while a HIP graph is being captured, then replayed: a step costs one
+small launch that loads the seeds and labels plus one graph launch.  Batches come either from the device sampler inside
+the graph (`sampler` given) or from a pool of pre-sampled batches loaded into the graph's fixed buffers
+(:meth:`load_batch`).  The data-dependent sizes of a batch never reach the host (include/graphpope_hip.h, "Device
+extents"), so nothing in the step synchronises.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, on_device
+from .sage import IndexedFeatures, cross_entropy
+from .sampler import DeviceBatch
+
+_SEED_STRIDE = 0x9E3779B97F4A7C15 % (1 << 63)        # odd: the seed words walk through all 2^64 values
+
+
+class StepState:
+    """Three device words a replayed step reads and one launch advances: dropout seed, sampling seed, Adam step count."""
+
+    def __init__(self, device, seed: int = 0, adam_step: int = 0):
+        self.words = torch.tensor([seed, seed ^ 0x5DEECE66D, adam_step + 1], dtype=torch.int64, device=device)
+        self._inc = (ctypes.c_int64 * 3)(_SEED_STRIDE, _SEED_STRIDE | 2, 1)
+
+    dropout_seed = property(lambda self: self.words[0:1])
+    sample_seed = property(lambda self: self.words[1:2])
+    adam_step = property(lambda self: self.words[2:3])
+
+    def advance(self) -> None:
+        lib = _lib.load()
+        with on_device(self.words.device):
+            check(lib.sage_advance_counters(ctypes.c_void_p(self.words.data_ptr()), self._inc, 3,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+def copy_segments(dst, src) -> None:
+    """dst[i][:] = src[i] for lists of contiguous device tensors (src[i] may be shorter than dst[i]) in ONE launch."""
+    lib = _lib.load()
+    n = len(dst)
+    assert n == len(src)
+    arr = ctypes.c_void_p * n
+    nbytes = []
+    for d, s in zip(dst, src):
+        assert d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous() and d.dtype == s.dtype
+        assert s.numel() <= d.numel()
+        nbytes.append(s.numel() * s.element_size())
+    with on_device(dst[0].device):
+        check(lib.sage_copy_segments(n, arr(*[d.data_ptr() for d in dst]), arr(*[s.data_ptr() for s in src]),
+                                     (ctypes.c_int64 * n)(*nbytes), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+class SageTrainStep:
+    """``step(seeds, y)`` = one optimiser step of `model` on the batch around `seeds`; see the module docstring.
+
+    model      graphpope_amd.sage.SAGE (training mode is set here)
+    opt        graphpope_amd.optim.Adam over model.parameters()
+    feats      float32 [N, C] on the device: features (+) POPE, resident in HBM
+    sampler    graphpope_amd.sampler.NeighborSampler, or None: batches are then loaded with :meth:`load_batch`
+    clip       max gradient norm (Lightning's gradient_clip_val), or None
+    graph      False: the same step, enqueued eagerly every time (A/B and debugging)
+    """
+
+    def __init__(self, model, opt, feats: torch.Tensor, batch_size: int, sizes=(25, 10), sampler=None, clip: float | None = None,
+                 graph: bool = True, seed: int = 0):
+        dev = feats.device
+        self.model, self.opt, self.feats, self.sampler, self.clip = model, opt, feats, sampler, clip
+        self.batch = DeviceBatch(batch_size, sizes if sampler is None else sampler.sizes, dev)
+        self.seeds = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self.y = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self.state = StepState(dev, seed)
+        self.params = [p for p in model.parameters()]
+        self.loss = None
+        self.logits = None
+        self._one = torch.ones((), device=dev)
+        self._graph = None
+        self._use_graph = graph
+        self._lr = None
+        self._calls = 0
+        model.dropout_seed_dev = self.state.dropout_seed
+        opt.use_device_step(self.state.adam_step)
+
+    # ---- the step body: ordinary autograd code, capturable ----
+    def _body(self):
+        if self.sampler is not None:
+            self.sampler.sample_device(self.seeds, seed=0, out=self.batch, seed_dev=self.state.sample_seed)
+        x = IndexedFeatures(self.feats, self.batch.n_id)             # main.py:118-123 without the copy
+        for p in self.params:
+            p.grad = None
+        self.logits = self.model(x, self.batch.adjs)
+        self.loss = cross_entropy(self.logits, self.y)               # main.py:216
+        self.loss.backward(gradient=self._one)
+        if self.clip is not None:
+            torch.nn.utils.clip_grad_norm_(self.params, self.clip)   # main.py:286 gradient_clip_val
+        self.opt.step()
+        self.state.advance()
+
+    def _capture(self):
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._body()
+        self._graph = g
+        self._lr = [grp["lr"] for grp in self.opt.param_groups]
+        for tab in self.opt._tables.values():                        # the captured opt.step() counted a step that did not run
+            tab["step"] -= 1
+            for st in tab["states"]:
+                st["step"] = tab["step"]
+
+    def _run(self):
+        self.model.train(True)
+        if not self._use_graph:
+            self._body()
+            return
+        if self._graph is not None and self._lr != [grp["lr"] for grp in self.opt.param_groups]:
+            self._graph = None                                       # the scheduler changed lr: it is a launch argument
+        if self._graph is None:
+            if self._calls < 2:                                      # first calls eager: lazy initialisations (LDS opt-ins,
+                self._calls += 1                                     # side streams, Adam state) happen outside the capture
+                with torch.autograd.set_multithreading_enabled(False):
+                    self._body()
+                return
+            with torch.autograd.set_multithreading_enabled(False):
+                self._capture()
+        self._graph.replay()
+        # the host-side step counters of the optimiser follow the replays
+        for tab in self.opt._tables.values():
+            tab["step"] += 1
+            for st in tab["states"]:
+                st["step"] = tab["step"]
+
+    def step(self, seeds: torch.Tensor, y: torch.Tensor):
+        """Sample around `seeds` (device int64 [batch_size]) inside the step, labels `y` (device int64 [batch_size])."""
+        assert self.sampler is not None, "no sampler: use load_batch() + run()"
+        copy_segments([self.seeds, self.y], [seeds, y])
+        self._run()
+        return self.loss
+
+    def load_batch(self, pooled: DeviceBatch, y: torch.Tensor) -> None:
+        """A batch of a pre-sampled pool (DeviceBatch.load) into the step's fixed buffers: one launch."""
+        copy_segments(self.batch.segments() + [self.y], pooled.segments() + [y])
+
+    def run(self):
+        """The step on whatever :meth:`load_batch` put into the buffers."""
+        assert self.sampler is None
+        self._run()
+        return self.loss

@@ -111,21 +111,22 @@ def sample_anchor_nodes(data, num_anchor_nodes, sampling_method):
 
 
 def _host_result(data, k):
-    """The tensor the call returns: a NEW contiguous CPU float32 [N, F+K] (utils.py:134), allocated in pinned memory so
-    that the embedding columns arrive by DMA without a staging copy (and mini-batches later leave it the same way)."""
+    """The tensor the call returns: a NEW contiguous CPU float32 [N, F+K] (utils.py:134) in ordinary pageable memory,
+    like the reference's.  (Rounds 1-2 returned a pinned tensor: 34 ms of hipHostMalloc on the one call a process makes,
+    and 270 MB -- 8.6 GB for R-MAT-22 x 512 -- page-locked for as long as the memoised result lives.)"""
     x = data.x.detach()
     n, f = int(x.shape[0]), int(x.shape[1])
-    return torch.empty((n, f + k), dtype=torch.float32, pin_memory=True), x, f
+    return torch.empty((n, f + k), dtype=torch.float32), x, f
 
 
 def _assemble_on_host(out, x, f, emb_dev):
-    """out[:, F:] = emb_dev (one pitched DMA on the current stream) while out[:, :F] = data.x is copied host to host by
-    a few threads: data.x never crosses PCIe (utils.py:129-135 torch.cat((data.x, embedding), 1))."""
-    engine.copy_columns_to_host(emb_dev, out[:, f:])
+    """out[:, F:] = emb_dev (pitched DMA, chunk by chunk, into pages registered for the length of the call) while
+    out[:, :F] = data.x is copied host to host by a few threads: data.x never crosses PCIe (utils.py:129-135
+    torch.cat((data.x, embedding), 1)).  engine.assemble_host_result returns when the tensor is complete."""
+    xc = None
     if f:
         xc = x if (x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1) else x.to(torch.float32).contiguous()
-        engine.host_copy_2d(xc, out[:, :f])                       # runs underneath the GPU work and the DMA
-    torch.cuda.current_stream().synchronize()
+    engine.assemble_host_result(xc, emb_dev.contiguous(), out, f)
     return out
 
 
@@ -147,10 +148,11 @@ def _geodesic_planes(ei, n, anchors, dev):
 
 def _geodesic_embedding_device(edge_index, n, anchors, dev):
     """float32 [N, K] on the device: 1 / (hops + 1) to every anchor (sharded over the ranks of a process group)."""
-    ei = engine.stage_to_device(edge_index.detach(), dev).to(torch.int64)
-    if not os.environ.get("GRAPHPOPE_CACHE_DIR"):
-        return engine.geodesic_features(None, ei, n, anchors, shard=_shard())
-    planes, bits = _geodesic_planes(ei, n, anchors, dev)
+    with engine.staged(edge_index.detach(), dev) as ei_dev:         # 14.4 MB straight from the caller's pages, released on exit
+        ei = ei_dev.to(torch.int64)
+        if not os.environ.get("GRAPHPOPE_CACHE_DIR"):
+            return engine.geodesic_features(None, ei, n, anchors, shard=_shard())
+        planes, bits = _geodesic_planes(ei, n, anchors, dev)
     emb = torch.empty((n, len(anchors)), dtype=torch.float32, device=dev)
     engine.finalize(planes.contiguous(), bits, n, len(anchors), None, 0, emb, 0)
     return emb

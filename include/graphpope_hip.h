@@ -83,6 +83,8 @@ int pope_require_device(int32_t *cu_count_host);
 #define POPE_KNOB_GEMM_TILE         3   /* SAGE GEMM: 0 auto, 1 64x64, 2 64x128, 3 128x256 tiles, 4 / 5 stream-K without loader waves */
 #define POPE_KNOB_COPY_BATCHES      5   /* node2vec embedding: 16-piece batches per wave of the feature-copy kernel beside the tile kernel (default 1) */
 #define POPE_KNOB_LEVEL_BLOCKS       6   /* level kernel: cap on the expand blocks of a launch (0 = one wave per 256-slot chunk, up to 2048 blocks)      */
+#define POPE_KNOB_FAIL_HOST_REGISTER 7  /* host -> host boundary: 1 = every hipHostRegister is refused (tests of the unregistered fallback)            */
+#define POPE_KNOB_SAGE_LANES        8   /* sage_conv_backward: 1 (default) bias gradient and grad_x chain on side streams beside the weight gradients, 0 one stream */
 #define POPE_KNOB_PAIRWISE_KERNEL   4   /* node2vec embedding: 0 auto (anchor-resident persistent kernel for depths <= 128), 1 one tile per block, 2 / 3 persistent kernel with one / two consumer sets */
 int pope_debug_set(int32_t knob, int32_t value);
 
@@ -321,10 +323,42 @@ int pope_host_copy_2d(const void *src_host, int64_t src_pitch_bytes, void *dst_h
 int pope_copy_2d_to_host(const void *src, int64_t src_pitch_bytes, void *dst_host, int64_t dst_pitch_bytes,
                          int64_t row_bytes, int64_t rows, void *stream);
 
+/*
+ * The whole torch.cat((data.x, embedding), 1) of the host -> host call (utils.py:129-135) into an ORDINARY PAGEABLE
+ * result, as the reference returns one: out[:, :x_row_bytes] = x_host rows (host threads, streaming stores) and
+ * out[:, x_row_bytes : x_row_bytes + emb_row_bytes] = emb rows (DEVICE memory, pitched DMA on `stream`, behind whatever
+ * produced emb there).  The result is cut into `chunks` row chunks (<= 0: 8): worker threads fill a chunk's feature
+ * columns (its first touch: MADV_HUGEPAGE is applied first), the calling thread then registers that chunk's pages with
+ * the HIP runtime and enqueues its DMA, so page faults, the host copy and PCIe overlap; every registration is released
+ * and `stream` is synchronised before the call returns.  If a registration is refused the remaining chunks are copied
+ * through the runtime's own staging (slower, same bytes).  x_row_bytes or emb_row_bytes may be 0.
+ */
+int pope_assemble_host_result(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, const void *emb,
+                              int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *out_host, int64_t out_pitch_bytes,
+                              int64_t rows, int32_t threads, int32_t chunks, void *stream);
+
+/*
+ * Caller-owned pageable HOST memory as a DMA endpoint for the length of one call: pope_host_pin registers [host, host +
+ * bytes) with the HIP runtime (POPE_ERR_HIP if refused -- the caller then stages through pinned memory instead),
+ * pope_copy_to_device enqueues one asynchronous host -> device copy on `stream`, pope_host_unpin releases the pages
+ * (after the copy has completed).  Used for edge_index (utils.py:121): 14.4 MB go up straight from the caller's tensor.
+ */
+int pope_host_pin(const void *host, size_t bytes);
+int pope_host_unpin(const void *host);
+int pope_copy_to_device(const void *src_host, void *dst, size_t bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * SAGEConv over a sampled bipartite block (CSR by destination; destinations are the first n_dst sources).
  *   out = lin_l(mean_{j in N(i)} x_src[j]) + lin_r(x_src[i]),  lin_l with bias, lin_r without.
  * ------------------------------------------------------------------------------------------------ */
+/*
+ * Device extents.  A mini-batch sampled on the device (sage_sample_batch_device) has data-dependent sizes; reading them
+ * back costs a host synchronisation per step.  Every SAGE entry point below therefore takes `dims`: NULL (the int64 size
+ * arguments ARE the sizes), or a DEVICE pointer to int32 [4] = {n_dst, n_src, nnz, 0} as the sampler wrote it.  The size
+ * arguments are then CAPACITIES (buffer extents, grid sizing; true value <= capacity) and every kernel reads the true
+ * sizes on the device: nothing is read back, and the same launches can be captured into a HIP graph and replayed on new
+ * batches.  Rows beyond the true extents of an output are left untouched.
+ */
 size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t nnz, int32_t c_in, int32_t c_out);   /* backward */
 size_t sage_conv_forward_scratch_bytes(int64_t n_dst, int32_t c_in, int32_t c_out);                         /* forward  */
 
@@ -338,7 +372,8 @@ size_t sage_conv_forward_scratch_bytes(int64_t n_dst, int32_t c_in, int32_t c_ou
  */
 int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
                       const float *x_src, int32_t c_in, const float *w_l, const float *b_l, const float *w_r,
-                      int32_t c_out, float *agg, float *out, void *scratch, size_t scratch_bytes, void *stream);
+                      int32_t c_out, float *agg, float *out, void *scratch, size_t scratch_bytes, const int32_t *dims,
+                      void *stream);
 
 /* The aggregation half on its own: agg[i, :] = mean_{p in row i} x_src[col[p], :] (zero for empty rows).  Asynchronous. */
 int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
@@ -358,11 +393,11 @@ int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_src, i
 int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
                               int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l, const float *b_l,
                               const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out, void *scratch,
-                              size_t scratch_bytes, void *stream);
+                              size_t scratch_bytes, const int32_t *dims, void *stream);
 int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
                        const float *x_src, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
                        int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l,
-                       float *grad_w_r, void *scratch, size_t scratch_bytes, void *stream);
+                       float *grad_w_r, void *scratch, size_t scratch_bytes, const int32_t *dims, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fan-out neighbour sampling on the device (one hop of PyG NeighborSampler / torch_sparse.sample_adj, main.py:100-116).
@@ -397,6 +432,18 @@ int sage_sample_batch(const int32_t *rowptr, const int32_t *col, int64_t N, cons
                       int32_t *const *out_col, int64_t *const *out_n_id, int64_t *nnz_host, int64_t *n_src_host, void *scratch,
                       size_t scratch_bytes, void *stream);
 
+/*
+ * sage_sample_batch WITHOUT any host synchronisation (the device-extent form): every hop runs over its capacity and reads
+ * the true target count of the hop before it on the device.  dims (out, device): int32 [n_hops][4], dims[h] =
+ * {n_dst, n_src, nnz, 0} of hop h -- what the SAGE entry points take as `dims`; out_rowptr[h] rows past n_dst are empty,
+ * out_col[h] / out_n_id[h] entries past nnz / n_src are unspecified.  seed_dev (device uint64, or NULL) is ADDED to `seed`
+ * on the device: a captured launch follows that word (sage_advance_counters).  Buffers and scratch as sage_sample_batch.
+ */
+int sage_sample_batch_device(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *seeds, int64_t n_seeds,
+                             const int32_t *fanouts_host, int32_t n_hops, uint64_t seed, const uint64_t *seed_dev,
+                             int32_t *const *out_rowptr, int32_t *const *out_col, int64_t *const *out_n_id, int32_t *dims,
+                             void *scratch, size_t scratch_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Hidden-layer epilogue: BatchNorm1d + ReLU + dropout as one op  (main.py:207-209)
  *
@@ -409,17 +456,19 @@ int sage_sample_batch(const int32_t *rowptr, const int32_t *col, int64_t N, cons
  *                  function of (seed, element index), recomputed in backward: no mask tensor.
  *   training == 0: running statistics, no dropout.
  * save_mean / save_rstd (out) feed the backward call.  grad_gamma / grad_beta may be NULL.  Asynchronous.
+ * rows_dev (device int32, or NULL): the true row count, M then being the capacity ("Device extents" above).
+ * seed_dev (device uint64, or NULL): added to `seed` on the device (a replayed HIP graph draws a new mask per replay).
  * scratch: sage_bn_scratch_bytes(C) bytes.
  * ------------------------------------------------------------------------------------------------ */
 size_t sage_bn_scratch_bytes(int32_t C);
 int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C, const float *gamma, const float *beta,
                                  float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps, int32_t training,
                                  float p, uint64_t seed, float *y, float *save_mean, float *save_rstd, void *scratch,
-                                 size_t scratch_bytes, void *stream);
+                                 size_t scratch_bytes, const int32_t *rows_dev, const uint64_t *seed_dev, void *stream);
 int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,
                                   const float *beta, const float *save_mean, const float *save_rstd, int32_t training,
                                   float p, uint64_t seed, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
-                                  size_t scratch_bytes, void *stream);
+                                  size_t scratch_bytes, const int32_t *rows_dev, const uint64_t *seed_dev, void *stream);
 
 /*
  * One Adam step over every parameter tensor in a single launch  (main.py:244: torch.optim.Adam(self.parameters(), lr)).
@@ -427,10 +476,20 @@ int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M
  * Update rule of torch.optim.Adam (amsgrad off): decoupled nothing, weight_decay added to the gradient, bias
  * corrections from `step` (1-based, the step being taken).  Hyper-parameters are doubles: 1 - beta, lr / (1 - beta1^t)
  * and sqrt(1 - beta2^t) are formed in double and rounded to float once, as torch does.  Asynchronous.
+ * step_dev (device int64, or NULL): the step count read on the device instead of `step` (replayed HIP graphs).
  */
 int sage_adam_step(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                    float *const *exp_avg_sq, const int64_t *numel, double lr, double beta1, double beta2, double eps,
-                   double weight_decay, int64_t step, void *stream);
+                   double weight_decay, int64_t step, const int64_t *step_dev, void *stream);
+
+/*
+ * Plumbing of a training step replayed as a HIP graph (main.py:213-222 training_step + Lightning's backward / optimizer
+ * step, with no host in the loop).  sage_advance_counters: counters[i] += increments_host[i] for i < n <= 8, one launch
+ * (the dropout / sampling seeds and Adam's step count live in device words).  sage_copy_segments: n device-to-device
+ * copies in ONE launch (a batch of a pre-sampled pool into the step's fixed buffers); dst / src / bytes are HOST arrays.
+ */
+int sage_advance_counters(int64_t *counters, const int64_t *increments_host, int32_t n, void *stream);
+int sage_copy_segments(int32_t n, void *const *dst, const void *const *src, const int64_t *bytes, void *stream);
 
 /*
  * Cross-entropy with integer labels, mean over the rows whose label is not ignore_index  (main.py:216, 224, 233:

@@ -62,13 +62,17 @@ def test_argument_validation_needs_no_gpu():
     assert b"pope_csr_build" in lib.pope_last_error()
     assert lib.pope_geodesic_finalize(null, 0, 10, 4, null, 0, null, 4, 0, null) == _lib.ERR_INVALID
     assert lib.pope_pairwise_minmax(null, 10, 4, null, 2, 7, null, 2, 0, null, 0, null) == _lib.ERR_INVALID
-    assert lib.sage_conv_forward(null, null, 5, 9, 0, null, 4, null, null, null, 4, null, null, null, 0, null) == _lib.ERR_INVALID
+    assert lib.sage_conv_forward(null, null, 5, 9, 0, null, 4, null, null, null, 4, null, null, null, 0, null, null) == _lib.ERR_INVALID
     assert lib.pope_geodesic_run_workspace_bytes(10, 10, 0, 8) == 0 and lib.pope_geodesic_run_workspace_bytes(89250, 899756, 256, 8) > 0
-    assert lib.sage_bn_relu_dropout_forward(null, 8, 4, null, null, null, null, null, 0.1, 1e-5, 1, 0.5, 0, null, null, null, null, 0, null) == _lib.ERR_INVALID
-    assert lib.sage_bn_relu_dropout_backward(null, null, 8, 4, null, null, null, null, 1, 0.5, 0, null, null, null, null, 0, null) == _lib.ERR_INVALID
-    assert lib.sage_adam_step(2, null, null, null, null, null, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, null) == _lib.ERR_INVALID
-    assert lib.sage_adam_step(0, null, null, null, null, null, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, null) == _lib.ERR_INVALID      # step is 1-based
+    assert lib.sage_bn_relu_dropout_forward(null, 8, 4, null, null, null, null, null, 0.1, 1e-5, 1, 0.5, 0, null, null, null, null, 0, null, null, null) == _lib.ERR_INVALID
+    assert lib.sage_bn_relu_dropout_backward(null, null, 8, 4, null, null, null, null, 1, 0.5, 0, null, null, null, null, 0, null, null, null) == _lib.ERR_INVALID
+    assert lib.sage_adam_step(2, null, null, null, null, null, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, null, null) == _lib.ERR_INVALID
+    assert lib.sage_adam_step(0, null, null, null, null, null, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, null, null) == _lib.ERR_INVALID      # step is 1-based
     assert lib.pope_geodesic_column_stats(null, 3, 10, 4, null, null, null, 0, null) == _lib.ERR_INVALID
+    assert lib.sage_sample_batch_device(null, null, 10, null, 4, null, 2, 0, null, null, null, null, null, null, 0, null) == _lib.ERR_INVALID
+    assert lib.sage_advance_counters(null, null, 3, null) == _lib.ERR_INVALID and lib.sage_copy_segments(2, null, null, null, null) == _lib.ERR_INVALID
+    assert lib.pope_assemble_host_result(null, 0, 0, null, 0, 0, null, 0, 4, 1, 0, null) == _lib.ERR_INVALID
+    assert lib.pope_host_pin(null, 0) == _lib.ERR_INVALID
     assert lib.sage_bn_scratch_bytes(256) > 0 and lib.pope_column_stats_scratch_bytes(256) > 0
     import pytest
     with pytest.raises(_lib.PopeError, match="null pointer"):

@@ -440,3 +440,46 @@ def test_general_csr_build_is_deterministic(dev):
     s1 = NeighborSampler(a.rowptr, a.col, n, (5, 3)).sample(seeds, seed=9)
     s2 = NeighborSampler(b.rowptr, b.col, n, (5, 3)).sample(seeds, seed=9)
     assert torch.equal(s1[0], s2[0]) and all(torch.equal(x.col, y.col) for x, y in zip(s1[1], s2[1]))
+
+
+@pytest.mark.parametrize("refuse", [0, 1], ids=["registered", "registration_refused"])
+def test_host_to_host_call_returns_a_pageable_tensor_and_survives_a_refused_registration(refuse, dev, oracle):
+    """utils.py:129-147 from CPU tensors to a CPU tensor, at a size that takes the chunked path (38 MB result, 8 chunks):
+    ordinary pageable memory like the reference's torch.cat, bit-exact, also when the runtime refuses to register the
+    caller's pages (POPE_KNOB_FAIL_HOST_REGISTER: edge_index then goes through pinned staging, the embedding columns
+    through the runtime's own staging)."""
+    from graphpope_amd import _lib, synth, utils as gp
+    lib = _lib.load()
+    ei, n = synth.rmat(15, edge_factor=8, seed=5)
+    f, k = 101, 192                                           # odd F: rows of 1172 bytes, chunks end inside pages
+    x = torch.rand(n, f, generator=torch.Generator().manual_seed(3))
+
+    class Data:
+        pass
+    d = Data()
+    d.x, d.edge_index, d.num_nodes = x, torch.as_tensor(ei), n
+    lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, refuse)
+    try:
+        gp.clear_cache()
+        np.random.seed(7)
+        out = gp.Graphpope(d, "flickr", "geodesic", "stochastic", k, None, 2)
+    finally:
+        lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, 0)
+        gp.clear_cache()
+    assert out.device.type == "cpu" and out.is_contiguous() and not out.is_pinned()
+    want = oracle.geodesic_features(x.numpy(), ei, n, d.anchor_nodes)
+    assert np.array_equal(out.numpy().view(np.uint32), want.view(np.uint32))
+    assert not d.edge_index.is_pinned()                       # the caller's tensor is released again
+
+
+def test_host_result_assembly_shapes(dev):
+    """pope_assemble_host_result on its own: no feature columns, one chunk, more chunks than rows, a strided x."""
+    from graphpope_amd import engine
+    g = torch.Generator().manual_seed(0)
+    for n, f, k, chunks in ((5, 3, 4, 8), (40000, 0, 64, 8), (70001, 40, 36, 3), (3000, 700, 8, 0)):
+        emb = torch.rand(n, k, generator=g).to(dev)
+        xw = torch.rand(n, f + 5, generator=g)
+        x = xw[:, :f]                                         # row pitch larger than the row
+        out = torch.full((n, f + k), -1.0)
+        engine.assemble_host_result(x if f else None, emb, out, f, threads=4, chunks=chunks)
+        assert torch.equal(out[:, :f], x) and torch.equal(out[:, f:], emb.cpu())

@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -181,7 +182,19 @@ extern "C" int pope_copy_to_device(const void *src_host, void *dst, size_t bytes
 // ------------------------------------------------------------------------------------------------
 // out[:, :F] = x (host cores) and out[:, F:] = emb (DMA), into a pageable result, chunk by chunk
 // ------------------------------------------------------------------------------------------------
+// Phase times of the last pope_assemble_host_result call of the process, in ms (diagnostic: tools/boundary_breakdown.py):
+// 0 madvise, 1 waiting for the chunks' host copies, 2 hipHostRegister, 3 enqueueing DMAs, 4 joining the workers,
+// 5 waiting for the stream, 6 hipHostUnregister, 7 total.
+static double g_assemble_trace[8];
+extern "C" void pope_debug_boundary_trace(double *host8) {
+    for (int i = 0; i < 8; ++i) host8[i] = g_assemble_trace[i];
+}
+
 namespace {
+
+inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 struct Assembly {
     const char *x = nullptr;
@@ -211,10 +224,12 @@ struct Assembly {
                     for (int64_t r = r0; r < r1; ++r) copy_segment(x + (size_t)r * x_pitch, out + (size_t)r * out_pitch, x_row);
                     _mm_sfence();
                 } else {
-                    // no feature columns: touch the pages so that registering them does not fault them in one by one
+                    // no feature columns: touch the pages so that registering them does not fault them in one by one.  An
+                    // atomic OR with 0: a page at a chunk boundary may already be receiving the previous region's DMA (whole
+                    // rows inside a region travel with it), and a locked read-modify-write cannot lose those bytes.
                     const size_t page = 4096;
                     char *b = out + (size_t)r0 * out_pitch, *e = out + (size_t)r1 * out_pitch;
-                    for (char *p = b; p < e; p += page) *reinterpret_cast<volatile char *>(p) = 0;
+                    for (char *p = b; p < e; p += page) (void)__atomic_fetch_or(p, 0, __ATOMIC_RELAXED);
                 }
             }
             done[(size_t)c].fetch_add(1, std::memory_order_release);
@@ -235,6 +250,8 @@ extern "C" int pope_assemble_host_result(const void *x_host, int64_t x_pitch_byt
         return POPE_ERR_INVALID;
     }
     if (rows == 0) return POPE_OK;
+    double tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double t_begin = now_ms();
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
     char *out = static_cast<char *>(out_host);
     const size_t total = (size_t)rows * (size_t)out_pitch_bytes;
@@ -244,6 +261,7 @@ extern "C" int pope_assemble_host_result(const void *x_host, int64_t x_pitch_byt
         const uintptr_t lo = (b + huge - 1) & ~(huge - 1), hi = (b + total) & ~(huge - 1);
         if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
     }
+    tr[0] = now_ms() - t_begin;
     int t = clamp_threads(threads);
     int nch = chunks > 0 ? chunks : 8;
     if (total < ((size_t)8 << 20)) nch = 1;
@@ -262,46 +280,90 @@ extern "C" int pope_assemble_host_result(const void *x_host, int64_t x_pitch_byt
 
     int rc = POPE_OK;
     std::vector<std::pair<void *, size_t>> pinned;
-    uintptr_t reg_hi = 0;
-    bool registering = emb_row_bytes > 0 && !pope::g_fail_host_register;
-    for (int c = 0; c < nch; ++c) {
-        while (a.done[(size_t)c].load(std::memory_order_acquire) < a.slices) std::this_thread::yield();
-        if (emb_row_bytes == 0) continue;
-        const int64_t r0 = a.chunk_lo[(size_t)c], r1 = a.chunk_lo[(size_t)c + 1];
-        if (r1 <= r0) continue;
-        if (registering) {
-            // pages [lo, hi): from where the previous chunk's registration ended to the end of this chunk's last row, so
-            // that no page is registered twice and every page a chunk's DMA writes is registered before it starts (the
-            // boundary page was touched by the chunk that owns its first bytes)
-            uintptr_t lo = reinterpret_cast<uintptr_t>(out + (size_t)r0 * a.out_pitch) & ~(uintptr_t)(page - 1);
-            if (lo < reg_hi) lo = reg_hi;
-            uintptr_t hi = (reinterpret_cast<uintptr_t>(out + (size_t)r1 * a.out_pitch) + page - 1) & ~(uintptr_t)(page - 1);
-            if (hi > lo) {
-                const hipError_t e = hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterDefault);
-                if (e == hipSuccess) {
-                    pinned.emplace_back(reinterpret_cast<void *>(lo), hi - lo);
-                    reg_hi = hi;
-                } else {
-                    (void)hipGetLastError();          // the runtime copies through its own staging buffers instead: slower, same bytes
-                    registering = false;
-                }
-            }
-        }
-        const hipError_t e = hipMemcpy2DAsync(out + (size_t)r0 * a.out_pitch + (size_t)x_row_bytes, a.out_pitch,
-                                              static_cast<const char *>(emb) + (size_t)r0 * (size_t)emb_pitch_bytes, (size_t)emb_pitch_bytes,
-                                              (size_t)emb_row_bytes, (size_t)(r1 - r0), hipMemcpyDeviceToHost, stream);
+    const uintptr_t base = reinterpret_cast<uintptr_t>(out), pmask = (uintptr_t)(page - 1);
+    const size_t xb = (size_t)x_row_bytes, eb = (size_t)emb_row_bytes, pitch = a.out_pitch, epitch = (size_t)emb_pitch_bytes;
+    const char *embp = static_cast<const char *>(emb);
+    auto S = [&](int64_t r) { return base + (uintptr_t)r * pitch + xb; };          // where row r's embedding columns start ...
+    auto T = [&](int64_t r) { return S(r) + eb; };                                  // ... and end
+    auto copy1d = [&](uintptr_t lo, uintptr_t hi, int64_t r) {                      // bytes [lo, hi) of row r's embedding columns
+        if (hi <= lo || rc != POPE_OK) return;
+        const hipError_t e = hipMemcpyAsync(reinterpret_cast<void *>(lo), embp + (size_t)r * epitch + (lo - S(r)), hi - lo, hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) {
-            pope::set_error("hipMemcpy2DAsync(D2H, chunk %d) failed: %s", c, hipGetErrorString(e));
+            pope::set_error("hipMemcpyAsync(D2H, row %lld) failed: %s", (long long)r, hipGetErrorString(e));
             rc = POPE_ERR_HIP;
-            break;
         }
+    };
+    auto copy2d = [&](int64_t r0, int64_t r1) {                                     // whole rows [r0, r1)
+        if (r1 <= r0 || rc != POPE_OK) return;
+        const hipError_t e = hipMemcpy2DAsync(reinterpret_cast<void *>(S(r0)), pitch, embp + (size_t)r0 * epitch, epitch, eb, (size_t)(r1 - r0),
+                                              hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) {
+            pope::set_error("hipMemcpy2DAsync(D2H, rows %lld..%lld) failed: %s", (long long)r0, (long long)r1, hipGetErrorString(e));
+            rc = POPE_ERR_HIP;
+        }
+    };
+    // Registered regions are page-aligned byte ranges [lo, hi) that follow one another; a DMA must stay inside ONE of them
+    // (the runtime rejects a destination that spans two registrations).  Region c ends behind chunk c's last row; whole rows
+    // inside it go as one pitched copy, and the one row whose embedding columns cross into the next region (row pitches
+    // are not multiples of the page size) is sent as two plain copies once both regions exist.
+    uintptr_t reg_hi = 0;
+    int64_t next_row = 0;                          // rows below have been enqueued
+    bool registering = eb > 0 && !pope::g_fail_host_register;
+    for (int c = 0; c < nch && rc == POPE_OK; ++c) {
+        double t0 = now_ms();
+        while (a.done[(size_t)c].load(std::memory_order_acquire) < a.slices) std::this_thread::yield();
+        tr[1] += now_ms() - t0;
+        if (eb == 0 || !registering) continue;
+        const int64_t r1 = a.chunk_lo[(size_t)c + 1];
+        const uintptr_t lo = c == 0 ? (base & ~pmask) : reg_hi;
+        const uintptr_t hi = c + 1 == nch ? ((base + total + pmask) & ~pmask) : ((base + (uintptr_t)r1 * pitch + pmask) & ~pmask);
+        if (hi <= lo) continue;
+        t0 = now_ms();
+        const hipError_t e = hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterDefault);
+        tr[2] += now_ms() - t0;
+        if (e != hipSuccess) {
+            (void)hipGetLastError();               // the rest goes through the runtime's own staging buffers: slower, same bytes
+            registering = false;
+            continue;
+        }
+        pinned.emplace_back(reinterpret_cast<void *>(lo), hi - lo);
+        reg_hi = hi;
+        t0 = now_ms();
+        if (next_row < rows && S(next_row) < lo) {                                  // the row that crosses from the previous region
+            copy1d(S(next_row), lo, next_row);
+            copy1d(lo, T(next_row), next_row);
+            ++next_row;
+        }
+        int64_t last = hi >= base + xb + eb ? (int64_t)((hi - base - xb - eb) / pitch) : -1;      // last row that ends inside the region
+        if (last >= rows) last = rows - 1;
+        if (last >= next_row) {
+            copy2d(next_row, last + 1);
+            next_row = last + 1;
+        }
+        tr[3] += now_ms() - t0;
     }
+    if (eb > 0 && next_row < rows && rc == POPE_OK) {                               // registration refused (or switched off)
+        if (reg_hi && S(next_row) < reg_hi) {
+            copy1d(S(next_row), reg_hi, next_row);
+            copy1d(reg_hi, T(next_row), next_row);
+            ++next_row;
+        }
+        copy2d(next_row, rows);
+    }
+    double t0 = now_ms();
     for (auto &th : pool) th.join();
+    tr[4] = now_ms() - t0;
+    t0 = now_ms();
     const hipError_t es = hipStreamSynchronize(stream);
+    tr[5] = now_ms() - t0;
     if (es != hipSuccess && rc == POPE_OK) {
         pope::set_error("hipStreamSynchronize failed: %s", hipGetErrorString(es));
         rc = POPE_ERR_HIP;
     }
+    t0 = now_ms();
     for (auto &p : pinned) (void)hipHostUnregister(p.first);
+    tr[6] = now_ms() - t0;
+    tr[7] = now_ms() - t_begin;
+    for (int i = 0; i < 8; ++i) g_assemble_trace[i] = tr[i];
     return rc;
 }

@@ -566,11 +566,13 @@ extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *c
     return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream, Twin{Operand{nullptr, 0, 0}, nullptr, 0}, dyn);
 }
 
-namespace pope { int g_sage_lanes = 1; }     // pope_debug_set(POPE_KNOB_SAGE_LANES): 0 = every launch of the backward pass on the caller's stream
+namespace pope { int g_sage_lanes = 0; }     // pope_debug_set(POPE_KNOB_SAGE_LANES): 1 = bias gradient and grad_x chain on side streams (measured: slower)
 
-// The three results of the backward pass only share grad_out: the weight gradients (the big GEMM) stay on the caller's
-// stream, the bias gradient (two short launches) and the grad_x chain (zero the scatter-only rows, grad_out * [W_r | W_l],
-// scatter) run beside them on side streams, forked and joined inside the call.
+// The three results of the backward pass only share grad_out.  POPE_KNOB_SAGE_LANES = 1 runs the bias gradient (two short
+// launches) and the grad_x chain (zero the scatter-only rows, grad_out * [W_r | W_l], scatter) on side streams beside the
+// weight gradients, forked and joined inside the call.  Measured on the Flickr-shaped step (tools/sage_step_ab.py): 0.449 ms
+// against 0.378 ms on one stream -- the persistent stream-K kernel deals its units out statically, so CUs that start late
+// because a side kernel sits on them delay the whole launch, and every fork / join is two cross-stream dependencies.  Off.
 extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
                                   const float *x_src, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
                                   int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l,

@@ -60,6 +60,15 @@ __device__ __forceinline__ int true_count(const int *t_dev, int cap) {
     return v < cap ? v : cap;
 }
 
+// map[:] = 0x7F7F7F7F (larger than any position key).  A kernel, not hipMemsetAsync: the call is captured into HIP graphs
+// (graphpope_amd/train.py), and a memset node is one more thing whose replay semantics would have to be trusted.
+__global__ __launch_bounds__(256) void k_sample_clear(int *__restrict__ map, int N) {
+    const int n4 = N >> 2;
+    const int4 v = make_int4(0x7F7F7F7F, 0x7F7F7F7F, 0x7F7F7F7F, 0x7F7F7F7F);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) reinterpret_cast<int4 *>(map)[i] = v;
+    if (blockIdx.x == 0 && (int)threadIdx.x < (N & 3)) map[(n4 << 2) + threadIdx.x] = 0x7F7F7F7F;
+}
+
 __global__ __launch_bounds__(256) void k_sample_count(const int *__restrict__ rowptr, const long long *__restrict__ targets,
                                                       int T_cap, int fanout, int *__restrict__ cnt, int *__restrict__ map,
                                                       long long *__restrict__ out_n_id, const int *__restrict__ t_dev,
@@ -234,7 +243,7 @@ static int enqueue_hop(const int32_t *rowptr, const int32_t *col, int64_t N, con
     size_t sb = L.total - L.scan;
     const int T = (int)n_targets;
 
-    POPE_HIP(hipMemsetAsync(map, 0x7F, (size_t)N * 4, stream));                       // 0x7F7F7F7F: larger than any key
+    hipLaunchKernelGGL(k_sample_clear, dim3(capped_grid((size_t)N / 4 + 1, 256)), dim3(256), 0, stream, map, (int)N);
     hipLaunchKernelGGL(k_sample_count, dim3((T + 256) / 256), dim3(256), 0, stream, rowptr, (const long long *)targets, T, fanout, cnt,
                        map, (long long *)out_n_id, t_dev, dims);
     POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, cnt, out_rowptr, 0, (size_t)T + 1, rocprim::plus<int>(), stream));

@@ -86,6 +86,7 @@ class SageTrainStep:
         self.loss = None
         self.logits = None
         self._one = torch.ones((), device=dev)
+        self._side = torch.cuda.Stream(device=dev)                   # warm-up calls and the capture run here
         self._graph = None
         self._use_graph = graph
         self._lr = None
@@ -100,18 +101,23 @@ class SageTrainStep:
         x = IndexedFeatures(self.feats, self.batch.n_id)             # main.py:118-123 without the copy
         for p in self.params:
             p.grad = None
-        self.logits = self.model(x, self.batch.adjs)
-        self.loss = cross_entropy(self.logits, self.y)               # main.py:216
-        self.loss.backward(gradient=self._one)
+        logits = self.model(x, self.batch.adjs)
+        loss = cross_entropy(logits, self.y)                         # main.py:216
+        loss.backward(gradient=self._one)
+        # detached views of the results: nothing outside this call keeps the autograd graph (and its AccumulateGrad nodes,
+        # which remember the stream they were created on) alive into the next call or into the capture
+        self.logits, self.loss = logits.detach(), loss.detach()
+        del logits, loss
         if self.clip is not None:
             torch.nn.utils.clip_grad_norm_(self.params, self.clip)   # main.py:286 gradient_clip_val
         self.opt.step()
         self.state.advance()
 
     def _capture(self):
+        self.loss = self.logits = None
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=self._side):
             self._body()
         self._graph = g
         self._lr = [grp["lr"] for grp in self.opt.param_groups]
@@ -129,9 +135,12 @@ class SageTrainStep:
             self._graph = None                                       # the scheduler changed lr: it is a launch argument
         if self._graph is None:
             if self._calls < 2:                                      # first calls eager: lazy initialisations (LDS opt-ins,
-                self._calls += 1                                     # side streams, Adam state) happen outside the capture
-                with torch.autograd.set_multithreading_enabled(False):
+                self._calls += 1                                     # side streams, Adam state) happen outside the capture --
+                cur = torch.cuda.current_stream()                    # on the stream the capture will use, as torch asks
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side), torch.autograd.set_multithreading_enabled(False):
                     self._body()
+                cur.wait_stream(self._side)
                 return
             with torch.autograd.set_multithreading_enabled(False):
                 self._capture()

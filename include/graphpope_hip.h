@@ -84,7 +84,7 @@ int pope_require_device(int32_t *cu_count_host);
 #define POPE_KNOB_COPY_BATCHES      5   /* node2vec embedding: 16-piece batches per wave of the feature-copy kernel beside the tile kernel (default 1) */
 #define POPE_KNOB_LEVEL_BLOCKS       6   /* level kernel: cap on the expand blocks of a launch (0 = one wave per 256-slot chunk, up to 2048 blocks)      */
 #define POPE_KNOB_FAIL_HOST_REGISTER 7  /* host -> host boundary: 1 = every hipHostRegister is refused (tests of the unregistered fallback)            */
-#define POPE_KNOB_SAGE_LANES        8   /* sage_conv_backward: 1 (default) bias gradient and grad_x chain on side streams beside the weight gradients, 0 one stream */
+#define POPE_KNOB_SAGE_LANES        8   /* sage_conv_backward: 0 (default) one stream; 1 bias gradient and grad_x chain on side streams beside the weight gradients (measured slower) */
 #define POPE_KNOB_PAIRWISE_KERNEL   4   /* node2vec embedding: 0 auto (anchor-resident persistent kernel for depths <= 128), 1 one tile per block, 2 / 3 persistent kernel with one / two consumer sets */
 int pope_debug_set(int32_t knob, int32_t value);
 

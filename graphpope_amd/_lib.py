@@ -26,6 +26,9 @@ SIGNATURES = {
     "pope_copy_2d_to_host": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "pope_assemble_host_result": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32,
                                           c_int32, c_void_p]),
+    "pope_assemble_begin": (c_void_p, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32]),
+    "pope_assemble_finish": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "pope_assemble_abort": (None, [c_void_p]),
     "pope_host_pin": (c_int, [c_void_p, c_size_t]),
     "pope_host_unpin": (c_int, [c_void_p]),
     "pope_copy_to_device": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

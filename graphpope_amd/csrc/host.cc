@@ -239,20 +239,29 @@ struct Assembly {
 
 }  // namespace
 
-extern "C" int pope_assemble_host_result(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, const void *emb,
-                                         int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *out_host, int64_t out_pitch_bytes,
-                                         int64_t rows, int32_t threads, int32_t chunks, void *stream_) {
+namespace {
+
+struct HostAssembly {
+    Assembly a;
+    std::vector<std::thread> pool;
+    size_t total = 0;
+    double t_begin = 0, t_madvise = 0;
+    explicit HostAssembly(int nch) : a(nch) {}
+};
+
+}  // namespace
+
+// The work that does not need the embedding -- page faults and the feature copy -- starts here, on `threads` host threads,
+// and runs underneath whatever the caller does next (upload edge_index, enqueue and wait for the GPU).
+extern "C" void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, void *out_host,
+                                     int64_t out_pitch_bytes, int64_t rows, int32_t threads, int32_t chunks) {
     pope::clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!out_host || rows < 0 || x_row_bytes < 0 || emb_row_bytes < 0 || (x_row_bytes > 0 && (!x_host || x_pitch_bytes < x_row_bytes)) ||
-        (emb_row_bytes > 0 && (!emb || emb_pitch_bytes < emb_row_bytes)) || out_pitch_bytes < x_row_bytes + emb_row_bytes) {
-        pope::set_error("pope_assemble_host_result: null pointer or bad size");
-        return POPE_ERR_INVALID;
+    if (!out_host || rows <= 0 || x_row_bytes < 0 || (x_row_bytes > 0 && (!x_host || x_pitch_bytes < x_row_bytes)) || out_pitch_bytes < x_row_bytes ||
+        out_pitch_bytes <= 0) {
+        pope::set_error("pope_assemble_begin: null pointer or bad size");
+        return nullptr;
     }
-    if (rows == 0) return POPE_OK;
-    double tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const double t_begin = now_ms();
-    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
     char *out = static_cast<char *>(out_host);
     const size_t total = (size_t)rows * (size_t)out_pitch_bytes;
     // 2 MB faults instead of 4 KB ones where the kernel allows it (THP "madvise" or "always"); a refusal changes nothing
@@ -261,12 +270,15 @@ extern "C" int pope_assemble_host_result(const void *x_host, int64_t x_pitch_byt
         const uintptr_t lo = (b + huge - 1) & ~(huge - 1), hi = (b + total) & ~(huge - 1);
         if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
     }
-    tr[0] = now_ms() - t_begin;
     int t = clamp_threads(threads);
     int nch = chunks > 0 ? chunks : 8;
     if (total < ((size_t)8 << 20)) nch = 1;
     if ((int64_t)nch > rows) nch = (int)rows;
-    Assembly a(nch);
+    HostAssembly *h = new HostAssembly(nch);
+    h->total = total;
+    h->t_begin = t_begin;
+    h->t_madvise = now_ms() - t_begin;
+    Assembly &a = h->a;
     a.x = static_cast<const char *>(x_host); a.x_pitch = (size_t)x_pitch_bytes; a.x_row = (size_t)x_row_bytes;
     a.out = out; a.out_pitch = (size_t)out_pitch_bytes; a.rows = rows; a.chunks = nch;
     a.slices = t;
@@ -274,10 +286,41 @@ extern "C" int pope_assemble_host_result(const void *x_host, int64_t x_pitch_byt
     // the first chunk is small so that the first DMA starts early; the rest are equal
     for (int c = 0; c <= nch; ++c) a.chunk_lo[(size_t)c] = rows * c / nch;
     if (nch >= 4) a.chunk_lo[1] = rows / (2 * nch);
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)t);
-    for (int i = 0; i < t; ++i) pool.emplace_back([&a] { a.work(); });
+    h->pool.reserve((size_t)t);
+    for (int i = 0; i < t; ++i) h->pool.emplace_back([h] { h->a.work(); });
+    return h;
+}
 
+// Give up an assembly that will not be finished (an error between begin and finish): waits for the host threads.
+extern "C" void pope_assemble_abort(void *handle) {
+    HostAssembly *h = static_cast<HostAssembly *>(handle);
+    if (!h) return;
+    for (auto &th : h->pool) th.join();
+    delete h;
+}
+
+extern "C" int pope_assemble_finish(void *handle, const void *emb, int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *stream_) {
+    pope::clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    HostAssembly *h = static_cast<HostAssembly *>(handle);
+    if (!h) {
+        pope::set_error("pope_assemble_finish: null handle");
+        return POPE_ERR_INVALID;
+    }
+    Assembly &a = h->a;
+    std::vector<std::thread> &pool = h->pool;
+    if (emb_row_bytes < 0 || (emb_row_bytes > 0 && (!emb || emb_pitch_bytes < emb_row_bytes)) || a.out_pitch < a.x_row + (size_t)emb_row_bytes) {
+        pope_assemble_abort(h);
+        pope::set_error("pope_assemble_finish: null pointer or bad size");
+        return POPE_ERR_INVALID;
+    }
+    double tr[8] = {h->t_madvise, 0, 0, 0, 0, 0, 0, 0};
+    const double t_begin = h->t_begin;
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    char *out = a.out;
+    const size_t total = h->total;
+    const int64_t rows = a.rows, x_row_bytes = (int64_t)a.x_row;
+    const int nch = a.chunks;
     int rc = POPE_OK;
     std::vector<std::pair<void *, size_t>> pinned;
     const uintptr_t base = reinterpret_cast<uintptr_t>(out), pmask = (uintptr_t)(page - 1);
@@ -365,5 +408,21 @@ extern "C" int pope_assemble_host_result(const void *x_host, int64_t x_pitch_byt
     tr[6] = now_ms() - t0;
     tr[7] = now_ms() - t_begin;
     for (int i = 0; i < 8; ++i) g_assemble_trace[i] = tr[i];
+    delete h;
     return rc;
+}
+
+extern "C" int pope_assemble_host_result(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, const void *emb,
+                                         int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *out_host, int64_t out_pitch_bytes,
+                                         int64_t rows, int32_t threads, int32_t chunks, void *stream_) {
+    pope::clear_error();
+    if (!out_host || rows < 0 || x_row_bytes < 0 || emb_row_bytes < 0 || (x_row_bytes > 0 && (!x_host || x_pitch_bytes < x_row_bytes)) ||
+        (emb_row_bytes > 0 && (!emb || emb_pitch_bytes < emb_row_bytes)) || out_pitch_bytes < x_row_bytes + emb_row_bytes) {
+        pope::set_error("pope_assemble_host_result: null pointer or bad size");
+        return POPE_ERR_INVALID;
+    }
+    if (rows == 0) return POPE_OK;
+    void *h = pope_assemble_begin(x_host, x_pitch_bytes, x_row_bytes, out_host, out_pitch_bytes, rows, threads, chunks);
+    if (!h) return POPE_ERR_INVALID;
+    return pope_assemble_finish(h, emb, emb_pitch_bytes, emb_row_bytes, stream_);
 }

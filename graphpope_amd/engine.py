@@ -132,6 +132,44 @@ class staged:
         return False
 
 
+class HostAssembly:
+    """``out[:, :f] = x`` (HOST, threads) started NOW, ``out[:, f:] = emb`` (DEVICE [N, K], DMA on the current stream) at
+    :meth:`finish`, for a pageable HOST result `out` [N, f + K] (pope_assemble_begin / _finish): the page faults and the
+    feature copy run underneath whatever happens between the two calls -- the upload of edge_index and the GPU work.
+    Use as a context manager: an exception in between aborts the assembly (waits for the host threads)."""
+
+    def __init__(self, x: torch.Tensor | None, out: torch.Tensor, f: int, threads: int = 0, chunks: int = 0):
+        lib = _lib.load()
+        assert not out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.dim() == 2 and out.shape[1] >= f
+        assert f == 0 or (x is not None and not x.is_cuda and x.dtype == torch.float32 and x.shape == (out.shape[0], f) and x.stride(1) == 1)
+        self.out, self.x, self.f, self.handle = out, x, f, None        # x is kept alive until finish
+        if out.shape[0] == 0:
+            return
+        self.handle = lib.pope_assemble_begin(ptr(x) if f else None, (x.stride(0) * 4) if f else 0, f * 4, ptr(out), out.shape[1] * 4,
+                                              out.shape[0], threads or host_threads(), chunks)
+        if not self.handle:
+            raise _lib.PopeError(_lib.ERR_INVALID, lib.pope_last_error().decode())
+
+    def finish(self, emb: torch.Tensor) -> torch.Tensor:
+        lib = _lib.load()
+        n, k = emb.shape
+        assert emb.is_cuda and emb.is_contiguous() and emb.dtype == torch.float32 and self.out.shape == (n, self.f + k)
+        h, self.handle = self.handle, None
+        if h:
+            with torch.cuda.device(emb.device):
+                check(lib.pope_assemble_finish(h, ptr(emb), k * 4, k * 4, _stream()))
+        return self.out
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.handle:
+            _lib.load().pope_assemble_abort(self.handle)
+            self.handle = None
+        return False
+
+
 def assemble_host_result(x: torch.Tensor | None, emb: torch.Tensor, out: torch.Tensor, f: int, threads: int = 0, chunks: int = 0) -> None:
     """out[:, :f] = x (HOST, threads) and out[:, f:] = emb (DEVICE [N, K], DMA on the current stream) for a pageable
     HOST result `out` [N, f + K]; returns when `out` is complete (pope_assemble_host_result)."""
@@ -518,6 +556,35 @@ def pairwise_embedding(emb: torch.Tensor, anchors, distance_function: str, ancho
     return out
 
 
+def _relocate_empty_clusters(xc: torch.Tensor, centers_old: torch.Tensor, centers_new: torch.Tensor, labels: torch.Tensor, k: int) -> bool:
+    """scikit-learn's ``_relocate_empty_clusters_dense`` (sklearn/cluster/_k_means_common.pyx) on the result of one Lloyd
+    update: every empty cluster takes, in order, one of the points that lie farthest from their own (old) centre -- the
+    farthest point goes to the first empty cluster -- and that point leaves the cluster it was counted in.  `centers_new`
+    holds MEANS (pope_kmeans_lloyd_step keeps an empty cluster's old centre), so the donor's mean is rebuilt from its sum.
+    Empty clusters are rare (k-means++ seeds every cluster with a data point): a handful of torch ops, run only then.
+    Returns True if anything was moved."""
+    counts = torch.bincount(labels.to(torch.int64), minlength=k)
+    empty = torch.nonzero(counts == 0, as_tuple=False).flatten()
+    n_empty = int(empty.numel())
+    if n_empty == 0:
+        return False
+    lab = labels.to(torch.int64)
+    dist = ((xc - centers_old.index_select(0, lab)).double() ** 2).sum(1)
+    far = torch.argsort(dist, descending=True, stable=True)[:n_empty]            # np.argpartition(...)[:-n_empty-1:-1]: farthest first
+    sums = centers_new.double() * counts.clamp(min=1).double()[:, None]
+    cnt = counts.clone().double()
+    for new_id, idx in zip(empty.tolist(), far.tolist()):
+        old_id = int(lab[idx])
+        sums[old_id] -= xc[idx].double()
+        sums[new_id] = xc[idx].double()
+        cnt[new_id] = 1.0
+        cnt[old_id] -= 1.0
+    fixed = (sums / cnt.clamp(min=1.0)[:, None]).to(torch.float32)
+    touched = torch.unique(torch.cat([empty, lab[far]]))
+    centers_new[touched] = fixed[touched]
+    return True
+
+
 def kmeans_centers(emb: torch.Tensor, n_clusters: int, max_iter: int = 300, tol: float = 1e-4):
     """``KMeans(n_clusters=K).fit(X).cluster_centers_`` (utils.py:168-170, scikit-learn defaults: k-means++ seeding with
     2 + int(log K) local trials, one run, Lloyd on the mean-centred data) with the distances, reductions and centre updates on
@@ -526,7 +593,10 @@ def kmeans_centers(emb: torch.Tensor, n_clusters: int, max_iter: int = 300, tol:
     stream is left where the reference leaves it.  float32 [K, D] on the device.
 
     Not bit-identical to scikit-learn (whose own result depends on its BLAS chunking); on well-separated data the same
-    points are seeded in the same order and the centres agree to float32 rounding."""
+    points are seeded in the same order and the centres agree to float32 rounding.  On overlapping data (an untrained
+    node2vec table) a rounding difference in the seeding's cumulative sums can pick another seed and the centres then differ
+    as two runs of scikit-learn with different seeds do: parity in distribution only, which is why ``utils.attach_node2vec``
+    makes the reference's own scikit-learn call unless GRAPHPOPE_KMEANS=gpu asks for this one."""
     lib = _lib.load()
     dev = require_gpu(emb.device)
     x = emb.to(dev, torch.float32).contiguous()
@@ -562,11 +632,13 @@ def kmeans_centers(emb: torch.Tensor, n_clusters: int, max_iter: int = 300, tol:
         for _ in range(max_iter):                                             # _kmeans_single_lloyd
             check(lib.pope_kmeans_lloyd_step(ptr(xc), n, d, ptr(centers), k, ptr(centers_new), ptr(labels), ptr(labels_prev),
                                              ptr(changed), ptr(shift), ptr(scratch), scratch.numel(), _stream()))
+            relocated = _relocate_empty_clusters(xc, centers, centers_new, labels, k)   # rare: scikit-learn's rule for empty clusters
             centers, centers_new = centers_new, centers
             labels, labels_prev = labels_prev, labels                          # labels_prev now holds this iteration's labels
             if int(changed.item()) == 0:                                      # strict convergence: the labels did not move
                 break
-            if float(shift.item()) <= tol_abs:
+            total_shift = float(((centers - centers_new).double() ** 2).sum().item()) if relocated else float(shift.item())
+            if total_shift <= tol_abs:
                 break
         out = torch.empty_like(centers)
         check(lib.pope_shift_columns(ptr(centers), ptr(mean), k, d, 1.0, ptr(out), _stream()))   # best_centers += X_mean

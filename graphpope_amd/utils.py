@@ -110,24 +110,28 @@ def sample_anchor_nodes(data, num_anchor_nodes, sampling_method):
     raise UnboundLocalError("local variable 'sampled_anchor_nodes' referenced before assignment")
 
 
-def _host_result(data, k):
-    """The tensor the call returns: a NEW contiguous CPU float32 [N, F+K] (utils.py:134) in ordinary pageable memory,
-    like the reference's.  (Rounds 1-2 returned a pinned tensor: 34 ms of hipHostMalloc on the one call a process makes,
-    and 270 MB -- 8.6 GB for R-MAT-22 x 512 -- page-locked for as long as the memoised result lives.)"""
+def _host_features(data):
     x = data.x.detach()
+    if not (x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        x = x.to(torch.float32).contiguous()
+    return x
+
+
+def _assemble_on_host(data, k, embedding_fn):
+    """The tensor the call returns: a NEW contiguous CPU float32 [N, F+K] (utils.py:134) in ordinary pageable memory, like
+    the reference's.  (Rounds 1-2 returned a pinned tensor: 34 ms of hipHostMalloc on the one call a process makes, and
+    270 MB -- 8.6 GB for R-MAT-22 x 512 -- page-locked for as long as the memoised result lives.)
+
+    out[:, :F] = data.x is copied host to host by a few threads (data.x never crosses PCIe), starting BEFORE
+    ``embedding_fn()`` uploads edge_index and runs the GPU work, so the page faults of the fresh result and most of the copy
+    hide underneath it; out[:, F:] = the device embedding then arrives by pitched DMA, chunk by chunk, into pages
+    registered for the length of the call (utils.py:129-135 torch.cat((data.x, embedding), 1))."""
+    x = _host_features(data)
     n, f = int(x.shape[0]), int(x.shape[1])
-    return torch.empty((n, f + k), dtype=torch.float32), x, f
-
-
-def _assemble_on_host(out, x, f, emb_dev):
-    """out[:, F:] = emb_dev (pitched DMA, chunk by chunk, into pages registered for the length of the call) while
-    out[:, :F] = data.x is copied host to host by a few threads: data.x never crosses PCIe (utils.py:129-135
-    torch.cat((data.x, embedding), 1)).  engine.assemble_host_result returns when the tensor is complete."""
-    xc = None
-    if f:
-        xc = x if (x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1) else x.to(torch.float32).contiguous()
-    engine.assemble_host_result(xc, emb_dev.contiguous(), out, f)
-    return out
+    out = torch.empty((n, f + k), dtype=torch.float32)
+    with engine.HostAssembly(x if f else None, out, f) as asm:
+        emb_dev = embedding_fn()
+        return asm.finish(emb_dev.contiguous())
 
 
 def _geodesic_planes(ei, n, anchors, dev):
@@ -169,8 +173,7 @@ def _geodesic_features(data, dev):
         out[:, : x.shape[1]] = x
         out[:, x.shape[1]:] = emb_cols
         return out.cpu()
-    out, x, f = _host_result(data, len(anchors))
-    return _assemble_on_host(out, x, f, _geodesic_embedding_device(data.edge_index, n, anchors, dev))
+    return _assemble_on_host(data, len(anchors), lambda: _geodesic_embedding_device(data.edge_index, n, anchors, dev))
 
 
 def get_geodesic_distance_vector(data, num_workers):
@@ -219,19 +222,25 @@ def attach_node2vec(data, dataset, num_anchor_nodes, sampling_method, distance_f
     if sampling_method == 'stochastic':
         anchor_nodes = sample_anchor_nodes(data, num_anchor_nodes, sampling_method='stochastic')
     else:
-        # utils.py:168-170: every other sampling_method means K-means centres as anchors -- scikit-learn's algorithm
-        # (k-means++ seeding from the global NumPy stream, Lloyd iterations) with the arithmetic on the GPU
-        # (engine.kmeans_centers); the N x K distance matrix and the min-max scaling follow on the same device.
-        anchor_embeddings = engine.kmeans_centers(table, num_anchor_nodes)
+        # utils.py:168-170: every other sampling_method means K-means centres as anchors.  Anchor SELECTION is not the
+        # accelerated path (the N x K distance matrix is), and K-means is discontinuous in its inputs: the default is
+        # the reference's own call, which reproduces its centres exactly from the same global NumPy stream.
+        # GRAPHPOPE_KMEANS=gpu opts into engine.kmeans_centers -- the same algorithm (k-means++ from the same stream,
+        # Lloyd, scikit-learn's empty-cluster rule) with the arithmetic on the GPU: 0.17 s instead of minutes at Flickr
+        # size, centres equal to scikit-learn's on separated data and equal IN DISTRIBUTION on overlapping data.
+        if os.environ.get("GRAPHPOPE_KMEANS", "sklearn").lower() == "gpu":
+            anchor_embeddings = engine.kmeans_centers(table, num_anchor_nodes)
+        else:
+            from sklearn.cluster import KMeans
+            anchor_embeddings = KMeans(n_clusters=num_anchor_nodes).fit(node2vec_embeddings.numpy()).cluster_centers_
         print('K means cluster anchor nodes derived!')
     if data.x.is_cuda:
         extended_features = engine.pairwise_features(data.x.detach().to(dev, torch.float32), table, anchor_nodes,
                                                      distance_function, anchor_embeddings=anchor_embeddings).cpu()
     else:
         k = len(anchor_embeddings) if anchor_embeddings is not None else len(anchor_nodes)
-        out, x, f = _host_result(data, k)
-        extended_features = _assemble_on_host(out, x, f, engine.pairwise_embedding(table, anchor_nodes, distance_function,
-                                                                                    anchor_embeddings=anchor_embeddings))
+        extended_features = _assemble_on_host(data, k, lambda: engine.pairwise_embedding(table, anchor_nodes, distance_function,
+                                                                                         anchor_embeddings=anchor_embeddings))
     print('feature matrix is blessed by the POPE')
     return extended_features
 

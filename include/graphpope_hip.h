@@ -338,6 +338,17 @@ int pope_assemble_host_result(const void *x_host, int64_t x_pitch_bytes, int64_t
                               int64_t rows, int32_t threads, int32_t chunks, void *stream);
 
 /*
+ * The same in two halves, so that the page faults and the feature copy run UNDERNEATH the upload of edge_index and the GPU
+ * work: pope_assemble_begin starts the host threads on out[:, :x_row_bytes] = x_host and returns a handle (NULL + an error
+ * message on bad arguments); pope_assemble_finish registers / DMAs the embedding columns as pope_assemble_host_result does,
+ * waits for everything and frees the handle (also when it fails).  pope_assemble_abort frees a handle that will not be finished.
+ */
+void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, void *out_host, int64_t out_pitch_bytes,
+                          int64_t rows, int32_t threads, int32_t chunks);
+int pope_assemble_finish(void *handle, const void *emb, int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *stream);
+void pope_assemble_abort(void *handle);
+
+/*
  * Caller-owned pageable HOST memory as a DMA endpoint for the length of one call: pope_host_pin registers [host, host +
  * bytes) with the HIP runtime (POPE_ERR_HIP if refused -- the caller then stages through pinned memory instead),
  * pope_copy_to_device enqueues one asynchronous host -> device copy on `stream`, pope_host_unpin releases the pages

@@ -298,7 +298,38 @@ def node2vec_fixtures():
     np.savez_compressed(os.path.join(HERE, "node2vec_kmeans512.npz"), emb=tab3.numpy(), **pack)
 
 
+def kmeans_large_fixture():
+    """A larger K-means anchor case from the reference (utils.py:168-170): 80 well separated blobs in 32 dimensions, 40
+    points each -- K spans two 64-column groups of the distance tile.  Separated, so that the clustering does not hinge on
+    float summation order (K-means is discontinuous in its inputs); euclidean only, to keep the file small."""
+    from sklearn.cluster import KMeans
+    f, kk, per, dim = 5, 80, 40, 32
+    g = torch.Generator().manual_seed(17)
+    blob_centres = torch.randn(kk, dim, generator=g) * 8
+    tab = (blob_centres.repeat_interleave(per, 0) + torch.randn(kk * per, dim, generator=g) * 0.4).contiguous()
+    tab = tab[torch.randperm(kk * per, generator=g)].contiguous()
+    n = kk * per
+    real_load = ref.torch.load
+    _reset_cache()
+    data = Data(_features(n, f, 11), np.zeros((2, 0), dtype=np.int64), n)
+    ref.torch.load = lambda *a, **kw: tab.clone().requires_grad_(True)
+    try:
+        np.random.seed(21)
+        out = ref.Graphpope(data, "flickr", "node2vec", "kmeans", kk, "euclidean", 2).numpy().astype(np.float32)
+    finally:
+        ref.torch.load = real_load
+        _reset_cache()
+    np.random.seed(21)
+    centres = KMeans(n_clusters=kk).fit(tab.numpy()).cluster_centers_
+    print(f"node2vec_kmeans_k80/euclidean: {out.shape} min {out[:, f:].min():.3g} max {out[:, f:].max():.3g}")
+    np.savez_compressed(os.path.join(HERE, "node2vec_kmeans_k80.npz"), emb=tab.numpy(), x=data.x.numpy(), centres=centres,
+                        scaled_euclidean=out[:, f:])
+
+
 if __name__ == "__main__":
+    if "--kmeans-large-only" in sys.argv:
+        kmeans_large_fixture()
+        sys.exit(0)
     if "--centrality-only" in sys.argv:
         anchor_centrality_fixtures()
         sys.exit(0)
@@ -307,3 +338,4 @@ if __name__ == "__main__":
         anchor_fixtures()
         anchor_centrality_fixtures()
     node2vec_fixtures()
+    kmeans_large_fixture()

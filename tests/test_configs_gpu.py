@@ -53,7 +53,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _config3_worker(rank, world, port, result_dir):
+def _config3_worker(rank, world, port, result_dir, k=1024):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -63,11 +63,11 @@ def _config3_worker(rank, world, port, result_dir):
         from graphpope_amd import engine, synth
         from oracle import oracle
         ei, n = synth.flickr_like()
-        anchors = synth.seeded_anchors(n, 1024, 42)
+        anchors = synth.seeded_anchors(n, 1024, 42)[:k]
         x = torch.rand((n, 16), generator=torch.Generator().manual_seed(1))
-        out = engine.geodesic_features(x.cuda(), torch.as_tensor(ei).cuda(), n, anchors)      # 512 anchors on this rank
+        out = engine.geodesic_features(x.cuda(), torch.as_tensor(ei).cuda(), n, anchors)      # ceil(k / world) anchors on this rank
         want = oracle.geodesic_features(x.numpy(), ei, n, anchors)
-        ok = tuple(out.shape) == (n, 16 + 1024) and np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        ok = tuple(out.shape) == (n, 16 + k) and np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
         open(os.path.join(result_dir, f"rank{rank}"), "w").write("ok" if ok else "MISMATCH")
     finally:
         dist.destroy_process_group()
@@ -77,6 +77,14 @@ def test_config3_flickr_1024_anchors_sharded_world2(tmp_path, oracle):
     """engine.geodesic_features inside a world-2 group: anchor shards, plane all-gather, one-pass expansion of both shards."""
     mp.spawn(_config3_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
+        assert open(tmp_path / f"rank{r}").read() == "ok"
+
+
+def test_config3_ragged_1020_anchors_sharded_world4(tmp_path, oracle):
+    """Four ranks on the one card (gloo carries the planes, the real kernels do the rest): 1 020 anchors -> 255 per rank,
+    W = 4 words per shard with a ragged last word, 4-shard expansion with the padded tail dropped."""
+    mp.spawn(_config3_worker, args=(4, _free_port(), str(tmp_path), 1020), nprocs=4, join=True)
+    for r in range(4):
         assert open(tmp_path / f"rank{r}").read() == "ok"
 
 

@@ -147,7 +147,11 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,k,deep,with_verdict", [(2, 128, True, False), (2, 7, True, True), (3, 10, True, True), (2, 1, True, False),
-                                                       (2, 128, False, True), (3, 10, False, False), (2, 40, False, True)])
+                                                       (2, 128, False, True), (3, 10, False, False), (2, 40, False, True),
+                                                       # BASELINE.json configs[3] as written: 8 ranks x 128 anchors (two 64-anchor words
+                                                       # per rank, an 8-shard expansion), and the ragged form (1 020 anchors: the last
+                                                       # shard is 4 short and padded)
+                                                       (8, 1024, False, True), (8, 1020, False, True), (8, 1020, True, False)])
 def test_sharded_all_gather_reassembles_the_matrix(world, k, deep, with_verdict, tmp_path, oracle):
     mp.spawn(_worker, args=(world, _free_port(), k, str(tmp_path), deep, with_verdict), nprocs=world, join=True)
     for r in range(world):

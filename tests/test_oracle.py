@@ -153,3 +153,37 @@ def test_pagerank_restatement_matches_networkx_and_the_reference_golden(oracle):
     g = np.load(os.path.join(GOLDEN, "anchors_centrality.npz"))
     score = oracle.pagerank_scores(g["edge_index"].astype(np.int64), int(g["num_nodes"]))
     assert np.argsort(score, kind="stable")[-24:].tolist() == g["pagerank"].tolist()
+
+
+def test_sage_conv_restatement_against_an_independent_dense_formulation(oracle):
+    """oracle.sage_conv_torch (gather + index_add_ + two F.linear, float32) against a second formulation that shares none
+    of its steps: the dense float64 operator  out = D^-1 A X W_l^T + b + X_dst W_r^T  with A the [n_dst, n_src] incidence
+    count matrix of the sampled block (repeated edges count twice, as a mean over the CSR entries does), and its
+    gradients from autograd on that expression.  PyG is absent, so the SAGE oracle cannot be pinned to the reference;
+    this at least checks the restatement against something the kernels were not written from."""
+    import torch
+    rs = np.random.RandomState(0)
+    n_src, n_dst, c_in, c_out = 70, 23, 11, 6
+    deg = rs.randint(0, 7, n_dst)
+    deg[3] = 0                                                   # an isolated destination aggregates to zero
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = rs.randint(0, n_src, int(deg.sum())).astype(np.int32)  # with repeats
+    x = torch.tensor(rs.randn(n_src, c_in), dtype=torch.float32, requires_grad=True)
+    w_l = torch.tensor(rs.randn(c_out, c_in), dtype=torch.float32, requires_grad=True)
+    b_l = torch.tensor(rs.randn(c_out), dtype=torch.float32, requires_grad=True)
+    w_r = torch.tensor(rs.randn(c_out, c_in), dtype=torch.float32, requires_grad=True)
+    out = oracle.sage_conv_torch(x, torch.as_tensor(rowptr), torch.as_tensor(col), w_l, b_l, w_r)
+    g = torch.tensor(rs.randn(n_dst, c_out), dtype=torch.float32)
+    out.backward(g)
+    A = np.zeros((n_dst, n_src))
+    for i in range(n_dst):
+        for p in range(rowptr[i], rowptr[i + 1]):
+            A[i, col[p]] += 1.0
+    Dinv = np.diag(1.0 / np.maximum(deg, 1))
+    X, Wl, Bl, Wr = (t.detach().double().requires_grad_(True) for t in (x, w_l, b_l, w_r))
+    M = torch.as_tensor(Dinv @ A)
+    dense = M @ X @ Wl.T + Bl + X[:n_dst] @ Wr.T
+    dense.backward(g.double())
+    assert torch.allclose(out.detach().double(), dense.detach(), rtol=1e-5, atol=1e-5)
+    for got, want in ((x.grad, X.grad), (w_l.grad, Wl.grad), (b_l.grad, Bl.grad), (w_r.grad, Wr.grad)):
+        assert torch.allclose(got.double(), want, rtol=1e-4, atol=1e-5)

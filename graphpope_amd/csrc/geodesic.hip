@@ -233,6 +233,26 @@ __device__ __forceinline__ Words<WT> load_words(const u64 *__restrict__ p) {
     return r;
 }
 
+typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
+// The same with the non-temporal hint (POPE_KNOB_LEVEL_VARIANT experiments: streams that should not evict the frontier).
+template <int WT>
+__device__ __forceinline__ Words<WT> load_words_nt(const u64 *__restrict__ p) {
+    Words<WT> r;
+    if constexpr (WT == 1) {
+        r.w[0] = __builtin_nontemporal_load(p);
+    } else {
+#pragma unroll
+        for (int i = 0; i < WT; i += 2) {
+            const u64x2v v = __builtin_nontemporal_load(reinterpret_cast<const u64x2v *>(p + i));
+            r.w[i] = v.x;
+            r.w[i + 1] = v.y;
+        }
+    }
+    return r;
+}
+
 // Frontier gathers go through L1 like any load: reading them with the non-temporal hint was measured 57 % slower
 // (BFS 349 us against 223 us, tools/ab_lib.py) -- the rows of hubs are gathered again and again and L1 serves them.
 template <int WT>
@@ -327,7 +347,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
                                                    size_t plane_elems, int level, BfsCtl *ctl, const int *aux,
                                                    int expand_blocks, const unsigned *__restrict__ live,
                                                    unsigned *__restrict__ live_acc, unsigned *__restrict__ live_idle,
-                                                   int live_words) {
+                                                   int live_words, int variant) {
     if (bfs_over(ctl, aux, level)) return;
     const int lane = threadIdx.x & 63;
     int woff = blockIdx.y * WT;                                    // housekeeping: tile = blockIdx.y
@@ -372,16 +392,31 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
     // same block, so the 128-byte frontier line that all of them gather from is fetched from L2 once and served to the
     // others by the CU's L1 (one tile per launch row of blocks fetched it once per tile, from different CUs).
     const int tiles = gridDim.y;
-    const int wid = ((blockIdx.y * expand_blocks + blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    // POPE_KNOB_LEVEL_VARIANT bit 1: blocks are dealt round-robin over the 8 XCDs (block b and b + 8 share one); give every
+    // XCD a CONTIGUOUS range of chunks, so that the seen / accumulator rows it touches are one eighth of those arrays.
+    int bx = blockIdx.x;
+    if (variant & 2) {
+        const int q = expand_blocks >> 3, r = expand_blocks & 7, x = bx & 7;
+        bx = x * q + min(x, r) + (bx >> 3);
+    }
+    const int wid = ((blockIdx.y * expand_blocks + bx) * blockDim.x + threadIdx.x) >> 6;
     const int wave = wid / tiles;                                  // which stream of chunks this wave walks
     woff = (wid - wave * tiles) * WT;
     const int nwaves = (expand_blocks * blockDim.x) >> 6;
     const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
     // The first chunk's slot loads are issued before the live table is staged: they fly while LDS fills.
     int4 vr = make_int4(-1, -1, -1, -1), ur = make_int4(0, 0, 0, 0);
+    // bit 0: the index streams are read once per launch: non-temporal, so that they do not evict the frontier from L2
+    auto load_idx = [&](const int *p) {
+        if (variant & 1) {
+            const i32x4v t = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(p));
+            return make_int4(t.x, t.y, t.z, t.w);
+        }
+        return *reinterpret_cast<const int4 *>(p);
+    };
     if (wave < nchunks && wave * CHUNK + lane * SLOTS < E) {
-        vr = *reinterpret_cast<const int4 *>(erow + wave * CHUNK + lane * SLOTS);
-        ur = *reinterpret_cast<const int4 *>(col + wave * CHUNK + lane * SLOTS);
+        vr = load_idx(erow + wave * CHUNK + lane * SLOTS);
+        ur = load_idx(col + wave * CHUNK + lane * SLOTS);
     }
     extern __shared__ uint4 live_lds4[];
     const unsigned *live_lds = reinterpret_cast<const unsigned *>(live_lds4);
@@ -397,8 +432,8 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
         int v0 = -1, v1 = -1, v2 = -1, v3 = -1, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
         if (base < E) {                       // arrays are padded to a multiple of 4 entries: the 16-byte load is in bounds
             if (chunk != wave) {
-                vr = *reinterpret_cast<const int4 *>(erow + base);
-                ur = *reinterpret_cast<const int4 *>(col + base);
+                vr = load_idx(erow + base);
+                ur = load_idx(col + base);
             }
             v0 = vr.x; u0 = ur.x;
             if (base + 1 < E) { v1 = vr.y; u1 = ur.y; }
@@ -433,7 +468,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
         // seen by the housekeeping blocks of THIS launch: either order gives the same mask.  Rows whose live bit is clear
         // have an all-zero (possibly never written) frontier row: not loaded.
         auto row_mask = [&](int v) {
-            Words<WT> m = load_words<WT>(seen + (size_t)v * Wp + woff);
+            Words<WT> m = (variant & 4) ? load_words_nt<WT>(seen + (size_t)v * Wp + woff) : load_words<WT>(seen + (size_t)v * Wp + woff);
             if (is_live(v)) {
                 const Words<WT> f = load_words<WT>(front + (size_t)v * Wp + woff);
 #pragma unroll
@@ -649,7 +684,7 @@ __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ p
                                                        int Wp, const float *__restrict__ x, int F,
                                                        float *__restrict__ out, long long out_cols, int c0,
                                                        int n_shards, size_t shard_elems, const int *__restrict__ aux,
-                                                       int *report, int ticket) {
+                                                       int *report, int ticket, int x_row_begin) {
     if (max_hop_dev) write_report(*max_hop_dev, aux, report, ticket);
     __shared__ float inv[16];
     if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
@@ -666,7 +701,7 @@ __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ p
     const int F4 = F >> 2, K4 = K >> 2;
     for (int v = v_begin; v < v_end; ++v) {
         f32x4 *orow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols);
-        if (x) {
+        if (x && v >= x_row_begin) {                           // rows below were copied beside the BFS (POPE_KNOB_COPY_GATE)
             const f32x4 *xs = reinterpret_cast<const f32x4 *>(x + (size_t)v * F);
             for (int q = lane; q < F4; q += 64) {
                 const f32x4 t = __builtin_nontemporal_load(xs + q);
@@ -965,6 +1000,8 @@ static int g_live_mode = -1;            // -1: by graph size (LDS table up to LI
 static int g_finalize_variant = 1;      // 0: generic kernel, 1: fast path with plain stores, 2: fast path, non-temporal stores
 static int g_finalize_blocks = 256 * 8;
 static int g_level_blocks = 0;           // cap on the expand blocks of a level launch (0: one wave per chunk up to 2048 blocks)
+static int g_level_variant = 0;          // POPE_KNOB_LEVEL_VARIANT bits: 1 nt index streams, 2 XCD-contiguous chunks, 4 nt reachability loads
+static int g_copy_gate = 0;              // POPE_KNOB_COPY_GATE: early% * 1000 + late% of the feature rows copied beside the sparse phases (0: off)
 namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0; extern int g_sage_lanes; }
 
 extern "C" int pope_debug_set(int32_t knob, int32_t value) {
@@ -979,6 +1016,8 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_LEVEL_BLOCKS:     g_level_blocks = value; break;
     case POPE_KNOB_FAIL_HOST_REGISTER: pope::g_fail_host_register = value; break;
     case POPE_KNOB_SAGE_LANES:       pope::g_sage_lanes = value; break;
+    case POPE_KNOB_LEVEL_VARIANT:    g_level_variant = value; break;
+    case POPE_KNOB_COPY_GATE:        g_copy_gate = value; break;
     default: set_error("pope_debug_set: unknown knob %d", knob); return POPE_ERR_INVALID;
     }
     return POPE_OK;
@@ -999,15 +1038,15 @@ static void launch_level(int E, int N, int Wp, const int *col, const int *erow, 
     if (mode == 1 && live_words <= LIVE_MAX_NODES / 32)
         hipLaunchKernelGGL((k_bfs_level<WT, 1>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256),
                            align_up((size_t)live_words * sizeof(unsigned), 16), stream, erow, col, E, N, Wp, front, seen, acc, idle, hop_planes,
-                           plane_elems, level, ctl, aux, expand_blocks, live, live_acc, live_idle, live_words);
+                           plane_elems, level, ctl, aux, expand_blocks, live, live_acc, live_idle, live_words, g_level_variant);
     else if (mode == 2)
         hipLaunchKernelGGL((k_bfs_level<WT, 2>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow,
                            col, E, N, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
-                           live_acc, live_idle, live_words);
+                           live_acc, live_idle, live_words, g_level_variant);
     else
         hipLaunchKernelGGL((k_bfs_level<WT, 0>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow,
                            col, E, N, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
-                           live_acc, live_idle, live_words);
+                           live_acc, live_idle, live_words, g_level_variant);
     profile_mark(stream, level, 1);
 }
 
@@ -1400,7 +1439,7 @@ extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, cons
 static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_hop_dev, int64_t N, int32_t K,
                             const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, hipStream_t stream,
                             int n_shards = 1, size_t shard_elems = 0, const int *aux = nullptr, int *report = nullptr,
-                            int ticket = 0) {
+                            int ticket = 0, int x_row_begin = 0) {
     const int Wp = words_for(K);
     const size_t plane_elems = (size_t)N * Wp;
     const bool vec = F % 4 == 0 && K % 4 == 0 && c0 % 4 == 0 && out_cols % 4 == 0 && aligned16(out) && (!x || aligned16(x));
@@ -1418,9 +1457,9 @@ static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_ho
     if (vec && (g_finalize_variant > 0 || n_shards > 1) && (max_hop_dev || n_hop_bits <= 4)) {
         dim3 fgrid(g_finalize_blocks);                          // 8 blocks per CU, contiguous row blocks per wave
         if (g_finalize_variant == 2)
-            hipLaunchKernelGGL(k_finalize_fast<1>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket);
+            hipLaunchKernelGGL(k_finalize_fast<1>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, x_row_begin);
         else
-            hipLaunchKernelGGL(k_finalize_fast<0>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket);
+            hipLaunchKernelGGL(k_finalize_fast<0>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, x_row_begin);
         POPE_HIP(hipGetLastError());
         return POPE_OK;
     }
@@ -1503,21 +1542,49 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     SlotGuard guard{&b.slot, stream};
     if ((rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, (uint64_t *)planes, plane_capacity,
                         ws + L.bfs_scratch, L.total - L.bfs_scratch))) return rc;
+    const int window = speculative_window(N, E, K);
+    // POPE_KNOB_COPY_GATE experiment (round 3): part of out[:, :F] = x beside the phases of the step that leave the memory system idle --
+    // `early` % of the rows on a side stream from here until level 3 starts (the clear, the CSR build and the first two, sparse
+    // levels), `late` % beside the last three levels -- gated by events so that nothing of it runs beside the dense levels,
+    // which the copy was measured to slow down 2x; the finalise kernel copies the rest.
+    const int early_pct = g_copy_gate / 1000, late_pct = g_copy_gate % 1000;
+    const bool gate = g_copy_gate > 0 && out && x && F > 0 && window >= 6 && early_pct + late_pct <= 100 &&
+                      SideCopy::eligible(x, F, out, out_cols, N);
+    const int64_t rA = gate ? N * early_pct / 100 : 0, rB = gate ? N * (early_pct + late_pct) / 100 : 0;
+    SideLanes early;
+    if (rA > 0) {
+        if ((rc = early.fork(stream, 1))) return rc;
+        if ((rc = enqueue_copy_features(x, F, out, out_cols, rA, early.lane(0)))) return rc;
+    }
     bfs_enqueue_clear(b, aux, stream);                    // BFS state and the CSR status header in one launch
     memcpy(b.slot->anchors, anchors_host, (size_t)K * sizeof(long long));     // this call's pinned, device-mapped slot: read in place
     SeedArgs seed;
     seed.anchors = b.slot->anchors_dev; seed.K = K; seed.Wp = b.Wp; seed.seen = b.seen; seed.front = b.front[0]; seed.live = b.live[0];
     rc = csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, seed, stream);
     if (rc) return rc;
-    const int window = speculative_window(N, E, K);
-    int level = bfs_enqueue_levels(b, 1, 1 + window, stream);
+    int level = 1, x_row_begin = 0;
+    if (gate) {
+        level = bfs_enqueue_levels(b, level, 3, stream);
+        if (rA > 0 && (rc = early.join(stream))) return rc;
+        level = bfs_enqueue_levels(b, level, 1 + window - 3, stream);
+        SideLanes late;
+        if (rB > rA) {
+            if ((rc = late.fork(stream, 1))) return rc;
+            if ((rc = enqueue_copy_features(x + (size_t)rA * F, F, out + (size_t)rA * out_cols, out_cols, rB - rA, late.lane(0)))) return rc;
+        }
+        level = bfs_enqueue_levels(b, level, 1 + window, stream);
+        if (rB > rA && (rc = late.join(stream))) return rc;
+        x_row_begin = (int)rB;
+    } else {
+        level = bfs_enqueue_levels(b, 1, 1 + window, stream);
+    }
     // The finalise kernel writes the verdict into the pinned report when it starts: no report launch, and the host
     // returns as soon as the BFS is known to be complete -- `out` is finished in stream order.
     int ticket = 0;
     if (out) {
         ticket = b.slot->ticket = b.slot->ticket == INT32_MAX ? 1 : b.slot->ticket + 1;
         if ((rc = finalize_enqueue(planes, 0, &b.ctl->last_active, N, K, x, F, out, out_cols, 0, stream, 1, 0, aux,
-                                   b.slot->report_dev, ticket))) return rc;
+                                   b.slot->report_dev, ticket, x_row_begin))) return rc;
     }
     int last_active = 0;
     bool done = false;

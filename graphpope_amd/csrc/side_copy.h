@@ -48,6 +48,8 @@ class SideLanes {
     std::unique_lock<std::mutex> hold_;
 };
 
+int enqueue_copy_features(const float *x, int32_t F, float *out, int64_t out_cols, int64_t N, hipStream_t stream);   // SideCopy's kernel on any stream
+
 extern int g_copy_batches_per_wave;            // pope_debug_set(POPE_KNOB_COPY_BATCHES)
 
 }  // namespace pope

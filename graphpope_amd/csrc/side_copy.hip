@@ -76,9 +76,8 @@ int SideCopy::fork(hipStream_t main) {
     return POPE_OK;
 }
 
-int SideCopy::launch(const float *x, int32_t F, float *out, int64_t out_cols, int64_t N) {
-    POPE_REQUIRE(side_, "feature copy: launch before fork");
-    POPE_HIP(hipStreamWaitEvent(side_->stream, side_->fork, 0));
+// out[r, :F] = x[r, :] for r < N on `stream` (the kernel above; eligible() shapes only).
+int enqueue_copy_features(const float *x, int32_t F, float *out, int64_t out_cols, int64_t N, hipStream_t stream) {
     const unsigned F4 = (unsigned)F / 4;
     const int per = (int)((F4 + 63) / 64);
     const int PER = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 16;
@@ -87,13 +86,21 @@ int SideCopy::launch(const float *x, int32_t F, float *out, int64_t out_cols, in
     const int64_t batches = (N + 16 / PER - 1) / (16 / PER), per_wave = g_copy_batches_per_wave > 0 ? g_copy_batches_per_wave : 1;
     // (A few resident grid-stride blocks per CU instead: 2 per CU copy at half the rate, 8 per CU hold the slots as well.)
     const dim3 grid((unsigned)((batches + 4 * per_wave - 1) / (4 * per_wave))), block(256);
-    hipStream_t stream = side_->stream;
     if (PER == 1) hipLaunchKernelGGL(k_copy_features<1>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
     else if (PER == 2) hipLaunchKernelGGL(k_copy_features<2>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
     else if (PER == 4) hipLaunchKernelGGL(k_copy_features<4>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
     else if (PER == 8) hipLaunchKernelGGL(k_copy_features<8>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
     else hipLaunchKernelGGL(k_copy_features<16>, grid, block, 0, stream, x, F4, out, (unsigned)out_cols, (int)N);
     POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+int SideCopy::launch(const float *x, int32_t F, float *out, int64_t out_cols, int64_t N) {
+    POPE_REQUIRE(side_, "feature copy: launch before fork");
+    POPE_HIP(hipStreamWaitEvent(side_->stream, side_->fork, 0));
+    hipStream_t stream = side_->stream;
+    int rc = enqueue_copy_features(x, F, out, out_cols, N, stream);
+    if (rc) return rc;
     POPE_HIP(hipEventRecord(side_->join, stream));
     return POPE_OK;
 }
@@ -151,6 +158,8 @@ int SideLanes::join(hipStream_t main) {
         POPE_HIP(hipEventRecord(set_->join[set_->cur][i], set_->stream[i]));
         POPE_HIP(hipStreamWaitEvent(main, set_->join[set_->cur][i], 0));
     }
+    set_ = nullptr;                      // the lanes are free for the next fork (of this or another caller)
+    hold_.unlock();
     return POPE_OK;
 }
 

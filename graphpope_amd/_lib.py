@@ -94,7 +94,7 @@ SIGNATURES = {
                                               c_int32, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                               c_void_p, c_void_p, c_void_p]),
     "sage_cross_entropy_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_void_p]),
+                                           c_void_p, c_int32, c_void_p]),
     "sage_cross_entropy_backward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sage_adam_step": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
                                c_double, c_int64, c_void_p, c_void_p]),

@@ -137,16 +137,15 @@ __global__ __launch_bounds__(256) void k_zero_rows(float *__restrict__ x, int C,
 constexpr int COLSUM_SPLITS = 256;
 
 // VEC: lane l owns 4 adjacent columns (16-byte loads, a wave covers 256 columns of a row); else one column per lane.
+// (bx, by) of (gx, gy): the block's place in the launch -- a kernel of its own (k_colsum_partial) or a role of k_gemm_dual.
 template <bool VEC>
-__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ g, int rows, int C, float *__restrict__ part,
-                                                        const int *__restrict__ rows_dev) {
+__device__ __forceinline__ void colsum_partial_block(const float *__restrict__ g, int rows, int C, float *__restrict__ part, int bx, int by, int gy) {
     constexpr int W = VEC ? 4 : 1;
-    rows = dyn_extent(rows_dev, rows);
     __shared__ float red[4][64 * W];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = (blockIdx.x * 64 + lane) * W;
-    const int per = (rows + gridDim.y - 1) / gridDim.y;
-    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    const int c = (bx * 64 + lane) * W;
+    const int per = (rows + gy - 1) / gy;
+    const int r0 = by * per, r1 = min(rows, r0 + per);
     float s[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) s[k] = 0.f;
@@ -166,8 +165,14 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             const int j = lane * W + k;
-            part[(size_t)blockIdx.y * C + c + k] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+            part[(size_t)by * C + c + k] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
         }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ g, int rows, int C, float *__restrict__ part,
+                                                        const int *__restrict__ rows_dev) {
+    colsum_partial_block<VEC>(g, dyn_extent(rows_dev, rows), C, part, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // 16 columns x 16 split-groups per block: a one-thread-per-column loop over the 64 partials is 64 dependent-latency
@@ -210,32 +215,41 @@ struct GemmDyn {
     const int *m = nullptr, *k0 = nullptr;
 };
 
+struct GemmArgs {
+    Operand A0, B0;
+    int K0;
+    Operand A1, B1;
+    int K1, M, N;
+    const float *bias;
+    float *C;
+    long long ldc;
+    float *slab;
+    Twin twin;
+    const int *m_dev, *k0_dev;     // device extents (GemmDyn)
+    int gx, gy, gz;                // the launch shape this problem was planned for: row tiles, column tiles (x2 in twin mode), splits
+};
+
+// One block of a planned GEMM: tile (bx, by), split bz.
 template <int TM, int TN, int WM, int WN, int LA, int LB>
-__global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Operand A1, Operand B1, int K1, int M, int N,
-                                              const float *__restrict__ bias, float *__restrict__ C, long long ldc,
-                                              float *__restrict__ slab, Twin twin, const int *__restrict__ m_dev,
-                                              const int *__restrict__ k0_dev) {
+__device__ __forceinline__ void gemm_block(GemmArgs p, int bx, int by, int z, float *As, float *Bs) {
     constexpr int NT = TN / WN / 32;
-    // device extents: the true row count / the true depth of product 0 (the launch covers the capacities).  The slab
-    // stride stays the capacity M: k_slab_reduce is given the same.
-    const int M_cap = M;
-    M = dyn_extent(m_dev, M);
-    K0 = dyn_extent(k0_dev, K0);
-    if ((int)blockIdx.x * TM >= M) return;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *As = reinterpret_cast<float *>(smem);
-    float *Bs = As + Tile<TM>::FLOATS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave % WM, wn = wave / WM;
-    const int splits = gridDim.z, z = blockIdx.z;
-    int by = blockIdx.y;
-    if (twin.tiles_n > 0 && by >= twin.tiles_n) {           // second result: its own B, C and slab region
-        by -= twin.tiles_n;
-        B0 = twin.B;
-        C = twin.C;
+    const int splits = p.gz;
+    // device extents: the true row count / the true depth of product 0 (the launch covers the capacities).  The slab
+    // stride stays the capacity M: k_slab_reduce is given the same.
+    const int M_cap = p.M;
+    const int M = dyn_extent(p.m_dev, p.M), N = p.N, K0 = dyn_extent(p.k0_dev, p.K0), K1 = p.K1;
+    if (bx * TM >= M) return;
+    Operand B0 = p.B0;
+    float *C = p.C, *slab = p.slab;
+    if (p.twin.tiles_n > 0 && by >= p.twin.tiles_n) {       // second result: its own B, C and slab region
+        by -= p.twin.tiles_n;
+        B0 = p.twin.B;
+        C = p.twin.C;
         slab += (size_t)splits * M_cap * N;
     }
-    const int m0 = blockIdx.x * TM, n0 = by * TN;
+    const int m0 = bx * TM, n0 = by * TN;
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -245,21 +259,85 @@ __global__ __launch_bounds__(256) void k_gemm(Operand A0, Operand B0, int K0, Op
     const int per0 = K0 > 0 ? ((K0 + splits - 1) / splits + GK - 1) / GK * GK : 0;
     const int per1 = K1 > 0 ? ((K1 + splits - 1) / splits + GK - 1) / GK * GK : 0;
     const int kb0 = z * per0, ke0 = min(K0, kb0 + per0), kb1 = z * per1, ke1 = min(K1, kb1 + per1);
-    mfma_accumulate<TM, TN, WM, WN, LA, LB>(acc, A0, B0, kb0, ke0, A1, B1, kb1, ke1, m0, n0, M, N, As, Bs);
+    mfma_accumulate<TM, TN, WM, WN, LA, LB>(acc, p.A0, B0, kb0, ke0, p.A1, p.B1, kb1, ke1, m0, n0, M, N, As, Bs);
     // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     float *dst = splits > 1 ? slab + (size_t)z * M_cap * N : C;
-    const long long ld = splits > 1 ? (long long)N : ldc;
+    const long long ld = splits > 1 ? (long long)N : p.ldc;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = n0 + wn * (TN / WN) + t * 32 + (lane & 31);
         if (n >= N) continue;
-        const float b = (bias && splits == 1) ? bias[n] : 0.0f;
+        const float b = (p.bias && splits == 1) ? p.bias[n] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m < M) dst[(size_t)m * ld + n] = acc[t][r] + b;
         }
     }
+}
+
+template <int TM, int TN, int WM, int WN, int LA, int LB>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *As = reinterpret_cast<float *>(smem);
+    gemm_block<TM, TN, WM, WN, LA, LB>(p, blockIdx.x, blockIdx.y, blockIdx.z, As, As + Tile<TM>::FLOATS);
+}
+
+// Four independent pieces of a small layer's backward pass that only share grad_out, as ONE launch (sage_conv_backward):
+//   blocks [0, n0)            grad_x[:n_dst] = grad_out * W_r  and  grad_agg = grad_out * W_l   (twin GEMM p0, operands KC x OC)
+//   blocks [n0, n0 + n1)      the split-K slabs of grad_w_l / grad_w_r                          (twin GEMM p1, operands OC x OC)
+//   the next zero_blocks      grad_x[n_dst : n_src] = 0 (the rows only the scatter adds to)
+//   the last cs_gx * cs_gy    partial column sums of grad_out (the bias gradient)
+// Each of them alone is a 5-13 us launch of ~200 blocks that leaves half the chip idle: 36 us in sequence, one launch together.
+struct DualAux {
+    float *zero_x;                 // grad_x, or null
+    int zero_C, zero_r0, zero_r1;
+    const int *zero_r0_dev, *zero_r1_dev;
+    int zero_blocks;
+    const float *cs_g;             // grad_out for the column sums, or null
+    int cs_rows, cs_C;
+    float *cs_part;
+    const int *cs_rows_dev;
+    int cs_gx, cs_gy;
+};
+
+__device__ __forceinline__ void zero_rows_block(float *__restrict__ x, int C, int r0, int r1, int b, int nb) {
+    if (r1 <= r0) return;
+    const size_t n = (size_t)(r1 - r0) * C;
+    const size_t stride = (size_t)nb * blockDim.x;
+    float *base = x + (size_t)r0 * C;
+    const size_t i = (size_t)b * blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+        const size_t n4 = n >> 2;
+        for (size_t q = i; q < n4; q += stride) reinterpret_cast<float4 *>(base)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t q = (n4 << 2) + i; q < n; q += stride) base[q] = 0.f;
+    } else {
+        for (size_t q = i; q < n; q += stride) base[q] = 0.f;
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_gemm_dual(GemmArgs p0, GemmArgs p1, DualAux aux) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *As = reinterpret_cast<float *>(smem), *Bs = As + Tile<TM>::FLOATS;
+    int b = blockIdx.x;
+    const int n0 = p0.gx * p0.gy * p0.gz, n1 = p1.gx * p1.gy * p1.gz;
+    if (b < n0) {
+        gemm_block<TM, TN, WM, WN, LAYOUT_KC_VEC, LAYOUT_OC_VEC>(p0, b % p0.gx, (b / p0.gx) % p0.gy, b / (p0.gx * p0.gy), As, Bs);
+        return;
+    }
+    b -= n0;
+    if (b < n1) {
+        gemm_block<TM, TN, WM, WN, LAYOUT_OC_VEC, LAYOUT_OC_VEC>(p1, b % p1.gx, (b / p1.gx) % p1.gy, b / (p1.gx * p1.gy), As, Bs);
+        return;
+    }
+    b -= n1;
+    if (b < aux.zero_blocks) {
+        zero_rows_block(aux.zero_x, aux.zero_C, dyn_extent(aux.zero_r0_dev, aux.zero_r0), dyn_extent(aux.zero_r1_dev, aux.zero_r1), b, aux.zero_blocks);
+        return;
+    }
+    b -= aux.zero_blocks;
+    if (aux.cs_g) colsum_partial_block<true>(aux.cs_g, dyn_extent(aux.cs_rows_dev, aux.cs_rows), aux.cs_C, aux.cs_part, b % aux.cs_gx, b / aux.cs_gx, aux.cs_gy);
 }
 
 // results = 2 in twin mode: the second result's slabs follow the first's.
@@ -276,6 +354,56 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float *__restrict__ s
     }
 }
 
+static GemmArgs gemm_args(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1, int M, int N,
+                          const float *bias, float *C, long long ldc, int splits, float *slab, const Twin &twin, const GemmDyn &dyn,
+                          int TM, int TN) {
+    GemmArgs p;
+    p.A0 = A0; p.B0 = B0; p.K0 = K0; p.A1 = A1; p.B1 = B1; p.K1 = K1; p.M = M; p.N = N; p.bias = bias; p.C = C; p.ldc = ldc;
+    p.slab = slab; p.twin = twin; p.m_dev = dyn.m; p.k0_dev = dyn.k0;
+    const int tiles_n = (N + TN - 1) / TN;
+    if (p.twin.C) p.twin.tiles_n = tiles_n;
+    p.gx = (M + TM - 1) / TM; p.gy = p.twin.C ? 2 * tiles_n : tiles_n; p.gz = splits;
+    return p;
+}
+
+// The two reductions behind k_gemm_dual in one launch: blocks [0, reduce_blocks) add the split-K slabs of both weight
+// gradients, the rest fold the partial column sums of the bias gradient (k_colsum_final's block shape).
+__device__ __forceinline__ void colsum_final_block(const float *__restrict__ part, int splits, int C, float *__restrict__ out, int bx) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = bx * 16 + cl;
+    float s = 0.f;
+    if (c < C)
+#pragma unroll 4
+        for (int z = grp; z < splits; z += 16) s += part[(size_t)z * C + c];
+    red[grp][cl] = s;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][cl];
+        out[c] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bwd_finals(const float *__restrict__ slab, int splits, size_t elems, int N, float *__restrict__ C,
+                                                    float *__restrict__ C2, long long ldc, int reduce_blocks,
+                                                    const float *__restrict__ cs_part, int cs_splits, int cs_C, float *__restrict__ cs_out) {
+    if ((int)blockIdx.x < reduce_blocks) {
+        for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < elems * 2; t += (size_t)reduce_blocks * blockDim.x) {
+            const int which = t >= elems;
+            const size_t i = t - (which ? elems : 0);
+            const float *src = slab + (size_t)which * splits * elems + i;
+            float s = 0.f;
+#pragma unroll 4
+            for (int z = 0; z < splits; ++z) s += src[(size_t)z * elems];
+            (which ? C2 : C)[(i / N) * ldc + (i % N)] = s;
+        }
+        return;
+    }
+    colsum_final_block(cs_part, cs_splits, cs_C, cs_out, (int)blockIdx.x - reduce_blocks);
+}
+
 template <int TM, int TN, int WM, int WN, int LA, int LB>
 static int launch_gemm_layout(const Operand &A0, const Operand &B0, int K0, const Operand &A1, const Operand &B1, int K1,
                               int M, int N, const float *bias, float *C, long long ldc, int splits, float *slab,
@@ -286,12 +414,8 @@ static int launch_gemm_layout(const Operand &A0, const Operand &B0, int K0, cons
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm<TM, TN, WM, WN, LA, LB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         opt_in.mark();
     }
-    Twin tw = twin;
-    const int tiles_n = (N + TN - 1) / TN;
-    if (tw.C) tw.tiles_n = tiles_n;
-    dim3 grid((M + TM - 1) / TM, tw.C ? 2 * tiles_n : tiles_n, splits);
-    hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN, LA, LB>), grid, dim3(256), lds, stream, A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, slab, tw,
-                       dyn.m, dyn.k0);
+    const GemmArgs p = gemm_args(A0, B0, K0, A1, B1, K1, M, N, bias, C, ldc, splits, slab, twin, dyn, TM, TN);
+    hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN, LA, LB>), dim3(p.gx, p.gy, p.gz), dim3(256), lds, stream, p);
     return POPE_OK;
 }
 
@@ -605,16 +729,57 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
     // grad_w_l[o, c] = sum_i grad_out[i, o] * agg[i, c];  grad_w_r likewise with x_dst   (depth = rows i)
     bool used = false;
     if ((rc = gemm_streamk_tn(grad_out, agg, x_src, n_dst, c_out, c_in, grad_w_l, grad_w_r, slab, slab_bytes, stream, &used, n_dst_dev))) return rc;
+    const Operand Gt{grad_out, 1, c_out};                       // (outer o, depth i) -> grad_out[i * c_out + o]
+    const Operand AggT{agg, 1, c_in}, XdT{x_src, 1, c_in};      // (outer c, depth i)
+    const Operand G{grad_out, c_out, 1};                        // (outer i, depth o)
+    const Operand WrT{w_r, 1, c_in}, WlT{w_l, 1, c_in};         // (outer c, depth o) -> w[o * c_in + c]
+    const bool colsum_vec = (c_out & 3) == 0 && aligned16(grad_out);
+
+    // Small layer (the weight gradients did not qualify for the stream-K kernel) with an input gradient: the two twin GEMMs,
+    // the zeroing of grad_x's scatter-only rows and the bias gradient's partial sums all read grad_out and nothing of one
+    // another -- one launch (k_gemm_dual), then one launch for both reductions, then the scatter.
+    const bool dual = !used && grad_x && !side && g_gemm_force_tile == 0 && splits > 1 && grad_b_l && colsum_vec &&
+                      pick_layout(G, (int)n_dst, c_out) == LAYOUT_KC_VEC && pick_layout(WrT, c_in, c_out) == LAYOUT_OC_VEC &&
+                      pick_layout(WlT, c_in, c_out) == LAYOUT_OC_VEC && pick_layout(Gt, c_out, (int)n_dst) == LAYOUT_OC_VEC &&
+                      pick_layout(AggT, c_in, (int)n_dst) == LAYOUT_OC_VEC && pick_layout(XdT, c_in, (int)n_dst) == LAYOUT_OC_VEC &&
+                      tiles((int)n_dst, c_in, 64, 128) * 2 < 384 && tiles(c_out, c_in, 64, 128) * splits * 2 < 384;   // both would take 64 x 64 tiles
+    if (dual) {
+        GemmDyn dx, dw;
+        dx.m = n_dst_dev;
+        dw.k0 = n_dst_dev;
+        const GemmArgs p0 = gemm_args(G, WrT, c_out, none, none, 0, (int)n_dst, c_in, nullptr, grad_x, c_in, 1, nullptr, Twin{WlT, gagg, 0}, dx, 64, 64);
+        const GemmArgs p1 = gemm_args(Gt, AggT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_l, c_in, splits, slab, Twin{XdT, grad_w_r, 0}, dw, 64, 64);
+        DualAux aux;
+        aux.zero_x = n_src > n_dst ? grad_x : nullptr;
+        aux.zero_C = c_in; aux.zero_r0 = (int)n_dst; aux.zero_r1 = (int)n_src; aux.zero_r0_dev = n_dst_dev; aux.zero_r1_dev = n_src_dev;
+        aux.zero_blocks = aux.zero_x ? (int)capped_grid((size_t)n_src * c_in / 4 / 8 + 1, 256, 256) : 0;
+        aux.cs_g = grad_out; aux.cs_rows = (int)n_dst; aux.cs_C = c_out; aux.cs_part = colsum; aux.cs_rows_dev = n_dst_dev;
+        aux.cs_gx = (c_out + 255) / 256; aux.cs_gy = COLSUM_SPLITS;
+        const size_t lds = tile_lds_bytes<64, 64>();
+        static LdsOptIn opt_in;
+        if (!opt_in.done()) {
+            POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_dual<64, 64, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            opt_in.mark();
+        }
+        const int blocks = p0.gx * p0.gy * p0.gz + p1.gx * p1.gy * p1.gz + aux.zero_blocks + aux.cs_gx * aux.cs_gy;
+        hipLaunchKernelGGL((k_gemm_dual<64, 64, 2, 2>), dim3(blocks), dim3(256), lds, stream, p0, p1, aux);
+        const int reduce_blocks = (int)capped_grid((size_t)c_out * c_in * 2, 256);
+        hipLaunchKernelGGL(k_bwd_finals, dim3(reduce_blocks + (c_out + 15) / 16), dim3(256), 0, stream, slab, splits, (size_t)c_out * c_in, c_in,
+                           grad_w_l, grad_w_r, (long long)c_in, reduce_blocks, colsum, COLSUM_SPLITS, c_out, grad_b_l);
+        if (nnz > 0)
+            hipLaunchKernelGGL(k_scatter_mean, dim3(capped_grid((size_t)n_dst * ((c_in + 255) / 256) * 64, 256)), dim3(256), 0, stream, rowptr, col,
+                               (int)n_dst, gagg, c_in, grad_x, n_dst_dev);
+        POPE_HIP(hipGetLastError());
+        return POPE_OK;
+    }
     if (!used) {
-        const Operand Gt{grad_out, 1, c_out};                   // (outer o, depth i) -> grad_out[i * c_out + o]
-        const Operand AggT{agg, 1, c_in}, XdT{x_src, 1, c_in};  // (outer c, depth i)
         GemmDyn dyn;
         dyn.k0 = n_dst_dev;
         if ((rc = gemm(Gt, AggT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_l, c_in, splits, slab, stream,
                        Twin{XdT, grad_w_r, 0}, dyn))) return rc;
     }
     if (grad_b_l) {
-        if ((c_out & 3) == 0 && aligned16(grad_out))
+        if (colsum_vec)
             hipLaunchKernelGGL(k_colsum_partial<true>, dim3((c_out + 255) / 256, COLSUM_SPLITS), dim3(256), 0, s_bias, grad_out, (int)n_dst, c_out, colsum, n_dst_dev);
         else
             hipLaunchKernelGGL(k_colsum_partial<false>, dim3((c_out + 63) / 64, COLSUM_SPLITS), dim3(256), 0, s_bias, grad_out, (int)n_dst, c_out, colsum, n_dst_dev);
@@ -625,8 +790,6 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
         if (n_src > n_dst)
             hipLaunchKernelGGL(k_zero_rows, dim3(capped_grid((size_t)(n_src - (dims ? 0 : n_dst)) * c_in / 4 + 1, 256)), dim3(256), 0, s_x, grad_x, c_in,
                                (int)n_dst, (int)n_src, n_dst_dev, n_src_dev);
-        const Operand G{grad_out, c_out, 1};                    // (outer i, depth o)
-        const Operand WrT{w_r, 1, c_in}, WlT{w_l, 1, c_in};     // (outer c, depth o) -> w[o * c_in + c]
         GemmDyn dyn;
         dyn.m = n_dst_dev;
         if ((rc = gemm(G, WrT, c_out, none, none, 0, (int)n_dst, c_in, nullptr, grad_x, c_in, 1, nullptr, s_x,

@@ -287,7 +287,7 @@ def bad_label_flag(device) -> torch.Tensor:
 
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, ignore_index):
+    def forward(ctx, logits, target, ignore_index, unit_upstream=False):
         lib = _lib.load()
         if not logits.is_cuda:
             raise RuntimeError("cross_entropy runs on the GPU only (no CPU fallback)")
@@ -299,29 +299,38 @@ class _CrossEntropyFn(torch.autograd.Function):
         rows = torch.empty(n, dtype=torch.float32, device=dev)
         with on_device(dev):
             check(lib.sage_cross_entropy_forward(ptr(logits), ptr(target), n, c, ignore_index, ptr(out), ptr(grad),
-                                                 ctypes.c_void_p(out.data_ptr() + 4), ptr(rows), ptr(bad_label_flag(dev)), _stream()))
+                                                 ctypes.c_void_p(out.data_ptr() + 4), ptr(rows), ptr(bad_label_flag(dev)),
+                                                 1 if unit_upstream else 0, _stream()))
         ctx.save_for_backward(grad, out)
+        ctx.unit_upstream = bool(unit_upstream)
         return out[0]
 
     @staticmethod
     def backward(ctx, grad_loss):
         lib = _lib.load()
         grad, out = ctx.saved_tensors
+        if ctx.unit_upstream:                 # the forward launch already produced d(mean loss) / d(logits): nothing to launch
+            return grad, None, None, None
         n, c = grad.shape
         grad_loss = grad_loss.contiguous()
         res = torch.empty_like(grad)
         with on_device(grad.device):
             check(lib.sage_cross_entropy_backward(ptr(grad), n, c, ptr(grad_loss), ctypes.c_void_p(out.data_ptr() + 4), ptr(res),
                                                   _stream()))
-        return res, None, None
+        return res, None, None, None
 
 
-def cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = -100, unit_upstream: bool = False) -> torch.Tensor:
     """``F.cross_entropy(logits, target)`` (main.py:216: mean over the rows, integer labels) in two launches forward and
-    one backward: the softmax - onehot gradient is produced with the loss and only scaled in the backward pass."""
+    one backward: the softmax - onehot gradient is produced with the loss and only scaled in the backward pass.
+
+    ``unit_upstream=True`` is a promise that the loss is the root of the backward pass and is seeded with a gradient of 1
+    (``loss.backward()``): the whole forward pass is then ONE launch that also scales the gradient by 1 / count, and the
+    backward pass launches nothing.  Any other upstream gradient would be ignored -- only a training step that owns its
+    ``backward()`` call (graphpope_amd.train.SageTrainStep) sets it."""
     if target.dtype != torch.int64 or target.dim() != 1 or logits.dim() != 2 or target.shape[0] != logits.shape[0]:
         raise ValueError("cross_entropy: logits [N, C] float32 and int64 labels [N] expected")
-    return _CrossEntropyFn.apply(logits, target.contiguous(), int(ignore_index))
+    return _CrossEntropyFn.apply(logits, target.contiguous(), int(ignore_index), bool(unit_upstream))
 
 
 class SAGE(nn.Module):

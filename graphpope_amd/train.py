@@ -102,7 +102,7 @@ class SageTrainStep:
         for p in self.params:
             p.grad = None
         logits = self.model(x, self.batch.adjs)
-        loss = cross_entropy(logits, self.y)                         # main.py:216
+        loss = cross_entropy(logits, self.y, unit_upstream=True)      # main.py:216; the backward pass below is seeded with 1
         loss.backward(gradient=self._one)
         # detached views of the results: nothing outside this call keeps the autograd graph (and its AccumulateGrad nodes,
         # which remember the stream they were created on) alive into the next call or into the capture

@@ -510,10 +510,13 @@ int sage_copy_segments(int32_t n, void *const *dst, const void *const *src, cons
  * softmax(logits) - onehot(target) [N, C] (zero rows for ignored labels); backward multiplies it by the upstream scalar
  * gradient and by 1 / count, both read on the device.  row_scratch: N floats.  *bad_label (device int, zeroed by the
  * caller) is set when a label lies outside [0, C) and is not ignore_index.  Asynchronous.
+ * fused != 0: ONE launch for the whole forward pass, and grad_unscaled then holds the gradient ALREADY SCALED by 1 / count,
+ * i.e. the gradient of the mean loss for an upstream gradient of 1 -- a training step that seeds its backward pass with 1
+ * (loss.backward()) needs no backward launch at all; sage_cross_entropy_backward must not be applied to it.
  */
 int sage_cross_entropy_forward(const float *logits, const int64_t *target, int64_t N, int32_t C, int64_t ignore_index,
                                float *loss, float *grad_unscaled, float *inv_count, float *row_scratch, int32_t *bad_label,
-                               void *stream);
+                               int32_t fused, void *stream);
 int sage_cross_entropy_backward(const float *grad_unscaled, int64_t N, int32_t C, const float *grad_loss, const float *inv_count,
                                 float *grad_logits, void *stream);
 

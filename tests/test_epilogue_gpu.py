@@ -148,6 +148,25 @@ def test_cross_entropy_matches_torch(n, c, dev):
     assert float(b.grad[::7].abs().max()) == 0.0                          # ignored rows get no gradient
 
 
+@pytest.mark.parametrize("n,c", [(1550, 256), (1550, 7), (33, 3), (5, 1000), (4097, 64)])
+def test_fused_cross_entropy_with_unit_upstream_matches_torch(n, c, dev):
+    """unit_upstream=True: ONE forward launch (every block counts the labels, the last block to arrive folds the row losses)
+    that already holds d(mean loss)/d(logits); loss.backward() launches nothing.  Repeated: the arrival counters reset."""
+    from graphpope_amd.sage import cross_entropy
+    torch.manual_seed(n * 3 + c)
+    for rep in range(3):
+        logits = (torch.randn(n, c, device=dev) * 3)
+        y = torch.randint(0, c, (n,), device=dev)
+        y[::5] = -100
+        a, b = logits.clone().requires_grad_(True), logits.clone().requires_grad_(True)
+        la, lb = F.cross_entropy(a, y), cross_entropy(b, y, unit_upstream=True)
+        assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(la)))
+        la.backward(); lb.backward()
+        _close(b.grad, a.grad, 1e-5)
+        assert float(b.grad[::5].abs().max()) == 0.0
+    assert torch.isnan(cross_entropy(torch.randn(8, 5, device=dev), torch.full((8,), -100, device=dev), unit_upstream=True))
+
+
 def test_cross_entropy_all_ignored_and_bad_labels(dev):
     from graphpope_amd.sage import bad_label_flag, cross_entropy
     logits = torch.randn(8, 5, device=dev)

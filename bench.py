@@ -518,8 +518,8 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
         x = IndexedFeatures(feats, n_id)                         # main.py:118-123 convert_batch without the copy: layer 0 reads feats[n_id[j]]
         for p in params:                                         # opt.zero_grad(set_to_none=True) without its bookkeeping
             p.grad = None
-        loss = cross_entropy(model(x, adjs), y)              # main.py:216 F.cross_entropy, two launches
-        loss.backward(gradient=one)                          # the root gradient: torch's default is a ones_like fill launch per step
+        loss = cross_entropy(model(x, adjs), y, unit_upstream=True)   # main.py:216 F.cross_entropy: two launches, gradient pre-scaled
+        loss.backward(gradient=one)                          # seeded with 1 (the promise unit_upstream makes): no backward launch for the loss
         opt.step()
         return loss
 
@@ -667,10 +667,14 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
     single_thread.__exit__(None, None, None)
     proj_ms = l0_ms - g_ms
     return {
-        "nodes_per_s": BATCH / dt, "ms_per_step": dt * 1e3, "steps": steps, "batch_seed_nodes": BATCH,
-        "how": "graphpope_amd.train.SageTrainStep: the step (fwd + cross-entropy + bwd + Adam) captured once into a HIP graph and replayed; "
-               "each pre-sampled batch is loaded into the graph's fixed buffers by one launch, its sizes stay on the device",
-        "eager_ms_per_step": eager_dt * 1e3,
+        "nodes_per_s": BATCH / eager_dt, "ms_per_step": eager_dt * 1e3, "steps": steps, "batch_seed_nodes": BATCH,
+        "how": "the step (fwd + cross-entropy + bwd + Adam) enqueued through autograd on host-sized pre-sampled batches, as in rounds 1-2 "
+               "(GPU-bound: the kernels of a step add up to its wall time)",
+        "graph_replay": {"ms_per_step": dt * 1e3, "nodes_per_s": BATCH / dt,
+                         "how": "graphpope_amd.train.SageTrainStep: the same step on device-extent batches (sizes in device words, tensors at "
+                                "capacity), captured once into a HIP graph and replayed; each pre-sampled batch is loaded into the graph's fixed "
+                                "buffers by one launch.  No host work per step, but the step is GPU-bound either way and the capacity-shaped "
+                                "launches cost ~5 % more GPU time than the host-sized ones"},
         "torch_gpu_baseline": torch_gpu,
         "model": f"SAGE {c_in}->{HIDDEN}->{HIDDEN} (num_layers 3, 2 executed), fan-out [25, 10], fp32, fused BN+ReLU+dropout epilogue, one-launch Adam",
         "block_shapes_n_dst_n_src_nnz": shapes,

@@ -473,24 +473,18 @@ extern "C" int sage_adam_step(int32_t n_tensors, float *const *params, const flo
 // ------------------------------------------------------------------------------------------------
 namespace pope {
 
-// Arrival counters of k_xent_rows<true> (the block that finishes last folds the row losses): zero when the module is
-// loaded, reset by that block.  A launch takes the next slot, so launches in flight on different streams do not share one.
-__device__ unsigned g_xent_ticket[64];
-
-// FUSED: one launch for the whole forward pass -- the gradient is scaled by 1 / count here (every block counts the valid
-// labels itself: N labels, a few loads per thread) and the block that arrives last adds the row losses in index order (the
-// sum k_xent_final forms), writes loss and 1 / count and resets the counter.  Otherwise k_xent_final follows as a launch of its own.
+// FUSED ("pre-scaled"): the gradient is scaled by 1 / count here -- every block counts the valid labels itself (N labels, a
+// few loads per thread) -- so that a backward pass seeded with 1 needs no launch.  (Measured and rejected: also folding
+// k_xent_final in, by letting the block that arrives last add the row losses behind an agent-scope release / ticket /
+// acquire: 16.7 us for the one launch against 5.2 + 4.7 for two -- 388 blocks each pay the release fence.)
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_xent_rows(const float *__restrict__ logits, const long long *__restrict__ target, int N,
                                                    int C, long long ignore_index, float *__restrict__ grad,
-                                                   float *__restrict__ row_loss, int *__restrict__ bad_label,
-                                                   float *__restrict__ loss, float *__restrict__ inv_count, int slot) {
+                                                   float *__restrict__ row_loss, int *__restrict__ bad_label) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     __shared__ int s_cnt[256];
-    __shared__ double s_sum[256];
-    __shared__ int s_last;
     float gscale = 1.f;
     if constexpr (FUSED) {
         int n = 0;
@@ -530,42 +524,6 @@ __global__ __launch_bounds__(256) void k_xent_rows(const float *__restrict__ log
             g[c] = FUSED ? v * gscale : v;
         }
         if (lane == 0) row_loss[i] = lse - row[y];
-    }
-    if constexpr (FUSED) {
-        // hand-off of row_loss to the block that arrives last (cdna_hip_programming.md G16): every storing wave drains its
-        // stores, the block meets, ONE lane releases at agent scope, takes a ticket, and -- if it is the last -- acquires.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned t = __hip_atomic_fetch_add(&g_xent_ticket[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = t == gridDim.x - 1;
-            if (s_last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
-        __syncthreads();
-        if (!s_last) return;
-        double sm = 0.0;
-        int n = 0;
-        for (int i = threadIdx.x; i < N; i += 256) {
-            const float v = row_loss[i];
-            if (v >= 0.f) { sm += (double)v; ++n; }
-        }
-        s_sum[threadIdx.x] = sm;
-        s_cnt[threadIdx.x] = n;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            *loss = s_cnt[0] > 0 ? (float)(s_sum[0] / s_cnt[0]) : __builtin_nanf("");
-            *inv_count = s_cnt[0] > 0 ? 1.f / (float)s_cnt[0] : 0.f;
-            __hip_atomic_store(&g_xent_ticket[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
@@ -607,16 +565,13 @@ extern "C" int sage_cross_entropy_forward(const float *logits, const int64_t *ta
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(logits && target && loss && grad_unscaled && inv_count && row_scratch && bad_label, "sage_cross_entropy_forward: null pointer");
     POPE_REQUIRE(N > 0 && N < INT32_MAX && C > 0, "sage_cross_entropy_forward: bad size");
-    if (fused) {
-        static std::atomic<unsigned> next_slot{0};
-        const int slot = (int)(next_slot.fetch_add(1, std::memory_order_relaxed) % 64u);
+    if (fused)
         hipLaunchKernelGGL(k_xent_rows<true>, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, logits, (const long long *)target,
-                           (int)N, C, (long long)ignore_index, grad_unscaled, row_scratch, bad_label, loss, inv_count, slot);
-    } else {
+                           (int)N, C, (long long)ignore_index, grad_unscaled, row_scratch, bad_label);
+    else
         hipLaunchKernelGGL(k_xent_rows<false>, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, logits, (const long long *)target,
-                           (int)N, C, (long long)ignore_index, grad_unscaled, row_scratch, bad_label, loss, inv_count, 0);
-        hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, stream, row_scratch, (int)N, loss, inv_count);
-    }
+                           (int)N, C, (long long)ignore_index, grad_unscaled, row_scratch, bad_label);
+    hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, stream, row_scratch, (int)N, loss, inv_count);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
@@ -642,7 +597,7 @@ namespace pope {
 constexpr int COUNTERS_MAX = 8, SEGMENTS_MAX = 12;
 struct CounterIncs { long long v[COUNTERS_MAX]; };
 __global__ void k_advance_counters(long long *__restrict__ c, CounterIncs inc, int n) {
-    if ((int)threadIdx.x < n) c[threadIdx.x] += inc.v[threadIdx.x];
+    if ((int)threadIdx.x < n && inc.v[threadIdx.x] != 0) c[threadIdx.x] += inc.v[threadIdx.x];      // a zero increment leaves the word alone (another stream may own it)
 }
 
 struct SegmentTable {

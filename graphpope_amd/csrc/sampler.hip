@@ -15,8 +15,6 @@
 #include <cstring>
 
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "common.h"
 
@@ -114,61 +112,9 @@ __global__ __launch_bounds__(256) void k_sample_pick(const int *__restrict__ row
     }
 }
 
-// Device-extent path: the two counting passes are not launches of their own, they are the INPUT ITERATORS of the scans.
-struct CountFn {                         // slot i of the first scan: neighbours target i keeps (0 past the true target count)
-    const int *rowptr;
-    const long long *targets;
-    const int *t_dev;
-    int T_cap, fanout;
-    __device__ int operator()(int i) const {
-        const int T = true_count(t_dev, T_cap);
-        if (i >= T) return 0;
-        const long long g = targets[i];
-        const int d = rowptr[g + 1] - rowptr[g];
-        return d <= fanout ? d : fanout;
-    }
-};
-
-struct FirstFn {                         // slot p of the second scan: 1 where sampled slot p is the first occurrence of a new node
-    const int *picked, *out_rowptr, *map, *t_dev;
-    int T_cap;
-    __device__ int operator()(int p) const {
-        const int T = true_count(t_dev, T_cap);
-        return (p < out_rowptr[T] && map[picked[p]] == T + p) ? 1 : 0;
-    }
-};
-
-// k_sample_pick with the targets' own bookkeeping folded in (the device-extent path has no count kernel): the thread of a
-// target's slot 0 enters the target into `map` (key = its index; atomicMin, like the sampled slots, so the order in which
-// the two kinds of entries arrive does not matter) and into n_id.
-__global__ __launch_bounds__(256) void k_sample_pick_dev(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                         const long long *__restrict__ targets, int T_cap, int fanout,
-                                                         unsigned long long seed, int hop, const int *__restrict__ out_rowptr,
-                                                         int *__restrict__ picked, int *__restrict__ map, const int *__restrict__ t_dev,
-                                                         const unsigned long long *__restrict__ seed_dev, long long *__restrict__ out_n_id,
-                                                         int *__restrict__ dims) {
-    const int T = true_count(t_dev, T_cap);
-    if (seed_dev) seed += *seed_dev;
-    if (blockIdx.x == 0 && threadIdx.x == 0) dims[0] = T;          // n_dst of this block
-    const long long total = (long long)T * fanout;
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
-        const int i = (int)(q / fanout), j = (int)(q % fanout);
-        const int g = (int)targets[i];
-        if (j == 0) {
-            atomicMin(&map[g], i);
-            out_n_id[i] = g;
-        }
-        const int beg_out = out_rowptr[i], c = out_rowptr[i + 1] - beg_out;
-        if (j >= c) continue;
-        const int beg = rowptr[g], d = rowptr[g + 1] - beg;
-        const int pick = d <= c ? j : feistel_perm(j, d, row_key(seed, hop, g));
-        const int u = col[beg + pick];
-        const int p = beg_out + j;
-        picked[p] = u;
-        atomicMin(&map[u], T + p);
-    }
-}
-
+// (Measured and rejected, round 3: the count and flag passes as rocprim transform iterators feeding the scans instead of
+//  launches of their own -- two launches less per hop, but the scans went from ~5 us to 19-21 us each: their per-item
+//  functor loads (rowptr[targets[i]], map[picked[p]]) run at ITEMS_PER_THREAD-fold lower parallelism than a flat kernel.)
 // fanout < 0 ("all neighbours"): rows are copied whole, one thread per output slot.
 __global__ __launch_bounds__(256) void k_sample_all(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                     const long long *__restrict__ targets, int T,
@@ -350,36 +296,6 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
     return POPE_OK;
 }
 
-// One hop of the device-extent path: 7 launches (clear, scan x2, pick, scan x2, relabel) -- the count and flag passes ride
-// inside the scans as transform iterators.
-static int enqueue_hop_device(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *targets, int64_t t_cap, int32_t fanout,
-                              uint64_t seed, int32_t hop, int32_t *out_rowptr, int32_t *out_col, int64_t cap, int64_t *out_n_id, void *scratch,
-                              size_t scratch_bytes, const int *t_dev, int *dims, const unsigned long long *seed_dev, hipStream_t stream) {
-    const SampleLayout L = sample_layout(N, t_cap, cap);
-    if (scratch_bytes < L.total) {
-        set_error("sage_sample_batch_device: scratch %zu < %zu bytes", scratch_bytes, L.total);
-        return POPE_ERR_WORKSPACE;
-    }
-    char *base = (char *)scratch;
-    int *picked = (int *)(base + L.picked), *rank = (int *)(base + L.rank), *map = (int *)(base + L.map);
-    void *scan_tmp = base + L.scan;
-    size_t sb = L.total - L.scan;
-    const int T = (int)t_cap;
-    hipLaunchKernelGGL(k_sample_clear, dim3(capped_grid((size_t)N / 4 + 1, 256)), dim3(256), 0, stream, map, (int)N);
-    const CountFn count{rowptr, (const long long *)targets, t_dev, T, fanout};
-    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), count), out_rowptr, 0,
-                                     (size_t)T + 1, rocprim::plus<int>(), stream));
-    hipLaunchKernelGGL(k_sample_pick_dev, dim3(capped_grid((size_t)T * fanout, 256)), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T,
-                       fanout, (unsigned long long)seed, hop, out_rowptr, picked, map, t_dev, seed_dev, (long long *)out_n_id, dims);
-    const FirstFn first{picked, out_rowptr, map, t_dev, T};
-    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), first), rank, 0,
-                                     (size_t)cap + 1, rocprim::plus<int>(), stream));
-    hipLaunchKernelGGL(k_sample_relabel, dim3((unsigned)((cap + 256) / 256)), dim3(256), 0, stream, picked, out_rowptr, T, map, rank, out_col,
-                       (long long *)out_n_id, (long long *)nullptr, t_dev, dims);
-    POPE_HIP(hipGetLastError());
-    return POPE_OK;
-}
-
 // Device-extent form of sage_sample_batch: NO host synchronisation.  Every hop runs over its capacity (hop h may meet up to
 // t_cap[h] targets) and reads the true target count of hop h - 1 on the device; dims[h] = {n_dst, n_src, nnz, 0} (int32,
 // device) is what the SAGE entry points take as their `dims` argument.  Capturable into a HIP graph: with seed_dev the
@@ -399,9 +315,9 @@ extern "C" int sage_sample_batch_device(const int32_t *rowptr, const int32_t *co
         POPE_REQUIRE(fanouts_host[h] > 0, "sage_sample_batch_device: fan-outs must be positive");
         const int64_t cap = t_cap * (int64_t)fanouts_host[h];
         POPE_REQUIRE(t_cap + cap < INT32_MAX, "sage_sample_batch_device: capacity of hop %d exceeds 31 bits", h);
-        const int rc = enqueue_hop_device(rowptr, col, N, targets, t_cap, fanouts_host[h], seed, h, out_rowptr[h], out_col[h], cap, out_n_id[h],
-                                          scratch, scratch_bytes, h == 0 ? nullptr : dims + 4 * (h - 1) + 1, dims + 4 * h,
-                                          (const unsigned long long *)seed_dev, stream);
+        const int rc = enqueue_hop(rowptr, col, N, targets, t_cap, fanouts_host[h], seed, h, out_rowptr[h], out_col[h], cap, out_n_id[h],
+                                   scratch, scratch_bytes, h == 0 ? nullptr : dims + 4 * (h - 1) + 1, dims + 4 * h,
+                                   (const unsigned long long *)seed_dev, nullptr, stream, "sage_sample_batch_device");
         if (rc) return rc;
         targets = out_n_id[h];
         t_cap = t_cap + cap;

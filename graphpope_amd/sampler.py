@@ -45,11 +45,18 @@ class DeviceBatch:
         self.n_ids = [torch.zeros(tc + c, dtype=torch.int64, device=device) for tc, c in zip(self.t_cap, self.caps)]
         self.dims = torch.zeros((h, 4), dtype=torch.int32, device=device)
         self.n_id = self.n_ids[-1]                                   # [capacity]: the true length is dims[-1, 1]
+        self.host_dims = None                                        # set by load(): sizes known on the host
         # outermost block first, like NeighborSampler's adjs (main.py:118-123)
         self.adjs = [SampledAdj(self.rowptrs[i], self.cols[i], self.t_cap[i] + self.caps[i], self.dims[i]) for i in range(h)][::-1]
 
-    def segments(self):
-        """Every buffer a batch consists of (same order for every DeviceBatch of the same shape): for sage_copy_segments."""
+    def segments(self, valid_only: bool = False):
+        """Every buffer a batch consists of (same order for every DeviceBatch of the same shape): for sage_copy_segments.
+        valid_only: the prefixes a batch loaded with :meth:`load` really fills (its sizes are known on the host) -- a pooled
+        batch is then moved with ~1 MB instead of the 5.5 MB of capacity."""
+        if valid_only and self.host_dims is not None:
+            d = self.host_dims
+            return ([r[: d[i][0] + 1] for i, r in enumerate(self.rowptrs)] + [c[: max(d[i][2], 1)] for i, c in enumerate(self.cols)]
+                    + [self.n_id[: d[-1][1]], self.dims])
         return self.rowptrs + self.cols + [self.n_id, self.dims]
 
     def load(self, n_id: torch.Tensor, adjs) -> None:
@@ -60,11 +67,11 @@ class DeviceBatch:
         self.n_id[: n_id.numel()].copy_(n_id)
         host_dims = []
         for i, adj in enumerate(adjs[::-1]):                       # hop order
-            self.rowptrs[i].fill_(int(adj.col.numel()))            # rows past n_dst are empty
             self.rowptrs[i][: adj.n_dst + 1].copy_(adj.rowptr)
             self.cols[i][: adj.col.numel()].copy_(adj.col)
             host_dims.append([adj.n_dst, adj.n_src, int(adj.col.numel()), 0])
         self.dims.copy_(torch.tensor(host_dims, dtype=torch.int32))
+        self.host_dims = host_dims
 
 
 class NeighborSampler:

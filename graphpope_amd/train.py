@@ -35,15 +35,25 @@ class StepState:
     def __init__(self, device, seed: int = 0, adam_step: int = 0):
         self.words = torch.tensor([seed, seed ^ 0x5DEECE66D, adam_step + 1], dtype=torch.int64, device=device)
         self._inc = (ctypes.c_int64 * 3)(_SEED_STRIDE, _SEED_STRIDE | 2, 1)
+        self._inc_keep_sample = (ctypes.c_int64 * 3)(_SEED_STRIDE, 0, 1)
+        self._inc_only_sample = (ctypes.c_int64 * 3)(0, _SEED_STRIDE | 2, 0)
 
     dropout_seed = property(lambda self: self.words[0:1])
     sample_seed = property(lambda self: self.words[1:2])
     adam_step = property(lambda self: self.words[2:3])
 
-    def advance(self) -> None:
+    def advance(self, sample_seed: bool = True) -> None:
+        lib = _lib.load()
+        inc = self._inc if sample_seed else self._inc_keep_sample
+        with on_device(self.words.device):
+            check(lib.sage_advance_counters(ctypes.c_void_p(self.words.data_ptr()), inc, 3,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def advance_sample_seed(self) -> None:
+        """Only the sampling seed (a batch sampled ahead on a side stream advances it there, in sampling order)."""
         lib = _lib.load()
         with on_device(self.words.device):
-            check(lib.sage_advance_counters(ctypes.c_void_p(self.words.data_ptr()), self._inc, 3,
+            check(lib.sage_advance_counters(ctypes.c_void_p(self.words.data_ptr()), self._inc_only_sample, 3,
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
@@ -75,7 +85,7 @@ class SageTrainStep:
     """
 
     def __init__(self, model, opt, feats: torch.Tensor, batch_size: int, sizes=(25, 10), sampler=None, clip: float | None = None,
-                 graph: bool = True, seed: int = 0):
+                 graph: bool = True, seed: int = 0, prefetch: bool = False):
         dev = feats.device
         self.model, self.opt, self.feats, self.sampler, self.clip = model, opt, feats, sampler, clip
         self.batch = DeviceBatch(batch_size, sizes if sampler is None else sampler.sizes, dev)
@@ -91,12 +101,21 @@ class SageTrainStep:
         self._use_graph = graph
         self._lr = None
         self._calls = 0
+        # prefetch (sampler given, graph=False): the NEXT batch is sampled on a side stream while this step computes -- the
+        # reference's DataLoader workers do the same on the host (main.py:100-104, persistent_workers).  Two batch buffers.
+        self._prefetch = bool(prefetch and sampler is not None and not graph)
+        if self._prefetch:
+            self._batches = [self.batch, DeviceBatch(batch_size, sampler.sizes, dev)]
+            self._ys = [self.y, torch.zeros_like(self.y)]
+            self._sample_stream = torch.cuda.Stream(device=dev)
+            self._ready = None          # (event, buffer index) of the batch sampled ahead
+            self._free = [None, None]   # per buffer: event behind the last step that read it
         model.dropout_seed_dev = self.state.dropout_seed
         opt.use_device_step(self.state.adam_step)
 
     # ---- the step body: ordinary autograd code, capturable ----
-    def _body(self):
-        if self.sampler is not None:
+    def _body(self, sample: bool = True):
+        if self.sampler is not None and sample:
             self.sampler.sample_device(self.seeds, seed=0, out=self.batch, seed_dev=self.state.sample_seed)
         x = IndexedFeatures(self.feats, self.batch.n_id)             # main.py:118-123 without the copy
         for p in self.params:
@@ -111,7 +130,7 @@ class SageTrainStep:
         if self.clip is not None:
             torch.nn.utils.clip_grad_norm_(self.params, self.clip)   # main.py:286 gradient_clip_val
         self.opt.step()
-        self.state.advance()
+        self.state.advance(sample_seed=sample)
 
     def _capture(self):
         self.loss = self.logits = None
@@ -151,16 +170,48 @@ class SageTrainStep:
             for st in tab["states"]:
                 st["step"] = tab["step"]
 
-    def step(self, seeds: torch.Tensor, y: torch.Tensor):
-        """Sample around `seeds` (device int64 [batch_size]) inside the step, labels `y` (device int64 [batch_size])."""
+    def _sample_ahead(self, seeds, y, idx):
+        """Enqueue the sampling of (seeds, y) into buffer idx on the side stream; returns the event behind it."""
+        cur = torch.cuda.current_stream()
+        side = self._sample_stream
+        side.wait_stream(cur)                                        # seeds / y were produced on the caller's stream
+        if self._free[idx] is not None:
+            side.wait_event(self._free[idx])                         # the step that last read this buffer is done
+        with torch.cuda.stream(side):
+            copy_segments([self._ys[idx]], [y])
+            self.sampler.sample_device(seeds.contiguous(), seed=0, out=self._batches[idx], seed_dev=self.state.sample_seed)
+            self.state.advance_sample_seed()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ev
+
+    def step(self, seeds: torch.Tensor, y: torch.Tensor, next_seeds: torch.Tensor | None = None, next_y: torch.Tensor | None = None):
+        """Sample around `seeds` (device int64 [batch_size]) inside the step, labels `y` (device int64 [batch_size]).
+        With prefetch=True, `next_seeds` / `next_y` (the batch of the NEXT call) are sampled on a side stream meanwhile."""
         assert self.sampler is not None, "no sampler: use load_batch() + run()"
-        copy_segments([self.seeds, self.y], [seeds, y])
-        self._run()
+        if not self._prefetch:
+            copy_segments([self.seeds, self.y], [seeds, y])
+            self._run()
+            return self.loss
+        cur = torch.cuda.current_stream()
+        if self._ready is None:                                      # first call: nothing was sampled ahead
+            self._ready = (self._sample_ahead(seeds, y, 0), 0)
+        ev, idx = self._ready
+        cur.wait_event(ev)
+        self.batch, self.y = self._batches[idx], self._ys[idx]
+        self._ready = None
+        if next_seeds is not None:
+            self._ready = (self._sample_ahead(next_seeds, next_y, idx ^ 1), idx ^ 1)
+        self.model.train(True)
+        self._body(sample=False)
+        done = torch.cuda.Event()
+        done.record(cur)
+        self._free[idx] = done
         return self.loss
 
     def load_batch(self, pooled: DeviceBatch, y: torch.Tensor) -> None:
         """A batch of a pre-sampled pool (DeviceBatch.load) into the step's fixed buffers: one launch."""
-        copy_segments(self.batch.segments() + [self.y], pooled.segments() + [y])
+        copy_segments(self.batch.segments() + [self.y], pooled.segments(valid_only=True) + [y])
 
     def run(self):
         """The step on whatever :meth:`load_batch` put into the buffers."""

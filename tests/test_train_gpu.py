@@ -137,3 +137,27 @@ def test_adam_device_step_matches_the_host_step(graph):
             word += 1
         outs.append(p.detach().clone())
     assert torch.allclose(outs[0], outs[1], rtol=1e-6, atol=1e-7)
+
+
+def test_sampling_ahead_on_a_side_stream_gives_the_same_steps(graph):
+    """prefetch=True (the next batch is sampled on a side stream while the step computes, two batch buffers) against the
+    same steps with the sampler in line: same seeds, same sampling-seed sequence -> same losses."""
+    from graphpope_amd.optim import Adam
+    from graphpope_amd.sampler import NeighborSampler
+    from graphpope_amd.train import SageTrainStep
+    dev, _, csr = graph
+    feats = torch.randn(6000, 40, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    labels = torch.randint(0, 5, (6000,), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    sampler = NeighborSampler(csr.rowptr, csr.col, 6000, (25, 10))
+    perm = torch.randperm(6000, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    batches = [perm[i * 256:(i + 1) * 256].contiguous() for i in range(10)]
+    runs = []
+    for prefetch in (False, True):
+        m = _model(dev)
+        st = SageTrainStep(m, Adam(m.parameters(), lr=0.01), feats, 256, sampler=sampler, graph=False, seed=5, prefetch=prefetch)
+        losses = []
+        for i, sd in enumerate(batches):
+            nxt = batches[i + 1] if i + 1 < len(batches) else None
+            losses.append(st.step(sd, labels[sd].contiguous(), nxt, None if nxt is None else labels[nxt].contiguous()).item())
+        runs.append(losses)
+    assert np.allclose(runs[0], runs[1], rtol=1e-4) and runs[0][-1] < runs[0][0]

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""The SAGE training step under rocprofv3 (GPU box):
+    cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python3 tools/sage_profile.py [pool|sampler] [steps] [graph]
+One configuration per run, so that the per-kernel averages belong to it."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from graphpope_amd import engine, synth  # noqa: E402
+from graphpope_amd.optim import Adam  # noqa: E402
+from graphpope_amd.sage import SAGE, sample_batch  # noqa: E402
+from graphpope_amd.sampler import DeviceBatch, NeighborSampler  # noqa: E402
+from graphpope_amd.train import SageTrainStep  # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "pool"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+use_graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
+dev = engine.require_gpu()
+ei_np, n = synth.flickr_like(seed=1)
+BATCH = 1550
+feats = torch.rand((n, 756), device=dev)
+torch.manual_seed(0)
+model = SAGE(756, 7, 256, 3).to(dev)
+opt = Adam(model.parameters(), lr=1e-3)
+torch.autograd.set_multithreading_enabled(False)
+if mode == "pool":
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei_np[0], minlength=n))])
+    rng = np.random.default_rng(0)
+    pool = []
+    for b in range(4):
+        seeds = rng.choice(n, BATCH, replace=False)
+        n_id, adjs = sample_batch(rowptr, ei_np[1], seeds, sizes=(25, 10), rng=rng)
+        db = DeviceBatch(BATCH, (25, 10), dev)
+        db.load(torch.as_tensor(n_id, device=dev), [a.to(dev) for a in adjs])
+        pool.append((db, torch.randint(0, 7, (BATCH,), device=dev)))
+    st = SageTrainStep(model, opt, feats, BATCH, (25, 10), sampler=None, graph=use_graph)
+
+    def step(i):
+        db, y = pool[i % 4]
+        st.load_batch(db, y)
+        st.run()
+else:
+    csr = engine.build_csr(torch.as_tensor(ei_np, device=dev), n)
+    sampler = NeighborSampler(csr.rowptr, csr.col, n, (25, 10))
+    perm = torch.randperm(n, device=dev)
+    labels = torch.randint(0, 7, (n,), device=dev)
+    st = SageTrainStep(model, opt, feats, BATCH, sampler=sampler, graph=use_graph)
+
+    def step(i):
+        lo = (i * BATCH) % (n - BATCH)
+        sd = perm[lo:lo + BATCH]
+        st.step(sd, labels[sd])
+for i in range(steps):
+    step(i)
+torch.cuda.synchronize()
+print("done", mode, steps, "graph" if use_graph else "eager")

@@ -60,7 +60,7 @@ def timeit(fn, label):
 
 
 torch.autograd.set_multithreading_enabled(False)
-for lanes in (1, 0):
+for lanes in (0,):
     lib.pope_debug_set(_lib.KNOB_SAGE_LANES, lanes)
     tag = f"lanes={lanes} "
     if not only or only == "eager":
@@ -94,3 +94,12 @@ for lanes in (1, 0):
             sd = perm[lo:lo + BATCH]
             st2.step(sd, labels[sd])
         timeit(sampled, tag + f"SageTrainStep graph={use_graph}, sampler inside the step")
+        if not use_graph:
+            m, opt = fresh()
+            st3 = SageTrainStep(m, opt, feats, BATCH, sampler=sampler, graph=False, prefetch=True)
+
+            def ahead(i):
+                lo, lo2 = (i * BATCH) % (n - BATCH), ((i + 1) * BATCH) % (n - BATCH)
+                sd, sd2 = perm[lo:lo + BATCH], perm[lo2:lo2 + BATCH]
+                st3.step(sd, labels[sd], sd2, labels[sd2])
+            timeit(ahead, tag + "SageTrainStep eager, next batch sampled on a side stream")

@@ -29,6 +29,7 @@ from .optim import Adam
 from . import engine
 from .sage import SAGE, IndexedFeatures, cross_entropy
 from .sampler import NeighborSampler
+from .train import SageTrainStep
 from .utils import Graphpope
 
 
@@ -92,10 +93,12 @@ def _batches(node_idx, batch_size, shuffle, gen):
         yield idx[i:i + batch_size]
 
 
-def _run_epoch(model, feats, labels, sampler, node_idx, args, gen, epoch, opt=None):
+def _run_epoch(model, feats, labels, sampler, node_idx, args, gen, epoch, opt=None, trainer=None):
     """One pass over node_idx.  Everything stays on the device: the fan-out sampler (main.py:100-116), the feature
     gather of convert_batch (main.py:118-123), the model, the optimiser; loss / accuracy are accumulated on the
-    device and read once per epoch."""
+    device and read once per epoch.  Full training batches go through `trainer` (graphpope_amd.train.SageTrainStep:
+    sampled with device extents, the whole step replayed as a HIP graph, nothing read back); the last, shorter batch of an
+    epoch and the evaluation passes take the eager path below."""
     train = opt is not None
     model.train(train)
     dev = feats.device
@@ -103,18 +106,24 @@ def _run_epoch(model, feats, labels, sampler, node_idx, args, gen, epoch, opt=No
     tot_correct = torch.zeros((), device=dev, dtype=torch.int64)
     tot = 0
     for b, seeds in enumerate(_batches(node_idx, args.batch_size, train, gen)):
-        n_id, adjs = sampler.sample(seeds, seed=(args.seed << 20) + (epoch << 10) + b)       # NeighborSampler(sizes=[25, 10])
-        x = IndexedFeatures(feats, n_id)                                                 # Batch.x = data.x[n_id], never materialised
         y = labels.index_select(0, seeds)                                                # Batch.y = data.y[n_id[:batch_size]]
-        with torch.set_grad_enabled(train):
-            y_hat = model(x, adjs)
-            loss = cross_entropy(y_hat, y)                                               # main.py:216 F.cross_entropy
-        if train:
-            for p in model.parameters():
-                p.grad = None
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)                      # gradient_clip_val=0.5 (main.py:286)
-            opt.step()
+        if train and trainer is not None and seeds.numel() == args.batch_size:
+            loss = trainer.step(seeds.contiguous(), y)
+            y_hat = trainer.logits
+        else:
+            n_id, adjs = sampler.sample(seeds, seed=(args.seed << 20) + (epoch << 10) + b)   # NeighborSampler(sizes=[25, 10])
+            x = IndexedFeatures(feats, n_id)                                             # Batch.x = data.x[n_id], never materialised
+            with torch.set_grad_enabled(train):
+                y_hat = model(x, adjs)
+                loss = cross_entropy(y_hat, y)                                           # main.py:216 F.cross_entropy
+            if train:
+                for p in model.parameters():
+                    p.grad = None
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)                  # gradient_clip_val=0.5 (main.py:286)
+                opt.step()
+                if trainer is not None:
+                    trainer.state.advance()                                              # the optimiser reads its step count from the trainer's device word
         tot_loss += loss.detach() * seeds.numel()
         tot_correct += (y_hat.argmax(-1) == y).sum()
         tot += seeds.numel()
@@ -146,8 +155,11 @@ def main(argv=None):
     idx = {k: torch.nonzero(getattr(data, f'{k}_mask'), as_tuple=False).flatten().to(dev) for k in ('train', 'val', 'test')}
     best, bad = -1.0, 0
     torch.autograd.set_multithreading_enabled(False)          # backward in the calling thread: the step is launch-bound on the host
+    trainer = None
+    if os.environ.get('GRAPHPOPE_TRAIN_STEP', 'graph') != 'eager' and idx['train'].numel() >= args.batch_size:
+        trainer = SageTrainStep(model, opt, feats, args.batch_size, sampler=sampler, clip=0.5, seed=args.seed)   # gradient_clip_val=0.5 (main.py:286)
     for epoch in range(args.epochs):
-        tr_loss, tr_acc = _run_epoch(model, feats, labels, sampler, idx['train'], args, gen, epoch, opt)
+        tr_loss, tr_acc = _run_epoch(model, feats, labels, sampler, idx['train'], args, gen, epoch, opt, trainer)
         va_loss, va_acc = _run_epoch(model, feats, labels, sampler, idx['val'], args, gen, epoch)
         sched.step(va_loss)
         print(f'epoch {epoch}: train_loss {tr_loss:.4f} train_acc {tr_acc:.4f} val_loss {va_loss:.4f} val_acc {va_acc:.4f}')

@@ -182,11 +182,16 @@ def boundary_leg(ei_np, n, x_cpu, want_hops, reps=5):
     with contextlib.redirect_stdout(sys.stderr):           # the reference's banners (utils.py:141-146) stay off the JSON line
         for _ in range(reps + 1):
             gp.clear_cache()
+            out = None                                   # the previous result is released OUTSIDE the timed call (a caller keeps its result)
             np.random.seed(42)
             t0 = time.perf_counter()
             out = gp.Graphpope(d, "flickr", "geodesic", "stochastic", K_PER_GPU, None, NUM_WORKERS)
             times.append(time.perf_counter() - t0)
     gp.clear_cache()
+    trace = (ctypes.c_double * 8)()
+    _lib.load().pope_debug_boundary_trace(trace)      # phases of the LAST call's result assembly (csrc/host.cc)
+    phases = dict(zip(("madvise", "wait_for_host_copy", "register_pages", "enqueue_dma", "join_threads", "stream_sync", "unregister", "total"),
+                      (round(float(v), 3) for v in trace)))
     e, k = ei_np.shape[1], K_PER_GPU
     crossed = 16.0 * e + 4.0 * n * k                   # edge_index int64 up, [N, K] float32 down; x stays on the host
     warm = float(np.median(times[1:]))
@@ -194,7 +199,8 @@ def boundary_leg(ei_np, n, x_cpu, want_hops, reps=5):
     ok = bool(np.array_equal(out.numpy()[:, F:].view(np.uint32), oracle.hops_to_embedding(want_hops).view(np.uint32))
               and torch.equal(out[:, :F], x_cpu))
     return {
-        "ms": warm * 1e3, "first_call_ms": times[0] * 1e3, "embeddings_per_s": n * k / warm,
+        "ms": warm * 1e3, "first_call_ms": times[0] * 1e3, "embeddings_per_s": n * k / warm, "all_calls_ms": [t * 1e3 for t in times],
+        "last_call_assembly_phases_ms": phases,
         "what": "utils.Graphpope(data, 'flickr', 'geodesic', 'stochastic', 256) from CPU tensors (x [N, 500] f32, edge_index "
                 "[2, E] int64) to the returned PAGEABLE CPU [N, 756] f32 tensor: anchor draw, H2D of edge_index straight from the "
                 "caller's pages, CSR + BFS + K-column expansion on the GPU, chunked D2H of the [N, 256] block into pages registered "

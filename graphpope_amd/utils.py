@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 from . import engine
+from . import _lib as _lib_mod
 
 # where attach_node2vec looks for {dataset}_node2vec.pt (reference: <dir of utils.py>/data, utils.py:155)
 NODE2VEC_DIR = os.environ.get("GRAPHPOPE_DATA_DIR", osp.join(osp.dirname(osp.realpath(__file__)), "data"))
@@ -122,16 +123,42 @@ def _assemble_on_host(data, k, embedding_fn):
     the reference's.  (Rounds 1-2 returned a pinned tensor: 34 ms of hipHostMalloc on the one call a process makes, and
     270 MB -- 8.6 GB for R-MAT-22 x 512 -- page-locked for as long as the memoised result lives.)
 
-    out[:, :F] = data.x is copied host to host by a few threads (data.x never crosses PCIe), starting BEFORE
-    ``embedding_fn()`` uploads edge_index and runs the GPU work, so the page faults of the fresh result and most of the copy
-    hide underneath it; out[:, F:] = the device embedding then arrives by pitched DMA, chunk by chunk, into pages
-    registered for the length of the call (utils.py:129-135 torch.cat((data.x, embedding), 1))."""
+    out[:, :F] = data.x is copied host to host by a few threads (data.x never crosses PCIe) while out[:, F:] = the device
+    embedding arrives by pitched DMA, chunk by chunk, into pages registered for the length of the call (utils.py:129-135
+    torch.cat((data.x, embedding), 1)).  The assembly starts AFTER ``embedding_fn()`` has uploaded edge_index and run the
+    GPU work: starting the host threads before it (engine.HostAssembly allows that) was measured 3.4-3.9 ms in a fresh process
+    but 13-20 ms inside bench.py -- sixteen threads taking page faults hold the address-space lock that the runtime's
+    own allocations behind a launch wait for."""
+    import time as _t
+    trace = os.environ.get("GRAPHPOPE_TRACE")
+    t0 = _t.perf_counter()
     x = _host_features(data)
     n, f = int(x.shape[0]), int(x.shape[1])
-    out = torch.empty((n, f + k), dtype=torch.float32)
-    with engine.HostAssembly(x if f else None, out, f) as asm:
-        emb_dev = embedding_fn()
-        return asm.finish(emb_dev.contiguous())
+    emb_dev = embedding_fn().contiguous()
+    t1 = _t.perf_counter()
+    mode = os.environ.get("GRAPHPOPE_HOST_RESULT", "registered")
+    if mode == "pinned":                               # rounds 1-2: a page-locked result (fast when torch's host cache holds one, 34 ms when not)
+        out = torch.empty((n, f + k), dtype=torch.float32, pin_memory=True)
+        engine.copy_columns_to_host(emb_dev, out[:, f:])
+        if f:
+            engine.host_copy_2d(x, out[:, :f])
+        torch.cuda.current_stream().synchronize()
+        res = out
+    else:
+        out = torch.empty((n, f + k), dtype=torch.float32)
+        lib = _lib_mod.load()
+        if mode == "staged":                           # no registration of the caller-visible pages: the runtime's own staging
+            lib.pope_debug_set(_lib_mod.KNOB_FAIL_HOST_REGISTER, 1)
+        try:
+            with engine.HostAssembly(x if f else None, out, f) as asm:
+                res = asm.finish(emb_dev)
+        finally:
+            if mode == "staged":
+                lib.pope_debug_set(_lib_mod.KNOB_FAIL_HOST_REGISTER, 0)
+    if trace:
+        import sys as _s
+        print(f"[trace] upload + GPU {1e3 * (t1 - t0):.2f} ms, result assembly {1e3 * (_t.perf_counter() - t1):.2f} ms", file=_s.stderr)
+    return res
 
 
 def _geodesic_planes(ei, n, anchors, dev):
@@ -152,10 +179,18 @@ def _geodesic_planes(ei, n, anchors, dev):
 
 def _geodesic_embedding_device(edge_index, n, anchors, dev):
     """float32 [N, K] on the device: 1 / (hops + 1) to every anchor (sharded over the ranks of a process group)."""
+    trace = os.environ.get("GRAPHPOPE_TRACE")
+    import time as _t
+    t0 = _t.perf_counter()
     with engine.staged(edge_index.detach(), dev) as ei_dev:         # 14.4 MB straight from the caller's pages, released on exit
         ei = ei_dev.to(torch.int64)
         if not os.environ.get("GRAPHPOPE_CACHE_DIR"):
-            return engine.geodesic_features(None, ei, n, anchors, shard=_shard())
+            t1 = _t.perf_counter()
+            emb = engine.geodesic_features(None, ei, n, anchors, shard=_shard())
+            if trace:
+                import sys as _s
+                print(f"[trace] stage {1e3 * (t1 - t0):.2f} ms, geodesic_features {1e3 * (_t.perf_counter() - t1):.2f} ms", file=_s.stderr)
+            return emb
         planes, bits = _geodesic_planes(ei, n, anchors, dev)
     emb = torch.empty((n, len(anchors)), dtype=torch.float32, device=dev)
     engine.finalize(planes.contiguous(), bits, n, len(anchors), None, 0, emb, 0)

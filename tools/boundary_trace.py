@@ -17,6 +17,12 @@ from graphpope_amd import utils as gp  # noqa: E402
 
 lib = _lib.load()
 dev = engine.require_gpu()
+if "--after-omp" in sys.argv:                       # what bench.py's CPU legs leave behind: torch's intra-op thread pool, warmed up
+    a = torch.randn(3000, 3000)
+    for _ in range(5):
+        (a @ a).sum()
+    print("torch threads", torch.get_num_threads(), flush=True)
+    sys.argv.remove("--after-omp")
 ei_np, n = synth.flickr_like()
 F, K = 500, 256
 x = torch.rand(n, F)

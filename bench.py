@@ -792,6 +792,19 @@ def main():
         src_rank = K_PER_GPU * (4.0 * e + 4.0 * (n + 1) + 4.0 * n)
         per_rank = [{"rank": i, "ms_per_step": float(t[0]) / args.steps * 1e3, "achieved_gbs_per_source_model": src_rank / (float(t[0]) / args.steps) / 1e9,
                      "all_gather_bytes_sent_per_step": int(t[1]), "all_gather_bytes_received_per_step": int(t[1]) * (world - 1)} for i, t in enumerate(allr)]
+    # the same step when the library's depth hint misses (what a process's FIRST call on a graph pays: 12 speculative level
+    # launches instead of the 10 this graph needs): a call with another anchor count in between invalidates the hint
+    hint_miss_ms = None
+    if world == 1:
+        tm = []
+        for _ in range(5):
+            engine.geodesic_run(x, ei, n, anchors[:192], reuse_workspace=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pope_step(x, ei, n, anchors, world)
+            torch.cuda.synchronize()
+            tm.append(time.perf_counter() - t1)
+        hint_miss_ms = float(np.median(tm)) * 1e3
     result = None
     ms = elapsed / args.steps * 1e3
     if rank == 0:
@@ -810,6 +823,7 @@ def main():
                                 "level launches from the depth the previous call found (a process's FIRST call enqueues 12 levels "
                                 "instead of 10, about +9 us).  The reference's own case -- host tensors in, host tensor out, once per "
                                 "process -- is the top-level key host_to_host (first_call_ms is that single call)")
+        result["ms_per_step_depth_hint_miss"] = hint_miss_ms
         if world > 1:
             result["backend"] = backend
             result["rccl_ranks"] = rccl_ranks

@@ -270,14 +270,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_streamk(SkArgs a) {
 // The same stream-K decomposition with the roles split (in-kernel stamps, tools/stamp_streamk.py: a stage of the
 // kernel above takes 5 640 cycles -- 4 100 for its 64 MFMAs per SIMD, 680 at the stage boundary and 850 for the ten
 // DMAs each wave issues, which an in-order wave cannot overlap with its own MFMAs): waves 0-3 only read fragments and
-// issue MFMAs (one per SIMD, 32 x 128 each), waves 4-5 only move data: each issues 20 of the stage's 40 DMA
-// wave-instructions, waits for them two stages later and joins the same one-barrier-per-stage rhythm.
+// issue MFMAs (one per SIMD, 32 x 128 each), waves 4-7 only move data and join the same one-barrier-per-stage rhythm.
+//
+// GK = depth of a stage.  32 (the default): three 40 KB buffers, two stages of DMA in flight, 4 790 cycles per stage for
+// 4 096 cycles of MFMA.  64 (round 3 experiment, POPE_KNOB_GEMM_TILE = 6): TWO 80 KB buffers (the CU's whole 160 KB), ONE
+// stage in flight -- the same prefetch distance in time, since a stage lasts twice as long -- and half as many stage
+// boundaries per unit of depth: within 1 % at a depth of 756, slower where the depth pads badly (sage.hip, skl_stage_depth).  A unit of the stream-K deal is one stage
+// of one tile either way (SkArgs::S0 / S1 are counted in stages of the kernel's GK; the fix-up only sees units).
 constexpr int SKL_CONSUMERS = 4, SKL_LOADERS = 4, SKL_THREADS = (SKL_CONSUMERS + SKL_LOADERS) * 64;
 
+template <int GK> struct SkStage {
+    static constexpr int CPR = GK / 4;                                   // 16-byte chunks per image row
+    static constexpr int RPI = 64 / CPR;                                 // image rows per DMA wave-instruction (1 KiB)
+    static constexpr int A_BYTES = SK_TM * GK * 4, B_BYTES = SK_TN * GK * 4, BYTES = A_BYTES + B_BYTES;
+    static constexpr int NBUF = GK == 32 ? 3 : 2;
+    static constexpr int LDS_BYTES = NBUF * BYTES;                       // 120 KB / 160 KB
+    static constexpr int A_INSTR = SK_TM / RPI, INSTR = (SK_TM + SK_TN) / RPI;   // 8 + 32 = 40 / 16 + 64 = 80 per stage
+    static constexpr int PASSES = GK / 8;                                // 8 depth values per fragment pass
+    // chunk index XOR that makes every ds_read_b128 of a fragment conflict-free (16 lanes of a read group sit in 16 rows)
+    __device__ static __forceinline__ int swz(int row) { return GK == 32 ? ((row >> 1) & 7) : (row & 15); }
+};
+
+template <int GK>
 __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_ld(SkArgs a) {
     sk_resolve(a);
+    using St = SkStage<GK>;
     constexpr int NT = 4;                               // 32 x 32 accumulator tiles per consumer wave: 32 rows x 128 columns
-    constexpr int ND = 40 / SKL_LOADERS;                // DMA wave-instructions per loader wave and stage
+    constexpr int ND = St::INSTR / SKL_LOADERS;         // DMA wave-instructions per loader wave and stage
+    constexpr int NBUF = St::NBUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -289,63 +309,66 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_ld(SkArgs a) {
     const long long u_end = sk_lo(blockIdx.x + 1, T, G);
 
     if (loader) {
-        // ---------------- loader waves: 20 DMA wave-instructions per stage each ----------------
+        // ---------------- loader waves ----------------
         // A loader shares its SIMD with a consumer whose MFMA stream would otherwise take every issue slot first (issue is
         // arbitrated by priority, then age: stamps showed 570 cycles per DMA); its few instructions go ahead of the MFMAs.
         __builtin_amdgcn_s_setprio(3);
         const int lw = wave - SKL_CONSUMERS;
-        const int sub = lane >> 3, cp = lane & 7;
+        const int sub = lane / St::CPR, cp = lane % St::CPR;
         while (u < u_end) {
             const int tile = (int)(u / S);
             const int s_begin = (int)(u - (long long)tile * S);
             const long long left = u_end - u;
             const int s_end = (long long)(S - s_begin) <= left ? S : s_begin + (int)left;
             const int m0 = (tile % a.tiles_m) * SK_TM, n0 = (tile / a.tiles_m) * SK_TN;
-            // Byte offsets of this lane's ND sources from the tile's A / B origin, for both products (instruction i < 8: A rows
-            // 8i.., else B rows 8(i - 8)..); 32 bits are enough (checked on the host: rows * ld * 4 < 2^32).
+            // Byte offsets of this lane's ND sources from the tile's A / B origin, for both products (instruction i < A_INSTR:
+            // A rows RPI * i .., else B rows); 32 bits are enough (checked on the host: rows * ld * 4 < 2^32).
             unsigned off[2][ND];
             int koff[ND];
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const int instr = lw * ND + d;
-                const int row = (instr < 8 ? instr : instr - 8) * 8 + sub;
-                koff[d] = (cp ^ ((row >> 1) & 7)) * 4;
+                const int row = (instr < St::A_INSTR ? instr : instr - St::A_INSTR) * St::RPI + sub;
+                koff[d] = (cp ^ St::swz(row)) * 4;
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
-                    off[q][d] = instr < 8 ? (unsigned)(((long long)min(m0 + row, a.M - 1) * a.p[q].lda + koff[d]) * 4)
-                                          : (unsigned)(((long long)min(n0 + row, a.N - 1) * a.p[q].ldb + koff[d]) * 4);
+                    off[q][d] = instr < St::A_INSTR ? (unsigned)(((long long)min(m0 + row, a.M - 1) * a.p[q].lda + koff[d]) * 4)
+                                                   : (unsigned)(((long long)min(n0 + row, a.N - 1) * a.p[q].ldb + koff[d]) * 4);
             }
             auto issue_all = [&](int s, int buf) {
                 const bool second = s >= a.S0;                         // wave-uniform
                 const int PK = second ? a.p[1].K : a.p[0].K;
-                const int k0 = (second ? s - a.S0 : s) * SK_GK;
+                const int k0 = (second ? s - a.S0 : s) * GK;
                 const float *A = (second ? a.p[1].A : a.p[0].A) + k0, *B = (second ? a.p[1].B : a.p[0].B) + k0;   // SGPR pairs
-                if (k0 + SK_GK <= PK) {                                // every stage but a product's last: no vector arithmetic
+                if (k0 + GK <= PK) {                                   // every stage but a product's last: no vector arithmetic
 #pragma unroll
                     for (int d = 0; d < ND; ++d)
-                        sk_glds16_saddr(lw * ND + d < 8 ? A : B, second ? off[1][d] : off[0][d], lds0 + buf * SK_STAGE_BYTES + (lw * ND + d) * 1024);
+                        sk_glds16_saddr(lw * ND + d < St::A_INSTR ? A : B, second ? off[1][d] : off[0][d], lds0 + buf * St::BYTES + (lw * ND + d) * 1024);
                 } else {                                               // depth padding: lanes past the depth read the zero page
 #pragma unroll
                     for (int d = 0; d < ND; ++d) {
-                        const float *src = (const float *)((const char *)(lw * ND + d < 8 ? A : B) + (second ? off[1][d] : off[0][d]));
+                        const float *src = (const float *)((const char *)(lw * ND + d < St::A_INSTR ? A : B) + (second ? off[1][d] : off[0][d]));
                         if (k0 + koff[d] >= PK) src = a.zero;
-                        sk_glds16(src, lds0 + buf * SK_STAGE_BYTES + (lw * ND + d) * 1024);
+                        sk_glds16(src, lds0 + buf * St::BYTES + (lw * ND + d) * 1024);
                     }
                 }
             };
-            // Rhythm (one barrier per stage, B_s at the top of stage s).  The loader arrives at B_s once stages <= s + 1 have
-            // landed, the consumers once they have finished reading stage s - 1.  Behind B_s the loader refills that buffer
-            // with stage s + 2, and the consumers may read stage s AND -- at the end of it, before B_(s+1) -- the first
-            // fragments of stage s + 1: their MFMA stream does not drain at the barrier.
+            // Rhythm (one barrier per stage, B_s at the top of stage s).  Three buffers: the loader arrives at B_s once stages
+            // <= s + 1 have landed and refills the buffer of stage s - 1 with stage s + 2 behind it.  Two buffers: it arrives once
+            // stage s has landed and fills the other buffer with stage s + 1 behind B_s (its readers left it before B_s).
             __syncthreads();                   // the previous segment's fragment reads are done: the buffers may be refilled
             issue_all(s_begin, 0);
-            if (s_begin + 1 < s_end) issue_all(s_begin + 1, 1);
+            if (NBUF == 3 && s_begin + 1 < s_end) issue_all(s_begin + 1, 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();      // B_(s_begin)
             int buf = 0;
             for (int s = s_begin; s < s_end; ++s) {
                 SK_STAMP(0);
-                if (s + 2 < s_end) issue_all(s + 2, buf == 0 ? 2 : buf - 1);
+                if (NBUF == 3) {
+                    if (s + 2 < s_end) issue_all(s + 2, buf == 0 ? 2 : buf - 1);
+                } else {
+                    if (s + 1 < s_end) issue_all(s + 1, buf ^ 1);
+                }
                 SK_STAMP(1);
                 if (s + 1 < s_end) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -354,7 +377,7 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_ld(SkArgs a) {
                 }
                 SK_STAMP(3);
                 SK_STAMP(4);
-                buf = buf == 2 ? 0 : buf + 1;
+                buf = NBUF == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
             }
             u += s_end - s_begin;
         }
@@ -364,12 +387,12 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_ld(SkArgs a) {
     // ---------------- consumer waves: fragments + MFMAs only ----------------
     const int wm = wave & 1, wn = wave >> 1;
     const int g = lane >> 5;
-    const int fa_row = wm * 32 + (lane & 31), fa_swz = (fa_row >> 1) & 7;
+    const int fa_row = wm * 32 + (lane & 31), fa_swz = St::swz(fa_row);
     int fb_row[NT], fb_swz[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         fb_row[t] = wn * 128 + t * 32 + (lane & 31);
-        fb_swz[t] = (fb_row[t] >> 1) & 7;
+        fb_swz[t] = St::swz(fb_row[t]);
     }
     while (u < u_end) {
         const int tile = (int)(u / S);
@@ -383,27 +406,27 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_ld(SkArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
         __syncthreads();
-        __builtin_amdgcn_s_barrier();          // B_(s_begin): stages s_begin and s_begin + 1 have landed
+        __builtin_amdgcn_s_barrier();          // B_(s_begin): stage s_begin (and s_begin + 1 with three buffers) has landed
         asm volatile("" ::: "memory");
         float4 fa[2], fb[NT][2];
         auto read_pass = [&](int b, int p, int set) {
-            const char *base = smem + b * SK_STAGE_BYTES;
+            const char *base = smem + b * St::BYTES;
             const int c = 2 * p + g;
-            fa[set] = *reinterpret_cast<const float4 *>(base + (fa_row * 8 + (c ^ fa_swz)) * 16);
+            fa[set] = *reinterpret_cast<const float4 *>(base + (fa_row * St::CPR + (c ^ fa_swz)) * 16);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                fb[t][set] = *reinterpret_cast<const float4 *>(base + SK_A_BYTES + (fb_row[t] * 8 + (c ^ fb_swz[t])) * 16);
+                fb[t][set] = *reinterpret_cast<const float4 *>(base + St::A_BYTES + (fb_row[t] * St::CPR + (c ^ fb_swz[t])) * 16);
         };
         int buf = 0;
         read_pass(0, 0, 0);
         for (int s = s_begin; s < s_end; ++s) {
             SK_STAMP(0);
             const bool next = s + 1 < s_end;
-            const int nbuf = buf == 2 ? 0 : buf + 1;
+            const int nbuf = NBUF == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (p + 1 < 4) read_pass(buf, p + 1, (p + 1) & 1);
-                else if (next) read_pass(nbuf, 0, 0);                  // pass 0 of stage s + 1: landed since B_s
+            for (int p = 0; p < St::PASSES; ++p) {
+                if (p + 1 < St::PASSES) read_pass(buf, p + 1, (p + 1) & 1);
+                else if (NBUF == 3 && next) read_pass(nbuf, 0, 0);     // pass 0 of stage s + 1: landed since B_s (three buffers only)
                 __builtin_amdgcn_sched_barrier(0);                     // the next pass's LDS reads are issued above this line
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p & 1].x, fb[t][p & 1].x, acc[t], 0, 0, 0);
@@ -420,6 +443,7 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_ld(SkArgs a) {
             if (next) {
                 __builtin_amdgcn_s_barrier();                          // B_(s+1)
                 asm volatile("" ::: "memory");
+                if (NBUF == 2) read_pass(nbuf, 0, 0);                  // two buffers: stage s + 1 is complete only now
             }
             SK_STAMP(3);
             SK_STAMP(4);

@@ -34,10 +34,11 @@ struct SkTnArgs {
     const int *depth_dev;        // device extent: the true depth (<= depth, which then is the capacity), or null
 };
 
+template <int GK>
 __device__ __forceinline__ void sk_tn_resolve(SkTnArgs &a) {
     if (a.depth_dev) {
         a.depth = dyn_extent(a.depth_dev, a.depth);
-        a.S = (a.depth + SK_GK - 1) / SK_GK;
+        a.S = (a.depth + GK - 1) / GK;
     }
 }
 
@@ -48,10 +49,15 @@ __device__ __forceinline__ void sk_tn_tile(const SkTnArgs &a, int tile, int &q, 
     n0 = (rest - q * a.tiles_nb) * SK_TN;
 }
 
+// GK: depth rows per stage, as in k_gemm_streamk_ld (32: three buffers, two stages in flight; 64: two 80 KB buffers, one).
+template <int GK>
 __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
-    sk_tn_resolve(a);
+    sk_tn_resolve<GK>(a);
     constexpr int NT = 4;                               // 32 x 32 accumulator tiles per consumer wave: 32 rows x 128 columns
-    constexpr int ND = 40 / SKL_LOADERS;                // DMA wave-instructions per loader wave and stage
+    constexpr int A_BYTES = SK_TM * GK * 4, STAGE_BYTES = (SK_TM + SK_TN) * GK * 4;
+    constexpr int NBUF = GK == 32 ? 3 : 2;
+    constexpr int A_INSTR = GK / 4, INSTR = GK / 4 + GK;   // A: four 256-byte depth rows per DMA instruction; B: one 1 KiB depth row
+    constexpr int ND = INSTR / SKL_LOADERS;             // DMA wave-instructions per loader wave and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,56 +79,60 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
             int q, m0, n0;
             sk_tn_tile(a, tile, q, m0, n0);
             const float *Bq = q ? a.B[1] : a.B[0];
-            // per-lane byte offsets from the stage's first depth row; instruction i < 8: four depth rows of G (16 lanes each),
-            // else depth row i - 8 of B.  Outer indices past the matrix are clamped into it (their products land in output
-            // rows / columns that are never stored); depth rows past the end are handled in the last stage only.
+            // per-lane byte offsets from the stage's first depth row; instruction i < A_INSTR: four depth rows of G (16 lanes
+            // each), else depth row i - A_INSTR of B.  Outer indices past the matrix are clamped into it (their products land in
+            // output rows / columns that are never stored); depth rows past the end are handled in the last stage only.
             unsigned off[ND];
             int drow[ND];
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const int instr = lw * ND + d;
-                if (instr < 8) {
+                if (instr < A_INSTR) {
                     drow[d] = instr * 4 + (lane >> 4);
                     const int m = min(m0 + (lane & 15) * 4, a.M - 4);
                     off[d] = (unsigned)(((long long)drow[d] * a.ldg + m) * 4);
                 } else {
-                    drow[d] = instr - 8;
+                    drow[d] = instr - A_INSTR;
                     const int n = min(n0 + lane * 4, a.Nb - 4);
                     off[d] = (unsigned)(((long long)drow[d] * a.ldb + n) * 4);
                 }
             }
             auto issue_all = [&](int s, int buf) {
-                const int k0 = s * SK_GK;
+                const int k0 = s * GK;
                 const float *Ga = a.G + (long long)k0 * a.ldg, *Ba = Bq + (long long)k0 * a.ldb;        // SGPR pairs
-                if (k0 + SK_GK <= a.depth) {
+                if (k0 + GK <= a.depth) {
 #pragma unroll
                     for (int d = 0; d < ND; ++d)
-                        sk_glds16_saddr(lw * ND + d < 8 ? Ga : Ba, off[d], lds0 + buf * SK_STAGE_BYTES + (lw * ND + d) * 1024);
+                        sk_glds16_saddr(lw * ND + d < A_INSTR ? Ga : Ba, off[d], lds0 + buf * STAGE_BYTES + (lw * ND + d) * 1024);
                 } else {                                               // the last stage: depth rows past the end
 #pragma unroll
                     for (int d = 0; d < ND; ++d) {
-                        const bool is_a = lw * ND + d < 8;
+                        const bool is_a = lw * ND + d < A_INSTR;
                         const bool past = k0 + drow[d] >= a.depth;
                         const float *src;
                         if (is_a) src = past ? a.zero : (const float *)((const char *)Ga + off[d]);           // zero kills the product
                         else src = (const float *)((const char *)Ba + off[d]) - (past ? (long long)(k0 + drow[d] - (a.depth - 1)) * a.ldb : 0);
-                        sk_glds16(src, lds0 + buf * SK_STAGE_BYTES + (lw * ND + d) * 1024);
+                        sk_glds16(src, lds0 + buf * STAGE_BYTES + (lw * ND + d) * 1024);
                     }
                 }
             };
             __syncthreads();
             issue_all(s_begin, 0);
-            if (s_begin + 1 < s_end) issue_all(s_begin + 1, 1);
+            if (NBUF == 3 && s_begin + 1 < s_end) issue_all(s_begin + 1, 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();      // B_(s_begin)
             int buf = 0;
             for (int s = s_begin; s < s_end; ++s) {
-                if (s + 2 < s_end) issue_all(s + 2, buf == 0 ? 2 : buf - 1);
+                if (NBUF == 3) {
+                    if (s + 2 < s_end) issue_all(s + 2, buf == 0 ? 2 : buf - 1);
+                } else {
+                    if (s + 1 < s_end) issue_all(s + 1, buf ^ 1);
+                }
                 if (s + 1 < s_end) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();                      // B_(s+1)
                 }
-                buf = buf == 2 ? 0 : buf + 1;
+                buf = NBUF == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
             }
             u += s_end - s_begin;
         }
@@ -145,13 +155,13 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
         __syncthreads();
-        __builtin_amdgcn_s_barrier();          // B_(s_begin): stages s_begin and s_begin + 1 have landed
+        __builtin_amdgcn_s_barrier();          // B_(s_begin): stage s_begin (and s_begin + 1 with three buffers) has landed
         asm volatile("" ::: "memory");
         // fragments of depth step j: A(m, 2j + g), B(n, 2j + g) -- 32 consecutive dwords per half-wave
         float fa[2], fb[NT][2];
         auto read_step = [&](int b, int j, int set) {
-            const float *As = reinterpret_cast<const float *>(smem + b * SK_STAGE_BYTES);
-            const float *Bs = reinterpret_cast<const float *>(smem + b * SK_STAGE_BYTES + SK_A_BYTES);
+            const float *As = reinterpret_cast<const float *>(smem + b * STAGE_BYTES);
+            const float *Bs = reinterpret_cast<const float *>(smem + b * STAGE_BYTES + A_BYTES);
             const int k = 2 * j + g;
             fa[set] = As[k * SK_TM + wm * 32 + l31];
 #pragma unroll
@@ -161,11 +171,11 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
         read_step(0, 0, 0);
         for (int s = s_begin; s < s_end; ++s) {
             const bool next = s + 1 < s_end;
-            const int nbuf = buf == 2 ? 0 : buf + 1;
+            const int nbuf = NBUF == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
 #pragma unroll
-            for (int j = 0; j < SK_GK / 2; ++j) {
-                if (j + 1 < SK_GK / 2) read_step(buf, j + 1, (j + 1) & 1);
-                else if (next) read_step(nbuf, 0, 0);                  // the next stage's first step: landed since B_s
+            for (int j = 0; j < GK / 2; ++j) {
+                if (j + 1 < GK / 2) read_step(buf, j + 1, (j + 1) & 1);
+                else if (NBUF == 3 && next) read_step(nbuf, 0, 0);     // the next stage's first step: landed since B_s (three buffers only)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1], fb[t][j & 1], acc[t], 0, 0, 0);
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
             if (next) {
                 __builtin_amdgcn_s_barrier();                          // B_(s+1)
                 asm volatile("" ::: "memory");
+                if (NBUF == 2) read_step(nbuf, 0, 0);                  // two buffers: stage s + 1 is complete only now
             }
             buf = nbuf;
         }
@@ -209,8 +220,9 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
 
 // SK_TN_FIX_PARTS blocks per tile, as k_streamk_fixup: 24 tiles only, so more parts per tile (384 blocks, one piece per thread).
 constexpr int SK_TN_FIX_PARTS = 16;
+template <int GK>
 __global__ __launch_bounds__(256) void k_streamk_tn_fixup(SkTnArgs a, int G) {
-    sk_tn_resolve(a);
+    sk_tn_resolve<GK>(a);
     const int S = a.S;
     const long long T = (long long)a.tiles_m * a.tiles_nb * 2 * S;
     if (T <= 0) return;                                                                   // (a device extent of 0 rows: nothing was computed)

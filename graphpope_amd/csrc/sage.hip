@@ -481,8 +481,14 @@ static bool streamk_shape_ok(int64_t M, int32_t K0, int32_t K1, int32_t N) {
     if ((K0 & 3) || (K1 & 3) || M <= 0 || N <= 0) return false;
     const long long tiles = ((M + SK_TM - 1) / SK_TM) * ((N + SK_TN - 1) / SK_TN);
     const long long S = (K0 + SK_GK - 1) / SK_GK + (K1 + SK_GK - 1) / SK_GK;
-    return tiles * S >= 4ll * SK_MAX_GRID;           // enough units for every block to amortise its partial tiles
+    return tiles * S >= 4ll * SK_MAX_GRID;           // enough work (in depth-32 units) for every block to amortise its partial tiles
 }
+
+// Stage depth of the loader-wave kernels: 32 (three 40 KB buffers, two stages in flight); POPE_KNOB_GEMM_TILE = 6 selects 64 (two
+// 80 KB buffers, one stage in flight, half the stage boundaries).  Measured on the layer-0 forward call (tools/gemm_fwd_ab.py,
+// round 3): 89.1-93.2 us against 90.2-95.7 at a depth of 2 x 756, 72.0-73.2 against 68.6-69.0 at 2 x 532 (a depth of 532 pads to
+// 576 in stages of 64, to 544 in stages of 32): the ~700 cycles a stage spends outside its MFMAs are not mostly its boundary.
+static int skl_stage_depth() { return g_gemm_force_tile == 6 ? 64 : 32; }
 
 static int device_cu_count(int *out) {
     static int cus[64];
@@ -501,7 +507,7 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
                         bool *used, const int *m_dev = nullptr) {
     *used = false;
     if (g_gemm_force_tile != 0 && g_gemm_force_tile < 4) return POPE_OK;
-    if (!(g_gemm_force_tile >= 4 || streamk_shape_ok(M, K0, K1, N))) return POPE_OK;
+    if (!((g_gemm_force_tile >= 4 && g_gemm_force_tile != 6) || streamk_shape_ok(M, K0, K1, N))) return POPE_OK;
     if ((long long)M * lda * 4 >= (1ll << 32) || (long long)N * ldb * 4 >= (1ll << 32)) return POPE_OK;   // the loaders' 32-bit byte offsets
     if (!sk_operand_ok(A0, lda, K0) || !sk_operand_ok(B0, ldb, K0) || (K1 > 0 && (!sk_operand_ok(A1, lda, K1) || !sk_operand_ok(B1, ldb, K1))))
         return POPE_OK;
@@ -512,7 +518,9 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
     a.p[1] = SkProduct{K1 > 0 ? A1 : A0, K1 > 0 ? B1 : B0, lda, ldb, K1};
     a.M = M; a.N = N; a.bias = bias; a.C = C; a.ldc = ldc; a.slab = (float *)slab;
     a.tiles_m = (M + SK_TM - 1) / SK_TM; a.tiles_n = (N + SK_TN - 1) / SK_TN;
-    a.S0 = (K0 + SK_GK - 1) / SK_GK; a.S1 = (K1 + SK_GK - 1) / SK_GK;
+    const bool diag = g_gemm_force_tile == 4 || g_gemm_force_tile == 5 || g_gemm_force_tile == 8 || g_gemm_force_tile == 9;   // depth-32 kernels without loader waves
+    const int gk = diag ? SK_GK : skl_stage_depth();
+    a.S0 = (K0 + gk - 1) / gk; a.S1 = (K1 + gk - 1) / gk;
     a.m_dev = m_dev;
     const long long T = (long long)a.tiles_m * a.tiles_n * (a.S0 + a.S1);
     long long grid = cus < SK_MAX_GRID ? cus : SK_MAX_GRID;
@@ -523,7 +531,8 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
     int dev = 0;
     POPE_HIP(hipGetDevice(&dev));
     if (!opt_in.done()) {
-        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk_ld, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk_ld<32>, hipFuncAttributeMaxDynamicSharedMemorySize, SkStage<32>::LDS_BYTES));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk_ld<64>, hipFuncAttributeMaxDynamicSharedMemorySize, SkStage<64>::LDS_BYTES));
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
         POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
 #ifdef POPE_STAMP
@@ -544,8 +553,10 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
     else if (g_gemm_force_tile == 9)             // diagnostic: no MFMA
         hipLaunchKernelGGL((k_gemm_streamk<4, 4>), dim3((unsigned)grid), dim3(256), SK_LDS_BYTES, stream, a);
 #endif
-    else                                         // default: 4 MFMA waves + 4 loader waves
-        hipLaunchKernelGGL(k_gemm_streamk_ld, dim3((unsigned)grid), dim3(SKL_THREADS), SK_LDS_BYTES, stream, a);
+    else if (gk == 32)                           // 4 MFMA waves + 4 loader waves, stages of 32 (rounds 1-2)
+        hipLaunchKernelGGL(k_gemm_streamk_ld<32>, dim3((unsigned)grid), dim3(SKL_THREADS), SkStage<32>::LDS_BYTES, stream, a);
+    else                                         // default: the same with stages of 64 in two 80 KB buffers
+        hipLaunchKernelGGL(k_gemm_streamk_ld<64>, dim3((unsigned)grid), dim3(SKL_THREADS), SkStage<64>::LDS_BYTES, stream, a);
     hipLaunchKernelGGL(k_streamk_fixup, dim3(a.tiles_m * a.tiles_n, SK_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
     POPE_HIP(hipGetLastError());
     *used = true;
@@ -571,7 +582,8 @@ static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int
     SkTnArgs a;
     a.G = G; a.ldg = M; a.B[0] = B0; a.B[1] = B1; a.ldb = Nb; a.C[0] = C0; a.C[1] = C1; a.ldc = Nb;
     a.M = M; a.Nb = Nb; a.depth = (int)depth; a.slab = (float *)slab;
-    a.tiles_m = (M + SK_TM - 1) / SK_TM; a.tiles_nb = (Nb + SK_TN - 1) / SK_TN; a.S = (int)((depth + SK_GK - 1) / SK_GK);
+    const int gk = skl_stage_depth();
+    a.tiles_m = (M + SK_TM - 1) / SK_TM; a.tiles_nb = (Nb + SK_TN - 1) / SK_TN; a.S = (int)((depth + gk - 1) / gk);
     a.depth_dev = depth_dev;
     const long long T = 2ll * a.tiles_m * a.tiles_nb * a.S;
     long long grid = cus < SK_MAX_GRID ? cus : SK_MAX_GRID;
@@ -582,13 +594,19 @@ static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int
     int dev = 0;
     POPE_HIP(hipGetDevice(&dev));
     if (!opt_in.done()) {
-        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk_tn, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk_tn<32>, hipFuncAttributeMaxDynamicSharedMemorySize, SkStage<32>::LDS_BYTES));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_streamk_tn<64>, hipFuncAttributeMaxDynamicSharedMemorySize, SkStage<64>::LDS_BYTES));
         opt_in.mark();
     }
     if (!zero_page[dev]) POPE_HIP(hipGetSymbolAddress((void **)&zero_page[dev], HIP_SYMBOL(g_sk_zero)));
     a.zero = zero_page[dev];
-    hipLaunchKernelGGL(k_gemm_streamk_tn, dim3((unsigned)grid), dim3(SKL_THREADS), SK_LDS_BYTES, stream, a);
-    hipLaunchKernelGGL(k_streamk_tn_fixup, dim3(2 * a.tiles_m * a.tiles_nb, SK_TN_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
+    if (gk == 32) {
+        hipLaunchKernelGGL(k_gemm_streamk_tn<32>, dim3((unsigned)grid), dim3(SKL_THREADS), SkStage<32>::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(k_streamk_tn_fixup<32>, dim3(2 * a.tiles_m * a.tiles_nb, SK_TN_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
+    } else {
+        hipLaunchKernelGGL(k_gemm_streamk_tn<64>, dim3((unsigned)grid), dim3(SKL_THREADS), SkStage<64>::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(k_streamk_tn_fixup<64>, dim3(2 * a.tiles_m * a.tiles_nb, SK_TN_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
+    }
     POPE_HIP(hipGetLastError());
     *used = true;
     return POPE_OK;

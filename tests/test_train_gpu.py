@@ -43,22 +43,26 @@ def _model(dev, c_in=40, hidden=48, layers=3):
     return SAGE(c_in, 5, hidden, layers).to(dev)
 
 
-def test_device_extent_layers_equal_the_host_sized_ones(graph):
+@pytest.mark.parametrize("sizes,layers,c_in,hidden", [((25, 10), 3, 40, 48), ((6, 4, 3), 4, 40, 48), ((5, 3), 3, 37, 30)],
+                         ids=["two_hops", "three_hops", "odd_widths"])
+def test_device_extent_layers_equal_the_host_sized_ones(graph, sizes, layers, c_in, hidden):
     """Forward, loss and every gradient of the model on a DeviceBatch (capacity-shaped tensors, sizes read on the device)
-    against the same batch with host-known sizes.  Dropout off: the masks are functions of the element index and the row
-    pitch is the same, but the comparison should not depend on that."""
+    against the same batch with host-known sizes.  Three hops: the middle layer has BOTH extents on the device (tile GEMMs
+    with a device row count forward, a device depth in the weight gradients); odd widths: the scalar kernel variants.
+    Dropout off: the masks are functions of the element index and the row pitch is the same, but the comparison should
+    not depend on that."""
     from graphpope_amd.sage import IndexedFeatures, cross_entropy
     from graphpope_amd.sampler import NeighborSampler
     dev, _, csr = graph
-    feats = torch.randn(6000, 40, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    feats = torch.randn(6000, c_in, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
     seeds = torch.arange(100, 612, device=dev)
     y = torch.randint(0, 5, (512,), device=dev)
-    s = NeighborSampler(csr.rowptr, csr.col, 6000, (25, 10))
+    s = NeighborSampler(csr.rowptr, csr.col, 6000, sizes)
     n_id, adjs = s.sample(seeds, seed=5)
     b = s.sample_device(seeds, seed=5)
     res = []
     for x, a in ((IndexedFeatures(feats, n_id), adjs), (IndexedFeatures(feats, b.n_id), b.adjs)):
-        m = _model(dev)
+        m = _model(dev, c_in, hidden, layers)
         m.dropout = 0.0
         out = m(x, a)
         loss = cross_entropy(out, y)
@@ -66,10 +70,11 @@ def test_device_extent_layers_equal_the_host_sized_ones(graph):
         res.append((out.detach(), loss.detach(), [p.grad.clone() for p in m.parameters() if p.grad is not None],
                     [bn.running_var.clone() for bn in m.bns[:1]]))
     (o0, l0, g0, r0), (o1, l1, g1, r1) = res
-    assert torch.equal(o0, o1[: o0.shape[0]]) and torch.equal(l0, l1)
+    assert torch.allclose(o0, o1[: o0.shape[0]], rtol=1e-5, atol=1e-6) and torch.allclose(l0, l1, rtol=1e-6)
+    assert len(g0) == len(g1) and len(g0) >= 3 * len(sizes)
     for a, c in zip(g0, g1):
-        assert torch.allclose(a, c, rtol=1e-4, atol=1e-6)      # the scatter's float atomics land in a different order
-    assert torch.allclose(r0[0], r1[0], rtol=1e-6)
+        assert torch.allclose(a, c, rtol=1e-3, atol=1e-5)      # the scatter's float atomics land in a different order
+    assert torch.allclose(r0[0], r1[0], rtol=1e-5)
 
 
 @pytest.mark.parametrize("with_sampler", [True, False], ids=["sampler_in_graph", "presampled_pool"])

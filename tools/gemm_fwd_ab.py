@@ -19,18 +19,18 @@ for n_dst, c_in, c_out in shapes:
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     want = xd.double() @ wr.double().t() + b.double()          # agg = 0 for the empty block
     res = {}
-    for name, tile in (("auto", 0), ("64x64", 1), ("64x128", 2), ("sk 4 waves", 4), ("sk 8 waves", 5), ("auto", 0)):
+    for name, tile in (("auto(GK64)", 0), ("ld GK32", 6), ("64x64", 1), ("sk 4 waves", 4), ("auto(GK64)", 0), ("ld GK32", 6)):
         lib.pope_debug_set(_lib.KNOB_GEMM_TILE, tile)
         def run():
             _lib.check(lib.sage_conv_forward(_lib.ptr(rowptr), _lib.ptr(col), n_dst, n_dst, 0, _lib.ptr(xd), c_in, _lib.ptr(wl), _lib.ptr(b), _lib.ptr(wr),
-                                             c_out, _lib.ptr(aggb), _lib.ptr(out), _lib.ptr(scratch), nbytes, stream))
+                                             c_out, _lib.ptr(aggb), _lib.ptr(out), _lib.ptr(scratch), nbytes, None, stream))
         for _ in range(3): run()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         ev[0].record()
         for _ in range(20): run()
         ev[1].record(); torch.cuda.synchronize()
         err = float((out.double() - want).abs().max())
-        res[name] = (ev[0].elapsed_time(ev[1]) / 20 * 1e3, err)
+        res.setdefault(name, []).append((ev[0].elapsed_time(ev[1]) / 20 * 1e3, err))
     lib.pope_debug_set(_lib.KNOB_GEMM_TILE, 0)
     xcat = torch.cat([aggb, xd], 1); wcat = torch.cat([wl, wr], 1)
     for _ in range(3): torch.addmm(b, xcat, wcat.t())
@@ -41,5 +41,6 @@ for n_dst, c_in, c_out in shapes:
     lib_us = ev[0].elapsed_time(ev[1]) / 20 * 1e3
     flops = 4.0 * n_dst * c_in * c_out
     print(f"M={n_dst} K=2x{c_in} N={c_out}  (gather of an empty block included: ~{n_dst*c_in*4/4e6:.0f} us-ish fill)  hipBLASLt {lib_us:.1f} us")
-    for k, (us, err) in res.items():
-        print(f"   {k:10s} {us:8.1f} us  {flops/us/1e6:6.1f} TF (whole call)  max err {err:.2e}")
+    for k, runs in res.items():
+        for us, err in runs:
+            print(f"   {k:10s} {us:8.1f} us  {flops/us/1e6:6.1f} TF (whole call)  max err {err:.2e}")

@@ -1,0 +1,223 @@
+// Whole-tile f32 MFMA GEMM whose tile COUNT is fitted to the chip: the layer-0 forward projection without a fix-up pass.
+//
+//     C[M, N] = A0[M, K0] * B0[N, K0]^T + A1[M, K1] * B1[N, K1]^T (+ bias[n])        all operands depth-contiguous
+//
+// The stream-K kernel (gemm_streamk.h) balances the 157 row tiles of the 9 988 x 256 product over 256 CUs perfectly, but
+// every one of its blocks ends inside a tile: 33 MB of partial slabs and a 10 us fix-up launch behind a 77 us kernel -- and
+// the vendor library does the product in 82 us with whole tiles of 256 x 48, 234 of them (profiles/r02_kernel_stats.csv).
+// The same idea, taken further: tiles of (16 RB) x 128 on v_mfma_f32_16x16x4_f32, RB chosen on the host so that
+// ceil(M / 16 RB) * ceil(N / 128) is just under a multiple of the CU count -- 80 x 128 gives 125 x 2 = 250 tiles for
+// M = 9 988: one tile per CU, the whole depth inside the block, every output written once with its bias, no slabs.
+//   4 consumer waves: wave w owns columns [32 w, 32 w + 32) of the tile and all its rows: RB x 2 accumulators of 16 x 16.
+//     Lane (r = l & 15, g = l >> 4) reads the 16-byte chunk 4 p + g of row r in pass p; its four floats feed four
+//     consecutive MFMAs as k-slot g -- A and B use the same (MFMA, slot) -> depth map, so the sum is complete.
+//   4 loader waves (one per SIMD, so that their issue slots are taken evenly from the four MFMA waves): LDS-DMA (SADDR form) of the next stages, three stage buffers, one barrier per stage -- the rhythm of
+//     k_gemm_streamk_ld.  LDS image [row][8 chunks of 16 B], chunk XOR (row >> 1) & 7: conflict-free for this read too.
+// Host-known M only (the tile height is fitted to it); device-extent launches stay on stream-K.
+#pragma once
+
+#include "gemm_streamk.h"
+
+namespace pope {
+
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+
+constexpr int T16_TN = 128, T16_GK = 32, T16_CONSUMERS = 4, T16_LOADERS = 4, T16_THREADS = (T16_CONSUMERS + T16_LOADERS) * 64;
+
+struct T16Args {
+    SkProduct p[2];
+    int M, N;
+    const float *bias;
+    float *C;
+    long long ldc;
+    int tiles_m, tiles_n, S0, S1;
+    const float *zero;
+};
+
+template <int RB> struct T16Shape {
+    static constexpr int TM = 16 * RB;
+    static constexpr int A_BYTES = TM * T16_GK * 4, STAGE_BYTES = (TM + T16_TN) * T16_GK * 4, LDS_BYTES = 3 * STAGE_BYTES;
+    static constexpr int A_INSTR = TM / 8, INSTR = (TM + T16_TN) / 8;      // DMA wave-instructions per stage: 8 rows x 8 chunks each
+    static constexpr int ND = (INSTR + T16_LOADERS - 1) / T16_LOADERS;     // per loader wave (the last one may have fewer)
+};
+
+template <int RB>
+__global__ __launch_bounds__(T16_THREADS) void k_gemm_tile16(T16Args a) {
+    using Sh = T16Shape<RB>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem);
+    // blocks b and b + 8 sit on one XCD (round-robin dispatch): they take the two column tiles of the same rows, so the A
+    // rows they both stream come out of that XCD's L2 the second time (speed only: any placement is correct)
+    int tm, tn;
+    if (a.tiles_n == 2) {
+        const int b = blockIdx.x;
+        tn = (b >> 3) & 1;
+        tm = (b & 7) + 8 * (b >> 4);
+    } else {
+        tm = blockIdx.x / a.tiles_n;
+        tn = blockIdx.x - tm * a.tiles_n;
+    }
+    if (tm >= a.tiles_m) return;                                  // (the paired mapping rounds the grid up to a multiple of 16)
+    const int m0 = tm * Sh::TM, n0 = tn * T16_TN;
+    const int S = a.S0 + a.S1;
+
+    if (wave >= T16_CONSUMERS) {
+        // ---------------- loader waves ----------------
+        __builtin_amdgcn_s_setprio(3);
+        const int lw = wave - T16_CONSUMERS;
+        const int sub = lane >> 3, cp = lane & 7;
+        unsigned off[2][Sh::ND];
+        int koff[Sh::ND];
+#pragma unroll
+        for (int d = 0; d < Sh::ND; ++d) {
+            const int instr = lw * Sh::ND + d;
+            const int row = (instr < Sh::A_INSTR ? instr : instr - Sh::A_INSTR) * 8 + sub;
+            koff[d] = (cp ^ ((row >> 1) & 7)) * 4;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                off[q][d] = instr < Sh::A_INSTR ? (unsigned)(((long long)min(m0 + row, a.M - 1) * a.p[q].lda + koff[d]) * 4)
+                                               : (unsigned)(((long long)min(n0 + row, a.N - 1) * a.p[q].ldb + koff[d]) * 4);
+        }
+        auto issue_all = [&](int s, int buf) {
+            const bool second = s >= a.S0;                             // wave-uniform
+            const int PK = second ? a.p[1].K : a.p[0].K;
+            const int k0 = (second ? s - a.S0 : s) * T16_GK;
+            const float *A = (second ? a.p[1].A : a.p[0].A) + k0, *B = (second ? a.p[1].B : a.p[0].B) + k0;   // SGPR pairs
+            if (k0 + T16_GK <= PK) {
+#pragma unroll
+                for (int d = 0; d < Sh::ND; ++d)
+                    if (lw * Sh::ND + d < Sh::INSTR)
+                        sk_glds16_saddr(lw * Sh::ND + d < Sh::A_INSTR ? A : B, second ? off[1][d] : off[0][d],
+                                        lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
+            } else {                                                   // depth padding: lanes past the depth read the zero page
+#pragma unroll
+                for (int d = 0; d < Sh::ND; ++d)
+                    if (lw * Sh::ND + d < Sh::INSTR) {
+                        const float *src = (const float *)((const char *)(lw * Sh::ND + d < Sh::A_INSTR ? A : B) + (second ? off[1][d] : off[0][d]));
+                        if (k0 + koff[d] >= PK) src = a.zero;
+                        sk_glds16(src, lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
+                    }
+            }
+        };
+        issue_all(0, 0);
+        if (1 < S) issue_all(1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // B_0: stages 0 and 1 have landed
+        int buf = 0;
+        for (int s = 0; s < S; ++s) {
+            if (s + 2 < S) issue_all(s + 2, buf == 0 ? 2 : buf - 1);   // the buffer of stage s - 1: its readers left it before B_s
+            if (s + 1 < S) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                          // B_(s+1)
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        return;
+    }
+
+    // ---------------- consumer waves ----------------
+    const int r15 = lane & 15, g = lane >> 4;
+    int fa_off[RB], fa_swz[RB], fb_off[2], fb_swz[2];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int row = i * 16 + r15;
+        fa_off[i] = row * 128;
+        fa_swz[i] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = wave * 32 + t * 16 + r15;
+        fb_off[t] = Sh::A_BYTES + row * 128;
+        fb_swz[t] = (row >> 1) & 7;
+    }
+    f32x4acc acc[RB][2];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][t][r] = 0.0f;
+    __builtin_amdgcn_s_barrier();              // B_0
+    asm volatile("" ::: "memory");
+    float4 fa[2][RB], fb[2][2];
+    auto read_pass = [&](int b, int p, int set) {
+        const char *base = smem + b * Sh::STAGE_BYTES;
+        const int c = 4 * p + g;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) fa[set][i] = *reinterpret_cast<const float4 *>(base + fa_off[i] + ((c ^ fa_swz[i]) << 4));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fb[set][t] = *reinterpret_cast<const float4 *>(base + fb_off[t] + ((c ^ fb_swz[t]) << 4));
+    };
+    int buf = 0;
+    read_pass(0, 0, 0);
+    for (int s = 0; s < S; ++s) {
+        const bool next = s + 1 < S;
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {                                  // 16 depth values per pass
+            if (p == 0) read_pass(buf, 1, 1);
+            else if (next) read_pass(nbuf, 0, 0);                      // pass 0 of stage s + 1: landed since B_s
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].x, fb[p][t].x, acc[i][t], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].y, fb[p][t].y, acc[i][t], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].z, fb[p][t].z, acc[i][t], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].w, fb[p][t].w, acc[i][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (next) {
+            __builtin_amdgcn_s_barrier();                              // B_(s+1)
+            asm volatile("" ::: "memory");
+        }
+        buf = nbuf;
+    }
+    // C/D layout of the 16 x 16 forms: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + wave * 32 + t * 16 + r15;
+        if (n >= a.N) continue;
+        float b = a.bias ? a.bias[n] : 0.0f;
+        asm volatile("" : "+v"(b));
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + i * 16 + 4 * g + r;
+                if (m < a.M) a.C[(size_t)m * a.ldc + n] = acc[i][t][r] + b;
+            }
+    }
+}
+
+// The tile height (in 16-row blocks, 3 .. 8) that wastes the least of the chip for this M x N, or 0 if no choice reaches
+// `min_util` (the caller then uses stream-K).  Cost model: rounds of `cus` tiles, each as long as its height.
+inline int t16_pick_rb(long long M, int N, int cus, double min_util = 0.85) {
+    const long long tiles_n = (N + T16_TN - 1) / T16_TN;
+    int best = 0;
+    double best_util = 0.0;
+    for (int rb = 3; rb <= 8; ++rb) {
+        const long long tiles = ((M + 16 * rb - 1) / (16 * rb)) * tiles_n;
+        const long long rounds = (tiles + cus - 1) / cus;
+        const double util = (double)M * N / ((double)rounds * cus * 16 * rb * T16_TN);      // useful outputs / outputs the rounds could produce
+        // prefer taller tiles at equal utilisation: fewer re-reads of B, longer MFMA runs per fragment
+        if (util > best_util + 1e-9 || (util > best_util - 1e-9 && rb > best)) {
+            best_util = util;
+            best = rb;
+        }
+    }
+    return best_util >= min_util ? best : 0;
+}
+
+}  // namespace pope

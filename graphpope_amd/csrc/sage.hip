@@ -18,6 +18,7 @@
 //   k_scatter_mean   grad_x[col[p]] += grad_agg[i] / deg(i) (float atomics, whole 16-byte-aligned row segments)
 //   k_colsum_*       grad_bias, two deterministic stages
 #include "gemm_streamk_tn.h"
+#include "gemm_tile16.h"
 #include "side_copy.h"
 
 namespace pope {
@@ -507,7 +508,7 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
                         bool *used, const int *m_dev = nullptr) {
     *used = false;
     if (g_gemm_force_tile != 0 && g_gemm_force_tile < 4) return POPE_OK;
-    if (!((g_gemm_force_tile >= 4 && g_gemm_force_tile != 6) || streamk_shape_ok(M, K0, K1, N))) return POPE_OK;
+    if (!((g_gemm_force_tile >= 4 && g_gemm_force_tile != 6 && g_gemm_force_tile != 7) || streamk_shape_ok(M, K0, K1, N))) return POPE_OK;
     if ((long long)M * lda * 4 >= (1ll << 32) || (long long)N * ldb * 4 >= (1ll << 32)) return POPE_OK;   // the loaders' 32-bit byte offsets
     if (!sk_operand_ok(A0, lda, K0) || !sk_operand_ok(B0, ldb, K0) || (K1 > 0 && (!sk_operand_ok(A1, lda, K1) || !sk_operand_ok(B1, ldb, K1))))
         return POPE_OK;
@@ -558,6 +559,57 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
     else                                         // default: the same with stages of 64 in two 80 KB buffers
         hipLaunchKernelGGL(k_gemm_streamk_ld<64>, dim3((unsigned)grid), dim3(SKL_THREADS), SkStage<64>::LDS_BYTES, stream, a);
     hipLaunchKernelGGL(k_streamk_fixup, dim3(a.tiles_m * a.tiles_n, SK_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
+    POPE_HIP(hipGetLastError());
+    *used = true;
+    return POPE_OK;
+}
+
+// ---- forward projection as whole tiles fitted to the chip (gemm_tile16.h): no partial tiles, no fix-up ----
+template <int RB>
+static int launch_tile16(const T16Args &a, int grid, hipStream_t stream) {
+    static LdsOptIn opt_in;
+    if (!opt_in.done()) {
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_tile16<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, T16Shape<RB>::LDS_BYTES));
+        opt_in.mark();
+    }
+    hipLaunchKernelGGL(k_gemm_tile16<RB>, dim3((unsigned)grid), dim3(T16_THREADS), T16Shape<RB>::LDS_BYTES, stream, a);
+    return POPE_OK;
+}
+
+// *used = false if the shape does not fit the chip well enough (or the operands do not qualify) and nothing was launched.
+static int gemm_tile16(const float *A0, const float *B0, int K0, const float *A1, const float *B1, int K1, long long lda, long long ldb,
+                       int M, int N, const float *bias, float *C, long long ldc, hipStream_t stream, bool *used) {
+    *used = false;
+    if (g_gemm_force_tile != 0) return POPE_OK;                      // any forced variant: not this kernel (7 = "stream-K as in round 2")
+    if ((K0 & 3) || (K1 & 3) || M <= 0 || N <= 0 || K0 <= 0) return POPE_OK;
+    if ((long long)M * lda * 4 >= (1ll << 32) || (long long)N * ldb * 4 >= (1ll << 32)) return POPE_OK;
+    if (!sk_operand_ok(A0, lda, K0) || !sk_operand_ok(B0, ldb, K0) || (K1 > 0 && (!sk_operand_ok(A1, lda, K1) || !sk_operand_ok(B1, ldb, K1))))
+        return POPE_OK;
+    if (!streamk_shape_ok(M, K0, K1, N)) return POPE_OK;             // small products stay on the plain tile kernel
+    int cus = 0, rc;
+    if ((rc = device_cu_count(&cus))) return rc;
+    const int rb = t16_pick_rb(M, N, cus);
+    if (rb == 0) return POPE_OK;
+    static const float *zero_page[64];
+    int dev = 0;
+    POPE_HIP(hipGetDevice(&dev));
+    if (!zero_page[dev]) POPE_HIP(hipGetSymbolAddress((void **)&zero_page[dev], HIP_SYMBOL(g_sk_zero)));
+    T16Args a;
+    a.p[0] = SkProduct{A0, B0, lda, ldb, K0};
+    a.p[1] = SkProduct{K1 > 0 ? A1 : A0, K1 > 0 ? B1 : B0, lda, ldb, K1};
+    a.M = M; a.N = N; a.bias = bias; a.C = C; a.ldc = ldc; a.zero = zero_page[dev];
+    a.tiles_m = (M + 16 * rb - 1) / (16 * rb); a.tiles_n = (N + T16_TN - 1) / T16_TN;
+    a.S0 = (K0 + T16_GK - 1) / T16_GK; a.S1 = (K1 + T16_GK - 1) / T16_GK;
+    const int grid = a.tiles_n == 2 ? (a.tiles_m + 7) / 8 * 16 : a.tiles_m * a.tiles_n;
+    switch (rb) {
+    case 3: rc = launch_tile16<3>(a, grid, stream); break;
+    case 4: rc = launch_tile16<4>(a, grid, stream); break;
+    case 5: rc = launch_tile16<5>(a, grid, stream); break;
+    case 6: rc = launch_tile16<6>(a, grid, stream); break;
+    case 7: rc = launch_tile16<7>(a, grid, stream); break;
+    default: rc = launch_tile16<8>(a, grid, stream); break;
+    }
+    if (rc) return rc;
     POPE_HIP(hipGetLastError());
     *used = true;
     return POPE_OK;
@@ -678,7 +730,10 @@ extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int6
     enqueue_gather_mean(rowptr, col, n_dst, x_src, c_in, agg, stream, nullptr, nullptr, dims);
     // out = agg * w_l^T + b_l + x_dst * w_r^T in one pass
     bool used = false;
-    int rc = gemm_streamk(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);
+    int rc = POPE_OK;
+    if (!dims && (rc = gemm_tile16(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used))) return rc;
+    if (used) return POPE_OK;
+    rc = gemm_streamk(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);
     if (rc || used) return rc;
     const Operand A0{agg, c_in, 1}, B0{w_l, c_in, 1}, A1{x_src, c_in, 1}, B1{w_r, c_in, 1};
     GemmDyn dyn;
@@ -700,7 +755,10 @@ extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *c
                  "sage_conv_forward_indexed: bad size (destinations must be the first n_dst entries of n_id)");
     enqueue_gather_mean(rowptr, col, n_dst, feats, c_in, agg, stream, n_id, x_dst, dims);
     bool used = false;
-    int rc = gemm_streamk(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);
+    int rc = POPE_OK;
+    if (!dims && (rc = gemm_tile16(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used))) return rc;
+    if (used) return POPE_OK;
+    rc = gemm_streamk(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);
     if (rc || used) return rc;
     const Operand A0{agg, c_in, 1}, B0{w_l, c_in, 1}, A1{x_dst, c_in, 1}, B1{w_r, c_in, 1};
     GemmDyn dyn;

@@ -192,3 +192,31 @@ def test_config2_block_input_gradient(config2_block, dev, oracle):
     ref.backward(g)
     _close(out.detach().cpu(), ref.detach(), 1e-4)
     _close(xd.grad.cpu(), xr.grad, 1e-3)
+
+
+@pytest.mark.parametrize("n_dst,c_in,c_out", [(5800, 256, 256), (8100, 200, 256), (9988, 756, 256), (12200, 132, 256), (14300, 128, 200),
+                                              (16300, 96, 128), (9988, 756, 250)])
+def test_forward_projection_as_whole_tiles_fitted_to_the_chip(n_dst, c_in, c_out, dev, oracle):
+    """Host-sized layer-0 shapes take gemm_tile16.h (tiles of 16 RB x 128 whose count fits the CU count: RB = 3 .. 8 over
+    these row counts; ragged last row tile, a column tile cut at 250 or 200, depth padding at 132): forward against the
+    torch restatement, and bit-identical to the stream-K path (POPE_KNOB_GEMM_TILE = 7) only up to summation order -- so
+    against the oracle at the same 1e-4."""
+    from graphpope_amd import _lib
+    from graphpope_amd.sage import SAGEConv, SampledAdj
+    lib = _lib.load()
+    n_src = n_dst + 50
+    rowptr, col = _random_block(n_dst, n_src, 4, seed=n_dst)
+    torch.manual_seed(1)
+    conv = SAGEConv(c_in, c_out).to(dev)
+    x = torch.randn(n_src, c_in)
+    adj = SampledAdj(rowptr, col, n_src).to(dev)
+    with torch.no_grad():
+        out = conv((x.to(dev), None), adj)
+        lib.pope_debug_set(_lib.KNOB_GEMM_TILE, 7)
+        try:
+            out_sk = conv((x.to(dev), None), adj)
+        finally:
+            lib.pope_debug_set(_lib.KNOB_GEMM_TILE, 0)
+        ref = oracle.sage_conv_torch(x, rowptr, col, conv.lin_l.weight.cpu(), conv.lin_l.bias.cpu(), conv.lin_r.weight.cpu())
+    _close(out.cpu(), ref, 1e-4)
+    _close(out_sk.cpu(), ref, 1e-4)

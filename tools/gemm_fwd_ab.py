@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 from graphpope_amd import _lib, engine
 lib = _lib.load(); dev = engine.require_gpu()
 torch.manual_seed(0)
-shapes = [(9988, 756, 256), (1550, 256, 256), (40300, 756, 256), (9988, 532, 256)] if len(sys.argv) < 2 else [tuple(int(v) for v in sys.argv[1:4])]
+shapes = [(9988, 756, 256), (10300, 756, 256), (9000, 756, 256), (40300, 756, 256), (9988, 532, 256), (19717, 532, 256)] if len(sys.argv) < 2 else [tuple(int(v) for v in sys.argv[1:4])]
 for n_dst, c_in, c_out in shapes:
     agg = torch.rand(n_dst, c_in, device=dev); xd = torch.rand(n_dst, c_in, device=dev)
     wl = torch.randn(c_out, c_in, device=dev) * 0.05; wr = torch.randn(c_out, c_in, device=dev) * 0.05; b = torch.randn(c_out, device=dev)
@@ -19,7 +19,7 @@ for n_dst, c_in, c_out in shapes:
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     want = xd.double() @ wr.double().t() + b.double()          # agg = 0 for the empty block
     res = {}
-    for name, tile in (("auto(GK64)", 0), ("ld GK32", 6), ("64x64", 1), ("sk 4 waves", 4), ("auto(GK64)", 0), ("ld GK32", 6)):
+    for name, tile in (("auto(tile16)", 0), ("stream-K", 7), ("sk GK64", 6), ("64x64", 1), ("auto(tile16)", 0), ("stream-K", 7)):
         lib.pope_debug_set(_lib.KNOB_GEMM_TILE, tile)
         def run():
             _lib.check(lib.sage_conv_forward(_lib.ptr(rowptr), _lib.ptr(col), n_dst, n_dst, 0, _lib.ptr(xd), c_in, _lib.ptr(wl), _lib.ptr(b), _lib.ptr(wr),

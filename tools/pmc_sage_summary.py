@@ -24,7 +24,7 @@ def main(tag, rnd):
     fetch, dur = load(tag, "fetch")
     write, _ = load(tag, "write")
     mfma, _ = load(tag, "mfma")
-    out = {"source": f"rocprofv3 --pmc, one group per pass, on tools/sage_step_breakdown.py fused (110 training steps), tag {tag}",
+    out = {"source": f"rocprofv3 --pmc, one group per pass, on tools/sage_profile.py eager 60 (bench.py's headline SAGE step, 60 training steps), tag {tag}",
            "units": "us per launch (under counter collection); bytes per launch: FETCH_SIZE KiB x 1024 x 2 (gfx950), WRITE_SIZE KiB x 1024",
            "kernels": {}}
     for name in sorted(fetch):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The SAGE training step under rocprofv3 (GPU box):
-    cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python3 tools/sage_profile.py [pool|sampler] [steps] [graph]
+    cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python3 tools/sage_profile.py [eager|pool|sampler] [steps] [graph]
+eager: bench.py's headline SAGE step (autograd on host-sized pre-sampled batches); pool / sampler: graphpope_amd.train.SageTrainStep.
 One configuration per run, so that the per-kernel averages belong to it."""
 import os
 import sys
@@ -27,7 +28,26 @@ torch.manual_seed(0)
 model = SAGE(756, 7, 256, 3).to(dev)
 opt = Adam(model.parameters(), lr=1e-3)
 torch.autograd.set_multithreading_enabled(False)
-if mode == "pool":
+if mode == "eager":
+    from graphpope_amd.sage import IndexedFeatures, cross_entropy
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei_np[0], minlength=n))])
+    rng = np.random.default_rng(0)
+    batches = []
+    for b in range(8):
+        seeds = rng.choice(n, BATCH, replace=False)
+        n_id, adjs = sample_batch(rowptr, ei_np[1], seeds, sizes=(25, 10), rng=rng)
+        batches.append((torch.as_tensor(n_id, device=dev), [a.to(dev) for a in adjs], torch.randint(0, 7, (BATCH,), device=dev)))
+    params = list(model.parameters())
+    one = torch.ones((), device=dev)
+
+    def step(i):
+        n_id, adjs, y = batches[i % 8]
+        for p in params:
+            p.grad = None
+        loss = cross_entropy(model(IndexedFeatures(feats, n_id), adjs), y, unit_upstream=True)
+        loss.backward(gradient=one)
+        opt.step()
+elif mode == "pool":
     rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei_np[0], minlength=n))])
     rng = np.random.default_rng(0)
     pool = []

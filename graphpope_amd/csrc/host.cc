@@ -17,7 +17,9 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <chrono>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -31,6 +33,7 @@
 namespace pope {
 void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void clear_error();
+extern int g_host_result_mode;          // pope_debug_set(POPE_KNOB_HOST_RESULT_MODE): 0 pinned ring (default), 1 register the result's pages
 extern int g_fail_host_register;         // pope_debug_set(POPE_KNOB_FAIL_HOST_REGISTER): tests of the fallback path
 }  // namespace pope
 
@@ -203,39 +206,89 @@ struct Assembly {
     size_t out_pitch = 0;
     int64_t rows = 0;
     int chunks = 0, slices = 0;                  // every chunk is cut into `slices` row slices, one work item each
+    bool touch_only_pages = false;               // registered mode without feature columns: fault the pages in
     std::vector<int64_t> chunk_lo;               // chunks + 1 row boundaries
     std::atomic<int> next{0};
     std::vector<std::atomic<int>> done;          // per chunk: slices finished
+    // ring mode (pope_assemble_finish): the embedding columns arrive in a small pinned ring, chunk by chunk, and the same
+    // threads copy them out.  Items (ring chunk e / slices, slice e % slices) become takable once the chunk is published.
+    std::atomic<int> emb_total{-1};              // number of embedding items, -1 until finish() knows it
+    std::atomic<int> emb_next{0}, emb_published{0};
+    std::atomic<bool> aborted{false};
+    std::vector<std::atomic<int>> emb_done;      // per ring chunk: slices copied out
+    const char *ring[4] = {nullptr, nullptr, nullptr, nullptr};
+    int ring_slots = 0;
+    int64_t emb_chunk_rows = 0;
+    size_t emb_row = 0;
 
-    explicit Assembly(int nchunks) : done((size_t)nchunks) {
+    explicit Assembly(int nchunks) : done((size_t)nchunks), emb_done(0) {
         for (auto &d : done) d.store(0, std::memory_order_relaxed);
+    }
+
+    void x_item(int it) {
+        const int c = it / slices, s = it % slices;
+        const int64_t lo = chunk_lo[(size_t)c], n = chunk_lo[(size_t)c + 1] - lo;
+        const int64_t r0 = lo + n * s / slices, r1 = lo + n * (s + 1) / slices;
+        if (r1 > r0) {
+            if (x_row) {
+                for (int64_t r = r0; r < r1; ++r) copy_segment(x + (size_t)r * x_pitch, out + (size_t)r * out_pitch, x_row);
+                _mm_sfence();
+            } else if (touch_only_pages) {
+                // no feature columns: touch the pages so that registering them does not fault them in one by one.  An
+                // atomic OR with 0: a page at a chunk boundary may already be receiving the previous region's DMA (whole
+                // rows inside a region travel with it), and a locked read-modify-write cannot lose those bytes.
+                const size_t page = 4096;
+                char *b = out + (size_t)r0 * out_pitch, *e = out + (size_t)r1 * out_pitch;
+                for (char *p = b; p < e; p += page) (void)__atomic_fetch_or(p, 0, __ATOMIC_RELAXED);
+            }
+        }
+        done[(size_t)c].fetch_add(1, std::memory_order_release);
+    }
+
+    void emb_item(int e) {
+        const int c = e / slices, s = e % slices;
+        const int64_t lo = (int64_t)c * emb_chunk_rows, hi = lo + emb_chunk_rows < rows ? lo + emb_chunk_rows : rows, n = hi - lo;
+        const int64_t r0 = lo + n * s / slices, r1 = lo + n * (s + 1) / slices;
+        const char *src = ring[c % ring_slots];
+        for (int64_t r = r0; r < r1; ++r) copy_segment(src + (size_t)(r - lo) * emb_row, out + (size_t)r * out_pitch + x_row, emb_row);
+        _mm_sfence();
+        emb_done[(size_t)c].fetch_add(1, std::memory_order_release);
     }
 
     void work() {
         const int items = chunks * slices;
         for (;;) {
-            const int it = next.fetch_add(1, std::memory_order_relaxed);
-            if (it >= items) return;
-            const int c = it / slices, s = it % slices;
-            const int64_t lo = chunk_lo[(size_t)c], n = chunk_lo[(size_t)c + 1] - lo;
-            const int64_t r0 = lo + n * s / slices, r1 = lo + n * (s + 1) / slices;
-            if (r1 > r0) {
-                if (x_row) {
-                    for (int64_t r = r0; r < r1; ++r) copy_segment(x + (size_t)r * x_pitch, out + (size_t)r * out_pitch, x_row);
-                    _mm_sfence();
-                } else {
-                    // no feature columns: touch the pages so that registering them does not fault them in one by one.  An
-                    // atomic OR with 0: a page at a chunk boundary may already be receiving the previous region's DMA (whole
-                    // rows inside a region travel with it), and a locked read-modify-write cannot lose those bytes.
-                    const size_t page = 4096;
-                    char *b = out + (size_t)r0 * out_pitch, *e = out + (size_t)r1 * out_pitch;
-                    for (char *p = b; p < e; p += page) (void)__atomic_fetch_or(p, 0, __ATOMIC_RELAXED);
+            const int tot = emb_total.load(std::memory_order_acquire);
+            if (tot >= 0) {                      // a landed ring chunk first: its slot is what the next DMA waits for
+                int e = emb_next.load(std::memory_order_relaxed);
+                if (e < tot && e / slices < emb_published.load(std::memory_order_acquire)) {
+                    if (emb_next.compare_exchange_weak(e, e + 1, std::memory_order_relaxed)) emb_item(e);
+                    continue;
                 }
             }
-            done[(size_t)c].fetch_add(1, std::memory_order_release);
+            if (next.load(std::memory_order_relaxed) < items) {
+                const int it = next.fetch_add(1, std::memory_order_relaxed);
+                if (it < items) x_item(it);
+                continue;
+            }
+            if (aborted.load(std::memory_order_relaxed)) return;
+            if (tot >= 0 && emb_next.load(std::memory_order_relaxed) >= tot) return;
+            std::this_thread::yield();
         }
     }
 };
+
+// The pinned ring the embedding columns travel through: allocated once per process (24 MB), guarded by a mutex that a
+// finishing assembly holds (concurrent host -> host calls of one process take turns in this last phase).
+constexpr int RING_SLOTS = 3;
+constexpr size_t RING_SLOT_BYTES = (size_t)8 << 20;
+struct PinnedRing {
+    std::mutex mu;
+    char *slot[RING_SLOTS] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[RING_SLOTS] = {nullptr, nullptr, nullptr};
+    bool ready = false;
+};
+PinnedRing g_ring;
 
 }  // namespace
 
@@ -246,6 +299,7 @@ struct HostAssembly {
     std::vector<std::thread> pool;
     size_t total = 0;
     double t_begin = 0, t_madvise = 0;
+    bool ring = false;                           // the embedding columns come through the pinned ring (else: the result's pages are registered)
     explicit HostAssembly(int nch) : a(nch) {}
 };
 
@@ -265,7 +319,7 @@ extern "C" void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, 
     char *out = static_cast<char *>(out_host);
     const size_t total = (size_t)rows * (size_t)out_pitch_bytes;
     // 2 MB faults instead of 4 KB ones where the kernel allows it (THP "madvise" or "always"); a refusal changes nothing
-    {
+    if (!getenv("GRAPHPOPE_NO_HUGEPAGE")) {
         const uintptr_t huge = (uintptr_t)1 << 21, b = reinterpret_cast<uintptr_t>(out);
         const uintptr_t lo = (b + huge - 1) & ~(huge - 1), hi = (b + total) & ~(huge - 1);
         if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
@@ -282,6 +336,9 @@ extern "C" void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, 
     a.x = static_cast<const char *>(x_host); a.x_pitch = (size_t)x_pitch_bytes; a.x_row = (size_t)x_row_bytes;
     a.out = out; a.out_pitch = (size_t)out_pitch_bytes; a.rows = rows; a.chunks = nch;
     a.slices = t;
+    h->ring = pope::g_host_result_mode == 0;
+    a.touch_only_pages = !h->ring;
+    if (!h->ring) a.emb_total.store(0, std::memory_order_relaxed);     // no ring items: the threads leave after the feature copy
     a.chunk_lo.resize((size_t)nch + 1);
     // the first chunk is small so that the first DMA starts early; the rest are equal
     for (int c = 0; c <= nch; ++c) a.chunk_lo[(size_t)c] = rows * c / nch;
@@ -295,6 +352,7 @@ extern "C" void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, 
 extern "C" void pope_assemble_abort(void *handle) {
     HostAssembly *h = static_cast<HostAssembly *>(handle);
     if (!h) return;
+    h->a.aborted.store(true, std::memory_order_relaxed);
     for (auto &th : h->pool) th.join();
     delete h;
 }
@@ -345,6 +403,92 @@ extern "C" int pope_assemble_finish(void *handle, const void *emb, int64_t emb_p
             rc = POPE_ERR_HIP;
         }
     };
+    // Ring mode (default): the embedding columns land in three 8 MB pinned slots allocated once per process, and the threads
+    // that copied the features copy each landed chunk out into the pageable result while the next one is on the bus.  No
+    // page of the result is ever registered, so nothing about the call depends on how the kernel driver handles pinning
+    // and unpinning a fresh quarter-gigabyte range (which made repeated calls erratic, 4 .. 18 ms).
+    bool ring_done = false;
+    if (h->ring && eb > 0 && eb <= RING_SLOT_BYTES) {
+        std::unique_lock<std::mutex> lock(g_ring.mu);
+        double t0 = now_ms();
+        if (!g_ring.ready) {
+            bool ok = true;
+            for (int i = 0; i < RING_SLOTS && ok; ++i) {
+                ok = hipHostMalloc(reinterpret_cast<void **>(&g_ring.slot[i]), RING_SLOT_BYTES, hipHostMallocDefault) == hipSuccess &&
+                     hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming) == hipSuccess;
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                for (int i = 0; i < RING_SLOTS; ++i) {
+                    if (g_ring.slot[i]) (void)hipHostFree(g_ring.slot[i]);
+                    if (g_ring.ev[i]) (void)hipEventDestroy(g_ring.ev[i]);
+                    g_ring.slot[i] = nullptr; g_ring.ev[i] = nullptr;
+                }
+            }
+            g_ring.ready = ok;
+        }
+        tr[2] = now_ms() - t0;
+        if (g_ring.ready) {
+            const int64_t crow = (int64_t)(RING_SLOT_BYTES / eb);
+            const int ne = (int)((rows + crow - 1) / crow);
+            a.emb_row = eb; a.emb_chunk_rows = crow; a.ring_slots = RING_SLOTS;
+            for (int i = 0; i < RING_SLOTS; ++i) a.ring[i] = g_ring.slot[i];
+            a.emb_done = std::vector<std::atomic<int>>((size_t)ne);
+            for (auto &d : a.emb_done) d.store(0, std::memory_order_relaxed);
+            a.emb_total.store(ne * a.slices, std::memory_order_release);
+            auto publish = [&](int c) {                                            // chunk c has landed: hand it to the threads
+                const double t1 = now_ms();
+                const hipError_t e = hipEventSynchronize(g_ring.ev[c % RING_SLOTS]);
+                tr[5] += now_ms() - t1;
+                if (e != hipSuccess && rc == POPE_OK) {
+                    pope::set_error("hipEventSynchronize(ring chunk %d) failed: %s", c, hipGetErrorString(e));
+                    rc = POPE_ERR_HIP;
+                }
+                if (rc == POPE_OK) a.emb_published.store(c + 1, std::memory_order_release);
+            };
+            for (int c = 0; c < ne && rc == POPE_OK; ++c) {
+                if (c >= RING_SLOTS) {                                             // the slot's previous chunk must have been copied out
+                    t0 = now_ms();
+                    while (a.emb_done[(size_t)(c - RING_SLOTS)].load(std::memory_order_acquire) < a.slices) std::this_thread::yield();
+                    tr[1] += now_ms() - t0;
+                }
+                const int64_t lo = (int64_t)c * crow, n = (lo + crow < rows ? lo + crow : rows) - lo;
+                t0 = now_ms();
+                hipError_t e = epitch == eb ? hipMemcpyAsync(g_ring.slot[c % RING_SLOTS], embp + (size_t)lo * epitch, (size_t)n * eb, hipMemcpyDeviceToHost, stream)
+                                            : hipMemcpy2DAsync(g_ring.slot[c % RING_SLOTS], eb, embp + (size_t)lo * epitch, epitch, eb, (size_t)n,
+                                                               hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) e = hipEventRecord(g_ring.ev[c % RING_SLOTS], stream);
+                tr[3] += now_ms() - t0;
+                if (e != hipSuccess) {
+                    pope::set_error("D2H into the pinned ring (chunk %d) failed: %s", c, hipGetErrorString(e));
+                    rc = POPE_ERR_HIP;
+                    break;
+                }
+                if (c >= 1) publish(c - 1);
+            }
+            if (rc == POPE_OK) publish(ne - 1);
+            if (rc != POPE_OK) {                                                   // let the threads go; drain what is in flight
+                a.aborted.store(true, std::memory_order_relaxed);
+                a.emb_total.store(0, std::memory_order_release);
+                (void)hipStreamSynchronize(stream);
+            }
+            t0 = now_ms();
+            for (auto &th : pool) th.join();
+            pool.clear();
+            tr[4] = now_ms() - t0;
+            ring_done = true;
+        } else {
+            a.emb_total.store(0, std::memory_order_release);                       // no ring: register the result's pages instead
+        }
+    } else if (h->ring) {
+        a.emb_total.store(0, std::memory_order_release);
+    }
+    if (ring_done) {
+        tr[7] = now_ms() - t_begin;
+        for (int i = 0; i < 8; ++i) g_assemble_trace[i] = tr[i];
+        delete h;
+        return rc;
+    }
     // Registered regions are page-aligned byte ranges [lo, hi) that follow one another; a DMA must stay inside ONE of them
     // (the runtime rejects a destination that spans two registrations).  Region c ends behind chunk c's last row; whole rows
     // inside it go as one pitched copy, and the one row whose embedding columns cross into the next region (row pitches

@@ -7,6 +7,11 @@ them behind the reference's ``Graphpope`` call.  PyTorch is plumbing only (alloc
 from __future__ import annotations
 
 import ctypes
+import os
+import sys
+import threading
+import time
+import weakref
 
 import numpy as np
 import torch
@@ -132,6 +137,42 @@ class staged:
         return False
 
 
+# The returned [N, F+K] tensor lives in ordinary pageable memory.  Its pages come from an anonymous private mapping that is
+# handed back here when the tensor dies and reused by the next call of the same size: a repeated call then takes no page
+# faults (66 000 of them, or 135 huge ones whose compaction was seen to stall the GPU queues of a large process for
+# 5-15 ms afterwards), and a process that calls once -- the reference memoises -- pays them once, as with torch.empty.
+_RESULT_POOL: dict = {}              # nbytes -> mmap object of a result that has been freed (at most one entry)
+_RESULT_POOL_LOCK = threading.Lock()
+
+
+def _result_pool_cap() -> int:
+    return int(float(os.environ.get("GRAPHPOPE_RESULT_POOL_MB", "1024")) * (1 << 20))
+
+
+def _give_back(mm, nbytes: int) -> None:
+    with _RESULT_POOL_LOCK:
+        if nbytes <= _result_pool_cap() and not _RESULT_POOL:
+            _RESULT_POOL[nbytes] = mm
+    # otherwise the last reference is dropped here and the mapping is unmapped with it
+
+
+def host_result_tensor(rows: int, cols: int) -> torch.Tensor:
+    """An uninitialised contiguous float32 [rows, cols] HOST tensor in pageable memory (not pinned, not shared), backed by
+    the one-entry pool above.  GRAPHPOPE_RESULT_POOL_MB caps what the pool may keep (default 1024; 0: plain torch.empty)."""
+    nbytes = rows * cols * 4
+    if nbytes < (1 << 20) or _result_pool_cap() <= 0:
+        return torch.empty((rows, cols), dtype=torch.float32)
+    import mmap
+    with _RESULT_POOL_LOCK:
+        mm = _RESULT_POOL.pop(nbytes, None)
+        _RESULT_POOL.clear()         # another size: its pages go back to the system
+    if mm is None:
+        mm = mmap.mmap(-1, nbytes, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, prot=mmap.PROT_READ | mmap.PROT_WRITE)
+    flat = np.frombuffer(mm, dtype=np.float32)       # the tensor keeps `flat` alive (as the base of its array); it dies last
+    weakref.finalize(flat, _give_back, mm, nbytes)
+    return torch.from_numpy(flat.reshape(rows, cols))
+
+
 class HostAssembly:
     """``out[:, :f] = x`` (HOST, threads) started NOW, ``out[:, f:] = emb`` (DEVICE [N, K], DMA on the current stream) at
     :meth:`finish`, for a pageable HOST result `out` [N, f + K] (pope_assemble_begin / _finish): the page faults and the
@@ -174,11 +215,11 @@ def assemble_host_result(x: torch.Tensor | None, emb: torch.Tensor, out: torch.T
     """out[:, :f] = x (HOST, threads) and out[:, f:] = emb (DEVICE [N, K], DMA on the current stream) for a pageable
     HOST result `out` [N, f + K]; returns when `out` is complete (pope_assemble_host_result)."""
     lib = _lib.load()
-    assert not out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and emb.is_cuda and emb.is_contiguous()
+    assert not out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and emb.is_cuda and emb.stride(1) == 1
     n, k = emb.shape
     assert out.shape == (n, f + k) and (f == 0 or (x is not None and not x.is_cuda and x.shape == (n, f) and x.stride(1) == 1))
     with torch.cuda.device(emb.device):
-        check(lib.pope_assemble_host_result(ptr(x) if f else None, (x.stride(0) * 4) if f else 0, f * 4, ptr(emb), k * 4, k * 4,
+        check(lib.pope_assemble_host_result(ptr(x) if f else None, (x.stride(0) * 4) if f else 0, f * 4, ptr(emb), emb.stride(0) * 4, k * 4,
                                             ptr(out), (f + k) * 4, n, threads or host_threads(), chunks, _stream()))
 
 
@@ -469,6 +510,8 @@ def geodesic_run(x, edge_index: torch.Tensor, num_nodes: int, anchors, capacity:
     k, e = int(anc.size), ei.shape[1]
     f = 0 if x is None else x.shape[1]
     w = lib.pope_words(k)
+    trace = os.environ.get("GRAPHPOPE_TRACE")
+    t_in = time.perf_counter()
     with torch.cuda.device(dev):
         out = torch.empty((num_nodes, f + k), dtype=torch.float32, device=dev) if want_out else None
         while True:
@@ -485,9 +528,13 @@ def geodesic_run(x, edge_index: torch.Tensor, num_nodes: int, anchors, capacity:
             else:
                 ws = _bytes(nbytes_ws, dev)
             max_hop, bits = ctypes.c_int32(0), ctypes.c_int32(0)
+            t_call = time.perf_counter()
             rc = lib.pope_geodesic_run(ptr(ei), e, num_nodes, ctypes.c_void_p(anc.ctypes.data), k, ptr(x), f, ptr(out),
                                        f + k, capacity, ptr(ws), ws.numel(), ctypes.byref(max_hop), ctypes.byref(bits),
                                        _stream())
+            if trace:
+                print(f"[trace] geodesic_run: allocations {1e3 * (t_call - t_in):.2f} ms, pope_geodesic_run {1e3 * (time.perf_counter() - t_call):.2f} ms",
+                      file=sys.stderr)
             if rc == _lib.ERR_HOP_OVERFLOW and capacity < 31:
                 capacity = min(31, capacity * 2)
                 continue

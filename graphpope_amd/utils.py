@@ -123,9 +123,13 @@ def _assemble_on_host(data, k, embedding_fn):
     the reference's.  (Rounds 1-2 returned a pinned tensor: 34 ms of hipHostMalloc on the one call a process makes, and
     270 MB -- 8.6 GB for R-MAT-22 x 512 -- page-locked for as long as the memoised result lives.)
 
-    out[:, :F] = data.x is copied host to host by a few threads (data.x never crosses PCIe) while out[:, F:] = the device
-    embedding arrives by pitched DMA, chunk by chunk, into pages registered for the length of the call (utils.py:129-135
-    torch.cat((data.x, embedding), 1)).  The assembly starts AFTER ``embedding_fn()`` has uploaded edge_index and run the
+    out[:, :F] = data.x is copied host to host by a few threads (data.x never crosses PCIe); out[:, F:] = the device
+    embedding (utils.py:129-135 torch.cat((data.x, embedding), 1)) comes over in 8 MB chunks through a ring of three pinned
+    slots allocated once per process, and the same threads copy each landed chunk out while the next is on the bus.
+    ``GRAPHPOPE_HOST_RESULT`` selects the other paths that were built and measured: ``registered`` (the result's own pages
+    are registered chunk by chunk and the DMA writes them directly -- 11.4 ms first call, but 4-18 ms on repeated calls,
+    the driver's pin/unpin of a fresh quarter gigabyte being erratic), ``staged`` (the runtime's own staging) and ``pinned``
+    (rounds 1-2: page-locked result).  The assembly starts AFTER ``embedding_fn()`` has uploaded edge_index and run the
     GPU work: starting the host threads before it (engine.HostAssembly allows that) was measured 3.4-3.9 ms in a fresh process
     but 13-20 ms inside bench.py -- sixteen threads taking page faults hold the address-space lock that the runtime's
     own allocations behind a launch wait for."""
@@ -136,7 +140,9 @@ def _assemble_on_host(data, k, embedding_fn):
     n, f = int(x.shape[0]), int(x.shape[1])
     emb_dev = embedding_fn().contiguous()
     t1 = _t.perf_counter()
-    mode = os.environ.get("GRAPHPOPE_HOST_RESULT", "registered")
+    mode = os.environ.get("GRAPHPOPE_HOST_RESULT", "ring")
+    if mode not in ("ring", "registered", "staged", "pinned"):
+        raise ValueError(f"GRAPHPOPE_HOST_RESULT={mode!r}: expected ring, registered, staged or pinned")
     if mode == "pinned":                               # rounds 1-2: a page-locked result (fast when torch's host cache holds one, 34 ms when not)
         out = torch.empty((n, f + k), dtype=torch.float32, pin_memory=True)
         engine.copy_columns_to_host(emb_dev, out[:, f:])
@@ -145,14 +151,16 @@ def _assemble_on_host(data, k, embedding_fn):
         torch.cuda.current_stream().synchronize()
         res = out
     else:
-        out = torch.empty((n, f + k), dtype=torch.float32)
+        out = engine.host_result_tensor(n, f + k)
         lib = _lib_mod.load()
+        lib.pope_debug_set(_lib_mod.KNOB_HOST_RESULT_MODE, 0 if mode == "ring" else 1)
         if mode == "staged":                           # no registration of the caller-visible pages: the runtime's own staging
             lib.pope_debug_set(_lib_mod.KNOB_FAIL_HOST_REGISTER, 1)
         try:
             with engine.HostAssembly(x if f else None, out, f) as asm:
                 res = asm.finish(emb_dev)
         finally:
+            lib.pope_debug_set(_lib_mod.KNOB_HOST_RESULT_MODE, 0)
             if mode == "staged":
                 lib.pope_debug_set(_lib_mod.KNOB_FAIL_HOST_REGISTER, 0)
     if trace:

@@ -77,3 +77,36 @@ def test_argument_validation_needs_no_gpu():
     import pytest
     with pytest.raises(_lib.PopeError, match="null pointer"):
         _lib.check(lib.pope_concat(null, 4, 4, null, 8, null))
+
+
+def test_result_tensor_pool_reuses_the_pages_of_a_freed_result(monkeypatch):
+    """engine.host_result_tensor: pageable, contiguous, handed back when the LAST view dies, reused only for the same size,
+    dropped for another size and when GRAPHPOPE_RESULT_POOL_MB forbids keeping it."""
+    import torch
+    from graphpope_amd import engine
+    engine._RESULT_POOL.clear()
+    t = engine.host_result_tensor(1000, 700)
+    assert t.shape == (1000, 700) and t.dtype == torch.float32 and t.is_contiguous() and not t.is_pinned() and not t.is_shared()
+    p = t.data_ptr()
+    t.fill_(3.0)
+    v = t[:, :4]
+    del t
+    assert not engine._RESULT_POOL                       # a view still uses the pages
+    del v
+    assert list(engine._RESULT_POOL) == [2800000]
+    t2 = engine.host_result_tensor(1000, 700)
+    assert t2.data_ptr() == p and not engine._RESULT_POOL
+    t3 = engine.host_result_tensor(1000, 700)            # the pool is empty: fresh pages
+    assert t3.data_ptr() != p
+    del t2, t3
+    assert list(engine._RESULT_POOL) == [2800000]        # one entry, the first to come back
+    t4 = engine.host_result_tensor(2000, 700)            # another size evicts it
+    assert not engine._RESULT_POOL
+    monkeypatch.setenv("GRAPHPOPE_RESULT_POOL_MB", "1")
+    del t4
+    assert not engine._RESULT_POOL                       # 5.6 MB > 1 MB: unmapped, not kept
+    monkeypatch.setenv("GRAPHPOPE_RESULT_POOL_MB", "0")
+    t5 = engine.host_result_tensor(1000, 700)            # pool off: torch's own allocation
+    del t5
+    assert not engine._RESULT_POOL
+    assert engine.host_result_tensor(3, 5).shape == (3, 5)

@@ -442,12 +442,14 @@ def test_general_csr_build_is_deterministic(dev):
     assert torch.equal(s1[0], s2[0]) and all(torch.equal(x.col, y.col) for x, y in zip(s1[1], s2[1]))
 
 
-@pytest.mark.parametrize("refuse", [0, 1], ids=["registered", "registration_refused"])
-def test_host_to_host_call_returns_a_pageable_tensor_and_survives_a_refused_registration(refuse, dev, oracle):
-    """utils.py:129-147 from CPU tensors to a CPU tensor, at a size that takes the chunked path (38 MB result, 8 chunks):
-    ordinary pageable memory like the reference's torch.cat, bit-exact, also when the runtime refuses to register the
+@pytest.mark.parametrize("mode,refuse", [("ring", 0), ("registered", 0), ("registered", 1), ("staged", 0), ("pinned", 0)],
+                         ids=["ring", "registered", "registration_refused", "staged", "pinned"])
+def test_host_to_host_call_returns_a_pageable_tensor_in_every_result_mode(mode, refuse, dev, oracle, monkeypatch):
+    """utils.py:129-147 from CPU tensors to a CPU tensor, at a size that takes the chunked paths (38 MB result: 4 chunks
+    through the 3-slot pinned ring, 8 registered chunks): ordinary pageable memory like the reference's torch.cat,
+    bit-exact, in the default ring mode, with the result's pages registered, and when the runtime refuses to register the
     caller's pages (POPE_KNOB_FAIL_HOST_REGISTER: edge_index then goes through pinned staging, the embedding columns
-    through the runtime's own staging)."""
+    through the runtime's own staging).  ``pinned`` is the rounds 1-2 behaviour (a page-locked result)."""
     from graphpope_amd import _lib, synth, utils as gp
     lib = _lib.load()
     ei, n = synth.rmat(15, edge_factor=8, seed=5)
@@ -458,28 +460,56 @@ def test_host_to_host_call_returns_a_pageable_tensor_and_survives_a_refused_regi
         pass
     d = Data()
     d.x, d.edge_index, d.num_nodes = x, torch.as_tensor(ei), n
+    monkeypatch.setenv("GRAPHPOPE_HOST_RESULT", mode)
     lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, refuse)
     try:
-        gp.clear_cache()
-        np.random.seed(7)
-        out = gp.Graphpope(d, "flickr", "geodesic", "stochastic", k, None, 2)
+        for _ in range(2):                                    # the ring is reused by the second call
+            gp.clear_cache()
+            np.random.seed(7)
+            out = gp.Graphpope(d, "flickr", "geodesic", "stochastic", k, None, 2)
+            assert out.device.type == "cpu" and out.is_contiguous() and out.is_pinned() == (mode == "pinned")
+            want = oracle.geodesic_features(x.numpy(), ei, n, d.anchor_nodes)
+            assert np.array_equal(out.numpy().view(np.uint32), want.view(np.uint32))
     finally:
         lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, 0)
         gp.clear_cache()
-    assert out.device.type == "cpu" and out.is_contiguous() and not out.is_pinned()
-    want = oracle.geodesic_features(x.numpy(), ei, n, d.anchor_nodes)
-    assert np.array_equal(out.numpy().view(np.uint32), want.view(np.uint32))
     assert not d.edge_index.is_pinned()                       # the caller's tensor is released again
 
 
-def test_host_result_assembly_shapes(dev):
-    """pope_assemble_host_result on its own: no feature columns, one chunk, more chunks than rows, a strided x."""
-    from graphpope_amd import engine
+def test_host_to_host_call_rejects_an_unknown_result_mode(dev, monkeypatch):
+    from graphpope_amd import synth, utils as gp
+    ei, n = synth.rmat(8, edge_factor=4, seed=1)
+
+    class Data:
+        pass
+    d = Data()
+    d.x, d.edge_index, d.num_nodes = torch.rand(n, 3), torch.as_tensor(ei), n
+    monkeypatch.setenv("GRAPHPOPE_HOST_RESULT", "mapped")
+    gp.clear_cache()
+    with pytest.raises(ValueError, match="GRAPHPOPE_HOST_RESULT"):
+        gp.Graphpope(d, "flickr", "geodesic", "stochastic", 8, None, 2)
+    gp.clear_cache()
+
+
+@pytest.mark.parametrize("register", [0, 1], ids=["ring", "registered"])
+def test_host_result_assembly_shapes(register, dev):
+    """pope_assemble_host_result on its own: no feature columns, one chunk, more chunks than rows, a strided x, and a result
+    of seven ring chunks with rows of 132 bytes (the ring wraps twice, chunks end inside rows' cache lines)."""
+    from graphpope_amd import _lib, engine
+    lib = _lib.load()
     g = torch.Generator().manual_seed(0)
-    for n, f, k, chunks in ((5, 3, 4, 8), (40000, 0, 64, 8), (70001, 40, 36, 3), (3000, 700, 8, 0)):
-        emb = torch.rand(n, k, generator=g).to(dev)
-        xw = torch.rand(n, f + 5, generator=g)
-        x = xw[:, :f]                                         # row pitch larger than the row
-        out = torch.full((n, f + k), -1.0)
-        engine.assemble_host_result(x if f else None, emb, out, f, threads=4, chunks=chunks)
-        assert torch.equal(out[:, :f], x) and torch.equal(out[:, f:], emb.cpu())
+    lib.pope_debug_set(_lib.KNOB_HOST_RESULT_MODE, register)
+    try:
+        for n, f, k, chunks in ((5, 3, 4, 8), (40000, 0, 64, 8), (70001, 40, 36, 3), (3000, 700, 8, 0), (400003, 7, 33, 8)):
+            emb = torch.rand(n, k, generator=g).to(dev)
+            xw = torch.rand(n, f + 5, generator=g)
+            x = xw[:, :f]                                     # row pitch larger than the row
+            out = torch.full((n, f + k), -1.0)
+            engine.assemble_host_result(x if f else None, emb, out, f, threads=4, chunks=chunks)
+            assert torch.equal(out[:, :f], x) and torch.equal(out[:, f:], emb.cpu())
+        emb = torch.rand(50000, 80, generator=g).to(dev)[:, :48]      # a pitched device embedding (320-byte rows, 192 used)
+        out = torch.full((50000, 48), -1.0)
+        engine.assemble_host_result(None, emb, out, 0, threads=3, chunks=2)
+        assert torch.equal(out, emb.cpu())
+    finally:
+        lib.pope_debug_set(_lib.KNOB_HOST_RESULT_MODE, 0)

@@ -28,8 +28,11 @@ F, K = 500, 256
 x = torch.rand(n, F)
 ei_cpu = torch.as_tensor(ei_np)
 anchors = synth.seeded_anchors(n, K, 42)
-names = ["madvise", "wait_chunks", "register", "enqueue_dma", "join", "stream_sync", "unregister", "total"]
+names = ["madvise", "wait_chunks/slots", "register/ring_alloc", "enqueue_dma", "join", "stream/event_sync", "unregister", "total"]
 trace = (ctypes.c_double * 8)()
+
+
+POOL = True                                          # the result's pages come from engine's one-entry pool (no faults after call 1)
 
 
 def one(threads, chunks, label):
@@ -39,7 +42,7 @@ def one(threads, chunks, label):
         emb = engine.geodesic_features(None, ei_dev, n, anchors, shard=False)
         t2 = time.perf_counter()
     t3 = time.perf_counter()
-    out = torch.empty((n, F + K), dtype=torch.float32)
+    out = engine.host_result_tensor(n, F + K) if POOL else torch.empty((n, F + K), dtype=torch.float32)
     t4 = time.perf_counter()
     engine.assemble_host_result(x, emb, out, F, threads=threads, chunks=chunks)
     t5 = time.perf_counter()
@@ -50,14 +53,24 @@ def one(threads, chunks, label):
     del out
 
 
+for threads, chunks in ((16, 8), (16, 8), (16, 8), (16, 8), (24, 8), (24, 8), (32, 8), (32, 8), (48, 8), (48, 8), (64, 8), (8, 8), (8, 8), (16, 8)):
+    one(threads, chunks, f"RING pooled result, threads {threads:2d} chunks {chunks:2d}")
+POOL = False
+for threads, chunks in ((16, 8), (16, 8), (16, 8), (32, 8), (32, 8)):
+    one(threads, chunks, f"RING fresh pages, threads {threads:2d} chunks {chunks:2d}")
+
+lib.pope_debug_set(_lib.KNOB_HOST_RESULT_MODE, 1)
 for threads, chunks in ((16, 8), (16, 8), (16, 8), (16, 16), (16, 4), (16, 1), (32, 8), (8, 8)):
-    one(threads, chunks, f"threads {threads:2d} chunks {chunks:2d}")
+    one(threads, chunks, f"REGISTERED threads {threads:2d} chunks {chunks:2d}")
 
 
 lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, 1)           # no registration at all: the runtime's own handling of pageable memory
 for threads, chunks in ((16, 8), (16, 8), (32, 8)):
     one(threads, chunks, f"UNREGISTERED threads {threads:2d} chunks {chunks:2d}")
 lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, 0)
+lib.pope_debug_set(_lib.KNOB_HOST_RESULT_MODE, 0)
+for threads, chunks in ((16, 8), (16, 8), (16, 8)):
+    one(threads, chunks, f"RING again threads {threads:2d} chunks {chunks:2d}")
 
 
 class Data:

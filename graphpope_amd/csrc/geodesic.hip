@@ -753,6 +753,46 @@ __global__ __launch_bounds__(256) void k_hops(const u64 *__restrict__ planes, si
     }
 }
 
+// Transport form of the embedding for the host -> host boundary: one byte per (node, anchor), 0 = no path, c = hops + 1
+// otherwise (the caller has checked max hop <= 254), plus the 256 floats the bytes stand for -- lut[c] = 1 / c computed
+// HERE with the finalise kernel's own expression, so the host only looks values up.  A quarter of the float matrix's bytes
+// cross PCIe.  Wave-per-row-block like k_finalize_fast; a lane turns four anchors of one plane word into one 32-bit store.
+__global__ __launch_bounds__(256) void k_hop_codes(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits, int N, int K, int Wp,
+                                                   unsigned char *__restrict__ codes, long long pitch, float *__restrict__ lut) {
+    if (blockIdx.x == 0) lut[threadIdx.x] = threadIdx.x ? 1.0f / (float)threadIdx.x : 0.0f;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int per = (N + nwaves - 1) / nwaves;
+    const int v_begin = wave * per, v_end = min(N, v_begin + per);
+    const int K4 = (K + 3) >> 2;
+    const bool words = (K & 3) == 0 && (pitch & 3) == 0;
+    for (int v = v_begin; v < v_end; ++v) {
+        unsigned char *row = codes + (size_t)v * pitch;
+        const size_t wbase = (size_t)v * Wp;
+        for (int q = lane; q < K4; q += 64) {
+            const int j = q * 4;
+            const size_t widx = wbase + (j >> 6);
+            const int bit = j & 63;
+            const unsigned reach = (unsigned)(planes[widx] >> bit) & 15u;
+            unsigned c[4] = {0, 0, 0, 0};
+            for (int b = 0; b < n_hop_bits; ++b) {
+                const unsigned t = (unsigned)(planes[(size_t)(b + 1) * plane_elems + widx] >> bit) & 15u;
+                c[0] |= (t & 1u) << b; c[1] |= ((t >> 1) & 1u) << b; c[2] |= ((t >> 2) & 1u) << b; c[3] |= ((t >> 3) & 1u) << b;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = ((reach >> i) & 1u) ? c[i] + 1u : 0u;
+            if (words) {
+                reinterpret_cast<unsigned *>(row)[q] = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (j + i < K) row[j + i] = (unsigned char)c[i];
+            }
+        }
+    }
+}
+
 // Per-anchor column statistics of the hop matrix straight from the planes: how many nodes reach anchor j and the sum of
 // their hop counts (closeness centrality = inward distances, utils.py:50-54).  Thread t of a block owns anchor column
 // tile * 256 + t and walks a slice of the rows; 64 threads share each plane word (one L1 line).  Two deterministic stages.
@@ -1640,6 +1680,23 @@ extern "C" int pope_geodesic_hops(const uint64_t *planes, int32_t n_hop_bits, in
     const int Wp = words_for(K);
     hipLaunchKernelGGL(k_hops, dim3(capped_grid((size_t)N * K, 256)), dim3(256), 0, stream, (const u64 *)planes,
                        (size_t)N * Wp, n_hop_bits, (int)N, K, Wp, hops);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+extern "C" int pope_geodesic_hop_codes(const uint64_t *planes, int32_t n_hop_bits, int32_t max_hop, int64_t N, int32_t K, uint8_t *codes,
+                                       int64_t codes_pitch_bytes, float *lut, void *stream_) {
+    clear_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    POPE_REQUIRE(planes && codes && lut, "pope_geodesic_hop_codes: null pointer");
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && K > 0 && codes_pitch_bytes >= K, "pope_geodesic_hop_codes: bad size");
+    POPE_REQUIRE(n_hop_bits >= 0 && n_hop_bits <= 8 && max_hop >= 0 && max_hop <= 254 && max_hop < (1 << n_hop_bits),
+                 "pope_geodesic_hop_codes: hop counts above 254 do not fit the byte code (use pope_geodesic_finalize)");
+    const int Wp = words_for(K);
+    const size_t waves = ((size_t)N + 7) / 8;                          // about eight rows per wave
+    const int grid = (int)std::min<size_t>(std::max<size_t>((waves + 3) / 4, 1), 4096);
+    hipLaunchKernelGGL(k_hop_codes, dim3(grid), dim3(256), 0, stream, (const u64 *)planes, (size_t)N * Wp, n_hop_bits, (int)N, K, Wp, codes,
+                       (long long)codes_pitch_bytes, lut);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }

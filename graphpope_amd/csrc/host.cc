@@ -199,6 +199,25 @@ inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// dst[0 .. n) (floats, 4-byte aligned) = the values the code bytes stand for.  `pair` maps TWO code bytes (low byte first) to
+// their two floats, so one 8-byte load serves two elements; only the entries of codes that occur are ever touched (hop
+// counts are small), so the lookups stay in L1.  Streaming stores once dst is 16-byte aligned, like copy_segment.
+inline void expand_codes(const unsigned char *src, char *dst_, size_t n, const uint64_t *pair) {
+    float *dst = reinterpret_cast<float *>(dst_);
+    const float *single = reinterpret_cast<const float *>(pair);                  // pair[c] for c < 256 is (lut[c], lut[0]): element 2c is lut[c]
+    size_t i = 0;
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 15u)) { dst[i] = single[2 * (size_t)src[i]]; ++i; }
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, src + i, 8);
+        const __m128i lo = _mm_set_epi64x((long long)pair[(w >> 16) & 0xFFFFu], (long long)pair[w & 0xFFFFu]);
+        const __m128i hi = _mm_set_epi64x((long long)pair[(w >> 48) & 0xFFFFu], (long long)pair[(w >> 32) & 0xFFFFu]);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i), lo);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 4), hi);
+    }
+    for (; i < n; ++i) dst[i] = single[2 * (size_t)src[i]];
+}
+
 struct Assembly {
     const char *x = nullptr;
     size_t x_pitch = 0, x_row = 0;
@@ -219,7 +238,9 @@ struct Assembly {
     const char *ring[4] = {nullptr, nullptr, nullptr, nullptr};
     int ring_slots = 0;
     int64_t emb_chunk_rows = 0;
-    size_t emb_row = 0;
+    size_t emb_row = 0;                          // bytes of one row in the ring
+    const uint64_t *pair_lut = nullptr;          // hop-code transport: the ring holds one byte per element, this table the floats
+    size_t emb_elems = 0;                        //   ... elements (bytes) per row
 
     explicit Assembly(int nchunks) : done((size_t)nchunks), emb_done(0) {
         for (auto &d : done) d.store(0, std::memory_order_relaxed);
@@ -250,7 +271,12 @@ struct Assembly {
         const int64_t lo = (int64_t)c * emb_chunk_rows, hi = lo + emb_chunk_rows < rows ? lo + emb_chunk_rows : rows, n = hi - lo;
         const int64_t r0 = lo + n * s / slices, r1 = lo + n * (s + 1) / slices;
         const char *src = ring[c % ring_slots];
-        for (int64_t r = r0; r < r1; ++r) copy_segment(src + (size_t)(r - lo) * emb_row, out + (size_t)r * out_pitch + x_row, emb_row);
+        if (pair_lut) {
+            for (int64_t r = r0; r < r1; ++r)
+                expand_codes(reinterpret_cast<const unsigned char *>(src) + (size_t)(r - lo) * emb_row, out + (size_t)r * out_pitch + x_row, emb_elems, pair_lut);
+        } else {
+            for (int64_t r = r0; r < r1; ++r) copy_segment(src + (size_t)(r - lo) * emb_row, out + (size_t)r * out_pitch + x_row, emb_row);
+        }
         _mm_sfence();
         emb_done[(size_t)c].fetch_add(1, std::memory_order_release);
     }
@@ -287,6 +313,9 @@ struct PinnedRing {
     char *slot[RING_SLOTS] = {nullptr, nullptr, nullptr};
     hipEvent_t ev[RING_SLOTS] = {nullptr, nullptr, nullptr};
     bool ready = false;
+    float *lut_pinned = nullptr;                 // hop-code transport: where the device's 256 floats land ...
+    float lut_seen[256];                         // ... the table pair_lut was built from ...
+    std::vector<uint64_t> pair_lut;              // ... and the 65 536-entry two-byte table (512 KB, built once: the floats never change)
 };
 PinnedRing g_ring;
 
@@ -357,7 +386,10 @@ extern "C" void pope_assemble_abort(void *handle) {
     delete h;
 }
 
-extern "C" int pope_assemble_finish(void *handle, const void *emb, int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *stream_) {
+// `lut_dev` == nullptr: `emb` holds the float columns themselves.  Otherwise `emb` holds one code byte per element
+// (pope_geodesic_hop_codes) and `lut_dev` the 256 floats the codes stand for: a quarter of the bytes cross PCIe and the host
+// threads look the floats up while they copy out of the ring (ring mode only).
+static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch_bytes, int64_t emb_row_bytes, const float *lut_dev, void *stream_) {
     pope::clear_error();
     hipStream_t stream = (hipStream_t)stream_;
     HostAssembly *h = static_cast<HostAssembly *>(handle);
@@ -367,9 +399,13 @@ extern "C" int pope_assemble_finish(void *handle, const void *emb, int64_t emb_p
     }
     Assembly &a = h->a;
     std::vector<std::thread> &pool = h->pool;
-    if (emb_row_bytes < 0 || (emb_row_bytes > 0 && (!emb || emb_pitch_bytes < emb_row_bytes)) || a.out_pitch < a.x_row + (size_t)emb_row_bytes) {
+    const bool coded = lut_dev != nullptr;
+    const size_t out_row = (size_t)(emb_row_bytes < 0 ? 0 : emb_row_bytes) * (coded ? sizeof(float) : 1);
+    if (emb_row_bytes < 0 || (emb_row_bytes > 0 && (!emb || emb_pitch_bytes < emb_row_bytes)) || a.out_pitch < a.x_row + out_row ||
+        (coded && (!h->ring || emb_row_bytes == 0))) {
         pope_assemble_abort(h);
-        pope::set_error("pope_assemble_finish: null pointer or bad size");
+        pope::set_error(coded && !h->ring ? "pope_assemble_finish_codes: the hop-code transport needs the ring mode (POPE_KNOB_HOST_RESULT_MODE 0)"
+                                          : "pope_assemble_finish: null pointer or bad size");
         return POPE_ERR_INVALID;
     }
     double tr[8] = {h->t_madvise, 0, 0, 0, 0, 0, 0, 0};
@@ -417,8 +453,11 @@ extern "C" int pope_assemble_finish(void *handle, const void *emb, int64_t emb_p
                 ok = hipHostMalloc(reinterpret_cast<void **>(&g_ring.slot[i]), RING_SLOT_BYTES, hipHostMallocDefault) == hipSuccess &&
                      hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming) == hipSuccess;
             }
+            ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g_ring.lut_pinned), 256 * sizeof(float), hipHostMallocDefault) == hipSuccess;
             if (!ok) {
                 (void)hipGetLastError();
+                if (g_ring.lut_pinned) (void)hipHostFree(g_ring.lut_pinned);
+                g_ring.lut_pinned = nullptr;
                 for (int i = 0; i < RING_SLOTS; ++i) {
                     if (g_ring.slot[i]) (void)hipHostFree(g_ring.slot[i]);
                     if (g_ring.ev[i]) (void)hipEventDestroy(g_ring.ev[i]);
@@ -431,7 +470,12 @@ extern "C" int pope_assemble_finish(void *handle, const void *emb, int64_t emb_p
         if (g_ring.ready) {
             const int64_t crow = (int64_t)(RING_SLOT_BYTES / eb);
             const int ne = (int)((rows + crow - 1) / crow);
-            a.emb_row = eb; a.emb_chunk_rows = crow; a.ring_slots = RING_SLOTS;
+            a.emb_row = eb; a.emb_elems = eb; a.emb_chunk_rows = crow; a.ring_slots = RING_SLOTS;
+            if (coded && hipMemcpyAsync(g_ring.lut_pinned, lut_dev, 256 * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess) {
+                (void)hipGetLastError();
+                pope::set_error("D2H of the code table failed");
+                rc = POPE_ERR_HIP;
+            }
             for (int i = 0; i < RING_SLOTS; ++i) a.ring[i] = g_ring.slot[i];
             a.emb_done = std::vector<std::atomic<int>>((size_t)ne);
             for (auto &d : a.emb_done) d.store(0, std::memory_order_relaxed);
@@ -443,6 +487,16 @@ extern "C" int pope_assemble_finish(void *handle, const void *emb, int64_t emb_p
                 if (e != hipSuccess && rc == POPE_OK) {
                     pope::set_error("hipEventSynchronize(ring chunk %d) failed: %s", c, hipGetErrorString(e));
                     rc = POPE_ERR_HIP;
+                }
+                if (rc == POPE_OK && coded && c == 0) {                           // the table travelled ahead of chunk 0
+                    if (g_ring.pair_lut.empty() || memcmp(g_ring.lut_seen, g_ring.lut_pinned, sizeof(g_ring.lut_seen)) != 0) {
+                        memcpy(g_ring.lut_seen, g_ring.lut_pinned, sizeof(g_ring.lut_seen));
+                        g_ring.pair_lut.resize(65536);
+                        uint32_t bits[256];
+                        memcpy(bits, g_ring.lut_seen, sizeof(bits));
+                        for (uint32_t p = 0; p < 65536; ++p) g_ring.pair_lut[p] = (uint64_t)bits[p & 255u] | ((uint64_t)bits[p >> 8] << 32);
+                    }
+                    a.pair_lut = g_ring.pair_lut.data();
                 }
                 if (rc == POPE_OK) a.emb_published.store(c + 1, std::memory_order_release);
             };
@@ -482,6 +536,11 @@ extern "C" int pope_assemble_finish(void *handle, const void *emb, int64_t emb_p
         }
     } else if (h->ring) {
         a.emb_total.store(0, std::memory_order_release);
+    }
+    if (coded && !ring_done) {
+        pope_assemble_abort(h);
+        pope::set_error("pope_assemble_finish_codes: no pinned ring (hipHostMalloc refused or rows wider than a ring slot)");
+        return POPE_ERR_HIP;
     }
     if (ring_done) {
         tr[7] = now_ms() - t_begin;
@@ -554,6 +613,20 @@ extern "C" int pope_assemble_finish(void *handle, const void *emb, int64_t emb_p
     for (int i = 0; i < 8; ++i) g_assemble_trace[i] = tr[i];
     delete h;
     return rc;
+}
+
+extern "C" int pope_assemble_finish(void *handle, const void *emb, int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *stream_) {
+    return assemble_finish_impl(handle, emb, emb_pitch_bytes, emb_row_bytes, nullptr, stream_);
+}
+
+extern "C" int pope_assemble_finish_codes(void *handle, const uint8_t *codes, int64_t codes_pitch_bytes, int32_t K, const float *lut, void *stream_) {
+    if (!lut) {
+        pope_assemble_abort(handle);
+        pope::clear_error();
+        pope::set_error("pope_assemble_finish_codes: null code table");
+        return POPE_ERR_INVALID;
+    }
+    return assemble_finish_impl(handle, codes, codes_pitch_bytes, K, lut, stream_);
 }
 
 extern "C" int pope_assemble_host_result(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, const void *emb,

@@ -201,6 +201,20 @@ class HostAssembly:
                 check(lib.pope_assemble_finish(h, ptr(emb), k * 4, k * 4, _stream()))
         return self.out
 
+    def finish_codes(self, codes: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
+        """:meth:`finish` for the embedding in its transport form (:func:`hop_codes`): uint8 [N, K] codes and the 256 floats
+        they stand for, both on the device; a quarter of the bytes cross PCIe and the host threads look the floats up
+        (pope_assemble_finish_codes, ring mode only)."""
+        lib = _lib.load()
+        n, k = codes.shape
+        assert codes.is_cuda and codes.dtype == torch.uint8 and codes.stride(1) == 1 and self.out.shape == (n, self.f + k)
+        assert lut.is_cuda and lut.dtype == torch.float32 and lut.numel() == 256 and lut.is_contiguous()
+        h, self.handle = self.handle, None
+        if h:
+            with torch.cuda.device(codes.device):
+                check(lib.pope_assemble_finish_codes(h, ptr(codes), codes.stride(0), k, ptr(lut), _stream()))
+        return self.out
+
     def __enter__(self):
         return self
 
@@ -279,6 +293,23 @@ class HopPlanes:
 
     def valid(self) -> torch.Tensor:
         return self.planes[: 1 + self.n_hop_bits]
+
+
+MAX_CODED_HOP = 254                 # the byte code of hop h is h + 1; 0 says "no path"
+
+
+def hop_codes(hp: HopPlanes):
+    """The embedding of ``hp`` in its transport form: (uint8 [N, K] on the device -- 0 = no path, hops + 1 otherwise --,
+    float32 [256] on the device: the value each code stands for).  Only for ``hp.max_hop <= MAX_CODED_HOP``
+    (pope_geodesic_hop_codes)."""
+    lib = _lib.load()
+    dev = hp.planes.device
+    assert hp.planes.is_contiguous() and hp.planes.shape[1] == hp.num_nodes
+    with torch.cuda.device(dev):
+        codes = torch.empty((hp.num_nodes, hp.k), dtype=torch.uint8, device=dev)
+        lut = torch.empty(256, dtype=torch.float32, device=dev)
+        check(lib.pope_geodesic_hop_codes(ptr(hp.planes), hp.n_hop_bits, hp.max_hop, hp.num_nodes, hp.k, ptr(codes), hp.k, ptr(lut), _stream()))
+    return codes, lut
 
 
 def bfs(csr: Csr, anchors, capacity: int = DEFAULT_PLANE_CAPACITY) -> HopPlanes:

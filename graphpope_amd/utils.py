@@ -138,11 +138,15 @@ def _assemble_on_host(data, k, embedding_fn):
     t0 = _t.perf_counter()
     x = _host_features(data)
     n, f = int(x.shape[0]), int(x.shape[1])
-    emb_dev = embedding_fn().contiguous()
+    emb_dev = embedding_fn()                           # float32 [N, K], or (uint8 codes [N, K], float32 lut [256]): engine.hop_codes
+    coded = isinstance(emb_dev, tuple)
+    if not coded:
+        emb_dev = emb_dev.contiguous()
     t1 = _t.perf_counter()
     mode = os.environ.get("GRAPHPOPE_HOST_RESULT", "ring")
     if mode not in ("ring", "registered", "staged", "pinned"):
         raise ValueError(f"GRAPHPOPE_HOST_RESULT={mode!r}: expected ring, registered, staged or pinned")
+    assert not coded or mode == "ring"
     if mode == "pinned":                               # rounds 1-2: a page-locked result (fast when torch's host cache holds one, 34 ms when not)
         out = torch.empty((n, f + k), dtype=torch.float32, pin_memory=True)
         engine.copy_columns_to_host(emb_dev, out[:, f:])
@@ -158,7 +162,7 @@ def _assemble_on_host(data, k, embedding_fn):
             lib.pope_debug_set(_lib_mod.KNOB_FAIL_HOST_REGISTER, 1)
         try:
             with engine.HostAssembly(x if f else None, out, f) as asm:
-                res = asm.finish(emb_dev)
+                res = asm.finish_codes(*emb_dev) if coded else asm.finish(emb_dev)
         finally:
             lib.pope_debug_set(_lib_mod.KNOB_HOST_RESULT_MODE, 0)
             if mode == "staged":
@@ -185,8 +189,12 @@ def _geodesic_planes(ei, n, anchors, dev):
     return hp.valid(), hp.n_hop_bits
 
 
-def _geodesic_embedding_device(edge_index, n, anchors, dev):
-    """float32 [N, K] on the device: 1 / (hops + 1) to every anchor (sharded over the ranks of a process group)."""
+def _geodesic_embedding_device(edge_index, n, anchors, dev, coded=False):
+    """float32 [N, K] on the device: 1 / (hops + 1) to every anchor (sharded over the ranks of a process group).
+
+    ``coded=True`` (the host -> host caller, one rank): the transport form instead when the hop counts allow it --
+    (uint8 codes [N, K], float32 lut [256]) from engine.hop_codes, a quarter of the bytes to bring down."""
+    from . import distributed as pdist
     trace = os.environ.get("GRAPHPOPE_TRACE")
     import time as _t
     t0 = _t.perf_counter()
@@ -194,7 +202,15 @@ def _geodesic_embedding_device(edge_index, n, anchors, dev):
         ei = ei_dev.to(torch.int64)
         if not os.environ.get("GRAPHPOPE_CACHE_DIR"):
             t1 = _t.perf_counter()
-            emb = engine.geodesic_features(None, ei, n, anchors, shard=_shard())
+            if coded and (not _shard() or pdist.world_size(None) == 1):
+                _, hp = engine.geodesic_run(None, ei, n, anchors, want_out=False, reuse_workspace=True)
+                if hp.max_hop <= engine.MAX_CODED_HOP:
+                    emb = engine.hop_codes(hp)
+                else:                                                # a graph deeper than a byte: the float columns
+                    emb = torch.empty((n, len(anchors)), dtype=torch.float32, device=dev)
+                    engine.finalize(hp.valid().contiguous(), hp.n_hop_bits, n, len(anchors), None, 0, emb, 0)
+            else:
+                emb = engine.geodesic_features(None, ei, n, anchors, shard=_shard())
             if trace:
                 import sys as _s
                 print(f"[trace] stage {1e3 * (t1 - t0):.2f} ms, geodesic_features {1e3 * (_t.perf_counter() - t1):.2f} ms", file=_s.stderr)
@@ -216,7 +232,11 @@ def _geodesic_features(data, dev):
         out[:, : x.shape[1]] = x
         out[:, x.shape[1]:] = emb_cols
         return out.cpu()
-    return _assemble_on_host(data, len(anchors), lambda: _geodesic_embedding_device(data.edge_index, n, anchors, dev))
+    transport = os.environ.get("GRAPHPOPE_HOST_TRANSPORT", "codes")
+    if transport not in ("codes", "float"):
+        raise ValueError(f"GRAPHPOPE_HOST_TRANSPORT={transport!r}: expected codes or float")
+    coded = transport == "codes" and os.environ.get("GRAPHPOPE_HOST_RESULT", "ring") == "ring"
+    return _assemble_on_host(data, len(anchors), lambda: _geodesic_embedding_device(data.edge_index, n, anchors, dev, coded))
 
 
 def get_geodesic_distance_vector(data, num_workers):

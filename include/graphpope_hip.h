@@ -329,12 +329,14 @@ int pope_copy_2d_to_host(const void *src, int64_t src_pitch_bytes, void *dst_hos
 /*
  * The whole torch.cat((data.x, embedding), 1) of the host -> host call (utils.py:129-135) into an ORDINARY PAGEABLE
  * result, as the reference returns one: out[:, :x_row_bytes] = x_host rows (host threads, streaming stores) and
- * out[:, x_row_bytes : x_row_bytes + emb_row_bytes] = emb rows (DEVICE memory, pitched DMA on `stream`, behind whatever
- * produced emb there).  The result is cut into `chunks` row chunks (<= 0: 8): worker threads fill a chunk's feature
- * columns (its first touch: MADV_HUGEPAGE is applied first), the calling thread then registers that chunk's pages with
- * the HIP runtime and enqueues its DMA, so page faults, the host copy and PCIe overlap; every registration is released
- * and `stream` is synchronised before the call returns.  If a registration is refused the remaining chunks are copied
- * through the runtime's own staging (slower, same bytes).  x_row_bytes or emb_row_bytes may be 0.
+ * out[:, x_row_bytes : x_row_bytes + emb_row_bytes] = emb rows (DEVICE memory, DMA on `stream`, behind whatever produced
+ * emb there).  Default (POPE_KNOB_HOST_RESULT_MODE 0): the embedding rows come over in 8 MB chunks through three pinned
+ * slots that are allocated once per process, and the worker threads copy each landed chunk out while the next one is on
+ * the bus -- no page of the result is ever registered.  Mode 1: the result is cut into `chunks` row chunks (<= 0: 8),
+ * worker threads fill a chunk's feature columns (its first touch: MADV_HUGEPAGE is applied first), the calling thread
+ * registers that chunk's pages with the HIP runtime and the pitched DMA writes them directly; every registration is
+ * released before the call returns, and if one is refused the remaining chunks go through the runtime's own staging
+ * (slower, same bytes).  `stream` is synchronised before the call returns.  x_row_bytes or emb_row_bytes may be 0.
  */
 int pope_assemble_host_result(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, const void *emb,
                               int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *out_host, int64_t out_pitch_bytes,
@@ -350,6 +352,18 @@ void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, int64_t x_r
                           int64_t rows, int32_t threads, int32_t chunks);
 int pope_assemble_finish(void *handle, const void *emb, int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *stream);
 void pope_assemble_abort(void *handle);
+
+/*
+ * The geodesic embedding in its transport form (utils.py:73 1 / len(path), one byte per element instead of four):
+ * pope_geodesic_hop_codes writes codes[v * pitch + j] = 0 if node v has no path to anchor j, hops + 1 otherwise, and the
+ * 256 floats the bytes stand for (lut[0] = 0, lut[c] = 1 / c, the finalise kernel's own arithmetic) -- hop counts above 254
+ * are refused (POPE_ERR_INVALID; use pope_geodesic_finalize).  pope_assemble_finish_codes is pope_assemble_finish for that
+ * form (ring mode only): K code bytes per row cross PCIe -- a quarter of the float columns -- and the worker threads write
+ * out[:, x_row_bytes + 4 j] = lut[code] while they copy out of the ring; the host looks floats up, it computes none.
+ */
+int pope_geodesic_hop_codes(const uint64_t *planes, int32_t n_hop_bits, int32_t max_hop, int64_t N, int32_t K, uint8_t *codes,
+                            int64_t codes_pitch_bytes, float *lut, void *stream);
+int pope_assemble_finish_codes(void *handle, const uint8_t *codes, int64_t codes_pitch_bytes, int32_t K, const float *lut, void *stream);
 
 /*
  * Caller-owned pageable HOST memory as a DMA endpoint for the length of one call: pope_host_pin registers [host, host +

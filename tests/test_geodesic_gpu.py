@@ -442,9 +442,10 @@ def test_general_csr_build_is_deterministic(dev):
     assert torch.equal(s1[0], s2[0]) and all(torch.equal(x.col, y.col) for x, y in zip(s1[1], s2[1]))
 
 
-@pytest.mark.parametrize("mode,refuse", [("ring", 0), ("registered", 0), ("registered", 1), ("staged", 0), ("pinned", 0)],
-                         ids=["ring", "registered", "registration_refused", "staged", "pinned"])
-def test_host_to_host_call_returns_a_pageable_tensor_in_every_result_mode(mode, refuse, dev, oracle, monkeypatch):
+@pytest.mark.parametrize("mode,refuse,transport", [("ring", 0, "codes"), ("ring", 0, "float"), ("registered", 0, "codes"), ("registered", 1, "codes"),
+                                                   ("staged", 0, "codes"), ("pinned", 0, "codes")],
+                         ids=["ring_codes", "ring_float", "registered", "registration_refused", "staged", "pinned"])
+def test_host_to_host_call_returns_a_pageable_tensor_in_every_result_mode(mode, refuse, transport, dev, oracle, monkeypatch):
     """utils.py:129-147 from CPU tensors to a CPU tensor, at a size that takes the chunked paths (38 MB result: 4 chunks
     through the 3-slot pinned ring, 8 registered chunks): ordinary pageable memory like the reference's torch.cat,
     bit-exact, in the default ring mode, with the result's pages registered, and when the runtime refuses to register the
@@ -461,6 +462,7 @@ def test_host_to_host_call_returns_a_pageable_tensor_in_every_result_mode(mode, 
     d = Data()
     d.x, d.edge_index, d.num_nodes = x, torch.as_tensor(ei), n
     monkeypatch.setenv("GRAPHPOPE_HOST_RESULT", mode)
+    monkeypatch.setenv("GRAPHPOPE_HOST_TRANSPORT", transport)       # byte codes only travel in ring mode; the others send floats
     lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, refuse)
     try:
         for _ in range(2):                                    # the ring is reused by the second call
@@ -513,3 +515,71 @@ def test_host_result_assembly_shapes(register, dev):
         assert torch.equal(out, emb.cpu())
     finally:
         lib.pope_debug_set(_lib.KNOB_HOST_RESULT_MODE, 0)
+
+
+@pytest.mark.parametrize("k", [1, 37, 64, 200])
+def test_hop_codes_are_the_hop_matrix_plus_one(k, dev, oracle):
+    """pope_geodesic_hop_codes, the transport form of the embedding: code 0 = no path, hops + 1 otherwise, and the table
+    holds exactly the floats the finalise kernel writes (utils.py:73) -- for widths that are and are not multiples of 4."""
+    from graphpope_amd import engine, synth
+    ei, n = synth.rmat(11, edge_factor=3, seed=2)                 # sparse enough to leave some pairs without a path
+    anchors = synth.seeded_anchors(n, k, 5)
+    ei_dev = torch.as_tensor(ei).to(dev)
+    emb, hp = engine.geodesic_run(None, ei_dev, n, anchors)
+    codes, lut = engine.hop_codes(hp)
+    hops = oracle.geodesic_hops(ei, n, anchors)
+    assert (hops < 0).any() and hops.max() >= 2
+    assert np.array_equal(codes.cpu().numpy().astype(np.int64), hops.astype(np.int64) + 1)
+    want_lut = np.zeros(256, dtype=np.float32)
+    want_lut[1:] = np.float32(1.0) / np.arange(1, 256, dtype=np.float32)
+    assert np.array_equal(lut.cpu().numpy().view(np.uint32), want_lut.view(np.uint32))
+    assert np.array_equal(lut.cpu().numpy()[codes.cpu().numpy()].view(np.uint32), emb.cpu().numpy().view(np.uint32))
+
+
+def test_hop_codes_refuse_hop_counts_that_do_not_fit_a_byte(dev):
+    from graphpope_amd import _lib, engine
+    n = 300                                                       # a path: node 299 is 299 hops from anchor 0
+    ei = np.stack([np.arange(n - 1), np.arange(1, n)]).astype(np.int64)
+    ei = np.concatenate([ei, ei[::-1]], axis=1)
+    _, hp = engine.geodesic_run(None, torch.as_tensor(ei).to(dev), n, [0, 150], want_out=False)
+    assert hp.max_hop == 299
+    with pytest.raises(_lib.PopeError, match="254"):
+        engine.hop_codes(hp)
+
+
+@pytest.mark.parametrize("transport", ["codes", "float"])
+def test_host_to_host_call_on_a_graph_deeper_than_a_byte(transport, dev, oracle, monkeypatch):
+    """299 hops: the byte transport does not apply and the call sends the float columns instead -- same result."""
+    from graphpope_amd import utils as gp
+    n = 300
+    ei = np.stack([np.arange(n - 1), np.arange(1, n)]).astype(np.int64)
+    ei = np.concatenate([ei, ei[::-1]], axis=1)
+
+    class Data:
+        pass
+    d = Data()
+    d.x, d.edge_index, d.num_nodes = torch.rand(n, 5), torch.as_tensor(ei), n
+    monkeypatch.setenv("GRAPHPOPE_HOST_TRANSPORT", transport)
+    gp.clear_cache()
+    np.random.seed(1)
+    out = gp.Graphpope(d, "flickr", "geodesic", "stochastic", 12, None, 2)
+    gp.clear_cache()
+    want = oracle.geodesic_features(d.x.numpy(), ei, n, d.anchor_nodes)
+    assert np.array_equal(out.numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_host_result_assembly_from_codes(dev):
+    """pope_assemble_finish_codes on its own: every code value, widths that are not multiples of 8, feature widths that put
+    the embedding columns at every alignment, a strided code matrix, and a result of four ring chunks."""
+    from graphpope_amd import engine
+    g = torch.Generator().manual_seed(1)
+    lut = torch.rand(256, generator=g).to(dev)
+    for n, f, k in ((7, 0, 1), (5000, 3, 37), (5000, 1, 8), (5000, 2, 255), (40000, 6, 64), (300007, 5, 100)):
+        wide = torch.randint(0, 256, (n, k + 3), generator=g, dtype=torch.uint8).to(dev)
+        codes = wide[:, :k]                                   # row pitch larger than the row
+        x = torch.rand(n, f, generator=g)
+        out = torch.full((n, f + k), -1.0)
+        with engine.HostAssembly(x if f else None, out, f, threads=5) as asm:
+            asm.finish_codes(codes, lut)
+        assert torch.equal(out[:, :f], x)
+        assert torch.equal(out[:, f:], lut.cpu()[codes.cpu().long()])

@@ -312,7 +312,7 @@ struct PinnedRing {
     std::mutex mu;
     char *slot[RING_SLOTS] = {nullptr, nullptr, nullptr};
     hipEvent_t ev[RING_SLOTS] = {nullptr, nullptr, nullptr};
-    bool ready = false;
+    bool ready = false, failed = false, preparing = false;
     float *lut_pinned = nullptr;                 // hop-code transport: where the device's 256 floats land ...
     float lut_seen[256];                         // ... the table pair_lut was built from ...
     std::vector<uint64_t> pair_lut;              // ... and the 65 536-entry two-byte table (512 KB, built once: the floats never change)
@@ -386,6 +386,44 @@ extern "C" void pope_assemble_abort(void *handle) {
     delete h;
 }
 
+// hipHostMalloc of the three slots, the code table and their events; g_ring.mu held.  Once per process (2 ms).
+static void ring_allocate_locked() {
+    if (g_ring.ready || g_ring.failed) return;
+    bool ok = true;
+    for (int i = 0; i < RING_SLOTS && ok; ++i) {
+        ok = hipHostMalloc(reinterpret_cast<void **>(&g_ring.slot[i]), RING_SLOT_BYTES, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g_ring.lut_pinned), 256 * sizeof(float), hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (g_ring.lut_pinned) (void)hipHostFree(g_ring.lut_pinned);
+        g_ring.lut_pinned = nullptr;
+        for (int i = 0; i < RING_SLOTS; ++i) {
+            if (g_ring.slot[i]) (void)hipHostFree(g_ring.slot[i]);
+            if (g_ring.ev[i]) (void)hipEventDestroy(g_ring.ev[i]);
+            g_ring.slot[i] = nullptr; g_ring.ev[i] = nullptr;
+        }
+        g_ring.failed = true;                    // not retried: every later call registers the result's pages instead
+    }
+    g_ring.ready = ok;
+}
+
+// The first host -> host call of a process can have the ring allocated beside its GPU work: this returns at once and a
+// helper thread does the allocation on `device`; pope_assemble_finish takes the same mutex and so waits for it if need be.
+extern "C" void pope_assemble_prepare(int32_t device) {
+    {
+        std::unique_lock<std::mutex> lock(g_ring.mu);
+        if (g_ring.ready || g_ring.failed || g_ring.preparing) return;
+        g_ring.preparing = true;
+    }
+    std::thread([device] {
+        std::unique_lock<std::mutex> lock(g_ring.mu);
+        if (device >= 0) (void)hipSetDevice(device);
+        ring_allocate_locked();
+    }).detach();
+}
+
 // `lut_dev` == nullptr: `emb` holds the float columns themselves.  Otherwise `emb` holds one code byte per element
 // (pope_geodesic_hop_codes) and `lut_dev` the 256 floats the codes stand for: a quarter of the bytes cross PCIe and the host
 // threads look the floats up while they copy out of the ring (ring mode only).
@@ -447,25 +485,7 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
     if (h->ring && eb > 0 && eb <= RING_SLOT_BYTES) {
         std::unique_lock<std::mutex> lock(g_ring.mu);
         double t0 = now_ms();
-        if (!g_ring.ready) {
-            bool ok = true;
-            for (int i = 0; i < RING_SLOTS && ok; ++i) {
-                ok = hipHostMalloc(reinterpret_cast<void **>(&g_ring.slot[i]), RING_SLOT_BYTES, hipHostMallocDefault) == hipSuccess &&
-                     hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming) == hipSuccess;
-            }
-            ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g_ring.lut_pinned), 256 * sizeof(float), hipHostMallocDefault) == hipSuccess;
-            if (!ok) {
-                (void)hipGetLastError();
-                if (g_ring.lut_pinned) (void)hipHostFree(g_ring.lut_pinned);
-                g_ring.lut_pinned = nullptr;
-                for (int i = 0; i < RING_SLOTS; ++i) {
-                    if (g_ring.slot[i]) (void)hipHostFree(g_ring.slot[i]);
-                    if (g_ring.ev[i]) (void)hipEventDestroy(g_ring.ev[i]);
-                    g_ring.slot[i] = nullptr; g_ring.ev[i] = nullptr;
-                }
-            }
-            g_ring.ready = ok;
-        }
+        ring_allocate_locked();
         tr[2] = now_ms() - t0;
         if (g_ring.ready) {
             const int64_t crow = (int64_t)(RING_SLOT_BYTES / eb);

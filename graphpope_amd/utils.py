@@ -138,14 +138,16 @@ def _assemble_on_host(data, k, embedding_fn):
     t0 = _t.perf_counter()
     x = _host_features(data)
     n, f = int(x.shape[0]), int(x.shape[1])
+    mode = os.environ.get("GRAPHPOPE_HOST_RESULT", "ring")
+    if mode not in ("ring", "registered", "staged", "pinned"):
+        raise ValueError(f"GRAPHPOPE_HOST_RESULT={mode!r}: expected ring, registered, staged or pinned")
+    if mode == "ring":                                 # first call of a process: the pinned ring is allocated beside the GPU work
+        _lib_mod.load().pope_assemble_prepare(torch.cuda.current_device())
     emb_dev = embedding_fn()                           # float32 [N, K], or (uint8 codes [N, K], float32 lut [256]): engine.hop_codes
     coded = isinstance(emb_dev, tuple)
     if not coded:
         emb_dev = emb_dev.contiguous()
     t1 = _t.perf_counter()
-    mode = os.environ.get("GRAPHPOPE_HOST_RESULT", "ring")
-    if mode not in ("ring", "registered", "staged", "pinned"):
-        raise ValueError(f"GRAPHPOPE_HOST_RESULT={mode!r}: expected ring, registered, staged or pinned")
     assert not coded or mode == "ring"
     if mode == "pinned":                               # rounds 1-2: a page-locked result (fast when torch's host cache holds one, 34 ms when not)
         out = torch.empty((n, f + k), dtype=torch.float32, pin_memory=True)

@@ -352,6 +352,9 @@ void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, int64_t x_r
                           int64_t rows, int32_t threads, int32_t chunks);
 int pope_assemble_finish(void *handle, const void *emb, int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *stream);
 void pope_assemble_abort(void *handle);
+/* Optional, returns at once: the process's pinned ring (24 MB, 2 ms of hipHostMalloc) is allocated by a helper thread on
+ * `device` (< 0: the thread's default), beside the caller's GPU work, instead of inside the first pope_assemble_finish. */
+void pope_assemble_prepare(int32_t device);
 
 /*
  * The geodesic embedding in its transport form (utils.py:73 1 / len(path), one byte per element instead of four):

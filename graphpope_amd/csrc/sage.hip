@@ -578,7 +578,7 @@ static int launch_tile16(const T16Args &a, int grid, hipStream_t stream) {
 
 // *used = false if the shape does not fit the chip well enough (or the operands do not qualify) and nothing was launched.
 static int gemm_tile16(const float *A0, const float *B0, int K0, const float *A1, const float *B1, int K1, long long lda, long long ldb,
-                       int M, int N, const float *bias, float *C, long long ldc, hipStream_t stream, bool *used) {
+                       int M, int N, const float *bias, float *C, long long ldc, hipStream_t stream, bool *used, const int *m_dev = nullptr) {
     *used = false;
     if (g_gemm_force_tile != 0) return POPE_OK;                      // any forced variant: not this kernel (7 = "stream-K as in round 2")
     if ((K0 & 3) || (K1 & 3) || M <= 0 || N <= 0 || K0 <= 0) return POPE_OK;
@@ -597,10 +597,11 @@ static int gemm_tile16(const float *A0, const float *B0, int K0, const float *A1
     T16Args a;
     a.p[0] = SkProduct{A0, B0, lda, ldb, K0};
     a.p[1] = SkProduct{K1 > 0 ? A1 : A0, K1 > 0 ? B1 : B0, lda, ldb, K1};
-    a.M = M; a.N = N; a.bias = bias; a.C = C; a.ldc = ldc; a.zero = zero_page[dev];
+    a.M = M; a.N = N; a.bias = bias; a.C = C; a.ldc = ldc; a.zero = zero_page[dev]; a.m_dev = m_dev;
     a.tiles_m = (M + 16 * rb - 1) / (16 * rb); a.tiles_n = (N + T16_TN - 1) / T16_TN;
     a.S0 = (K0 + T16_GK - 1) / T16_GK; a.S1 = (K1 + T16_GK - 1) / T16_GK;
-    const int grid = a.tiles_n == 2 ? (a.tiles_m + 7) / 8 * 16 : a.tiles_m * a.tiles_n;
+    int grid = a.tiles_n == 2 ? (a.tiles_m + 7) / 8 * 16 : a.tiles_m * a.tiles_n;
+    if (m_dev) grid = std::min(grid, a.tiles_n == 2 ? (cus + 15) / 16 * 16 : cus);      // capacity rows: one block per CU walks the true tiles
     switch (rb) {
     case 3: rc = launch_tile16<3>(a, grid, stream); break;
     case 4: rc = launch_tile16<4>(a, grid, stream); break;
@@ -731,7 +732,7 @@ extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int6
     // out = agg * w_l^T + b_l + x_dst * w_r^T in one pass
     bool used = false;
     int rc = POPE_OK;
-    if (!dims && (rc = gemm_tile16(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used))) return rc;
+    if ((rc = gemm_tile16(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used, dims))) return rc;
     if (used) return POPE_OK;
     rc = gemm_streamk(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);
     if (rc || used) return rc;
@@ -756,7 +757,7 @@ extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *c
     enqueue_gather_mean(rowptr, col, n_dst, feats, c_in, agg, stream, n_id, x_dst, dims);
     bool used = false;
     int rc = POPE_OK;
-    if (!dims && (rc = gemm_tile16(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used))) return rc;
+    if ((rc = gemm_tile16(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used, dims))) return rc;
     if (used) return POPE_OK;
     rc = gemm_streamk(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);
     if (rc || used) return rc;

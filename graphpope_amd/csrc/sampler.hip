@@ -14,8 +14,6 @@
 // torch_sparse's C++ RNG inside DataLoader workers -- is not reproducible outside that stack: SURVEY.md §7 trap 9.)
 #include <cstring>
 
-#include <rocprim/device/device_scan.hpp>
-
 #include "common.h"
 
 namespace pope {
@@ -60,35 +58,7 @@ __device__ __forceinline__ int true_count(const int *t_dev, int cap) {
     return v < cap ? v : cap;
 }
 
-// map[:] = 0x7F7F7F7F (larger than any position key).  A kernel, not hipMemsetAsync: the call is captured into HIP graphs
-// (graphpope_amd/train.py), and a memset node is one more thing whose replay semantics would have to be trusted.
-__global__ __launch_bounds__(256) void k_sample_clear(int *__restrict__ map, int N) {
-    const int n4 = N >> 2;
-    const int4 v = make_int4(0x7F7F7F7F, 0x7F7F7F7F, 0x7F7F7F7F, 0x7F7F7F7F);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) reinterpret_cast<int4 *>(map)[i] = v;
-    if (blockIdx.x == 0 && (int)threadIdx.x < (N & 3)) map[(n4 << 2) + threadIdx.x] = 0x7F7F7F7F;
-}
-
-__global__ __launch_bounds__(256) void k_sample_count(const int *__restrict__ rowptr, const long long *__restrict__ targets,
-                                                      int T_cap, int fanout, int *__restrict__ cnt, int *__restrict__ map,
-                                                      long long *__restrict__ out_n_id, const int *__restrict__ t_dev,
-                                                      int *__restrict__ dims) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int T = true_count(t_dev, T_cap);
-    if (i == 0 && dims) dims[0] = T;                               // n_dst of this block
-    if (i > T_cap) return;
-    int c = 0;
-    if (i < T) {
-        const long long g = targets[i];
-        const int d = rowptr[g + 1] - rowptr[g];
-        c = (fanout < 0 || d <= fanout) ? d : fanout;
-        map[g] = i;                        // position key of a target = its index (target lists hold distinct nodes)
-        out_n_id[i] = g;                   // n_id starts with the targets, in order
-    }
-    cnt[i] = c;                                                    // cnt[T] = 0: the scan then yields rowptr_out[T] = nnz
-}
-
-// map[g] = smallest "position key" at which node g occurs: targets occupy keys [0, T) (k_sample_count), sampled slot p key T + p.
+// map[g] = smallest "position key" at which node g occurs: targets occupy keys [0, T) (k_sample_count_scan), sampled slot p key T + p.
 __global__ __launch_bounds__(256) void k_sample_pick(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                      const long long *__restrict__ targets, int T_cap, int fanout,
                                                      unsigned long long seed, int hop, const int *__restrict__ out_rowptr,
@@ -112,9 +82,10 @@ __global__ __launch_bounds__(256) void k_sample_pick(const int *__restrict__ row
     }
 }
 
-// (Measured and rejected, round 3: the count and flag passes as rocprim transform iterators feeding the scans instead of
-//  launches of their own -- two launches less per hop, but the scans went from ~5 us to 19-21 us each: their per-item
-//  functor loads (rowptr[targets[i]], map[picked[p]]) run at ITEMS_PER_THREAD-fold lower parallelism than a flat kernel.)
+// (Measured and rejected, round 3: the count and flag passes as rocprim transform iterators feeding rocprim's scans instead
+//  of launches of their own -- two launches less per hop, but the scans went from ~5 us to 19-21 us each: their per-item
+//  functor loads (rowptr[targets[i]], map[picked[p]]) run at ITEMS_PER_THREAD-fold lower parallelism than a flat kernel.
+//  The fused kernels further down do their own chained scan instead.)
 // fanout < 0 ("all neighbours"): rows are copied whole, one thread per output slot.
 __global__ __launch_bounds__(256) void k_sample_all(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                     const long long *__restrict__ targets, int T,
@@ -129,18 +100,6 @@ __global__ __launch_bounds__(256) void k_sample_all(const int *__restrict__ rowp
         picked[beg_out + j] = u;
         atomicMin(&map[u], T + beg_out + j);
     }
-}
-
-// The passes after the pick run over the CAPACITY (known on the host) and read the true edge count from out_rowptr[T],
-// so the host needs no readback until the very end.
-__global__ __launch_bounds__(256) void k_sample_flag(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int cap,
-                                                     int T_cap, const int *__restrict__ map, int *__restrict__ first,
-                                                     const int *__restrict__ t_dev) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int T = true_count(t_dev, T_cap);
-    if (p > cap) return;
-    const int nnz = out_rowptr[T];
-    first[p] = (p < nnz && map[picked[p]] == T + p) ? 1 : 0;      // zeros from nnz on: rank[nnz] = number of new nodes
 }
 
 // Local ids.  A node's position key tells everything: a target keeps its index; a new node first seen at slot p0 = key - T
@@ -177,6 +136,150 @@ __global__ __launch_bounds__(256) void k_sample_relabel(const int *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused passes (round 3): count + scan and flag + scan each in ONE launch -- nine launches per hop became four, and in a
+// captured step a launch of a 2 us kernel still costs ~4.5 us.  The scans are chained inside the launch: a block draws a
+// ticket (so a block only ever waits for blocks that have started), publishes the sum of its 1 024 items in a status word
+// and adds up the status words of ALL lower tickets -- they depend on nothing but their blocks' own items, so there is no
+// serial chain (at most ~400 words per block).  Status words and tickets are zeroed one launch ahead (k_sample_begin at
+// the start of a batch, then hop h's first kernel for hop h + 1: two regions alternate, like the two position-key maps).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int CHAIN_ITEMS = 1024;               // items per block: 256 threads x 4
+
+struct Chain {
+    int *ticket;                                // one counter per kernel
+    unsigned long long *status;                 // (1 << 32) | block sum, 0 = not there yet
+};
+
+__device__ __forceinline__ int chain_ticket(const Chain &c) {
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(c.ticket, 1);
+    __syncthreads();
+    return s_ticket;
+}
+
+// Exclusive scan of `v` over the 256 threads of the block; *total = the block's sum.
+__device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
+    __shared__ int s_wave[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int t = s_wave[w];
+        if (w < wave) before += t;
+        all += t;
+    }
+    __syncthreads();                            // s_wave is reused by the caller's next scan
+    *total = all;
+    return before + inc - v;
+}
+
+// Publishes this block's sum under its ticket and returns the sum of all lower tickets' (every thread gets it).
+__device__ __forceinline__ int chain_prefix(const Chain &c, int ticket, int block_sum) {
+    __shared__ int s_part[4];
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&c.status[ticket], (1ull << 32) | (unsigned)block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int sum = 0;
+    for (int j = threadIdx.x; j < ticket; j += blockDim.x) {
+        unsigned long long w;
+        do {
+            w = __hip_atomic_load(&c.status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((w >> 32) == 0);               // ticket j was drawn before ours: that block is running or done
+        sum += (int)(unsigned)w;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    const int r = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+    return r;
+}
+
+// map[:] = 0x7F7F7F7F (larger than any position key) and words[:] = 0; grid-stride, any grid.
+__device__ __forceinline__ void clear_region(int *__restrict__ map, int N, unsigned long long *__restrict__ words, int n_words) {
+    const int n4 = N >> 2;
+    const int4 v = make_int4(0x7F7F7F7F, 0x7F7F7F7F, 0x7F7F7F7F, 0x7F7F7F7F);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) reinterpret_cast<int4 *>(map)[i] = v;
+    if (blockIdx.x == 0 && (int)threadIdx.x < (N & 3)) map[(n4 << 2) + threadIdx.x] = 0x7F7F7F7F;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) words[i] = 0ull;
+}
+
+// Start of a batch: the first hop's map and chain state.
+__global__ __launch_bounds__(256) void k_sample_begin(int *__restrict__ map, int N, unsigned long long *__restrict__ words, int n_words) {
+    clear_region(map, N, words, n_words);
+}
+
+// The per-target counts and their scan: out_rowptr[i] = number of sampled edges of the targets before i, i in [0, T_cap]
+// (targets past the true count contribute nothing, so every entry from T on holds nnz).  Also prepares the NEXT hop's map
+// and chain state (next_map / next_words: buffers this hop does not touch).
+__global__ __launch_bounds__(256) void k_sample_count_scan(const int *__restrict__ rowptr, const long long *__restrict__ targets, int T_cap,
+                                                           int fanout, int *__restrict__ out_rowptr, int *__restrict__ map,
+                                                           long long *__restrict__ out_n_id, const int *__restrict__ t_dev,
+                                                           int *__restrict__ dims, Chain chain, int *__restrict__ next_map, int N,
+                                                           unsigned long long *__restrict__ next_words, int n_next_words) {
+    const int T = true_count(t_dev, T_cap);
+    const int t = chain_ticket(chain);
+    if (t == 0 && threadIdx.x == 0 && dims) dims[0] = T;           // n_dst of this block
+    const int base = t * CHAIN_ITEMS + (int)threadIdx.x * 4;
+    int c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = base + k;
+        c[k] = 0;
+        if (i < T) {
+            const long long g = targets[i];
+            const int d = rowptr[g + 1] - rowptr[g];
+            c[k] = (fanout < 0 || d <= fanout) ? d : fanout;
+            map[g] = i;                    // position key of a target = its index (target lists hold distinct nodes)
+            out_n_id[i] = g;               // n_id starts with the targets, in order
+        }
+    }
+    int block_sum;
+    const int ex = block_exclusive_scan(c[0] + c[1] + c[2] + c[3], &block_sum);
+    int run = chain_prefix(chain, t, block_sum) + ex;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k <= T_cap) out_rowptr[base + k] = run;
+        run += c[k];
+    }
+    if (next_map) clear_region(next_map, N, next_words, n_next_words);
+}
+
+// The first-occurrence flags and their scan: rank[p] = number of first occurrences among the slots before p, p in [0, nnz]
+// (rank[nnz] = number of new nodes).  Blocks past nnz have nothing to do -- and nobody waits for them.
+__global__ __launch_bounds__(256) void k_sample_flag_rank(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int T_cap,
+                                                          const int *__restrict__ map, int *__restrict__ rank,
+                                                          const int *__restrict__ t_dev, Chain chain) {
+    const int T = true_count(t_dev, T_cap);
+    const int nnz = out_rowptr[T];
+    const int t = chain_ticket(chain);
+    if (t * CHAIN_ITEMS > nnz) return;
+    const int base = t * CHAIN_ITEMS + (int)threadIdx.x * 4;
+    int f[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = base + k;
+        f[k] = (p < nnz && map[picked[p]] == T + p) ? 1 : 0;
+    }
+    int block_sum;
+    const int ex = block_exclusive_scan(f[0] + f[1] + f[2] + f[3], &block_sum);
+    int run = chain_prefix(chain, t, block_sum) + ex;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k <= nnz) rank[base + k] = run;
+        run += f[k];
+    }
+}
+
 // Per (device, host thread) pinned report slot, created on first use (a worker thread may sample beside the main thread).
 static int pinned_report(long long **host, long long **dev) {
     static thread_local long long *h[64] = {nullptr}, *d[64] = {nullptr};
@@ -192,29 +295,24 @@ static int pinned_report(long long **host, long long **dev) {
     return POPE_OK;
 }
 
-static size_t scan_bytes(size_t n) {
-    size_t bytes = 0;
-    (void)rocprim::exclusive_scan(nullptr, bytes, (int *)nullptr, (int *)nullptr, 0, n, rocprim::plus<int>());
-    return bytes;
-}
-
 struct SampleLayout {
-    size_t cnt, picked, first, rank, map, newid, report, scan, total;
-    int cap;
+    size_t picked, rank, map, newid, report, state, total;   // map / newid: the position-key maps of even / odd hops
+    int cap, nb_count, nb_flag, state_words;     // chained-scan state: two regions of state_words 64-bit words each
 };
 
 static SampleLayout sample_layout(int64_t N, int64_t T, int64_t cap) {
     SampleLayout L;
     L.cap = (int)cap;
     size_t o = 0;
-    L.cnt = o;    o += align_up((size_t)(T + 1) * 4, 256);
     L.picked = o; o += align_up((size_t)(cap + 1) * 4, 256);
-    L.first = o;  o += align_up((size_t)(cap + 1) * 4, 256);
     L.rank = o;   o += align_up((size_t)(cap + 1) * 4, 256);
     L.map = o;    o += align_up((size_t)N * 4, 256);
     L.newid = o;  o += align_up((size_t)N * 4, 256);
     L.report = o; o += 256;
-    L.scan = o;   o += align_up(scan_bytes((size_t)(cap > T ? cap : T) + 1), 256);
+    L.nb_count = (int)((T + 1 + CHAIN_ITEMS - 1) / CHAIN_ITEMS);
+    L.nb_flag = (int)((cap + 1 + CHAIN_ITEMS - 1) / CHAIN_ITEMS);
+    L.state_words = 2 + L.nb_count + L.nb_flag;                  // [ticket of count_scan, ticket of flag_rank, status words ...]
+    L.state = o;  o += 2 * align_up((size_t)L.state_words * 8, 256);
     L.total = o;
     return L;
 }
@@ -230,36 +328,45 @@ extern "C" size_t sage_sample_scratch_bytes(int64_t N, int64_t n_targets, int64_
 
 // One hop, enqueued without waiting.  t_dev / dims / seed_dev: device-extent mode (see sage_sample_batch_device); report:
 // pinned host words for the host-sized mode.
+// `L` is the layout of the scratch buffer (sized for the largest hop of the call); `first` = this is the first hop enqueued by
+// the call (its map and chain state are cleared by a launch of their own), `prepare_next` = another hop follows (this hop's
+// first kernel clears that hop's map and state, which live in the other of the two regions).
 static int enqueue_hop(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *targets, int64_t n_targets, int32_t fanout,
                        uint64_t seed, int32_t hop, int32_t *out_rowptr, int32_t *out_col, int64_t nnz_capacity, int64_t *out_n_id,
-                       void *scratch, size_t scratch_bytes, const int *t_dev, int *dims, const unsigned long long *seed_dev,
-                       long long *report_dev, hipStream_t stream, const char *who) {
-    const SampleLayout L = sample_layout(N, n_targets, nnz_capacity);
+                       void *scratch, size_t scratch_bytes, const SampleLayout &L, bool first, bool prepare_next, const int *t_dev, int *dims,
+                       const unsigned long long *seed_dev, long long *report_dev, hipStream_t stream, const char *who) {
     if (scratch_bytes < L.total) {
         set_error("%s: scratch %zu < %zu bytes", who, scratch_bytes, L.total);
         return POPE_ERR_WORKSPACE;
     }
     char *base = (char *)scratch;
-    int *cnt = (int *)(base + L.cnt), *picked = (int *)(base + L.picked), *first = (int *)(base + L.first);
-    int *rank = (int *)(base + L.rank), *map = (int *)(base + L.map);
-    void *scan_tmp = base + L.scan;
-    size_t sb = L.total - L.scan;
-    const int T = (int)n_targets;
+    int *picked = (int *)(base + L.picked), *rank = (int *)(base + L.rank);
+    const size_t region_bytes = align_up((size_t)L.state_words * 8, 256);
+    const int r = hop & 1;
+    int *map = (int *)(base + (r ? L.newid : L.map)), *other_map = (int *)(base + (r ? L.map : L.newid));
+    unsigned long long *words = (unsigned long long *)(base + L.state + r * region_bytes);
+    unsigned long long *other_words = (unsigned long long *)(base + L.state + (1 - r) * region_bytes);
+    const Chain count_chain{(int *)words, words + 2}, flag_chain{(int *)(words + 1), words + 2 + L.nb_count};
+    const int T = (int)n_targets, cap = (int)nnz_capacity;
+    if ((T + 1 + CHAIN_ITEMS - 1) / CHAIN_ITEMS > L.nb_count || (cap + 1 + CHAIN_ITEMS - 1) / CHAIN_ITEMS > L.nb_flag) {
+        set_error("%s: hop %d is larger than the scratch layout", who, hop);
+        return POPE_ERR_WORKSPACE;
+    }
 
-    hipLaunchKernelGGL(k_sample_clear, dim3(capped_grid((size_t)N / 4 + 1, 256)), dim3(256), 0, stream, map, (int)N);
-    hipLaunchKernelGGL(k_sample_count, dim3((T + 256) / 256), dim3(256), 0, stream, rowptr, (const long long *)targets, T, fanout, cnt,
-                       map, (long long *)out_n_id, t_dev, dims);
-    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, cnt, out_rowptr, 0, (size_t)T + 1, rocprim::plus<int>(), stream));
+    if (first)
+        hipLaunchKernelGGL(k_sample_begin, dim3(capped_grid((size_t)N / 4 + 1, 256)), dim3(256), 0, stream, map, (int)N, words, L.state_words);
+    hipLaunchKernelGGL(k_sample_count_scan, dim3((T + 1 + CHAIN_ITEMS - 1) / CHAIN_ITEMS), dim3(256), 0, stream, rowptr, (const long long *)targets, T,
+                       fanout, out_rowptr, map, (long long *)out_n_id, t_dev, dims, count_chain, prepare_next ? other_map : nullptr, (int)N,
+                       other_words, L.state_words);
     if (fanout < 0) {
         // all neighbours: the total is only known on the device; the caller sized nnz_capacity for it
-        hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, (int)nnz_capacity, picked, map);
+        hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, cap, picked, map);
     } else {
         hipLaunchKernelGGL(k_sample_pick, dim3(capped_grid((size_t)T * fanout, 256)), dim3(256), 0, stream, rowptr, col,
                            (const long long *)targets, T, fanout, (unsigned long long)seed, hop, out_rowptr, picked, map, t_dev, seed_dev);
     }
-    const int cap = (int)nnz_capacity;
-    hipLaunchKernelGGL(k_sample_flag, dim3((cap + 256) / 256), dim3(256), 0, stream, picked, out_rowptr, cap, T, map, first, t_dev);
-    POPE_HIP(rocprim::exclusive_scan(scan_tmp, sb, first, rank, 0, (size_t)cap + 1, rocprim::plus<int>(), stream));
+    hipLaunchKernelGGL(k_sample_flag_rank, dim3((cap + 1 + CHAIN_ITEMS - 1) / CHAIN_ITEMS), dim3(256), 0, stream, picked, out_rowptr, T, map, rank,
+                       t_dev, flag_chain);
     hipLaunchKernelGGL(k_sample_relabel, dim3((cap + 256) / 256), dim3(256), 0, stream, picked, out_rowptr, T, map, rank, out_col,
                        (long long *)out_n_id, report_dev, t_dev, dims);   // at least one block: thread 0 also reports the counts
     POPE_HIP(hipGetLastError());
@@ -283,7 +390,8 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
     int rc = pinned_report(&rep, &rep_dev);
     if (rc) return rc;
     rc = enqueue_hop(rowptr, col, N, targets, n_targets, fanout, seed, hop, out_rowptr, out_col, nnz_capacity, out_n_id, scratch,
-                     scratch_bytes, nullptr, nullptr, nullptr, rep_dev, stream, "sage_sample_hop");
+                     scratch_bytes, sample_layout(N, n_targets, nnz_capacity), true, false, nullptr, nullptr, nullptr, rep_dev, stream,
+                     "sage_sample_hop");
     if (rc) return rc;
     POPE_HIP(hipStreamSynchronize(stream));
     POPE_HIP(hipGetLastError());
@@ -310,13 +418,20 @@ extern "C" int sage_sample_batch_device(const int32_t *rowptr, const int32_t *co
                  "sage_sample_batch_device: null pointer or bad hop count");
     POPE_REQUIRE(N > 0 && N < INT32_MAX && n_seeds > 0, "sage_sample_batch_device: bad size");
     const int64_t *targets = seeds;
-    int64_t t_cap = n_seeds;
-    for (int h = 0; h < n_hops; ++h) {
+    int64_t t_cap = n_seeds, t_last = n_seeds, cap_last = 0;
+    for (int h = 0; h < n_hops; ++h) {                              // the scratch layout of the largest (= last) hop serves every hop
         POPE_REQUIRE(fanouts_host[h] > 0, "sage_sample_batch_device: fan-outs must be positive");
+        t_last = t_cap;
+        cap_last = t_cap * (int64_t)fanouts_host[h];
+        POPE_REQUIRE(t_cap + cap_last < INT32_MAX, "sage_sample_batch_device: capacity of hop %d exceeds 31 bits", h);
+        t_cap += cap_last;
+    }
+    const SampleLayout L = sample_layout(N, t_last, cap_last);
+    t_cap = n_seeds;
+    for (int h = 0; h < n_hops; ++h) {
         const int64_t cap = t_cap * (int64_t)fanouts_host[h];
-        POPE_REQUIRE(t_cap + cap < INT32_MAX, "sage_sample_batch_device: capacity of hop %d exceeds 31 bits", h);
         const int rc = enqueue_hop(rowptr, col, N, targets, t_cap, fanouts_host[h], seed, h, out_rowptr[h], out_col[h], cap, out_n_id[h],
-                                   scratch, scratch_bytes, h == 0 ? nullptr : dims + 4 * (h - 1) + 1, dims + 4 * h,
+                                   scratch, scratch_bytes, L, h == 0, h + 1 < n_hops, h == 0 ? nullptr : dims + 4 * (h - 1) + 1, dims + 4 * h,
                                    (const unsigned long long *)seed_dev, nullptr, stream, "sage_sample_batch_device");
         if (rc) return rc;
         targets = out_n_id[h];

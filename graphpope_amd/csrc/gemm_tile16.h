@@ -190,8 +190,8 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
 
 // Host-sized launches give every tile a block of its own (the loop runs once).  With a device extent (`m_dev`: the rows are a
 // capacity, the true count lives on the device) the grid is at most one block per CU and a block walks the tiles it owns:
-// a grid sized for the capacity would be mostly blocks with nothing to do, and with 120 KB of LDS each they still queue
-// for a CU one at a time (measured: 87 us instead of 78 for the same product behind a 4x capacity).
+// a grid sized for the capacity would be mostly blocks with nothing to do, and with 80 KB of LDS each they still queue
+// for the CUs behind the working blocks (measured: 87 us instead of 78 for the same product behind a 4x capacity).
 template <int RB>
 __global__ __launch_bounds__(T16_THREADS) void k_gemm_tile16(T16Args a) {
     using Sh = T16Shape<RB>;

@@ -564,6 +564,25 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
         ev[1].record()
     torch.cuda.synchronize()
     l0_ms = ev[0].elapsed_time(ev[1]) / 10
+    # OPT-IN arithmetic, never part of the step or of `value`: the same layer with POPE_KNOB_GEMM_SPLIT_BF16 (every f32 operand
+    # as three bf16 terms, six bf16 MFMAs per product, f32 accumulate), timed the same way and compared with the exact-f32 output
+    with torch.no_grad():
+        exact = conv((x, x[:adjs[0].n_dst]), adjs[0]).clone()
+        _lib.load().pope_debug_set(_lib.KNOB_GEMM_SPLIT_BF16, 1)
+        try:
+            for _ in range(3):
+                split_out = conv((x, x[:adjs[0].n_dst]), adjs[0])
+            ev2 = [_event() for _ in range(2)]
+            ev2[0].record()
+            for _ in range(10):
+                split_out = conv((x, x[:adjs[0].n_dst]), adjs[0])
+            ev2[1].record()
+            torch.cuda.synchronize()
+            split_l0_ms = ev2[0].elapsed_time(ev2[1]) / 10
+            split_err = float((split_out - exact).abs().max())
+            split_scale = float(exact.abs().max())
+        finally:
+            _lib.load().pope_debug_set(_lib.KNOB_GEMM_SPLIT_BF16, 0)
     n_dst, _, nnz = shapes[0]
     # the neighbour gather + mean on its own (memory-bound half of the layer)
     lib = _lib.load()
@@ -700,6 +719,12 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
                               "vendor_library_ms": lib_ms,
                               "note": "layer-0 forward minus the gather, HIP events; vendor_library_ms = torch.addmm (hipBLASLt) on "
                                       "the concatenated operands of the same product, timed in the same run"},
+        "layer0_projection_split_bf16_opt_in": {
+            "ms": split_l0_ms - g_ms, "max_abs_diff_vs_exact_f32": split_err, "output_max_abs": split_scale,
+            "note": "OPT-IN (POPE_KNOB_GEMM_SPLIT_BF16, off by default, not used by any other figure in this line): each f32 operand "
+                    "split into three bf16 terms in the consumer waves, six v_mfma_f32_16x16x32_bf16 per product, f32 accumulate; "
+                    "same accuracy class as f32, not the same bits.  The conversion's vector instructions (44 per eight floats) now "
+                    "bound the loop instead of the MFMAs (DESIGN.md 7h)"},
         "with_gpu_sampling": sampled,
         "cpu_baseline": cpu,
     }

@@ -43,7 +43,40 @@ template <int RB> struct T16Shape {
 };
 
 // One output tile: rows [tm * TM, ...) x columns [tn * 128, ...).  All eight waves of the block call it together.
-template <int RB>
+typedef __bf16 t16_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float t16_f32x2 __attribute__((ext_vector_type(2)));
+
+// Eight floats (two 16-byte pieces of a row) as three bf16 vectors h + m + l: h = the top 16 bits of x, m = the top 16 bits
+// of x - h, l = the top 16 bits of x - h - m (both differences are exact), so h + m + l carries 24 significant bits.
+__device__ __forceinline__ float t16_sub(float a, float b) {
+    float r;                                     // a plain v_sub_f32: beside MFMAs the packed form the compiler would pick costs more
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // than two scalar ones (MI355X_MICROARCH.md, cycle constants)
+    return r;
+}
+
+__device__ __forceinline__ void t16_split8(const float4 &p0, const float4 &p1, t16_bf16x8 &h, t16_bf16x8 &m, t16_bf16x8 &l) {
+    const float f[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned u0 = __float_as_uint(f[2 * q]), u1 = __float_as_uint(f[2 * q + 1]);
+        hh[q] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                       // {top half of f[2q], top half of f[2q+1]}
+        const float ra = t16_sub(f[2 * q], __uint_as_float(u0 & 0xffff0000u)), rb = t16_sub(f[2 * q + 1], __uint_as_float(u1 & 0xffff0000u));
+        const unsigned r0 = __float_as_uint(ra), r1 = __float_as_uint(rb);
+        mm[q] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);
+        const float ta = t16_sub(ra, __uint_as_float(r0 & 0xffff0000u)), tb = t16_sub(rb, __uint_as_float(r1 & 0xffff0000u));
+        ll[q] = __builtin_amdgcn_perm(__float_as_uint(tb), __float_as_uint(ta), 0x07060302u);
+    }
+    h = __builtin_bit_cast(t16_bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+    m = __builtin_bit_cast(t16_bf16x8, make_uint4(mm[0], mm[1], mm[2], mm[3]));
+    l = __builtin_bit_cast(t16_bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+}
+
+// SPLIT = false: exact f32 products on v_mfma_f32_16x16x4_f32 (the product path).  SPLIT = true (opt-in,
+// POPE_KNOB_GEMM_SPLIT_BF16): every f32 operand as three bf16 terms and six v_mfma_f32_16x16x32_bf16 per product
+// (hh, hm, mh, mm, hl, lh; the dropped terms are below 2^-24 of |a||b|), f32 accumulate -- the same accuracy class, not the
+// same bits; the LDS images, the loader waves and the epilogue are shared.
+template <int RB, bool SPLIT>
 __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const int tm, const int tn, char *smem, const unsigned lds0,
                                          const int lane, const int wave) {
     using Sh = T16Shape<RB>;
@@ -128,48 +161,102 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
             for (int r = 0; r < 4; ++r) acc[i][t][r] = 0.0f;
     __builtin_amdgcn_s_barrier();              // B_0
     asm volatile("" ::: "memory");
-    float4 fa[2][RB], fb[2][2];
-    auto read_pass = [&](int b, int p, int set) {
-        const char *base = smem + b * Sh::STAGE_BYTES;
-        const int c = 4 * p + g;
+    if constexpr (SPLIT) {
+        // one 16x16x32 MFMA spans a whole 32-deep stage: lane (r15, g) holds depth 8g .. 8g + 7 = pieces 2g, 2g + 1 of its row
+        float4 ra[RB][2], rb[2][2];
+        auto read_a = [&](int b, int i) {
+            const char *base = smem + b * Sh::STAGE_BYTES + fa_off[i];
+            ra[i][0] = *reinterpret_cast<const float4 *>(base + (((2 * g) ^ fa_swz[i]) << 4));
+            ra[i][1] = *reinterpret_cast<const float4 *>(base + (((2 * g + 1) ^ fa_swz[i]) << 4));
+        };
+        auto read_b = [&](int b, int t) {
+            const char *base = smem + b * Sh::STAGE_BYTES + fb_off[t];
+            rb[t][0] = *reinterpret_cast<const float4 *>(base + (((2 * g) ^ fb_swz[t]) << 4));
+            rb[t][1] = *reinterpret_cast<const float4 *>(base + (((2 * g + 1) ^ fb_swz[t]) << 4));
+        };
 #pragma unroll
-        for (int i = 0; i < RB; ++i) fa[set][i] = *reinterpret_cast<const float4 *>(base + fa_off[i] + ((c ^ fa_swz[i]) << 4));
+        for (int t = 0; t < 2; ++t) read_b(0, t);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) fb[set][t] = *reinterpret_cast<const float4 *>(base + fb_off[t] + ((c ^ fb_swz[t]) << 4));
-    };
-    int buf = 0;
-    read_pass(0, 0, 0);
-    for (int s = 0; s < S; ++s) {
-        const bool next = s + 1 < S;
-        const int nbuf = buf == 2 ? 0 : buf + 1;
+        for (int i = 0; i < RB; ++i) read_a(0, i);
+        int buf = 0;
+        for (int s = 0; s < S; ++s) {
+            const bool next = s + 1 < S;
+            const int nbuf = buf == 2 ? 0 : buf + 1;
+            t16_bf16x8 bh[2], bm[2], bl[2], ah[2], am[2], al[2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {                                  // 16 depth values per pass
-            if (p == 0) read_pass(buf, 1, 1);
-            else if (next) read_pass(nbuf, 0, 0);                      // pass 0 of stage s + 1: landed since B_s
-            __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < 2; ++t) {
+                t16_split8(rb[t][0], rb[t][1], bh[t], bm[t], bl[t]);
+                if (next) read_b(nbuf, t);                             // stage s + 1 has landed since B_s; the raw registers are free again
+            }
+            t16_split8(ra[0][0], ra[0][1], ah[0], am[0], al[0]);
+            if (next) read_a(nbuf, 0);
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
+            for (int i = 0; i < RB; ++i) {
+                const int cur = i & 1, nxt = cur ^ 1;
+                if (i + 1 < RB) {                                      // the next row block is split while this one's MFMAs run
+                    t16_split8(ra[i + 1][0], ra[i + 1][1], ah[nxt], am[nxt], al[nxt]);
+                    if (next) read_a(nbuf, i + 1);
+                }
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].x, fb[p][t].x, acc[i][t], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].y, fb[p][t].y, acc[i][t], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].z, fb[p][t].z, acc[i][t], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].w, fb[p][t].w, acc[i][t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < 2; ++t) {
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cur], bh[t], acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur], bl[t], acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[cur], bm[t], acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[cur], bh[t], acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur], bm[t], acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur], bh[t], acc[i][t], 0, 0, 0);
+                }
+            }
+            if (next) {
+                __builtin_amdgcn_s_barrier();                          // B_(s+1)
+                asm volatile("" ::: "memory");
+            }
+            buf = nbuf;
         }
-        if (next) {
-            __builtin_amdgcn_s_barrier();                              // B_(s+1)
-            asm volatile("" ::: "memory");
+    } else {
+        float4 fa[2][RB], fb[2][2];
+        auto read_pass = [&](int b, int p, int set) {
+            const char *base = smem + b * Sh::STAGE_BYTES;
+            const int c = 4 * p + g;
+    #pragma unroll
+            for (int i = 0; i < RB; ++i) fa[set][i] = *reinterpret_cast<const float4 *>(base + fa_off[i] + ((c ^ fa_swz[i]) << 4));
+    #pragma unroll
+            for (int t = 0; t < 2; ++t) fb[set][t] = *reinterpret_cast<const float4 *>(base + fb_off[t] + ((c ^ fb_swz[t]) << 4));
+        };
+        int buf = 0;
+        read_pass(0, 0, 0);
+        for (int s = 0; s < S; ++s) {
+            const bool next = s + 1 < S;
+            const int nbuf = buf == 2 ? 0 : buf + 1;
+    #pragma unroll
+            for (int p = 0; p < 2; ++p) {                                  // 16 depth values per pass
+                if (p == 0) read_pass(buf, 1, 1);
+                else if (next) read_pass(nbuf, 0, 0);                      // pass 0 of stage s + 1: landed since B_s
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int i = 0; i < RB; ++i)
+    #pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].x, fb[p][t].x, acc[i][t], 0, 0, 0);
+    #pragma unroll
+                for (int i = 0; i < RB; ++i)
+    #pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].y, fb[p][t].y, acc[i][t], 0, 0, 0);
+    #pragma unroll
+                for (int i = 0; i < RB; ++i)
+    #pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].z, fb[p][t].z, acc[i][t], 0, 0, 0);
+    #pragma unroll
+                for (int i = 0; i < RB; ++i)
+    #pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][i].w, fb[p][t].w, acc[i][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (next) {
+                __builtin_amdgcn_s_barrier();                              // B_(s+1)
+                asm volatile("" ::: "memory");
+            }
+            buf = nbuf;
         }
-        buf = nbuf;
     }
     // C/D layout of the 16 x 16 forms: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
@@ -192,7 +279,7 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
 // capacity, the true count lives on the device) the grid is at most one block per CU and a block walks the tiles it owns:
 // a grid sized for the capacity would be mostly blocks with nothing to do, and with 80 KB of LDS each they still queue
 // for the CUs behind the working blocks (measured: 87 us instead of 78 for the same product behind a 4x capacity).
-template <int RB>
+template <int RB, bool SPLIT = false>
 __global__ __launch_bounds__(T16_THREADS) void k_gemm_tile16(T16Args a) {
     using Sh = T16Shape<RB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -220,7 +307,7 @@ __global__ __launch_bounds__(T16_THREADS) void k_gemm_tile16(T16Args a) {
             break;
         }
         if (again) __syncthreads();                               // the previous tile's last stage has been read: its buffers are free
-        t16_tile<RB>(a, M, tm, tn, smem, lds0, lane, wave);
+        t16_tile<RB, SPLIT>(a, M, tm, tn, smem, lds0, lane, wave);
         again = true;
     }
 }

@@ -439,6 +439,7 @@ static int launch_gemm(const Operand &A0, const Operand &B0, int K0, const Opera
 }
 
 extern int g_gemm_force_tile;          // pope_debug_set(POPE_KNOB_GEMM_TILE, ...) in geodesic.hip: 0 = automatic choice
+extern int g_gemm_split_bf16;         // pope_debug_set(POPE_KNOB_GEMM_SPLIT_BF16, ...): 1 = opt-in split-bf16 arithmetic in the whole-tile forward GEMM
 
 static long long tiles(int M, int N, int tm, int tn) { return (long long)((M + tm - 1) / tm) * ((N + tn - 1) / tn); }
 
@@ -565,15 +566,21 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
 }
 
 // ---- forward projection as whole tiles fitted to the chip (gemm_tile16.h): no partial tiles, no fix-up ----
-template <int RB>
-static int launch_tile16(const T16Args &a, int grid, hipStream_t stream) {
+template <int RB, bool SPLIT>
+static int launch_tile16_as(const T16Args &a, int grid, hipStream_t stream) {
     static LdsOptIn opt_in;
     if (!opt_in.done()) {
-        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_tile16<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, T16Shape<RB>::LDS_BYTES));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_tile16<RB, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, T16Shape<RB>::LDS_BYTES));
         opt_in.mark();
     }
-    hipLaunchKernelGGL(k_gemm_tile16<RB>, dim3((unsigned)grid), dim3(T16_THREADS), T16Shape<RB>::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_gemm_tile16<RB, SPLIT>), dim3((unsigned)grid), dim3(T16_THREADS), T16Shape<RB>::LDS_BYTES, stream, a);
     return POPE_OK;
+}
+
+// POPE_KNOB_GEMM_SPLIT_BF16 = 1 (opt-in, off by default): the split-bf16 arithmetic of gemm_tile16.h instead of exact f32 products.
+template <int RB>
+static int launch_tile16(const T16Args &a, int grid, hipStream_t stream) {
+    return g_gemm_split_bf16 ? launch_tile16_as<RB, true>(a, grid, stream) : launch_tile16_as<RB, false>(a, grid, stream);
 }
 
 // *used = false if the shape does not fit the chip well enough (or the operands do not qualify) and nothing was launched.

@@ -220,3 +220,36 @@ def test_forward_projection_as_whole_tiles_fitted_to_the_chip(n_dst, c_in, c_out
         ref = oracle.sage_conv_torch(x, rowptr, col, conv.lin_l.weight.cpu(), conv.lin_l.bias.cpu(), conv.lin_r.weight.cpu())
     _close(out.cpu(), ref, 1e-4)
     _close(out_sk.cpu(), ref, 1e-4)
+
+
+@pytest.mark.parametrize("n_dst,c_in,c_out", [(9988, 756, 256), (8100, 200, 256), (12200, 132, 250)])
+def test_opt_in_split_bf16_projection_stays_in_the_f32_accuracy_class(n_dst, c_in, c_out, dev, oracle):
+    """POPE_KNOB_GEMM_SPLIT_BF16 (off by default): the whole-tile forward GEMM with every f32 operand as three bf16 terms and six
+    bf16 MFMAs per product.  Not the reference's bits -- but within 1e-5 of the exact-f32 kernel relative to the largest
+    output (the f32 accumulation order differs too: blocks of 32 depth values instead of 4), against the f64 product as close as the exact kernel is, and the knob
+    leaves no trace once it is cleared."""
+    from graphpope_amd import _lib
+    from graphpope_amd.sage import SAGEConv, SampledAdj
+    lib = _lib.load()
+    n_src = n_dst + 50
+    rowptr, col = _random_block(n_dst, n_src, 4, seed=n_dst)
+    torch.manual_seed(2)
+    conv = SAGEConv(c_in, c_out).to(dev)
+    x = torch.randn(n_src, c_in)
+    adj = SampledAdj(rowptr, col, n_src).to(dev)
+    with torch.no_grad():
+        exact = conv((x.to(dev), None), adj).clone()
+        lib.pope_debug_set(_lib.KNOB_GEMM_SPLIT_BF16, 1)
+        try:
+            split = conv((x.to(dev), None), adj).clone()
+        finally:
+            lib.pope_debug_set(_lib.KNOB_GEMM_SPLIT_BF16, 0)
+        again = conv((x.to(dev), None), adj)
+        ref64 = oracle.sage_conv_torch(x.double(), rowptr, col, conv.lin_l.weight.cpu().double(), conv.lin_l.bias.cpu().double(),
+                                       conv.lin_r.weight.cpu().double())
+    scale = float(exact.abs().max())
+    assert torch.equal(again, exact)
+    assert float((split - exact).abs().max()) <= 1e-5 * scale
+    err_exact = float((exact.cpu().double() - ref64).abs().max())
+    err_split = float((split.cpu().double() - ref64).abs().max())
+    assert err_split <= 1.5 * err_exact + 1e-7 * scale

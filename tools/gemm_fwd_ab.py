@@ -19,8 +19,9 @@ for n_dst, c_in, c_out in shapes:
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     want = xd.double() @ wr.double().t() + b.double()          # agg = 0 for the empty block
     res = {}
-    for name, tile in (("auto(tile16)", 0), ("stream-K", 7), ("sk GK64", 6), ("64x64", 1), ("auto(tile16)", 0), ("stream-K", 7)):
+    for name, tile, split in (("auto(tile16)", 0, 0), ("split-bf16", 0, 1), ("stream-K", 7, 0), ("64x64", 1, 0), ("auto(tile16)", 0, 0), ("split-bf16", 0, 1)):
         lib.pope_debug_set(_lib.KNOB_GEMM_TILE, tile)
+        lib.pope_debug_set(_lib.KNOB_GEMM_SPLIT_BF16, split)
         def run():
             _lib.check(lib.sage_conv_forward(_lib.ptr(rowptr), _lib.ptr(col), n_dst, n_dst, 0, _lib.ptr(xd), c_in, _lib.ptr(wl), _lib.ptr(b), _lib.ptr(wr),
                                              c_out, _lib.ptr(aggb), _lib.ptr(out), _lib.ptr(scratch), nbytes, None, stream))
@@ -32,6 +33,7 @@ for n_dst, c_in, c_out in shapes:
         err = float((out.double() - want).abs().max())
         res.setdefault(name, []).append((ev[0].elapsed_time(ev[1]) / 20 * 1e3, err))
     lib.pope_debug_set(_lib.KNOB_GEMM_TILE, 0)
+    lib.pope_debug_set(_lib.KNOB_GEMM_SPLIT_BF16, 0)
     xcat = torch.cat([aggb, xd], 1); wcat = torch.cat([wl, wr], 1)
     for _ in range(3): torch.addmm(b, xcat, wcat.t())
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -43,4 +45,4 @@ for n_dst, c_in, c_out in shapes:
     print(f"M={n_dst} K=2x{c_in} N={c_out}  (gather of an empty block included: ~{n_dst*c_in*4/4e6:.0f} us-ish fill)  hipBLASLt {lib_us:.1f} us")
     for k, runs in res.items():
         for us, err in runs:
-            print(f"   {k:10s} {us:8.1f} us  {flops/us/1e6:6.1f} TF (whole call)  max err {err:.2e}")
+            print(f"   {k:13s} {us:8.1f} us  {flops/us/1e6:6.1f} TF (whole call)  max err {err:.2e}")

@@ -564,6 +564,22 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
         ev[1].record()
     torch.cuda.synchronize()
     l0_ms = ev[0].elapsed_time(ev[1]) / 10
+    # the same layer with the gather and the projection one after the other (POPE_KNOB_SAGE_FORWARD_OVERLAP = 0): the projection
+    # kernel's own time (one launch, both products) is this minus the gather
+    with torch.no_grad():
+        _lib.load().pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, 0)
+        try:
+            for _ in range(3):
+                conv((x, x[:adjs[0].n_dst]), adjs[0])
+            ev3 = [_event() for _ in range(2)]
+            ev3[0].record()
+            for _ in range(10):
+                conv((x, x[:adjs[0].n_dst]), adjs[0])
+            ev3[1].record()
+            torch.cuda.synchronize()
+            l0_seq_ms = ev3[0].elapsed_time(ev3[1]) / 10
+        finally:
+            _lib.load().pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, 1)
     # OPT-IN arithmetic, never part of the step or of `value`: the same layer with POPE_KNOB_GEMM_SPLIT_BF16 (every f32 operand
     # as three bf16 terms, six bf16 MFMAs per product, f32 accumulate), timed the same way and compared with the exact-f32 output
     with torch.no_grad():
@@ -693,7 +709,7 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
     except Exception as exc:                                    # the CPU leg must never take the bench down
         cpu = {"error": repr(exc)}
     single_thread.__exit__(None, None, None)
-    proj_ms = l0_ms - g_ms
+    proj_ms = l0_seq_ms - g_ms
     return {
         "nodes_per_s": BATCH / eager_dt, "ms_per_step": eager_dt * 1e3, "steps": steps, "batch_seed_nodes": BATCH,
         "how": "the step (fwd + cross-entropy + bwd + Adam) enqueued through autograd on host-sized pre-sampled batches, as in rounds 1-2 "
@@ -707,6 +723,10 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
         "model": f"SAGE {c_in}->{HIDDEN}->{HIDDEN} (num_layers 3, 2 executed), fan-out [25, 10], fp32, fused BN+ReLU+dropout epilogue, one-launch Adam",
         "block_shapes_n_dst_n_src_nnz": shapes,
         "layer0_forward_ms": l0_ms,
+        "layer0_forward_sequential_ms": l0_seq_ms,
+        "layer0_forward_note": "layer0_forward_ms: the layer as the step runs it -- launch 1 = the neighbour gather in the blocks beside the "
+                               "x_dst W_r^T half of the projection, launch 2 = the agg W_l^T half added in; _sequential_ms: gather, then "
+                               "the whole projection in one launch (round 2's order, POPE_KNOB_SAGE_FORWARD_OVERLAP = 0)",
         "layer0_forward_tflops": l0_flops / (l0_ms * 1e-3) / 1e12,
         "layer0_forward_gbs": l0_bytes / (l0_ms * 1e-3) / 1e9,
         "layer0_gather_mean": {"ms": g_ms, "algorithmic_bytes": g_bytes, "achieved_gbs": g_bytes / (g_ms * 1e-3) / 1e9,
@@ -717,7 +737,7 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
                               "roofline": {"bound": "mfma", "achieved": l0_flops / (proj_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF,
                                            "unit": "TFLOP/s", "frac": l0_flops / (proj_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF},
                               "vendor_library_ms": lib_ms,
-                              "note": "layer-0 forward minus the gather, HIP events; vendor_library_ms = torch.addmm (hipBLASLt) on "
+                              "note": "sequential layer-0 forward minus the gather (the one-launch projection kernel), HIP events; vendor_library_ms = torch.addmm (hipBLASLt) on "
                                       "the concatenated operands of the same product, timed in the same run"},
         "layer0_projection_split_bf16_opt_in": {
             "ms": split_l0_ms - g_ms, "max_abs_diff_vs_exact_f32": split_err, "output_max_abs": split_scale,

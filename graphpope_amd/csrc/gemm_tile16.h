@@ -33,6 +33,9 @@ struct T16Args {
     int tiles_m, tiles_n, S0, S1;
     const float *zero;
     const int *m_dev;          // device extent: the true row count (<= M, the capacity the grid was sized for), or nullptr
+    const long long *rows;     // nullptr, or: row m of the FIRST product's A operand is p[0].A + rows[m] * p[0].lda (the resident
+                               // feature matrix read through n_id; byte offsets must fit 32 bits)
+    int accumulate;            // 1: C += product (no bias): the second half of a layer whose first half another launch wrote
 };
 
 template <int RB> struct T16Shape {
@@ -96,9 +99,12 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
             const int row = (instr < Sh::A_INSTR ? instr : instr - Sh::A_INSTR) * 8 + sub;
             koff[d] = (cp ^ ((row >> 1) & 7)) * 4;
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                off[q][d] = instr < Sh::A_INSTR ? (unsigned)(((long long)min(m0 + row, M - 1) * a.p[q].lda + koff[d]) * 4)
+            for (int q = 0; q < 2; ++q) {
+                long long arow = min(m0 + row, M - 1);
+                if (q == 0 && a.rows && instr < Sh::A_INSTR) arow = a.rows[arow];
+                off[q][d] = instr < Sh::A_INSTR ? (unsigned)((arow * a.p[q].lda + koff[d]) * 4)
                                                : (unsigned)(((long long)min(n0 + row, a.N - 1) * a.p[q].ldb + koff[d]) * 4);
+            }
         }
         auto issue_all = [&](int s, int buf) {
             const bool second = s >= a.S0;                             // wave-uniform
@@ -265,24 +271,28 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
         if (n >= a.N) continue;
         float b = a.bias ? a.bias[n] : 0.0f;
         asm volatile("" : "+v"(b));
+        float add[RB][4];                                              // what the product is added to: the bias, or (accumulate) what C holds
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + i * 16 + 4 * g + r;
-                if (m < M) a.C[(size_t)m * a.ldc + n] = acc[i][t][r] + b;
+                add[i][r] = a.accumulate ? a.C[(size_t)min(m, M - 1) * a.ldc + n] : b;      // all loads issued before the first store
+            }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + i * 16 + 4 * g + r;
+                if (m < M) a.C[(size_t)m * a.ldc + n] = acc[i][t][r] + add[i][r];
             }
     }
 }
 
-// Host-sized launches give every tile a block of its own (the loop runs once).  With a device extent (`m_dev`: the rows are a
-// capacity, the true count lives on the device) the grid is at most one block per CU and a block walks the tiles it owns:
-// a grid sized for the capacity would be mostly blocks with nothing to do, and with 80 KB of LDS each they still queue
-// for the CUs behind the working blocks (measured: 87 us instead of 78 for the same product behind a 4x capacity).
-template <int RB, bool SPLIT = false>
-__global__ __launch_bounds__(T16_THREADS) void k_gemm_tile16(T16Args a) {
+// The tiles `first`, `first + stride`, ... of the product, one after the other, by the calling block (all eight waves).
+template <int RB, bool SPLIT>
+__device__ __forceinline__ void t16_block_loop(const T16Args &a, char *smem, const int first, const int stride) {
     using Sh = T16Shape<RB>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem);
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(T16_THREADS) void k_gemm_tile16(T16Args a) {
     if (a.m_dev) M = min(M, __builtin_amdgcn_readfirstlane(*a.m_dev));
     const int tiles_m = (M + Sh::TM - 1) / Sh::TM;
     bool again = false;
-    for (int b = blockIdx.x;; b += gridDim.x) {
+    for (int b = first;; b += stride) {
         // tiles b and b + 8 sit on one XCD (round-robin dispatch, grids are multiples of 16 here): they take the two column
         // tiles of the same rows, so the A rows they both stream come out of that XCD's L2 the second time (speed only)
         int tm, tn;
@@ -310,6 +320,12 @@ __global__ __launch_bounds__(T16_THREADS) void k_gemm_tile16(T16Args a) {
         t16_tile<RB, SPLIT>(a, M, tm, tn, smem, lds0, lane, wave);
         again = true;
     }
+}
+
+template <int RB, bool SPLIT = false>
+__global__ __launch_bounds__(T16_THREADS) void k_gemm_tile16(T16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    t16_block_loop<RB, SPLIT>(a, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // The tile height (in 16-row blocks, 3 .. 8) that wastes the least of the chip for this M x N, or 0 if no choice reaches

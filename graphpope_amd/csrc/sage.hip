@@ -439,6 +439,8 @@ static int launch_gemm(const Operand &A0, const Operand &B0, int K0, const Opera
 }
 
 extern int g_gemm_force_tile;          // pope_debug_set(POPE_KNOB_GEMM_TILE, ...) in geodesic.hip: 0 = automatic choice
+extern int g_sage_forward_overlap;     // pope_debug_set(POPE_KNOB_SAGE_FORWARD_OVERLAP, ...): 1 (default) gather beside half of the projection, 0 one after the other
+extern int g_gather_lds_pad_kb;        // pope_debug_set(POPE_KNOB_GATHER_LDS_PAD_KB, ...): occupancy experiment
 extern int g_gemm_split_bf16;         // pope_debug_set(POPE_KNOB_GEMM_SPLIT_BF16, ...): 1 = opt-in split-bf16 arithmetic in the whole-tile forward GEMM
 
 static long long tiles(int M, int N, int tm, int tn) { return (long long)((M + tm - 1) / tm) * ((N + tn - 1) / tn); }
@@ -583,16 +585,22 @@ static int launch_tile16(const T16Args &a, int grid, hipStream_t stream) {
     return g_gemm_split_bf16 ? launch_tile16_as<RB, true>(a, grid, stream) : launch_tile16_as<RB, false>(a, grid, stream);
 }
 
-// *used = false if the shape does not fit the chip well enough (or the operands do not qualify) and nothing was launched.
-static int gemm_tile16(const float *A0, const float *B0, int K0, const float *A1, const float *B1, int K1, long long lda, long long ldb,
-                       int M, int N, const float *bias, float *C, long long ldc, hipStream_t stream, bool *used, const int *m_dev = nullptr) {
-    *used = false;
+// A whole-tile product ready to launch: arguments, tile height and grid; ok = false if the shape does not fit the chip well
+// enough or the operands do not qualify.
+struct T16Plan {
+    T16Args a;
+    int rb = 0, grid = 0;
+    bool ok = false;
+};
+
+static int t16_plan(const float *A0, const float *B0, int K0, const float *A1, const float *B1, int K1, long long lda, long long ldb, int M, int N,
+                    const float *bias, float *C, long long ldc, const int *m_dev, T16Plan *plan, long long a0_rows = 0) {
+    plan->ok = false;
     if (g_gemm_force_tile != 0) return POPE_OK;                      // any forced variant: not this kernel (7 = "stream-K as in round 2")
     if ((K0 & 3) || (K1 & 3) || M <= 0 || N <= 0 || K0 <= 0) return POPE_OK;
-    if ((long long)M * lda * 4 >= (1ll << 32) || (long long)N * ldb * 4 >= (1ll << 32)) return POPE_OK;
+    if ((long long)std::max<long long>(M, a0_rows) * lda * 4 >= (1ll << 32) || (long long)N * ldb * 4 >= (1ll << 32)) return POPE_OK;
     if (!sk_operand_ok(A0, lda, K0) || !sk_operand_ok(B0, ldb, K0) || (K1 > 0 && (!sk_operand_ok(A1, lda, K1) || !sk_operand_ok(B1, ldb, K1))))
         return POPE_OK;
-    if (!streamk_shape_ok(M, K0, K1, N)) return POPE_OK;             // small products stay on the plain tile kernel
     int cus = 0, rc;
     if ((rc = device_cu_count(&cus))) return rc;
     const int rb = t16_pick_rb(M, N, cus);
@@ -601,24 +609,221 @@ static int gemm_tile16(const float *A0, const float *B0, int K0, const float *A1
     int dev = 0;
     POPE_HIP(hipGetDevice(&dev));
     if (!zero_page[dev]) POPE_HIP(hipGetSymbolAddress((void **)&zero_page[dev], HIP_SYMBOL(g_sk_zero)));
-    T16Args a;
+    T16Args &a = plan->a;
     a.p[0] = SkProduct{A0, B0, lda, ldb, K0};
     a.p[1] = SkProduct{K1 > 0 ? A1 : A0, K1 > 0 ? B1 : B0, lda, ldb, K1};
     a.M = M; a.N = N; a.bias = bias; a.C = C; a.ldc = ldc; a.zero = zero_page[dev]; a.m_dev = m_dev;
+    a.rows = nullptr; a.accumulate = 0;
     a.tiles_m = (M + 16 * rb - 1) / (16 * rb); a.tiles_n = (N + T16_TN - 1) / T16_TN;
     a.S0 = (K0 + T16_GK - 1) / T16_GK; a.S1 = (K1 + T16_GK - 1) / T16_GK;
-    int grid = a.tiles_n == 2 ? (a.tiles_m + 7) / 8 * 16 : a.tiles_m * a.tiles_n;
-    if (m_dev) grid = std::min(grid, a.tiles_n == 2 ? (cus + 15) / 16 * 16 : cus);      // capacity rows: one block per CU walks the true tiles
-    switch (rb) {
-    case 3: rc = launch_tile16<3>(a, grid, stream); break;
-    case 4: rc = launch_tile16<4>(a, grid, stream); break;
-    case 5: rc = launch_tile16<5>(a, grid, stream); break;
-    case 6: rc = launch_tile16<6>(a, grid, stream); break;
-    case 7: rc = launch_tile16<7>(a, grid, stream); break;
-    default: rc = launch_tile16<8>(a, grid, stream); break;
+    plan->grid = a.tiles_n == 2 ? (a.tiles_m + 7) / 8 * 16 : a.tiles_m * a.tiles_n;
+    if (m_dev) plan->grid = std::min(plan->grid, a.tiles_n == 2 ? (cus + 15) / 16 * 16 : cus);   // capacity rows: one block per CU walks the true tiles
+    plan->rb = rb;
+    plan->ok = true;
+    return POPE_OK;
+}
+
+static int t16_launch(const T16Plan &plan, hipStream_t stream) {
+    int rc;
+    switch (plan.rb) {
+    case 3: rc = launch_tile16<3>(plan.a, plan.grid, stream); break;
+    case 4: rc = launch_tile16<4>(plan.a, plan.grid, stream); break;
+    case 5: rc = launch_tile16<5>(plan.a, plan.grid, stream); break;
+    case 6: rc = launch_tile16<6>(plan.a, plan.grid, stream); break;
+    case 7: rc = launch_tile16<7>(plan.a, plan.grid, stream); break;
+    default: rc = launch_tile16<8>(plan.a, plan.grid, stream); break;
     }
     if (rc) return rc;
     POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+// *used = false if nothing was launched (see T16Plan).
+static int gemm_tile16(const float *A0, const float *B0, int K0, const float *A1, const float *B1, int K1, long long lda, long long ldb,
+                       int M, int N, const float *bias, float *C, long long ldc, hipStream_t stream, bool *used, const int *m_dev = nullptr) {
+    *used = false;
+    if (!streamk_shape_ok(M, K0, K1, N)) return POPE_OK;             // small products stay on the plain tile kernel
+    T16Plan plan;
+    int rc = t16_plan(A0, B0, K0, A1, B1, K1, lda, ldb, M, N, bias, C, ldc, m_dev, &plan);
+    if (rc || !plan.ok) return rc;
+    if ((rc = t16_launch(plan, stream))) return rc;
+    *used = true;
+    return POPE_OK;
+}
+
+// ---- layer forward as TWO launches that overlap the gather with half of the projection (round 3) ----
+// The gather is HBM-bound (64 us inside the step), the projection MFMA-bound (78 us), and they ran one after the other.
+// out = x_dst W_r^T + b does not need the gather: launch 1 carries that product (reading the destination rows straight from
+// the source / feature matrix, through n_id in indexed mode) in its first blocks -- one per CU, dispatched first -- and the
+// gather in the remaining blocks, which share the CUs with them; launch 2 adds agg W_l^T into out.  No block waits for
+// another block.  Every block of launch 1 carries the GEMM role's LDS reservation, so only one or two gather blocks fit a
+// CU: the gather role keeps twelve 16-byte loads in flight per lane (k_gather_mean: four) to make up for it.
+struct GatherArgs {
+    const int *rowptr, *col;
+    int n_dst;
+    const float *x;
+    int C;
+    float *agg;
+    const long long *n_id;
+    float *x_dst;
+    const int *n_dst_dev;
+};
+
+// Only one or two of these blocks fit a CU beside the GEMM role's LDS, so what k_gather_mean hides behind occupancy is
+// hidden here by a pipeline over the rows of a wave: while row j's data is in flight the wave loads rowptr of row j + 3, the
+// neighbour ids of row j + 2 (one coalesced load, a lane per neighbour) and their n_id entries for row j + 1; the data
+// phase takes its row addresses from registers (shuffles) and keeps twelve 16-byte loads in flight per lane.  Sums are
+// formed in k_gather_mean's order (a short last group re-reads the last neighbour with weight 0: v * 1 and s + v * 0 are
+// exact), so agg is bit for bit the same.  Rows with more than 64 neighbours take the plain loop.
+__device__ __forceinline__ void gather_role(const GatherArgs &g, const int block, const int nblocks) {
+    __builtin_amdgcn_s_setprio(3);               // memory-bound: it needs few issue slots, but it needs them when its data arrives
+    const int lane = threadIdx.x & 63;
+    const int wave = block * (T16_THREADS / 64) + (threadIdx.x >> 6), nwaves = nblocks * (T16_THREADS / 64);
+    const int n_dst = dyn_extent(g.n_dst_dev, g.n_dst);
+    const int C = g.C, C4 = C >> 2;
+    // pipeline registers: row r3 has its rowptr pair requested, r2 its neighbour ids, r1 their source rows, r0 is being summed
+    int b1 = 0, e1 = 0, b2 = 0, e2 = 0, c1 = 0;
+    long long id0 = 0, own0 = 0;
+    int b0 = 0, e0 = 0;
+    auto rowptr_pair = [&](int i, int &b, int &e) {
+        if (i < n_dst) { b = g.rowptr[i]; e = g.rowptr[i + 1]; } else { b = e = 0; }
+    };
+    auto neighbour = [&](int b, int e) { return b + lane < e && lane < 64 ? g.col[b + lane] : 0; };
+    auto source = [&](int c) { return g.n_id ? g.n_id[c] : (long long)c; };
+    // prologue: fill the pipeline for the wave's first three rows
+    rowptr_pair(wave, b0, e0);
+    rowptr_pair(wave + nwaves, b1, e1);
+    rowptr_pair(wave + 2 * nwaves, b2, e2);
+    {
+        const int c0 = neighbour(b0, e0);
+        c1 = neighbour(b1, e1);
+        id0 = source(c0);
+        own0 = g.x_dst && wave < n_dst ? g.n_id[wave] : 0;
+    }
+    for (int i = wave; i < n_dst; i += nwaves) {
+        // requests for the rows behind this one (nothing here depends on a load of this iteration)
+        int b3, e3;
+        rowptr_pair(i + 3 * nwaves, b3, e3);
+        const int c2 = neighbour(b2, e2);
+        const long long id1 = source(c1);
+        const long long own1 = g.x_dst && i + nwaves < n_dst ? g.n_id[i + nwaves] : 0;
+        // the data of row i
+        const int beg = b0, end = e0, deg = end - beg;
+        const float inv = deg > 0 ? 1.0f / (float)deg : 0.0f;
+        for (int q0 = 0; q0 < C4; q0 += 192) {
+            int q[3];
+            bool ok[3];
+            float4 s[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                q[k] = q0 + 64 * k + lane;
+                ok[k] = q[k] < C4;
+                s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4 o[3];
+            if (g.x_dst) {
+                const float4 *own = reinterpret_cast<const float4 *>(g.x + (size_t)own0 * C);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) o[k] = own[ok[k] ? q[k] : 0];
+            }
+            for (int p = 0; p < deg; p += 4) {                             // four neighbour rows x three pieces in flight
+                long long row[4];
+                float w[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int pp = min(p + t, deg - 1);
+                    w[t] = p + t < deg ? 1.0f : 0.0f;
+                    if (deg <= 64) {
+                        const int lo = __shfl((int)(unsigned)(id0 & 0xffffffffll), pp), hi = __shfl((int)(id0 >> 32), pp);
+                        row[t] = ((long long)hi << 32) | (unsigned)lo;
+                    } else {
+                        row[t] = source(g.col[beg + pp]);                  // a long row: ids straight from memory
+                    }
+                }
+                float4 v[4][3];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 *r = reinterpret_cast<const float4 *>(g.x + (size_t)row[t] * C);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) v[t][k] = r[ok[k] ? q[k] : 0];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        s[k].x += v[t][k].x * w[t]; s[k].y += v[t][k].y * w[t]; s[k].z += v[t][k].z * w[t]; s[k].w += v[t][k].w * w[t];
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (!ok[k]) continue;
+                s[k].x *= inv; s[k].y *= inv; s[k].z *= inv; s[k].w *= inv;
+                reinterpret_cast<float4 *>(g.agg + (size_t)i * C)[q[k]] = s[k];
+                if (g.x_dst) reinterpret_cast<float4 *>(g.x_dst + (size_t)i * C)[q[k]] = o[k];
+            }
+        }
+        // advance the pipeline
+        b0 = b1; e0 = e1; id0 = id1; own0 = own1;
+        b1 = b2; e1 = e2; c1 = c2;
+        b2 = b3; e2 = e3;
+    }
+}
+
+// (registers are allotted per kernel, not per role: at the GEMM role's 138 a gather block's two extra waves per SIMD would not fit
+//  beside a GEMM block -- 4 x 144 > 512 -- and the roles ran one after the other: 62 + 45 us.  Hence four waves per SIMD.)
+template <int RB>
+__global__ __launch_bounds__(T16_THREADS, 4) void k_gather_beside_gemm(T16Args a, GatherArgs g, int gemm_blocks, int only) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < gemm_blocks) {
+        if (only != 2) t16_block_loop<RB, false>(a, smem, (int)blockIdx.x, gemm_blocks);
+    } else if (only != 3) {
+        gather_role(g, (int)blockIdx.x - gemm_blocks, (int)gridDim.x - gemm_blocks);
+    }
+}
+
+template <int RB>
+static int launch_gather_beside_gemm(const T16Args &a, const GatherArgs &g, int gemm_blocks, int gather_blocks, hipStream_t stream) {
+    static LdsOptIn opt_in;
+    if (!opt_in.done()) {
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gather_beside_gemm<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, T16Shape<RB>::LDS_BYTES));
+        opt_in.mark();
+    }
+    hipLaunchKernelGGL(k_gather_beside_gemm<RB>, dim3((unsigned)(gemm_blocks + gather_blocks)), dim3(T16_THREADS), T16Shape<RB>::LDS_BYTES, stream, a, g,
+                       gemm_blocks, g_sage_forward_overlap);        // (knob values 2 / 3: one role only -- timing experiments, wrong results)
+    return POPE_OK;
+}
+
+// x: the matrix the rows are gathered from (the block's own sources, or the whole feature matrix with n_id); x_rows its
+// row count.  *used = false: nothing launched, the caller runs gather + one-pass projection as before.
+static int forward_overlapped(const int32_t *rowptr, const int32_t *col, int64_t n_dst, const float *x, int64_t x_rows, int32_t c_in,
+                              const long long *n_id, float *x_dst, float *agg, const float *w_l, const float *b_l, const float *w_r,
+                              int32_t c_out, float *out, const int32_t *dims, hipStream_t stream, bool *used) {
+    *used = false;
+    if (g_sage_forward_overlap == 0 || g_gemm_split_bf16) return POPE_OK;
+    if (!streamk_shape_ok(n_dst, c_in, c_in, c_out) || !aligned16(x) || !aligned16(agg) || (x_dst && !aligned16(x_dst))) return POPE_OK;
+    T16Plan first, second;
+    int rc = t16_plan(x, w_r, c_in, nullptr, nullptr, 0, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, dims, &first, x_rows);
+    if (rc || !first.ok) return rc;
+    if ((rc = t16_plan(agg, w_l, c_in, nullptr, nullptr, 0, c_in, c_in, (int)n_dst, c_out, nullptr, out, c_out, dims, &second))) return rc;
+    if (!second.ok || second.rb != first.rb) return POPE_OK;
+    first.a.rows = n_id;                                            // nullptr: destination i is row i of x
+    second.a.accumulate = 1;
+    int cus = 0;
+    if ((rc = device_cu_count(&cus))) return rc;
+    const int gemm_blocks = first.a.tiles_n == 2 ? std::min(first.grid, (cus + 15) / 16 * 16) : std::min(first.grid, cus);
+    const int gather_blocks = 2 * cus;
+    const GatherArgs g{rowptr, col, (int)n_dst, x, c_in, agg, n_id, x_dst, dims};
+    switch (first.rb) {
+    case 3: rc = launch_gather_beside_gemm<3>(first.a, g, gemm_blocks, gather_blocks, stream); break;
+    case 4: rc = launch_gather_beside_gemm<4>(first.a, g, gemm_blocks, gather_blocks, stream); break;
+    case 5: rc = launch_gather_beside_gemm<5>(first.a, g, gemm_blocks, gather_blocks, stream); break;
+    case 6: rc = launch_gather_beside_gemm<6>(first.a, g, gemm_blocks, gather_blocks, stream); break;
+    case 7: rc = launch_gather_beside_gemm<7>(first.a, g, gemm_blocks, gather_blocks, stream); break;
+    default: rc = launch_gather_beside_gemm<8>(first.a, g, gemm_blocks, gather_blocks, stream); break;
+    }
+    if (rc) return rc;
+    POPE_HIP(hipGetLastError());
+    if ((rc = t16_launch(second, stream))) return rc;
     *used = true;
     return POPE_OK;
 }
@@ -707,11 +912,12 @@ static void enqueue_gather_mean(const int32_t *rowptr, const int32_t *col, int64
                                 float *agg, hipStream_t stream, const int64_t *n_id = nullptr, float *x_dst = nullptr,
                                 const int32_t *n_dst_dev = nullptr) {
     dim3 grid(capped_grid((size_t)n_dst * 64, 256));
+    const size_t lds_pad = (size_t)g_gather_lds_pad_kb << 10;       // diagnostic: reserve LDS to cap the kernel's occupancy
     if ((c_in & 3) == 0 && aligned16(x_src) && aligned16(agg) && (!x_dst || aligned16(x_dst)))
-        hipLaunchKernelGGL(k_gather_mean<true>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
+        hipLaunchKernelGGL(k_gather_mean<true>, grid, dim3(256), lds_pad, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
                            (const long long *)n_id, x_dst, n_dst_dev);
     else
-        hipLaunchKernelGGL(k_gather_mean<false>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
+        hipLaunchKernelGGL(k_gather_mean<false>, grid, dim3(256), lds_pad, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
                            (const long long *)n_id, x_dst, n_dst_dev);
 }
 
@@ -735,10 +941,11 @@ extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int6
     POPE_REQUIRE(rowptr && (col || nnz == 0) && x_src && w_l && w_r && agg && out, "sage_conv_forward: null pointer");
     POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && nnz >= 0 && nnz < INT32_MAX && c_in > 0 && c_out > 0,
                  "sage_conv_forward: bad size (destinations must be the first n_dst sources)");
+    bool used = false;
+    int rc = forward_overlapped(rowptr, col, n_dst, x_src, n_src, c_in, nullptr, nullptr, agg, w_l, b_l, w_r, c_out, out, dims, stream, &used);
+    if (rc || used) return rc;
     enqueue_gather_mean(rowptr, col, n_dst, x_src, c_in, agg, stream, nullptr, nullptr, dims);
     // out = agg * w_l^T + b_l + x_dst * w_r^T in one pass
-    bool used = false;
-    int rc = POPE_OK;
     if ((rc = gemm_tile16(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used, dims))) return rc;
     if (used) return POPE_OK;
     rc = gemm_streamk(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);
@@ -761,9 +968,11 @@ extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *c
     POPE_REQUIRE(rowptr && (col || nnz == 0) && n_id && feats && w_l && w_r && agg && x_dst && out, "sage_conv_forward_indexed: null pointer");
     POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && n_rows > 0 && nnz >= 0 && nnz < INT32_MAX && c_in > 0 && c_out > 0,
                  "sage_conv_forward_indexed: bad size (destinations must be the first n_dst entries of n_id)");
-    enqueue_gather_mean(rowptr, col, n_dst, feats, c_in, agg, stream, n_id, x_dst, dims);
     bool used = false;
-    int rc = POPE_OK;
+    int rc = forward_overlapped(rowptr, col, n_dst, feats, n_rows, c_in, (const long long *)n_id, x_dst, agg, w_l, b_l, w_r, c_out, out, dims, stream,
+                                &used);
+    if (rc || used) return rc;
+    enqueue_gather_mean(rowptr, col, n_dst, feats, c_in, agg, stream, n_id, x_dst, dims);
     if ((rc = gemm_tile16(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used, dims))) return rc;
     if (used) return POPE_OK;
     rc = gemm_streamk(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);

@@ -145,10 +145,22 @@ def config2_block():
     return n, torch.as_tensor(n_id), a0
 
 
+@pytest.fixture(params=[1, 0], ids=["gather_beside_projection", "gather_then_projection"])
+def forward_order(request):
+    """POPE_KNOB_SAGE_FORWARD_OVERLAP: 1 (default) = the gather in the blocks beside the x_dst half of the projection + a
+    second launch for the agg half; 0 = gather, then the whole projection."""
+    from graphpope_amd import _lib
+    lib = _lib.load()
+    lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, request.param)
+    yield request.param
+    lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, 1)
+
+
 @pytest.mark.parametrize("indexed", [False, True], ids=["materialised", "indexed"])
-def test_config2_block_shape_matches_torch(indexed, config2_block, dev, oracle):
+def test_config2_block_shape_matches_torch(indexed, forward_order, config2_block, dev, oracle):
     """Layer 0 at the shape bench.py times (9 988 x 37 799, 756 -> 256): forward and every gradient against
-    oracle.sage_conv_torch, for the plain call and for IndexedFeatures (neighbours read through n_id, no x[n_id] copy)."""
+    oracle.sage_conv_torch, for the plain call and for IndexedFeatures (neighbours read through n_id, no x[n_id] copy),
+    in both forward orders."""
     from graphpope_amd.sage import SAGEConv, IndexedFeatures
     n, n_id, a0 = config2_block
     c_in, c_out = 756, 256
@@ -253,3 +265,41 @@ def test_opt_in_split_bf16_projection_stays_in_the_f32_accuracy_class(n_dst, c_i
     err_exact = float((exact.cpu().double() - ref64).abs().max())
     err_split = float((split.cpu().double() - ref64).abs().max())
     assert err_split <= 1.5 * err_exact + 1e-7 * scale
+
+
+@pytest.mark.parametrize("n_dst,c_in,c_out,fan", [(9988, 756, 256, 8), (8100, 200, 256, 3), (12200, 132, 250, 70)])
+def test_gather_beside_the_projection_gives_the_same_aggregate_and_the_same_layer(n_dst, c_in, c_out, fan, dev):
+    """The overlapped forward (launch 1: pipelined gather role beside x_dst W_r^T + b, launch 2: += agg W_l^T) against the
+    sequential one: the aggregate and the copied destination rows bit for bit (same order of additions; rows of more than
+    64 neighbours take the role's long-row path at fan = 70), the layer output to 1e-5 of its largest value (the two halves
+    are added in another order)."""
+    import ctypes
+    from graphpope_amd import _lib
+    lib = _lib.load()
+    n_src, n_rows = n_dst + 500, n_dst + 4000
+    rowptr, col = _random_block(n_dst, n_src, fan, seed=n_dst)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.rand(n_rows, c_in, generator=g).to(dev)
+    n_id = torch.randperm(n_rows, generator=g)[:n_src].to(dev)
+    w_l, w_r = (torch.randn(c_out, c_in, generator=g) * 0.05).to(dev), (torch.randn(c_out, c_in, generator=g) * 0.05).to(dev)
+    b = torch.randn(c_out, generator=g).to(dev)
+    rp, cl = rowptr.to(dev), col.to(dev)
+    scratch = torch.empty(max(lib.sage_conv_forward_scratch_bytes(n_dst, c_in, c_out), 16), dtype=torch.uint8, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    res = {}
+    for order in (1, 0):
+        agg = torch.full((n_dst, c_in), -7.0, device=dev)
+        x_dst = torch.full((n_dst, c_in), -7.0, device=dev)
+        out = torch.full((n_dst, c_out), -7.0, device=dev)
+        lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, order)
+        try:
+            _lib.check(lib.sage_conv_forward_indexed(_lib.ptr(rp), _lib.ptr(cl), _lib.ptr(n_id), n_src, n_dst, cl.numel(), _lib.ptr(feats), n_rows,
+                                                     c_in, _lib.ptr(w_l), _lib.ptr(b), _lib.ptr(w_r), c_out, _lib.ptr(agg), _lib.ptr(x_dst),
+                                                     _lib.ptr(out), _lib.ptr(scratch), scratch.numel(), None, stream))
+        finally:
+            lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, 1)
+        res[order] = (agg, x_dst, out)
+    assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1])
+    assert torch.equal(res[0][1], feats[n_id[:n_dst]])
+    scale = float(res[0][2].abs().max())
+    assert float((res[1][2] - res[0][2]).abs().max()) <= 1e-5 * scale

@@ -32,6 +32,11 @@ struct SkTnArgs {
     const float *zero;
     int tiles_m, tiles_nb, S;    // tiles along M, along Nb (per product), depth stages
     const int *depth_dev;        // device extent: the true depth (<= depth, which then is the capacity), or null
+    // a second role of the fix-up launch (blocks behind the tiles'): out[c] = sum over z of part[z * C + c], the final stage of the
+    // bias gradient's column sums, whose partials an earlier launch wrote -- one launch less in the backward pass
+    const float *cs_part;
+    float *cs_out;
+    int cs_splits, cs_C;
 };
 
 template <int GK>
@@ -218,6 +223,26 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
     }
 }
 
+// 16 columns x 16 split-groups per block of 256 threads: every thread adds splits / 16 partials, LDS folds the 16 groups in a
+// fixed order (k_colsum_final in sage.hip is this block as a kernel of its own).
+__device__ __forceinline__ void colsum_final_block(const float *__restrict__ part, int splits, int C, float *__restrict__ out, int block) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = block * 16 + cl;
+    float s = 0.f;
+    if (c < C)
+#pragma unroll 4
+        for (int z = grp; z < splits; z += 16) s += part[(size_t)z * C + c];
+    red[grp][cl] = s;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][cl];
+        out[c] = t;
+    }
+}
+
 // SK_TN_FIX_PARTS blocks per tile, as k_streamk_fixup: 24 tiles only, so more parts per tile (384 blocks, one piece per thread).
 constexpr int SK_TN_FIX_PARTS = 16;
 template <int GK>
@@ -225,8 +250,12 @@ __global__ __launch_bounds__(256) void k_streamk_tn_fixup(SkTnArgs a, int G) {
     sk_tn_resolve<GK>(a);
     const int S = a.S;
     const long long T = (long long)a.tiles_m * a.tiles_nb * 2 * S;
-    if (T <= 0) return;                                                                   // (a device extent of 0 rows: nothing was computed)
     const int tile = blockIdx.x;
+    if (tile >= 2 * a.tiles_m * a.tiles_nb) {                                             // the column-sum role (sixteen columns per block)
+        if (blockIdx.y == 0 && a.cs_part) colsum_final_block(a.cs_part, a.cs_splits, a.cs_C, a.cs_out, tile - 2 * a.tiles_m * a.tiles_nb);
+        return;
+    }
+    if (T <= 0) return;                                                                   // (a device extent of 0 rows: nothing was computed)
     const long long u0 = (long long)tile * S, u1 = u0 + S;
     const int b_lo = (int)(((u0 + 1) * G - 1) / T), b_hi = (int)((u1 * G - 1) / T);
     if (b_lo == b_hi) return;

@@ -81,12 +81,12 @@ __global__ __launch_bounds__(256) void k_gather_mean(const int *__restrict__ row
 // ids are loaded once, 64 at a time, and broadcast with shuffles, and the slab's four gradient values per lane are in
 // registers before the first atomic -- the loop issues nothing but no-return atomics (256 contiguous bytes per wave
 // instruction), instead of a dependent col[p] load in front of every one (38 us -> see DESIGN.md §7).
-__global__ __launch_bounds__(256) void k_scatter_mean(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                      int n_dst, const float *__restrict__ gagg, int C,
-                                                      float *__restrict__ gx, const int *__restrict__ n_dst_dev) {
+__device__ __forceinline__ void scatter_mean_block(const int *__restrict__ rowptr, const int *__restrict__ col, int n_dst,
+                                                   const float *__restrict__ gagg, int C, float *__restrict__ gx,
+                                                   const int *__restrict__ n_dst_dev, const int block, const int nblocks) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int wave = (block * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (nblocks * blockDim.x) >> 6;
     const int slabs = (C + 255) / 256;
     n_dst = dyn_extent(n_dst_dev, n_dst);
     for (int w = wave; w < n_dst * slabs; w += nwaves) {
@@ -113,6 +113,12 @@ __global__ __launch_bounds__(256) void k_scatter_mean(const int *__restrict__ ro
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_mean(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                      int n_dst, const float *__restrict__ gagg, int C,
+                                                      float *__restrict__ gx, const int *__restrict__ n_dst_dev) {
+    scatter_mean_block(rowptr, col, n_dst, gagg, C, gx, n_dst_dev, blockIdx.x, gridDim.x);
 }
 
 // x[r, :] = 0 for r in [r0, r1): the rows of grad_x that only the scatter adds to.  Both bounds may live on the device.
@@ -179,21 +185,7 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
 // 16 columns x 16 split-groups per block: a one-thread-per-column loop over the 64 partials is 64 dependent-latency
 // loads (15 us measured); here every thread adds 4 and LDS folds the 16 groups in a fixed order.
 __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ part, int splits, int C, float *__restrict__ out) {
-    __shared__ float red[16][17];
-    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    float s = 0.f;
-    if (c < C)
-#pragma unroll 4
-        for (int z = grp; z < splits; z += 16) s += part[(size_t)z * C + c];
-    red[grp][cl] = s;
-    __syncthreads();
-    if (grp == 0 && c < C) {
-        float t = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[g][cl];
-        out[c] = t;
-    }
+    colsum_final_block(part, splits, C, out, blockIdx.x);            // (gemm_streamk_tn.h: also a role of the weight gradients' fix-up launch)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -369,40 +361,45 @@ static GemmArgs gemm_args(const Operand &A0, const Operand &B0, int K0, const Op
 
 // The two reductions behind k_gemm_dual in one launch: blocks [0, reduce_blocks) add the split-K slabs of both weight
 // gradients, the rest fold the partial column sums of the bias gradient (k_colsum_final's block shape).
-__device__ __forceinline__ void colsum_final_block(const float *__restrict__ part, int splits, int C, float *__restrict__ out, int bx) {
-    __shared__ float red[16][17];
-    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int c = bx * 16 + cl;
-    float s = 0.f;
-    if (c < C)
-#pragma unroll 4
-        for (int z = grp; z < splits; z += 16) s += part[(size_t)z * C + c];
-    red[grp][cl] = s;
-    __syncthreads();
-    if (grp == 0 && c < C) {
-        float t = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[g][cl];
-        out[c] = t;
-    }
-}
+// (colsum_final_block: gemm_streamk_tn.h)
+struct BwdFinals {
+    const float *slab;
+    int splits;
+    size_t elems;
+    int N;
+    float *C, *C2;
+    long long ldc;
+    int reduce_blocks;
+    const float *cs_part;
+    int cs_splits, cs_C;
+    float *cs_out;
+};
 
-__global__ __launch_bounds__(256) void k_bwd_finals(const float *__restrict__ slab, int splits, size_t elems, int N, float *__restrict__ C,
-                                                    float *__restrict__ C2, long long ldc, int reduce_blocks,
-                                                    const float *__restrict__ cs_part, int cs_splits, int cs_C, float *__restrict__ cs_out) {
-    if ((int)blockIdx.x < reduce_blocks) {
-        for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < elems * 2; t += (size_t)reduce_blocks * blockDim.x) {
-            const int which = t >= elems;
-            const size_t i = t - (which ? elems : 0);
-            const float *src = slab + (size_t)which * splits * elems + i;
+__device__ __forceinline__ void bwd_finals_block(const BwdFinals &f, const int block) {
+    if (block < f.reduce_blocks) {
+        for (size_t t = (size_t)block * blockDim.x + threadIdx.x; t < f.elems * 2; t += (size_t)f.reduce_blocks * blockDim.x) {
+            const int which = t >= f.elems;
+            const size_t i = t - (which ? f.elems : 0);
+            const float *src = f.slab + (size_t)which * f.splits * f.elems + i;
             float s = 0.f;
 #pragma unroll 4
-            for (int z = 0; z < splits; ++z) s += src[(size_t)z * elems];
-            (which ? C2 : C)[(i / N) * ldc + (i % N)] = s;
+            for (int z = 0; z < f.splits; ++z) s += src[(size_t)z * f.elems];
+            (which ? f.C2 : f.C)[(i / f.N) * f.ldc + (i % f.N)] = s;
         }
         return;
     }
-    colsum_final_block(cs_part, cs_splits, cs_C, cs_out, (int)blockIdx.x - reduce_blocks);
+    colsum_final_block(f.cs_part, f.cs_splits, f.cs_C, f.cs_out, block - f.reduce_blocks);
+}
+
+__global__ __launch_bounds__(256) void k_bwd_finals(BwdFinals f) { bwd_finals_block(f, (int)blockIdx.x); }
+
+// The scatter of grad_agg and the two reductions behind k_gemm_dual read nothing of one another: one launch, the (few, short)
+// reduction blocks first.
+__global__ __launch_bounds__(256) void k_scatter_and_finals(const int *__restrict__ rowptr, const int *__restrict__ col, int n_dst,
+                                                            const float *__restrict__ gagg, int C, float *__restrict__ gx,
+                                                            const int *__restrict__ n_dst_dev, BwdFinals f, int finals_blocks) {
+    if ((int)blockIdx.x < finals_blocks) bwd_finals_block(f, (int)blockIdx.x);
+    else scatter_mean_block(rowptr, col, n_dst, gagg, C, gx, n_dst_dev, (int)blockIdx.x - finals_blocks, (int)gridDim.x - finals_blocks);
 }
 
 template <int TM, int TN, int WM, int WN, int LA, int LB>
@@ -837,7 +834,8 @@ static bool streamk_tn_shape_ok(int64_t depth, int32_t M, int32_t Nb) {
 
 // C0 = G^T * B0, C1 = G^T * B1 (G [depth, M], B_q [depth, Nb], C_q [M, Nb]); *used = false if the operands do not qualify.
 static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int64_t depth, int M, int Nb, float *C0, float *C1,
-                           void *slab, size_t slab_bytes, hipStream_t stream, bool *used, const int *depth_dev = nullptr) {
+                           void *slab, size_t slab_bytes, hipStream_t stream, bool *used, const int *depth_dev = nullptr,
+                           float *cs_part = nullptr, float *cs_out = nullptr, bool cs_vec = false) {
     *used = false;
     if (g_gemm_force_tile != 0 && g_gemm_force_tile < 4) return POPE_OK;
     if (!streamk_tn_shape_ok(depth, M, Nb)) return POPE_OK;
@@ -850,6 +848,11 @@ static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int
     const int gk = skl_stage_depth();
     a.tiles_m = (M + SK_TM - 1) / SK_TM; a.tiles_nb = (Nb + SK_TN - 1) / SK_TN; a.S = (int)((depth + gk - 1) / gk);
     a.depth_dev = depth_dev;
+    // the bias gradient = column sums of G: its partial sums are a launch of their own in front of the GEMM (they read G and
+    // nothing else), its final stage rides in the fix-up launch behind it
+    a.cs_part = cs_part; a.cs_out = cs_out; a.cs_splits = COLSUM_SPLITS; a.cs_C = M;
+    const int cs_C = M;
+    const unsigned fix_blocks = 2u * a.tiles_m * a.tiles_nb + (cs_part ? (unsigned)(cs_C + 15) / 16 : 0u);
     const long long T = 2ll * a.tiles_m * a.tiles_nb * a.S;
     long long grid = cus < SK_MAX_GRID ? cus : SK_MAX_GRID;
     if (grid > T) grid = T;
@@ -865,12 +868,18 @@ static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int
     }
     if (!zero_page[dev]) POPE_HIP(hipGetSymbolAddress((void **)&zero_page[dev], HIP_SYMBOL(g_sk_zero)));
     a.zero = zero_page[dev];
+    if (cs_part) {
+        if (cs_vec)
+            hipLaunchKernelGGL(k_colsum_partial<true>, dim3((M + 255) / 256, COLSUM_SPLITS), dim3(256), 0, stream, G, (int)depth, M, cs_part, depth_dev);
+        else
+            hipLaunchKernelGGL(k_colsum_partial<false>, dim3((M + 63) / 64, COLSUM_SPLITS), dim3(256), 0, stream, G, (int)depth, M, cs_part, depth_dev);
+    }
     if (gk == 32) {
         hipLaunchKernelGGL(k_gemm_streamk_tn<32>, dim3((unsigned)grid), dim3(SKL_THREADS), SkStage<32>::LDS_BYTES, stream, a);
-        hipLaunchKernelGGL(k_streamk_tn_fixup<32>, dim3(2 * a.tiles_m * a.tiles_nb, SK_TN_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
+        hipLaunchKernelGGL(k_streamk_tn_fixup<32>, dim3(fix_blocks, SK_TN_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
     } else {
         hipLaunchKernelGGL(k_gemm_streamk_tn<64>, dim3((unsigned)grid), dim3(SKL_THREADS), SkStage<64>::LDS_BYTES, stream, a);
-        hipLaunchKernelGGL(k_streamk_tn_fixup<64>, dim3(2 * a.tiles_m * a.tiles_nb, SK_TN_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
+        hipLaunchKernelGGL(k_streamk_tn_fixup<64>, dim3(fix_blocks, SK_TN_FIX_PARTS), dim3(256), 0, stream, a, (int)grid);
     }
     POPE_HIP(hipGetLastError());
     *used = true;
@@ -1021,12 +1030,15 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
 
     // grad_w_l[o, c] = sum_i grad_out[i, o] * agg[i, c];  grad_w_r likewise with x_dst   (depth = rows i)
     bool used = false;
-    if ((rc = gemm_streamk_tn(grad_out, agg, x_src, n_dst, c_out, c_in, grad_w_l, grad_w_r, slab, slab_bytes, stream, &used, n_dst_dev))) return rc;
+    const bool colsum_vec = (c_out & 3) == 0 && aligned16(grad_out);
+    const bool bias_with_gemm = grad_b_l && !side;               // the bias gradient's two stages travel with the stream-K launches
+    if ((rc = gemm_streamk_tn(grad_out, agg, x_src, n_dst, c_out, c_in, grad_w_l, grad_w_r, slab, slab_bytes, stream, &used, n_dst_dev,
+                              bias_with_gemm ? colsum : nullptr, grad_b_l, colsum_vec))) return rc;
+    const bool bias_done = used && bias_with_gemm;
     const Operand Gt{grad_out, 1, c_out};                       // (outer o, depth i) -> grad_out[i * c_out + o]
     const Operand AggT{agg, 1, c_in}, XdT{x_src, 1, c_in};      // (outer c, depth i)
     const Operand G{grad_out, c_out, 1};                        // (outer i, depth o)
     const Operand WrT{w_r, 1, c_in}, WlT{w_l, 1, c_in};         // (outer c, depth o) -> w[o * c_in + c]
-    const bool colsum_vec = (c_out & 3) == 0 && aligned16(grad_out);
 
     // Small layer (the weight gradients did not qualify for the stream-K kernel) with an input gradient: the two twin GEMMs,
     // the zeroing of grad_x's scatter-only rows and the bias gradient's partial sums all read grad_out and nothing of one
@@ -1057,11 +1069,13 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
         const int blocks = p0.gx * p0.gy * p0.gz + p1.gx * p1.gy * p1.gz + aux.zero_blocks + aux.cs_gx * aux.cs_gy;
         hipLaunchKernelGGL((k_gemm_dual<64, 64, 2, 2>), dim3(blocks), dim3(256), lds, stream, p0, p1, aux);
         const int reduce_blocks = (int)capped_grid((size_t)c_out * c_in * 2, 256);
-        hipLaunchKernelGGL(k_bwd_finals, dim3(reduce_blocks + (c_out + 15) / 16), dim3(256), 0, stream, slab, splits, (size_t)c_out * c_in, c_in,
-                           grad_w_l, grad_w_r, (long long)c_in, reduce_blocks, colsum, COLSUM_SPLITS, c_out, grad_b_l);
+        const BwdFinals fin{slab, splits, (size_t)c_out * c_in, c_in, grad_w_l, grad_w_r, (long long)c_in, reduce_blocks, colsum, COLSUM_SPLITS, c_out, grad_b_l};
+        const int finals_blocks = reduce_blocks + (c_out + 15) / 16;
         if (nnz > 0)
-            hipLaunchKernelGGL(k_scatter_mean, dim3(capped_grid((size_t)n_dst * ((c_in + 255) / 256) * 64, 256)), dim3(256), 0, stream, rowptr, col,
-                               (int)n_dst, gagg, c_in, grad_x, n_dst_dev);
+            hipLaunchKernelGGL(k_scatter_and_finals, dim3(finals_blocks + capped_grid((size_t)n_dst * ((c_in + 255) / 256) * 64, 256)), dim3(256), 0, stream,
+                               rowptr, col, (int)n_dst, gagg, c_in, grad_x, n_dst_dev, fin, finals_blocks);
+        else
+            hipLaunchKernelGGL(k_bwd_finals, dim3(finals_blocks), dim3(256), 0, stream, fin);
         POPE_HIP(hipGetLastError());
         return POPE_OK;
     }
@@ -1071,7 +1085,7 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
         if ((rc = gemm(Gt, AggT, (int)n_dst, none, none, 0, c_out, c_in, nullptr, grad_w_l, c_in, splits, slab, stream,
                        Twin{XdT, grad_w_r, 0}, dyn))) return rc;
     }
-    if (grad_b_l) {
+    if (grad_b_l && !bias_done) {
         if (colsum_vec)
             hipLaunchKernelGGL(k_colsum_partial<true>, dim3((c_out + 255) / 256, COLSUM_SPLITS), dim3(256), 0, s_bias, grad_out, (int)n_dst, c_out, colsum, n_dst_dev);
         else

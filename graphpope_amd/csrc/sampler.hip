@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_sample_pick(const int *__restrict__ row
                                                      const long long *__restrict__ targets, int T_cap, int fanout,
                                                      unsigned long long seed, int hop, const int *__restrict__ out_rowptr,
                                                      int *__restrict__ picked, int *__restrict__ map, const int *__restrict__ t_dev,
-                                                     const unsigned long long *__restrict__ seed_dev) {
+                                                     const unsigned long long *__restrict__ seed_dev, int *__restrict__ rank) {
     const int T = true_count(t_dev, T_cap);
     if (seed_dev) seed += *seed_dev;                               // replayed launches (HIP graph): the seed lives on the device
     const int stride = fanout < 0 ? 1 : fanout;
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void k_sample_pick(const int *__restrict__ row
         const int u = col[beg + pick];
         const int p = beg_out + j;
         picked[p] = u;
+        rank[p] = -1;                      // "not ranked yet": k_sample_rank_relabel's readers wait on it
         atomicMin(&map[u], T + p);
     }
 }
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void k_sample_pick(const int *__restrict__ row
 __global__ __launch_bounds__(256) void k_sample_all(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                     const long long *__restrict__ targets, int T,
                                                     const int *__restrict__ out_rowptr, int cap, int *__restrict__ picked,
-                                                    int *__restrict__ map) {
+                                                    int *__restrict__ map, int *__restrict__ rank) {
     const int i = blockIdx.x;                                      // one block per target row
     if (i >= T) return;
     const int g = (int)targets[i];
@@ -98,46 +99,13 @@ __global__ __launch_bounds__(256) void k_sample_all(const int *__restrict__ rowp
     for (int j = threadIdx.x; j < c && beg_out + j < cap; j += blockDim.x) {     // cap too small: reported by the host below
         const int u = col[beg + j];
         picked[beg_out + j] = u;
+        rank[beg_out + j] = -1;
         atomicMin(&map[u], T + beg_out + j);
     }
 }
 
-// Local ids.  A node's position key tells everything: a target keeps its index; a new node first seen at slot p0 = key - T
-// gets T + rank[p0] (rank = exclusive scan of the first-occurrence flags), and the thread that owns p0 also writes it into
-// n_id.  One pass, no per-node id table; thread 0 reports the two counts into pinned host memory.
-__global__ __launch_bounds__(256) void k_sample_relabel(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int T_cap,
-                                                        const int *__restrict__ map, const int *__restrict__ rank,
-                                                        int *__restrict__ out_col, long long *__restrict__ n_id,
-                                                        long long *__restrict__ report, const int *__restrict__ t_dev,
-                                                        int *__restrict__ dims) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int T = true_count(t_dev, T_cap);
-    const int nnz = out_rowptr[T];
-    if (p == 0) {
-        if (dims) {                                                // device-extent mode: the sizes stay on the device
-            dims[1] = T + rank[nnz];                               // n_src: targets + distinct new nodes
-            dims[2] = nnz;
-            dims[3] = 0;
-        }
-        if (report) {
-            report[0] = nnz;
-            report[1] = T + rank[nnz];
-            __threadfence_system();                                // `report` is pinned host memory: no copy kernel
-        }
-    }
-    if (p >= nnz) return;
-    const int u = picked[p], k = map[u];
-    if (k < T) {
-        out_col[p] = k;
-    } else {
-        const int id = T + rank[k - T];
-        out_col[p] = id;
-        if (k - T == p) n_id[id] = u;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
-// Fused passes (round 3): count + scan and flag + scan each in ONE launch -- nine launches per hop became four, and in a
+// Fused passes (round 3): count + scan and flag + scan each in ONE launch -- nine launches per hop became three, and in a
 // captured step a launch of a 2 us kernel still costs ~4.5 us.  The scans are chained inside the launch: a block draws a
 // ticket (so a block only ever waits for blocks that have started), publishes the sum of its 1 024 items in a status word
 // and adds up the status words of ALL lower tickets -- they depend on nothing but their blocks' own items, so there is no
@@ -254,29 +222,70 @@ __global__ __launch_bounds__(256) void k_sample_count_scan(const int *__restrict
     if (next_map) clear_region(next_map, N, next_words, n_next_words);
 }
 
-// The first-occurrence flags and their scan: rank[p] = number of first occurrences among the slots before p, p in [0, nnz]
-// (rank[nnz] = number of new nodes).  Blocks past nnz have nothing to do -- and nobody waits for them.
-__global__ __launch_bounds__(256) void k_sample_flag_rank(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int T_cap,
-                                                          const int *__restrict__ map, int *__restrict__ rank,
-                                                          const int *__restrict__ t_dev, Chain chain) {
+// The first-occurrence flags, their scan AND the local ids, one launch.  A node's position key tells everything: a target
+// keeps its index; a new node first seen at slot p0 = key - T gets T + rank[p0] (rank = exclusive scan of the flags), and the
+// thread that owns p0 also writes it into n_id.  rank[p0] may belong to another block: p0 <= p, so that block drew a lower
+// ticket and is running or done, and the reader waits on the word itself (the pick kernel left -1 there).  Blocks past nnz
+// have nothing to do -- and nobody waits for them.  The thread that owns slot nnz reports the two counts.
+__global__ __launch_bounds__(256) void k_sample_rank_relabel(const int *__restrict__ picked, const int *__restrict__ out_rowptr, int T_cap,
+                                                             int cap, const int *__restrict__ map, int *__restrict__ rank,
+                                                             int *__restrict__ out_col, long long *__restrict__ n_id,
+                                                             long long *__restrict__ report, const int *__restrict__ t_dev,
+                                                             int *__restrict__ dims, Chain chain) {
     const int T = true_count(t_dev, T_cap);
-    const int nnz = out_rowptr[T];
+    const int nnz_true = out_rowptr[T];
+    const int nnz = min(nnz_true, cap);                            // (more only in "all neighbours" mode with an undersized buffer: reported below)
     const int t = chain_ticket(chain);
     if (t * CHAIN_ITEMS > nnz) return;
     const int base = t * CHAIN_ITEMS + (int)threadIdx.x * 4;
-    int f[4];
+    int f[4], u[4], key[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int p = base + k;
-        f[k] = (p < nnz && map[picked[p]] == T + p) ? 1 : 0;
+        u[k] = p < nnz ? picked[p] : 0;
+        key[k] = p < nnz ? map[u[k]] : 0;
+        f[k] = (p < nnz && key[k] == T + p) ? 1 : 0;
     }
     int block_sum;
     const int ex = block_exclusive_scan(f[0] + f[1] + f[2] + f[3], &block_sum);
     int run = chain_prefix(chain, t, block_sum) + ex;
+    int mine[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (base + k <= nnz) rank[base + k] = run;
+        const int p = base + k;
+        mine[k] = run;
+        if (p < nnz) __hip_atomic_store(&rank[p], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == nnz) {                                            // run = number of new nodes
+            if (dims) {                                            // device-extent mode: the sizes stay on the device
+                dims[1] = T + run;                                 // n_src: targets + distinct new nodes
+                dims[2] = nnz_true;
+                dims[3] = 0;
+            }
+            if (report) {
+                report[0] = nnz_true;
+                report[1] = T + run;
+                __threadfence_system();                            // `report` is pinned host memory: no copy kernel
+            }
+        }
         run += f[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = base + k;
+        if (p >= nnz) continue;
+        if (key[k] < T) {
+            out_col[p] = key[k];
+        } else {
+            const int p0 = key[k] - T;
+            int r = mine[k];
+            if (p0 != p) {
+                do {
+                    r = __hip_atomic_load(&rank[p0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while (r < 0);
+            }
+            out_col[p] = T + r;
+            if (p0 == p) n_id[T + r] = u[k];
+        }
     }
 }
 
@@ -360,15 +369,13 @@ static int enqueue_hop(const int32_t *rowptr, const int32_t *col, int64_t N, con
                        other_words, L.state_words);
     if (fanout < 0) {
         // all neighbours: the total is only known on the device; the caller sized nnz_capacity for it
-        hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, cap, picked, map);
+        hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, cap, picked, map, rank);
     } else {
         hipLaunchKernelGGL(k_sample_pick, dim3(capped_grid((size_t)T * fanout, 256)), dim3(256), 0, stream, rowptr, col,
-                           (const long long *)targets, T, fanout, (unsigned long long)seed, hop, out_rowptr, picked, map, t_dev, seed_dev);
+                           (const long long *)targets, T, fanout, (unsigned long long)seed, hop, out_rowptr, picked, map, t_dev, seed_dev, rank);
     }
-    hipLaunchKernelGGL(k_sample_flag_rank, dim3((cap + 1 + CHAIN_ITEMS - 1) / CHAIN_ITEMS), dim3(256), 0, stream, picked, out_rowptr, T, map, rank,
-                       t_dev, flag_chain);
-    hipLaunchKernelGGL(k_sample_relabel, dim3((cap + 256) / 256), dim3(256), 0, stream, picked, out_rowptr, T, map, rank, out_col,
-                       (long long *)out_n_id, report_dev, t_dev, dims);   // at least one block: thread 0 also reports the counts
+    hipLaunchKernelGGL(k_sample_rank_relabel, dim3((cap + 1 + CHAIN_ITEMS - 1) / CHAIN_ITEMS), dim3(256), 0, stream, picked, out_rowptr, T, cap, map, rank,
+                       out_col, (long long *)out_n_id, report_dev, t_dev, dims, flag_chain);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }

@@ -142,7 +142,7 @@ extern "C" int pope_host_pin(const void *host, size_t bytes) {
         pope::set_error("pope_host_pin: null pointer or zero size");
         return POPE_ERR_INVALID;
     }
-    if (pope::g_fail_host_register) {
+    if (pope::g_fail_host_register & 1) {
         pope::set_error("pope_host_pin: refused (POPE_KNOB_FAIL_HOST_REGISTER)");
         return POPE_ERR_HIP;
     }
@@ -312,7 +312,7 @@ struct PinnedRing {
     std::mutex mu;
     char *slot[RING_SLOTS] = {nullptr, nullptr, nullptr};
     hipEvent_t ev[RING_SLOTS] = {nullptr, nullptr, nullptr};
-    bool ready = false, failed = false, preparing = false;
+    bool ready = false, failed = false, preparing = false, pinned = true;
     float *lut_pinned = nullptr;                 // hop-code transport: where the device's 256 floats land ...
     float lut_seen[256];                         // ... the table pair_lut was built from ...
     std::vector<uint64_t> pair_lut;              // ... and the 65 536-entry two-byte table (512 KB, built once: the floats never change)
@@ -386,27 +386,49 @@ extern "C" void pope_assemble_abort(void *handle) {
     delete h;
 }
 
-// hipHostMalloc of the three slots, the code table and their events; g_ring.mu held.  Once per process (2 ms).
-static void ring_allocate_locked() {
-    if (g_ring.ready || g_ring.failed) return;
-    bool ok = true;
-    for (int i = 0; i < RING_SLOTS && ok; ++i) {
-        ok = hipHostMalloc(reinterpret_cast<void **>(&g_ring.slot[i]), RING_SLOT_BYTES, hipHostMallocDefault) == hipSuccess &&
-             hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming) == hipSuccess;
+static void ring_release_locked() {
+    for (int i = 0; i < RING_SLOTS; ++i) {
+        if (g_ring.slot[i]) { if (g_ring.pinned) (void)hipHostFree(g_ring.slot[i]); else free(g_ring.slot[i]); }
+        if (g_ring.ev[i]) (void)hipEventDestroy(g_ring.ev[i]);
+        g_ring.slot[i] = nullptr; g_ring.ev[i] = nullptr;
     }
+    if (g_ring.lut_pinned) { if (g_ring.pinned) (void)hipHostFree(g_ring.lut_pinned); else free(g_ring.lut_pinned); }
+    g_ring.lut_pinned = nullptr;
+    g_ring.ready = false;
+}
+
+// The three slots, the code table and their events; g_ring.mu held.  Once per process: hipHostMalloc (2 ms), or -- if the
+// runtime refuses to pin 24 MB (POPE_KNOB_FAIL_HOST_REGISTER bit 1 simulates that) -- ordinary memory: the same chunked
+// protocol then runs through the runtime's own staging, slower and still correct.
+static void ring_allocate_locked() {
+    const bool refuse_pinned = (pope::g_fail_host_register & 2) != 0;
+    if (g_ring.ready && g_ring.pinned == !refuse_pinned) return;
+    if (g_ring.ready) ring_release_locked();                     // (the test knob changed: build the other kind)
+    if (g_ring.failed) return;
+    bool ok = !refuse_pinned;
+    for (int i = 0; i < RING_SLOTS && ok; ++i)
+        ok = hipHostMalloc(reinterpret_cast<void **>(&g_ring.slot[i]), RING_SLOT_BYTES, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g_ring.lut_pinned), 256 * sizeof(float), hipHostMallocDefault) == hipSuccess;
+    g_ring.pinned = ok;
     if (!ok) {
         (void)hipGetLastError();
-        if (g_ring.lut_pinned) (void)hipHostFree(g_ring.lut_pinned);
-        g_ring.lut_pinned = nullptr;
         for (int i = 0; i < RING_SLOTS; ++i) {
             if (g_ring.slot[i]) (void)hipHostFree(g_ring.slot[i]);
-            if (g_ring.ev[i]) (void)hipEventDestroy(g_ring.ev[i]);
-            g_ring.slot[i] = nullptr; g_ring.ev[i] = nullptr;
+            g_ring.slot[i] = nullptr;
         }
-        g_ring.failed = true;                    // not retried: every later call registers the result's pages instead
+        if (g_ring.lut_pinned) (void)hipHostFree(g_ring.lut_pinned);
+        g_ring.lut_pinned = nullptr;
+        ok = true;
+        for (int i = 0; i < RING_SLOTS && ok; ++i) ok = (g_ring.slot[i] = static_cast<char *>(aligned_alloc(4096, RING_SLOT_BYTES))) != nullptr;
+        ok = ok && (g_ring.lut_pinned = static_cast<float *>(aligned_alloc(4096, 4096))) != nullptr;
     }
-    g_ring.ready = ok;
+    for (int i = 0; i < RING_SLOTS && ok; ++i) ok = hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming) == hipSuccess;
+    g_ring.ready = true;                                           // so that release frees whatever exists
+    if (!ok) {
+        (void)hipGetLastError();
+        ring_release_locked();
+        g_ring.failed = true;                                      // neither kind: float columns go through registration of the result's pages
+    }
 }
 
 // The first host -> host call of a process can have the ring allocated beside its GPU work: this returns at once and a
@@ -574,7 +596,7 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
     // are not multiples of the page size) is sent as two plain copies once both regions exist.
     uintptr_t reg_hi = 0;
     int64_t next_row = 0;                          // rows below have been enqueued
-    bool registering = eb > 0 && !pope::g_fail_host_register;
+    bool registering = eb > 0 && !(pope::g_fail_host_register & 1);
     for (int c = 0; c < nch && rc == POPE_OK; ++c) {
         double t0 = now_ms();
         while (a.done[(size_t)c].load(std::memory_order_acquire) < a.slices) std::this_thread::yield();

@@ -442,15 +442,17 @@ def test_general_csr_build_is_deterministic(dev):
     assert torch.equal(s1[0], s2[0]) and all(torch.equal(x.col, y.col) for x, y in zip(s1[1], s2[1]))
 
 
-@pytest.mark.parametrize("mode,refuse,transport", [("ring", 0, "codes"), ("ring", 0, "float"), ("registered", 0, "codes"), ("registered", 1, "codes"),
-                                                   ("staged", 0, "codes"), ("pinned", 0, "codes")],
-                         ids=["ring_codes", "ring_float", "registered", "registration_refused", "staged", "pinned"])
+@pytest.mark.parametrize("mode,refuse,transport", [("ring", 0, "codes"), ("ring", 0, "float"), ("ring", 3, "codes"), ("ring", 2, "float"),
+                                                   ("registered", 0, "codes"), ("registered", 1, "codes"), ("staged", 0, "codes"), ("pinned", 0, "codes")],
+                         ids=["ring_codes", "ring_float", "nothing_can_be_pinned", "ring_refused_float", "registered", "registration_refused", "staged",
+                              "pinned"])
 def test_host_to_host_call_returns_a_pageable_tensor_in_every_result_mode(mode, refuse, transport, dev, oracle, monkeypatch):
     """utils.py:129-147 from CPU tensors to a CPU tensor, at a size that takes the chunked paths (38 MB result: 4 chunks
     through the 3-slot pinned ring, 8 registered chunks): ordinary pageable memory like the reference's torch.cat,
     bit-exact, in the default ring mode, with the result's pages registered, and when the runtime refuses to register the
-    caller's pages (POPE_KNOB_FAIL_HOST_REGISTER: edge_index then goes through pinned staging, the embedding columns
-    through the runtime's own staging).  ``pinned`` is the rounds 1-2 behaviour (a page-locked result)."""
+    caller's pages (POPE_KNOB_FAIL_HOST_REGISTER bit 0: edge_index then goes through pinned staging, the embedding columns
+    through the runtime's own staging) or to allocate the pinned ring (bit 1: the ring's slots are ordinary memory then).
+    ``pinned`` is the rounds 1-2 behaviour (a page-locked result)."""
     from graphpope_amd import _lib, synth, utils as gp
     lib = _lib.load()
     ei, n = synth.rmat(15, edge_factor=8, seed=5)

@@ -326,7 +326,36 @@ def kmeans_large_fixture():
                         scaled_euclidean=out[:, f:])
 
 
+def kmeans_overlap_fixture():
+    """K-means anchors on the kind of data the reference really feeds it (generate_node2vec_embedding.py:23-28 ships an
+    untrained N(0, 1) table): 1 600 overlapping points in 16 dimensions, K = 256.  Nothing separates the clusters here, so
+    the result depends on every rounding of k-means++ and Lloyd: only the reference's own scikit-learn call is expected to
+    reproduce it (the default path); the file also stores the inertia for the GPU mode's weaker check."""
+    from sklearn.cluster import KMeans
+    f, kk, n, dim = 5, 256, 1600, 16
+    g = torch.Generator().manual_seed(23)
+    tab = torch.randn(n, dim, generator=g).contiguous()
+    real_load = ref.torch.load
+    _reset_cache()
+    data = Data(_features(n, f, 13), np.zeros((2, 0), dtype=np.int64), n)
+    ref.torch.load = lambda *a, **kw: tab.clone().requires_grad_(True)
+    try:
+        np.random.seed(33)
+        out = ref.Graphpope(data, "flickr", "node2vec", "kmeans", kk, "euclidean", 2).numpy().astype(np.float32)
+    finally:
+        ref.torch.load = real_load
+        _reset_cache()
+    np.random.seed(33)
+    km = KMeans(n_clusters=kk).fit(tab.numpy())
+    print(f"node2vec_kmeans_overlap256/euclidean: {out.shape} inertia {km.inertia_:.6g}")
+    np.savez_compressed(os.path.join(HERE, "node2vec_kmeans_overlap256.npz"), emb=tab.numpy(), x=data.x.numpy(), centres=km.cluster_centers_,
+                        inertia=np.float64(km.inertia_), scaled_euclidean=out[:, f:])
+
+
 if __name__ == "__main__":
+    if "--kmeans-overlap-only" in sys.argv:
+        kmeans_overlap_fixture()
+        sys.exit(0)
     if "--kmeans-large-only" in sys.argv:
         kmeans_large_fixture()
         sys.exit(0)
@@ -339,3 +368,4 @@ if __name__ == "__main__":
         anchor_centrality_fixtures()
     node2vec_fixtures()
     kmeans_large_fixture()
+    kmeans_overlap_fixture()

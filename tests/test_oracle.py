@@ -85,6 +85,17 @@ def test_node2vec_kmeans_anchors_oracle_matches_reference(oracle, fn):
     np.testing.assert_allclose(out[:, f:], g[f"scaled_{fn}"], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("name", ["node2vec_kmeans_k80.npz", "node2vec_kmeans_overlap256.npz"])
+def test_node2vec_larger_kmeans_goldens_pin_the_oracle(oracle, name):
+    """The two larger reference-held K-means cases (80 separated blobs; 256 clusters on an overlapping N(0, 1) table, the
+    kind of data the reference really clusters): given the reference's centres, the oracle's distances + min-max scaling
+    reproduce the reference's columns."""
+    g = load_golden(os.path.join(GOLDEN, name))
+    out = oracle.node2vec_features(g["x"], g["emb"], None, "euclidean", anchor_embeddings=g["centres"])
+    f = g["x"].shape[1]
+    np.testing.assert_allclose(out[:, f:], g["scaled_euclidean"], rtol=0, atol=1e-5)
+
+
 def test_node2vec_unknown_distance_function_is_keyerror(oracle):
     with pytest.raises(KeyError):
         oracle.pairwise(np.zeros((2, 2), np.float32), np.zeros((1, 2), np.float32), "manhattan")

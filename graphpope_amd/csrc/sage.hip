@@ -671,9 +671,9 @@ struct GatherArgs {
 // neighbour ids of row j + 2 (one coalesced load, a lane per neighbour) and their n_id entries for row j + 1; the data
 // phase takes its row addresses from registers (shuffles) and keeps twelve 16-byte loads in flight per lane.  Sums are
 // formed in k_gather_mean's order (a short last group re-reads the last neighbour with weight 0: v * 1 and s + v * 0 are
-// exact), so agg is bit for bit the same.  Rows with more than 64 neighbours take the plain loop.
+// exact), so agg is bit for bit the same.  Rows with more than 64 neighbours take the plain loop.  (s_setprio 3 for this role:
+// measured, no difference.)
 __device__ __forceinline__ void gather_role(const GatherArgs &g, const int block, const int nblocks) {
-    __builtin_amdgcn_s_setprio(3);               // memory-bound: it needs few issue slots, but it needs them when its data arrives
     const int lane = threadIdx.x & 63;
     const int wave = block * (T16_THREADS / 64) + (threadIdx.x >> 6), nwaves = nblocks * (T16_THREADS / 64);
     const int n_dst = dyn_extent(g.n_dst_dev, g.n_dst);

@@ -808,7 +808,7 @@ static int forward_overlapped(const int32_t *rowptr, const int32_t *col, int64_t
     int cus = 0;
     if ((rc = device_cu_count(&cus))) return rc;
     const int gemm_blocks = first.a.tiles_n == 2 ? std::min(first.grid, (cus + 15) / 16 * 16) : std::min(first.grid, cus);
-    const int gather_blocks = 2 * cus;
+    const int gather_blocks = cus;                                  // one per CU, beside its GEMM block (2-6 per CU measured: 2-10 us slower -- the row pipeline wants rows)
     const GatherArgs g{rowptr, col, (int)n_dst, x, c_in, agg, n_id, x_dst, dims};
     switch (first.rb) {
     case 3: rc = launch_gather_beside_gemm<3>(first.a, g, gemm_blocks, gather_blocks, stream); break;

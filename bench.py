@@ -646,13 +646,16 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
         labels = torch.randint(0, 7, (n,), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
         strainer = SageTrainStep(model, opt, feats, BATCH, sampler=sampler, graph=True)
 
+        # epoch mode: the loader's part is on the device too -- the step reads its seeds from the epoch's shuffled order through
+        # a device cursor and gathers their labels itself (main.py:100-123: NeighborSampler(..., shuffle=True) + y = data.y[n_id[:B]])
+        strainer.set_epoch(perm, labels)
+
         def sstep(i):
-            lo = (i * BATCH) % (n - BATCH)
-            seeds = perm[lo: lo + BATCH]
-            return strainer.step(seeds, labels[seeds])            # main.py:122 y = data.y[n_id[:batch_size]]: one small gather outside the graph
+            return strainer.step_epoch()
 
         for i in range(max(warmup, 4)):
             sstep(i)
+        assert strainer.batches_left() >= steps, "the epoch is shorter than the timed loop"
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -661,7 +664,8 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
         sdt = (time.perf_counter() - t0) / steps
         sampled = {"nodes_per_s": BATCH / sdt, "ms_per_step": sdt * 1e3,
                    "note": "fan-out [25, 10] sampled on the GPU inside the replayed step (device-extent sampler, no host synchronisation), "
-                           "features gathered from the HBM-resident matrix"}
+                           "seeds taken from the epoch's shuffled order through a device cursor and their labels gathered by the sampler's first "
+                           "kernel (SageTrainStep.set_epoch / step_epoch), features gathered from the HBM-resident matrix"}
         # and as rounds 1-2 ran it: eager launches, sizes read back by the host every hop
         model.dropout_seed_dev = None
         opt.use_device_step(None)

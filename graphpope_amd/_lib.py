@@ -106,6 +106,8 @@ SIGNATURES = {
     "sage_copy_segments": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sage_sample_batch_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_uint64, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sage_sample_epoch_batch_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_uint64,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sage_sample_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "sage_sample_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_uint64, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

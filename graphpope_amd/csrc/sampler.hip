@@ -193,8 +193,11 @@ __global__ __launch_bounds__(256) void k_sample_count_scan(const int *__restrict
                                                            int fanout, int *__restrict__ out_rowptr, int *__restrict__ map,
                                                            long long *__restrict__ out_n_id, const int *__restrict__ t_dev,
                                                            int *__restrict__ dims, Chain chain, int *__restrict__ next_map, int N,
-                                                           unsigned long long *__restrict__ next_words, int n_next_words) {
+                                                           unsigned long long *__restrict__ next_words, int n_next_words,
+                                                           const long long *__restrict__ first_dev, const long long *__restrict__ labels,
+                                                           long long *__restrict__ y_out) {
     const int T = true_count(t_dev, T_cap);
+    if (first_dev) targets += *first_dev;          // epoch mode: this batch's targets start at a device cursor into the epoch's order
     const int t = chain_ticket(chain);
     if (t == 0 && threadIdx.x == 0 && dims) dims[0] = T;           // n_dst of this block
     const int base = t * CHAIN_ITEMS + (int)threadIdx.x * 4;
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(256) void k_sample_count_scan(const int *__restrict
             c[k] = (fanout < 0 || d <= fanout) ? d : fanout;
             map[g] = i;                    // position key of a target = its index (target lists hold distinct nodes)
             out_n_id[i] = g;               // n_id starts with the targets, in order
+            if (labels) y_out[i] = labels[g];   // main.py:122 y = data.y[n_id[:batch_size]]
         }
     }
     int block_sum;
@@ -343,7 +347,8 @@ extern "C" size_t sage_sample_scratch_bytes(int64_t N, int64_t n_targets, int64_
 static int enqueue_hop(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *targets, int64_t n_targets, int32_t fanout,
                        uint64_t seed, int32_t hop, int32_t *out_rowptr, int32_t *out_col, int64_t nnz_capacity, int64_t *out_n_id,
                        void *scratch, size_t scratch_bytes, const SampleLayout &L, bool first, bool prepare_next, const int *t_dev, int *dims,
-                       const unsigned long long *seed_dev, long long *report_dev, hipStream_t stream, const char *who) {
+                       const unsigned long long *seed_dev, long long *report_dev, hipStream_t stream, const char *who,
+                       const long long *first_dev = nullptr, const long long *labels = nullptr, long long *y_out = nullptr) {
     if (scratch_bytes < L.total) {
         set_error("%s: scratch %zu < %zu bytes", who, scratch_bytes, L.total);
         return POPE_ERR_WORKSPACE;
@@ -366,7 +371,8 @@ static int enqueue_hop(const int32_t *rowptr, const int32_t *col, int64_t N, con
         hipLaunchKernelGGL(k_sample_begin, dim3(capped_grid((size_t)N / 4 + 1, 256)), dim3(256), 0, stream, map, (int)N, words, L.state_words);
     hipLaunchKernelGGL(k_sample_count_scan, dim3((T + 1 + CHAIN_ITEMS - 1) / CHAIN_ITEMS), dim3(256), 0, stream, rowptr, (const long long *)targets, T,
                        fanout, out_rowptr, map, (long long *)out_n_id, t_dev, dims, count_chain, prepare_next ? other_map : nullptr, (int)N,
-                       other_words, L.state_words);
+                       other_words, L.state_words, first_dev, labels, y_out);
+    targets = out_n_id;                          // the later kernels read the targets where the first one wrote them: n_id[0 .. T)
     if (fanout < 0) {
         // all neighbours: the total is only known on the device; the caller sized nnz_capacity for it
         hipLaunchKernelGGL(k_sample_all, dim3(T), dim3(256), 0, stream, rowptr, col, (const long long *)targets, T, out_rowptr, cap, picked, map, rank);
@@ -415,22 +421,18 @@ extern "C" int sage_sample_hop(const int32_t *rowptr, const int32_t *col, int64_
 // t_cap[h] targets) and reads the true target count of hop h - 1 on the device; dims[h] = {n_dst, n_src, nnz, 0} (int32,
 // device) is what the SAGE entry points take as their `dims` argument.  Capturable into a HIP graph: with seed_dev the
 // draw follows a device word (sage_advance_counters bumps it between replays).
-extern "C" int sage_sample_batch_device(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *seeds, int64_t n_seeds,
-                                        const int32_t *fanouts_host, int32_t n_hops, uint64_t seed, const uint64_t *seed_dev,
-                                        int32_t *const *out_rowptr, int32_t *const *out_col, int64_t *const *out_n_id, int32_t *dims,
-                                        void *scratch, size_t scratch_bytes, void *stream_) {
-    clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    POPE_REQUIRE(rowptr && col && seeds && fanouts_host && out_rowptr && out_col && out_n_id && dims && scratch && n_hops > 0 && n_hops <= 16,
-                 "sage_sample_batch_device: null pointer or bad hop count");
-    POPE_REQUIRE(N > 0 && N < INT32_MAX && n_seeds > 0, "sage_sample_batch_device: bad size");
+static int sample_batch_device_impl(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *seeds, int64_t n_seeds,
+                                    const int32_t *fanouts_host, int32_t n_hops, uint64_t seed, const uint64_t *seed_dev,
+                                    int32_t *const *out_rowptr, int32_t *const *out_col, int64_t *const *out_n_id, int32_t *dims,
+                                    void *scratch, size_t scratch_bytes, hipStream_t stream, const char *who, const long long *first_dev,
+                                    const long long *labels, long long *y_out) {
     const int64_t *targets = seeds;
     int64_t t_cap = n_seeds, t_last = n_seeds, cap_last = 0;
     for (int h = 0; h < n_hops; ++h) {                              // the scratch layout of the largest (= last) hop serves every hop
-        POPE_REQUIRE(fanouts_host[h] > 0, "sage_sample_batch_device: fan-outs must be positive");
+        POPE_REQUIRE(fanouts_host[h] > 0, "%s: fan-outs must be positive", who);
         t_last = t_cap;
         cap_last = t_cap * (int64_t)fanouts_host[h];
-        POPE_REQUIRE(t_cap + cap_last < INT32_MAX, "sage_sample_batch_device: capacity of hop %d exceeds 31 bits", h);
+        POPE_REQUIRE(t_cap + cap_last < INT32_MAX, "%s: capacity of hop %d exceeds 31 bits", who, h);
         t_cap += cap_last;
     }
     const SampleLayout L = sample_layout(N, t_last, cap_last);
@@ -439,12 +441,44 @@ extern "C" int sage_sample_batch_device(const int32_t *rowptr, const int32_t *co
         const int64_t cap = t_cap * (int64_t)fanouts_host[h];
         const int rc = enqueue_hop(rowptr, col, N, targets, t_cap, fanouts_host[h], seed, h, out_rowptr[h], out_col[h], cap, out_n_id[h],
                                    scratch, scratch_bytes, L, h == 0, h + 1 < n_hops, h == 0 ? nullptr : dims + 4 * (h - 1) + 1, dims + 4 * h,
-                                   (const unsigned long long *)seed_dev, nullptr, stream, "sage_sample_batch_device");
+                                   (const unsigned long long *)seed_dev, nullptr, stream, who, h == 0 ? first_dev : nullptr,
+                                   h == 0 ? labels : nullptr, h == 0 ? y_out : nullptr);
         if (rc) return rc;
         targets = out_n_id[h];
         t_cap = t_cap + cap;
     }
     return POPE_OK;
+}
+
+extern "C" int sage_sample_batch_device(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *seeds, int64_t n_seeds,
+                                        const int32_t *fanouts_host, int32_t n_hops, uint64_t seed, const uint64_t *seed_dev,
+                                        int32_t *const *out_rowptr, int32_t *const *out_col, int64_t *const *out_n_id, int32_t *dims,
+                                        void *scratch, size_t scratch_bytes, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(rowptr && col && seeds && fanouts_host && out_rowptr && out_col && out_n_id && dims && scratch && n_hops > 0 && n_hops <= 16,
+                 "sage_sample_batch_device: null pointer or bad hop count");
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && n_seeds > 0, "sage_sample_batch_device: bad size");
+    return sample_batch_device_impl(rowptr, col, N, seeds, n_seeds, fanouts_host, n_hops, seed, seed_dev, out_rowptr, out_col, out_n_id, dims, scratch,
+                                    scratch_bytes, (hipStream_t)stream_, "sage_sample_batch_device", nullptr, nullptr, nullptr);
+}
+
+// The batch an epoch's loader would hand out next (main.py:100-123: NeighborSampler(node_idx, batch_size, shuffle) + y =
+// data.y[n_id[:batch_size]]) without the loader: the seeds are order[*first_dev .. + n_seeds) -- `order` = the epoch's
+// (shuffled) node list on the device, `first_dev` a device word the caller advances by n_seeds per step
+// (sage_advance_counters) -- and, with `labels`, y_out[i] = labels[seed i].  The caller keeps *first_dev + n_seeds within
+// `order`.  Otherwise sage_sample_batch_device: no synchronisation, capturable, replayable.
+extern "C" int sage_sample_epoch_batch_device(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *order, const int64_t *first_dev,
+                                              int64_t n_seeds, const int64_t *labels, int64_t *y_out, const int32_t *fanouts_host, int32_t n_hops,
+                                              uint64_t seed, const uint64_t *seed_dev, int32_t *const *out_rowptr, int32_t *const *out_col,
+                                              int64_t *const *out_n_id, int32_t *dims, void *scratch, size_t scratch_bytes, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(rowptr && col && order && first_dev && fanouts_host && out_rowptr && out_col && out_n_id && dims && scratch && n_hops > 0 && n_hops <= 16,
+                 "sage_sample_epoch_batch_device: null pointer or bad hop count");
+    POPE_REQUIRE((labels == nullptr) == (y_out == nullptr), "sage_sample_epoch_batch_device: labels and y_out go together");
+    POPE_REQUIRE(N > 0 && N < INT32_MAX && n_seeds > 0, "sage_sample_epoch_batch_device: bad size");
+    return sample_batch_device_impl(rowptr, col, N, order, n_seeds, fanouts_host, n_hops, seed, seed_dev, out_rowptr, out_col, out_n_id, dims, scratch,
+                                    scratch_bytes, (hipStream_t)stream_, "sage_sample_epoch_batch_device", (const long long *)first_dev,
+                                    (const long long *)labels, (long long *)y_out);
 }
 
 // All hops of a mini-batch in one call (main.py:100-116 NeighborSampler(sizes=[25, 10]) draws every hop of a batch at once):

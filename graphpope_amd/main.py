@@ -87,30 +87,34 @@ def load_dataset(name: str, data_dir: str) -> tuple[GraphData, int]:
     return GraphData(x, y, torch.as_tensor(ei), split < 0.5, (split >= 0.5) & (split < 0.75), split >= 0.75), classes
 
 
-def _batches(node_idx, batch_size, shuffle, gen):
-    idx = node_idx[torch.randperm(node_idx.numel(), device=node_idx.device, generator=gen)] if shuffle else node_idx
-    for i in range(0, idx.numel(), batch_size):
-        yield idx[i:i + batch_size]
+def _epoch_order(node_idx, shuffle, gen):
+    return node_idx[torch.randperm(node_idx.numel(), device=node_idx.device, generator=gen)] if shuffle else node_idx
 
 
 def _run_epoch(model, feats, labels, sampler, node_idx, args, gen, epoch, opt=None, trainer=None):
     """One pass over node_idx.  Everything stays on the device: the fan-out sampler (main.py:100-116), the feature
     gather of convert_batch (main.py:118-123), the model, the optimiser; loss / accuracy are accumulated on the
     device and read once per epoch.  Full training batches go through `trainer` (graphpope_amd.train.SageTrainStep:
-    sampled with device extents, the whole step replayed as a HIP graph, nothing read back); the last, shorter batch of an
-    epoch and the evaluation passes take the eager path below."""
+    sampled with device extents, the whole step replayed as a HIP graph, nothing read back -- in its epoch mode the step
+    also takes its seeds from the epoch's shuffled order and gathers their labels itself, so a training step has no
+    per-batch input at all); the last, shorter batch of an epoch and the evaluation passes take the eager path below."""
     train = opt is not None
     model.train(train)
     dev = feats.device
     tot_loss = torch.zeros((), device=dev)
     tot_correct = torch.zeros((), device=dev, dtype=torch.int64)
     tot = 0
-    for b, seeds in enumerate(_batches(node_idx, args.batch_size, train, gen)):
-        y = labels.index_select(0, seeds)                                                # Batch.y = data.y[n_id[:batch_size]]
-        if train and trainer is not None and seeds.numel() == args.batch_size:
-            loss = trainer.step(seeds.contiguous(), y)
-            y_hat = trainer.logits
+    order = _epoch_order(node_idx, train, gen)                                           # NeighborSampler(node_idx, shuffle=train)
+    use_trainer = train and trainer is not None
+    if use_trainer:
+        trainer.set_epoch(order, labels)
+    for b, lo in enumerate(range(0, order.numel(), args.batch_size)):
+        seeds = order[lo:lo + args.batch_size]
+        if use_trainer and seeds.numel() == args.batch_size:
+            loss = trainer.step_epoch()                                                  # seeds = order[lo : lo + batch_size], y gathered on the way
+            y_hat, y = trainer.logits, trainer.y
         else:
+            y = labels.index_select(0, seeds)                                            # Batch.y = data.y[n_id[:batch_size]]
             n_id, adjs = sampler.sample(seeds, seed=(args.seed << 20) + (epoch << 10) + b)   # NeighborSampler(sizes=[25, 10])
             x = IndexedFeatures(feats, n_id)                                             # Batch.x = data.x[n_id], never materialised
             with torch.set_grad_enabled(train):

@@ -104,6 +104,33 @@ class NeighborSampler:
                                                self._scratch.numel(), _stream()))
         return out
 
+    def sample_epoch_device(self, order: torch.Tensor, first_dev: torch.Tensor, labels: torch.Tensor | None, y_out: torch.Tensor | None,
+                            seed: int = 0, out: DeviceBatch | None = None, seed_dev: torch.Tensor | None = None) -> DeviceBatch:
+        """:meth:`sample_device` around the seeds ``order[first : first + out.n_seeds]`` with ``first`` read from the device word
+        `first_dev` (int64), and -- with `labels` -- ``y_out[:] = labels[seeds]`` written by the sampler's first kernel
+        (sage_sample_epoch_batch_device; main.py:100-123 without a loader).  No host synchronisation; capturable."""
+        lib = _lib.load()
+        dev = self.rowptr.device
+        assert out is not None and order.is_cuda and order.dtype == torch.int64 and order.is_contiguous()
+        assert first_dev.is_cuda and first_dev.dtype == torch.int64 and first_dev.numel() == 1
+        assert (labels is None) == (y_out is None)
+        if labels is not None:
+            assert labels.is_cuda and labels.dtype == torch.int64 and labels.is_contiguous() and y_out.dtype == torch.int64
+            assert y_out.is_contiguous() and y_out.numel() >= out.n_seeds
+        h = len(out.sizes)
+        need = lib.sage_sample_scratch_bytes(self.num_nodes, out.t_cap[-1], out.caps[-1])
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+        arr = ctypes.c_void_p * h
+        with on_device(dev):
+            check(lib.sage_sample_epoch_batch_device(ptr(self.rowptr), ptr(self.col), self.num_nodes, ptr(order), ptr(first_dev), out.n_seeds,
+                                                     ptr(labels), ptr(y_out), (ctypes.c_int32 * h)(*out.sizes), h,
+                                                     int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(seed_dev),
+                                                     arr(*[r.data_ptr() for r in out.rowptrs]), arr(*[c.data_ptr() for c in out.cols]),
+                                                     arr(*[n.data_ptr() for n in out.n_ids]), ptr(out.dims), ptr(self._scratch),
+                                                     self._scratch.numel(), _stream()))
+        return out
+
     def _hop(self, targets: torch.Tensor, fanout: int, seed: int, hop: int):
         lib = _lib.load()
         dev = targets.device

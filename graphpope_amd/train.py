@@ -30,30 +30,34 @@ _SEED_STRIDE = 0x9E3779B97F4A7C15 % (1 << 63)        # odd: the seed words walk 
 
 
 class StepState:
-    """Three device words a replayed step reads and one launch advances: dropout seed, sampling seed, Adam step count."""
+    """Four device words a replayed step reads and one launch advances: dropout seed, sampling seed, Adam step count, and
+    the position in the epoch's node order (epoch mode: the next batch's seeds start there)."""
 
     def __init__(self, device, seed: int = 0, adam_step: int = 0):
-        self.words = torch.tensor([seed, seed ^ 0x5DEECE66D, adam_step + 1], dtype=torch.int64, device=device)
-        self._inc = (ctypes.c_int64 * 3)(_SEED_STRIDE, _SEED_STRIDE | 2, 1)
-        self._inc_keep_sample = (ctypes.c_int64 * 3)(_SEED_STRIDE, 0, 1)
-        self._inc_only_sample = (ctypes.c_int64 * 3)(0, _SEED_STRIDE | 2, 0)
+        self.words = torch.tensor([seed, seed ^ 0x5DEECE66D, adam_step + 1, 0], dtype=torch.int64, device=device)
+        self._inc = (ctypes.c_int64 * 4)(_SEED_STRIDE, _SEED_STRIDE | 2, 1, 0)
+        self._inc_keep_sample = (ctypes.c_int64 * 4)(_SEED_STRIDE, 0, 1, 0)
+        self._inc_only_sample = (ctypes.c_int64 * 4)(0, _SEED_STRIDE | 2, 0, 0)
 
     dropout_seed = property(lambda self: self.words[0:1])
     sample_seed = property(lambda self: self.words[1:2])
     adam_step = property(lambda self: self.words[2:3])
+    cursor = property(lambda self: self.words[3:4])
 
-    def advance(self, sample_seed: bool = True) -> None:
+    def advance(self, sample_seed: bool = True, cursor_by: int = 0) -> None:
         lib = _lib.load()
         inc = self._inc if sample_seed else self._inc_keep_sample
+        if cursor_by:
+            inc = (ctypes.c_int64 * 4)(inc[0], inc[1], inc[2], cursor_by)
         with on_device(self.words.device):
-            check(lib.sage_advance_counters(ctypes.c_void_p(self.words.data_ptr()), inc, 3,
+            check(lib.sage_advance_counters(ctypes.c_void_p(self.words.data_ptr()), inc, 4,
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     def advance_sample_seed(self) -> None:
         """Only the sampling seed (a batch sampled ahead on a side stream advances it there, in sampling order)."""
         lib = _lib.load()
         with on_device(self.words.device):
-            check(lib.sage_advance_counters(ctypes.c_void_p(self.words.data_ptr()), self._inc_only_sample, 3,
+            check(lib.sage_advance_counters(ctypes.c_void_p(self.words.data_ptr()), self._inc_only_sample, 4,
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
@@ -101,6 +105,10 @@ class SageTrainStep:
         self._use_graph = graph
         self._lr = None
         self._calls = 0
+        # epoch mode (set_epoch / step_epoch): the step draws its own seeds and labels from device-resident tables
+        self._epoch_mode = False
+        self._order = self._labels = None
+        self._epoch_len = self._epoch_pos = 0
         # prefetch (sampler given, graph=False): the NEXT batch is sampled on a side stream while this step computes -- the
         # reference's DataLoader workers do the same on the host (main.py:100-104, persistent_workers).  Two batch buffers.
         self._prefetch = bool(prefetch and sampler is not None and not graph)
@@ -116,7 +124,11 @@ class SageTrainStep:
     # ---- the step body: ordinary autograd code, capturable ----
     def _body(self, sample: bool = True):
         if self.sampler is not None and sample:
-            self.sampler.sample_device(self.seeds, seed=0, out=self.batch, seed_dev=self.state.sample_seed)
+            if self._epoch_mode:
+                self.sampler.sample_epoch_device(self._order, self.state.cursor, self._labels, self.y, seed=0, out=self.batch,
+                                                 seed_dev=self.state.sample_seed)
+            else:
+                self.sampler.sample_device(self.seeds, seed=0, out=self.batch, seed_dev=self.state.sample_seed)
         x = IndexedFeatures(self.feats, self.batch.n_id)             # main.py:118-123 without the copy
         for p in self.params:
             p.grad = None
@@ -130,7 +142,7 @@ class SageTrainStep:
         if self.clip is not None:
             torch.nn.utils.clip_grad_norm_(self.params, self.clip)   # main.py:286 gradient_clip_val
         self.opt.step()
-        self.state.advance(sample_seed=sample)
+        self.state.advance(sample_seed=sample, cursor_by=self.batch.n_seeds if self._epoch_mode else 0)
 
     def _capture(self):
         self.loss = self.logits = None
@@ -189,6 +201,8 @@ class SageTrainStep:
         """Sample around `seeds` (device int64 [batch_size]) inside the step, labels `y` (device int64 [batch_size]).
         With prefetch=True, `next_seeds` / `next_y` (the batch of the NEXT call) are sampled on a side stream meanwhile."""
         assert self.sampler is not None, "no sampler: use load_batch() + run()"
+        if self._epoch_mode:                                         # back to caller-provided seeds: another graph
+            self._epoch_mode, self._graph, self._calls = False, None, 0
         if not self._prefetch:
             copy_segments([self.seeds, self.y], [seeds, y])
             self._run()
@@ -207,6 +221,36 @@ class SageTrainStep:
         done = torch.cuda.Event()
         done.record(cur)
         self._free[idx] = done
+        return self.loss
+
+    # ---- epoch mode: the loader's part of an epoch on the device too (main.py:100-123) ----
+    def set_epoch(self, order: torch.Tensor, labels: torch.Tensor) -> None:
+        """Start an epoch over `order` (device int64: the training nodes in this epoch's -- shuffled -- order; the reference's
+        NeighborSampler(node_idx, batch_size, shuffle=True)) with `labels` (device int64 [N]: data.y).  :meth:`step_epoch` then
+        trains on consecutive slices of batch_size nodes without any per-step input: the position lives in a device word the
+        replayed step advances, the labels of a batch are gathered by the sampler's first kernel."""
+        assert self.sampler is not None and order.is_cuda and order.dtype == torch.int64 and labels.is_cuda and labels.dtype == torch.int64
+        if self._order is None or self._order.numel() < order.numel() or self._labels.numel() != labels.numel():
+            self._order = torch.empty(max(order.numel(), 1), dtype=torch.int64, device=order.device)
+            self._labels = torch.empty_like(labels)
+            self._graph = None                                       # other buffers: the capture has to be redone
+        if not self._epoch_mode:
+            self._graph = None
+            self._calls = 0
+        self._epoch_mode = True
+        copy_segments([self._order, self._labels, self.state.words[3:4]], [order.contiguous(), labels.contiguous(),
+                                                                          torch.zeros(1, dtype=torch.int64, device=order.device)])
+        self._epoch_len, self._epoch_pos = order.numel(), 0
+
+    def batches_left(self) -> int:
+        """Full batches the current epoch still holds (a shorter tail is the caller's, as in main.py's eager tail batch)."""
+        return (self._epoch_len - self._epoch_pos) // self.batch.n_seeds
+
+    def step_epoch(self):
+        """One step on the next batch_size nodes of the epoch's order; the batch's node ids are self.batch.n_id[:batch_size]."""
+        assert self._epoch_mode and self.batches_left() > 0, "set_epoch() first; the epoch's full batches are used up"
+        self._run()
+        self._epoch_pos += self.batch.n_seeds
         return self.loss
 
     def load_batch(self, pooled: DeviceBatch, y: torch.Tensor) -> None:

@@ -477,6 +477,13 @@ int sage_sample_batch_device(const int32_t *rowptr, const int32_t *col, int64_t 
                              const int32_t *fanouts_host, int32_t n_hops, uint64_t seed, const uint64_t *seed_dev,
                              int32_t *const *out_rowptr, int32_t *const *out_col, int64_t *const *out_n_id, int32_t *dims,
                              void *scratch, size_t scratch_bytes, void *stream);
+/* The next batch of an epoch without a loader (main.py:100-123): seeds = order[*first_dev .. + n_seeds) with `order` the epoch's
+ * (shuffled) node list and `first_dev` a device word the caller advances by n_seeds per step; with `labels` (and y_out)
+ * y_out[i] = labels[seed i] (main.py:122).  Everything else as sage_sample_batch_device. */
+int sage_sample_epoch_batch_device(const int32_t *rowptr, const int32_t *col, int64_t N, const int64_t *order, const int64_t *first_dev,
+                                   int64_t n_seeds, const int64_t *labels, int64_t *y_out, const int32_t *fanouts_host, int32_t n_hops,
+                                   uint64_t seed, const uint64_t *seed_dev, int32_t *const *out_rowptr, int32_t *const *out_col,
+                                   int64_t *const *out_n_id, int32_t *dims, void *scratch, size_t scratch_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Hidden-layer epilogue: BatchNorm1d + ReLU + dropout as one op  (main.py:207-209)

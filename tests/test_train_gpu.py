@@ -123,6 +123,53 @@ def test_replayed_step_equals_the_eager_step(graph, with_sampler):
         assert float((a - c).norm()) <= 0.1 * float(a.norm()) + 1e-6
 
 
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "replayed"])
+def test_epoch_mode_draws_the_batches_a_loader_would(graph, use_graph):
+    """set_epoch / step_epoch (seeds = consecutive slices of the epoch's order read through a device cursor, labels gathered
+    by the sampler's first kernel: sage_sample_epoch_batch_device) against step(seeds, labels[seeds]) fed by the host with
+    the same slices: the same batches (node lists bit for bit), the same labels, the same losses -- over two epochs with
+    different orders, the second one shorter."""
+    from graphpope_amd.optim import Adam
+    from graphpope_amd.sampler import NeighborSampler
+    from graphpope_amd.train import SageTrainStep
+    dev, _, csr = graph
+    feats = torch.randn(6000, 40, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    labels = torch.randint(0, 5, (6000,), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    sampler = NeighborSampler(csr.rowptr, csr.col, 6000, (25, 10))
+    orders = [torch.randperm(6000, device=dev, generator=torch.Generator(device=dev).manual_seed(3))[:1300],
+              torch.randperm(6000, device=dev, generator=torch.Generator(device=dev).manual_seed(4))[:800]]
+    runs = []
+    for epoch_mode in (False, True):
+        m = _model(dev)
+        opt = Adam(m.parameters(), lr=0.01)
+        st = SageTrainStep(m, opt, feats, 256, (25, 10), sampler=sampler, clip=0.5, graph=use_graph, seed=11)
+        losses, ids, ys = [], [], []
+        for order in orders:
+            if epoch_mode:
+                st.set_epoch(order, labels)
+                assert st.batches_left() == order.numel() // 256
+                while st.batches_left():
+                    losses.append(st.step_epoch().item())
+                    ids.append(st.batch.n_id[: int(st.batch.dims[-1][1])].clone())      # the outermost block's node list
+                    ys.append(st.y.clone())
+                with pytest.raises(AssertionError):
+                    st.step_epoch()                                  # the short tail is the caller's
+            else:
+                for b in range(order.numel() // 256):
+                    sd = order[b * 256:(b + 1) * 256].contiguous()
+                    losses.append(st.step(sd, labels[sd].contiguous()).item())
+                    ids.append(st.batch.n_id[: int(st.batch.dims[-1][1])].clone())
+                    ys.append(st.y.clone())
+        runs.append((losses, ids, ys))
+    (la, ia, ya), (lb, ib, yb) = runs
+    assert len(la) == len(lb) == 5 + 3
+    for a, b in zip(ia, ib):
+        assert torch.equal(a, b)
+    for a, b in zip(ya, yb):
+        assert torch.equal(a, b)
+    assert np.allclose(la, lb, rtol=1e-4)
+
+
 def test_adam_device_step_matches_the_host_step(graph):
     from graphpope_amd.optim import Adam
     dev = graph[0]

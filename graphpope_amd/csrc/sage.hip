@@ -717,12 +717,6 @@ __device__ __forceinline__ void gather_role(const GatherArgs &g, const int block
                 ok[k] = q[k] < C4;
                 s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            float4 o[3];
-            if (g.x_dst) {
-                const float4 *own = reinterpret_cast<const float4 *>(g.x + (size_t)own0 * C);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) o[k] = own[ok[k] ? q[k] : 0];
-            }
             for (int p = 0; p < deg; p += 4) {                             // four neighbour rows x three pieces in flight
                 long long row[4];
                 float w[4];
@@ -756,7 +750,14 @@ __device__ __forceinline__ void gather_role(const GatherArgs &g, const int block
                 if (!ok[k]) continue;
                 s[k].x *= inv; s[k].y *= inv; s[k].z *= inv; s[k].w *= inv;
                 reinterpret_cast<float4 *>(g.agg + (size_t)i * C)[q[k]] = s[k];
-                if (g.x_dst) reinterpret_cast<float4 *>(g.x_dst + (size_t)i * C)[q[k]] = o[k];
+            }
+            if (g.x_dst) {                                                 // the destination's own row: requested after the neighbour loop, so that
+                const float4 *own = reinterpret_cast<const float4 *>(g.x + (size_t)own0 * C);      // it does not hold twelve registers across it
+                float4 *dst = reinterpret_cast<float4 *>(g.x_dst + (size_t)i * C);
+                const float4 o0 = own[ok[0] ? q[0] : 0], o1 = own[ok[1] ? q[1] : 0], o2 = own[ok[2] ? q[2] : 0];
+                if (ok[0]) dst[q[0]] = o0;
+                if (ok[1]) dst[q[1]] = o1;
+                if (ok[2]) dst[q[2]] = o2;
             }
         }
         // advance the pipeline

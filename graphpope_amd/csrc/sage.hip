@@ -804,6 +804,7 @@ static int forward_overlapped(const int32_t *rowptr, const int32_t *col, int64_t
     if (rc || !first.ok) return rc;
     if ((rc = t16_plan(agg, w_l, c_in, nullptr, nullptr, 0, c_in, c_in, (int)n_dst, c_out, nullptr, out, c_out, dims, &second))) return rc;
     if (!second.ok || second.rb != first.rb) return POPE_OK;
+    if (first.rb > 5) return POPE_OK;                               // taller tiles do not fit the fused kernel's 128 registers (they spill 140-430 bytes per lane)
     first.a.rows = n_id;                                            // nullptr: destination i is row i of x
     second.a.accumulate = 1;
     int cus = 0;
@@ -814,10 +815,7 @@ static int forward_overlapped(const int32_t *rowptr, const int32_t *col, int64_t
     switch (first.rb) {
     case 3: rc = launch_gather_beside_gemm<3>(first.a, g, gemm_blocks, gather_blocks, stream); break;
     case 4: rc = launch_gather_beside_gemm<4>(first.a, g, gemm_blocks, gather_blocks, stream); break;
-    case 5: rc = launch_gather_beside_gemm<5>(first.a, g, gemm_blocks, gather_blocks, stream); break;
-    case 6: rc = launch_gather_beside_gemm<6>(first.a, g, gemm_blocks, gather_blocks, stream); break;
-    case 7: rc = launch_gather_beside_gemm<7>(first.a, g, gemm_blocks, gather_blocks, stream); break;
-    default: rc = launch_gather_beside_gemm<8>(first.a, g, gemm_blocks, gather_blocks, stream); break;
+    default: rc = launch_gather_beside_gemm<5>(first.a, g, gemm_blocks, gather_blocks, stream); break;
     }
     if (rc) return rc;
     POPE_HIP(hipGetLastError());

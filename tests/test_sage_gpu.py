@@ -267,7 +267,7 @@ def test_opt_in_split_bf16_projection_stays_in_the_f32_accuracy_class(n_dst, c_i
     assert err_split <= 1.5 * err_exact + 1e-7 * scale
 
 
-@pytest.mark.parametrize("n_dst,c_in,c_out,fan", [(9988, 756, 256, 8), (8100, 200, 256, 3), (12200, 132, 250, 70)])
+@pytest.mark.parametrize("n_dst,c_in,c_out,fan", [(9988, 756, 256, 8), (8100, 200, 256, 3), (10200, 132, 250, 70), (12200, 132, 256, 5)])
 def test_gather_beside_the_projection_gives_the_same_aggregate_and_the_same_layer(n_dst, c_in, c_out, fan, dev):
     """The overlapped forward (launch 1: pipelined gather role beside x_dst W_r^T + b, launch 2: += agg W_l^T) against the
     sequential one: the aggregate and the copied destination rows bit for bit (same order of additions; rows of more than

@@ -145,19 +145,11 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
 
     // ---------------- consumer waves ----------------
     const int r15 = lane & 15, g = lane >> 4;
-    int fa_off[RB], fa_swz[RB], fb_off[2], fb_swz[2];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int row = i * 16 + r15;
-        fa_off[i] = row * 128;
-        fa_swz[i] = (row >> 1) & 7;
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int row = wave * 32 + t * 16 + r15;
-        fb_off[t] = Sh::A_BYTES + row * 128;
-        fb_swz[t] = (row >> 1) & 7;
-    }
+    // fragment addresses: row i * 16 + r15 of A, row wave * 32 + t * 16 + r15 of B, 128 bytes per row.  The swizzle of a row is
+    // (row >> 1) & 7 -- the multiples of 16 drop out, so ONE value serves every fragment -- and the row offsets differ by
+    // compile-time constants: one register each instead of 2 (RB + 2).
+    const int swz = (r15 >> 1) & 7;
+    const int fa_base = r15 * 128, fb_base = Sh::A_BYTES + (wave * 32 + r15) * 128;
     f32x4acc acc[RB][2];
 #pragma unroll
     for (int i = 0; i < RB; ++i)
@@ -171,14 +163,14 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
         // one 16x16x32 MFMA spans a whole 32-deep stage: lane (r15, g) holds depth 8g .. 8g + 7 = pieces 2g, 2g + 1 of its row
         float4 ra[RB][2], rb[2][2];
         auto read_a = [&](int b, int i) {
-            const char *base = smem + b * Sh::STAGE_BYTES + fa_off[i];
-            ra[i][0] = *reinterpret_cast<const float4 *>(base + (((2 * g) ^ fa_swz[i]) << 4));
-            ra[i][1] = *reinterpret_cast<const float4 *>(base + (((2 * g + 1) ^ fa_swz[i]) << 4));
+            const char *base = smem + b * Sh::STAGE_BYTES + fa_base + i * 2048;
+            ra[i][0] = *reinterpret_cast<const float4 *>(base + (((2 * g) ^ swz) << 4));
+            ra[i][1] = *reinterpret_cast<const float4 *>(base + (((2 * g + 1) ^ swz) << 4));
         };
         auto read_b = [&](int b, int t) {
-            const char *base = smem + b * Sh::STAGE_BYTES + fb_off[t];
-            rb[t][0] = *reinterpret_cast<const float4 *>(base + (((2 * g) ^ fb_swz[t]) << 4));
-            rb[t][1] = *reinterpret_cast<const float4 *>(base + (((2 * g + 1) ^ fb_swz[t]) << 4));
+            const char *base = smem + b * Sh::STAGE_BYTES + fb_base + t * 2048;
+            rb[t][0] = *reinterpret_cast<const float4 *>(base + (((2 * g) ^ swz) << 4));
+            rb[t][1] = *reinterpret_cast<const float4 *>(base + (((2 * g + 1) ^ swz) << 4));
         };
 #pragma unroll
         for (int t = 0; t < 2; ++t) read_b(0, t);
@@ -225,9 +217,9 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
             const char *base = smem + b * Sh::STAGE_BYTES;
             const int c = 4 * p + g;
     #pragma unroll
-            for (int i = 0; i < RB; ++i) fa[set][i] = *reinterpret_cast<const float4 *>(base + fa_off[i] + ((c ^ fa_swz[i]) << 4));
+            for (int i = 0; i < RB; ++i) fa[set][i] = *reinterpret_cast<const float4 *>(base + fa_base + i * 2048 + ((c ^ swz) << 4));
     #pragma unroll
-            for (int t = 0; t < 2; ++t) fb[set][t] = *reinterpret_cast<const float4 *>(base + fb_off[t] + ((c ^ fb_swz[t]) << 4));
+            for (int t = 0; t < 2; ++t) fb[set][t] = *reinterpret_cast<const float4 *>(base + fb_base + t * 2048 + ((c ^ swz) << 4));
         };
         int buf = 0;
         read_pass(0, 0, 0);

@@ -519,7 +519,7 @@ def test_host_result_assembly_shapes(register, dev):
         lib.pope_debug_set(_lib.KNOB_HOST_RESULT_MODE, 0)
 
 
-@pytest.mark.parametrize("k", [1, 37, 64, 200])
+@pytest.mark.parametrize("k", [1, 37, 64, 200, 1024])
 def test_hop_codes_are_the_hop_matrix_plus_one(k, dev, oracle):
     """pope_geodesic_hop_codes, the transport form of the embedding: code 0 = no path, hops + 1 otherwise, and the table
     holds exactly the floats the finalise kernel writes (utils.py:73) -- for widths that are and are not multiples of 4."""
@@ -576,7 +576,7 @@ def test_host_result_assembly_from_codes(dev):
     from graphpope_amd import engine
     g = torch.Generator().manual_seed(1)
     lut = torch.rand(256, generator=g).to(dev)
-    for n, f, k in ((7, 0, 1), (5000, 3, 37), (5000, 1, 8), (5000, 2, 255), (40000, 6, 64), (300007, 5, 100)):
+    for n, f, k in ((7, 0, 1), (5000, 3, 37), (5000, 1, 8), (5000, 2, 255), (40000, 6, 64), (300007, 5, 100), (30011, 4, 1024)):
         wide = torch.randint(0, 256, (n, k + 3), generator=g, dtype=torch.uint8).to(dev)
         codes = wide[:, :k]                                   # row pitch larger than the row
         x = torch.rand(n, f, generator=g)

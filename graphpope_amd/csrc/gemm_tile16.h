@@ -322,11 +322,11 @@ __global__ __launch_bounds__(T16_THREADS) void k_gemm_tile16(T16Args a) {
 
 // The tile height (in 16-row blocks, 3 .. 8) that wastes the least of the chip for this M x N, or 0 if no choice reaches
 // `min_util` (the caller then uses stream-K).  Cost model: rounds of `cus` tiles, each as long as its height.
-inline int t16_pick_rb(long long M, int N, int cus, double min_util = 0.85) {
+inline int t16_pick_rb(long long M, int N, int cus, double min_util = 0.85, int rb_min = 3) {
     const long long tiles_n = (N + T16_TN - 1) / T16_TN;
     int best = 0;
     double best_util = 0.0;
-    for (int rb = 3; rb <= 8; ++rb) {
+    for (int rb = rb_min; rb <= 8; ++rb) {
         const long long tiles = ((M + 16 * rb - 1) / (16 * rb)) * tiles_n;
         const long long rounds = (tiles + cus - 1) / cus;
         const double util = (double)M * N / ((double)rounds * cus * 16 * rb * T16_TN);      // useful outputs / outputs the rounds could produce

@@ -1042,7 +1042,7 @@ static int g_finalize_blocks = 256 * 8;
 static int g_level_blocks = 0;           // cap on the expand blocks of a level launch (0: one wave per chunk up to 2048 blocks)
 static int g_level_variant = 0;          // POPE_KNOB_LEVEL_VARIANT bits: 1 nt index streams, 2 XCD-contiguous chunks, 4 nt reachability loads
 static int g_copy_gate = 0;              // POPE_KNOB_COPY_GATE: early% * 1000 + late% of the feature rows copied beside the sparse phases (0: off)
-namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0, g_host_result_mode = 0, g_gemm_split_bf16 = 0, g_gather_lds_pad_kb = 0, g_sage_forward_overlap = 1; extern int g_sage_lanes; }
+namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0, g_host_result_mode = 0, g_gemm_split_bf16 = 0, g_gather_lds_pad_kb = 0, g_sage_forward_overlap = 1, g_gemm_small_tile16 = 1; extern int g_sage_lanes; }
 
 extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     clear_error();
@@ -1059,6 +1059,7 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_GEMM_SPLIT_BF16:  pope::g_gemm_split_bf16 = value; break;
     case POPE_KNOB_GATHER_LDS_PAD_KB: pope::g_gather_lds_pad_kb = value; break;
     case POPE_KNOB_SAGE_FORWARD_OVERLAP: pope::g_sage_forward_overlap = value; break;
+    case POPE_KNOB_GEMM_SMALL_TILE16: pope::g_gemm_small_tile16 = value; break;
     case POPE_KNOB_SAGE_LANES:       pope::g_sage_lanes = value; break;
     case POPE_KNOB_LEVEL_VARIANT:    g_level_variant = value; break;
     case POPE_KNOB_COPY_GATE:        g_copy_gate = value; break;

@@ -436,6 +436,7 @@ static int launch_gemm(const Operand &A0, const Operand &B0, int K0, const Opera
 }
 
 extern int g_gemm_force_tile;          // pope_debug_set(POPE_KNOB_GEMM_TILE, ...) in geodesic.hip: 0 = automatic choice
+extern int g_gemm_small_tile16;        // POPE_KNOB_GEMM_SMALL_TILE16: 1 (default) = forward products too small for stream-K take 16 / 32-row whole tiles (layer 1: 14.4 us against 21)
 extern int g_sage_forward_overlap;     // pope_debug_set(POPE_KNOB_SAGE_FORWARD_OVERLAP, ...): 1 (default) gather beside half of the projection, 0 one after the other
 extern int g_gather_lds_pad_kb;        // pope_debug_set(POPE_KNOB_GATHER_LDS_PAD_KB, ...): occupancy experiment
 extern int g_gemm_split_bf16;         // pope_debug_set(POPE_KNOB_GEMM_SPLIT_BF16, ...): 1 = opt-in split-bf16 arithmetic in the whole-tile forward GEMM
@@ -591,7 +592,7 @@ struct T16Plan {
 };
 
 static int t16_plan(const float *A0, const float *B0, int K0, const float *A1, const float *B1, int K1, long long lda, long long ldb, int M, int N,
-                    const float *bias, float *C, long long ldc, const int *m_dev, T16Plan *plan, long long a0_rows = 0) {
+                    const float *bias, float *C, long long ldc, const int *m_dev, T16Plan *plan, long long a0_rows = 0, bool small = false) {
     plan->ok = false;
     if (g_gemm_force_tile != 0) return POPE_OK;                      // any forced variant: not this kernel (7 = "stream-K as in round 2")
     if ((K0 & 3) || (K1 & 3) || M <= 0 || N <= 0 || K0 <= 0) return POPE_OK;
@@ -600,7 +601,8 @@ static int t16_plan(const float *A0, const float *B0, int K0, const float *A1, c
         return POPE_OK;
     int cus = 0, rc;
     if ((rc = device_cu_count(&cus))) return rc;
-    const int rb = t16_pick_rb(M, N, cus);
+    // small = a product that cannot fill the chip whatever the tile: the shortest tiles (16 or 32 rows) that give the most blocks
+    const int rb = small ? t16_pick_rb(M, N, cus, 0.3, 1) : t16_pick_rb(M, N, cus);
     if (rb == 0) return POPE_OK;
     static const float *zero_page[64];
     int dev = 0;
@@ -623,6 +625,8 @@ static int t16_plan(const float *A0, const float *B0, int K0, const float *A1, c
 static int t16_launch(const T16Plan &plan, hipStream_t stream) {
     int rc;
     switch (plan.rb) {
+    case 1: rc = launch_tile16<1>(plan.a, plan.grid, stream); break;
+    case 2: rc = launch_tile16<2>(plan.a, plan.grid, stream); break;
     case 3: rc = launch_tile16<3>(plan.a, plan.grid, stream); break;
     case 4: rc = launch_tile16<4>(plan.a, plan.grid, stream); break;
     case 5: rc = launch_tile16<5>(plan.a, plan.grid, stream); break;
@@ -639,9 +643,10 @@ static int t16_launch(const T16Plan &plan, hipStream_t stream) {
 static int gemm_tile16(const float *A0, const float *B0, int K0, const float *A1, const float *B1, int K1, long long lda, long long ldb,
                        int M, int N, const float *bias, float *C, long long ldc, hipStream_t stream, bool *used, const int *m_dev = nullptr) {
     *used = false;
-    if (!streamk_shape_ok(M, K0, K1, N)) return POPE_OK;             // small products stay on the plain tile kernel
+    const bool small = !streamk_shape_ok(M, K0, K1, N);
+    if (small && (g_gemm_small_tile16 == 0 || (long long)M * N < 64 * 1024)) return POPE_OK;   // (tiny products stay on the plain tile kernel)
     T16Plan plan;
-    int rc = t16_plan(A0, B0, K0, A1, B1, K1, lda, ldb, M, N, bias, C, ldc, m_dev, &plan);
+    int rc = t16_plan(A0, B0, K0, A1, B1, K1, lda, ldb, M, N, bias, C, ldc, m_dev, &plan, 0, small);
     if (rc || !plan.ok) return rc;
     if ((rc = t16_launch(plan, stream))) return rc;
     *used = true;

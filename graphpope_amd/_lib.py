@@ -90,6 +90,10 @@ SIGNATURES = {
     "sage_conv_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int32,
                                    c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p, c_void_p]),
+    "sage_conv_forward_indexed_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "sage_conv_backward_indexed_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int32, c_int32]),
+    "sage_conv_backward_indexed": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p,
+                                           c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "sage_bn_scratch_bytes": (c_size_t, [c_int32]),
     "sage_bn_relu_dropout_forward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                              c_int32, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

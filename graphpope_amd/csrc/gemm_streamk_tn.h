@@ -32,6 +32,8 @@ struct SkTnArgs {
     const float *zero;
     int tiles_m, tiles_nb, S;    // tiles along M, along Nb (per product), depth stages
     const int *depth_dev;        // device extent: the true depth (<= depth, which then is the capacity), or null
+    const long long *rows1;      // null, or: depth row k of the SECOND product's B operand is B[1] + rows1[k] * ldb (the destination rows
+                                 // of a sampled block read straight from the resident feature matrix through n_id: no x_dst copy)
     // a second role of the fix-up launch (blocks behind the tiles'): out[c] = sum over z of part[z * C + c], the final stage of the
     // bias gradient's column sums, whose partials an earlier launch wrote -- one launch less in the backward pass
     const float *cs_part;
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
             // output rows / columns that are never stored); depth rows past the end are handled in the last stage only.
             unsigned off[ND];
             int drow[ND];
+            const bool indexed = q == 1 && a.rows1 != nullptr;         // B rows through an index: the row offset is added per stage
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const int instr = lw * ND + d;
@@ -99,12 +102,39 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
                 } else {
                     drow[d] = instr - A_INSTR;
                     const int n = min(n0 + lane * 4, a.Nb - 4);
-                    off[d] = (unsigned)(((long long)drow[d] * a.ldb + n) * 4);
+                    off[d] = indexed ? (unsigned)(n * 4) : (unsigned)(((long long)drow[d] * a.ldb + n) * 4);
                 }
+            }
+            long long rowv = 0;
+            if (indexed) {
+                rowv = a.rows1[min(s_begin * GK + (lane & (GK - 1)), a.depth - 1)];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             auto issue_all = [&](int s, int buf) {
                 const int k0 = s * GK;
                 const float *Ga = a.G + (long long)k0 * a.ldg, *Ba = Bq + (long long)k0 * a.ldb;        // SGPR pairs
+                if (indexed) {
+                    // G as below; every B instruction is one depth row.  Lane r of the wave holds the place of the stage's depth
+                    // row r in the feature matrix (rowv: loaded one stage ahead, behind the previous stage's DMAs, so the wait in
+                    // front of the stage barrier covers it); a depth row past the end re-reads the last one: its G row is zero.
+                    const long long cur = rowv;
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) {
+                        const int instr = lw * ND + d;                 // wave-uniform
+                        if (instr < A_INSTR) {
+                            const bool past = k0 + drow[d] >= a.depth;
+                            if (k0 + GK <= a.depth) sk_glds16_saddr(Ga, off[d], lds0 + buf * STAGE_BYTES + instr * 1024);
+                            else sk_glds16(past ? a.zero : (const float *)((const char *)Ga + off[d]), lds0 + buf * STAGE_BYTES + instr * 1024);
+                        } else {
+                            const int r = instr - A_INSTR;
+                            const unsigned lo = __builtin_amdgcn_readlane((unsigned)cur, r), hi = __builtin_amdgcn_readlane((unsigned)(cur >> 32), r);
+                            const long long row = (long long)(((unsigned long long)hi << 32) | lo);
+                            sk_glds16_saddr(Bq + row * a.ldb, off[d], lds0 + buf * STAGE_BYTES + instr * 1024);
+                        }
+                    }
+                    rowv = a.rows1[min(k0 + GK + (lane & (GK - 1)), a.depth - 1)];        // for the next stage (stages are issued in order)
+                    return;
+                }
                 if (k0 + GK <= a.depth) {
 #pragma unroll
                     for (int d = 0; d < ND; ++d)

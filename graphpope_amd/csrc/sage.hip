@@ -660,6 +660,9 @@ static int gemm_tile16(const float *A0, const float *B0, int K0, const float *A1
 // gather in the remaining blocks, which share the CUs with them; launch 2 adds agg W_l^T into out.  No block waits for
 // another block.  Every block of launch 1 carries the GEMM role's LDS reservation, so only one or two gather blocks fit a
 // CU: the gather role keeps twelve 16-byte loads in flight per lane (k_gather_mean: four) to make up for it.
+// (Measured and not kept: x_dst written by the GEMM role out of LDS instead of read + written by the gather role -- the consumer
+//  waves' copy doubled the fused kernel's spills and the launch took 84 us instead of 79; and no x_dst at all, the weight-gradient
+//  kernel reading the rows through n_id (sage_conv_backward_indexed): its 1 KB random reads cost 29 us more than the copy.)
 struct GatherArgs {
     const int *rowptr, *col;
     int n_dst;
@@ -839,7 +842,7 @@ static bool streamk_tn_shape_ok(int64_t depth, int32_t M, int32_t Nb) {
 // C0 = G^T * B0, C1 = G^T * B1 (G [depth, M], B_q [depth, Nb], C_q [M, Nb]); *used = false if the operands do not qualify.
 static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int64_t depth, int M, int Nb, float *C0, float *C1,
                            void *slab, size_t slab_bytes, hipStream_t stream, bool *used, const int *depth_dev = nullptr,
-                           float *cs_part = nullptr, float *cs_out = nullptr, bool cs_vec = false) {
+                           float *cs_part = nullptr, float *cs_out = nullptr, bool cs_vec = false, const long long *rows1 = nullptr) {
     *used = false;
     if (g_gemm_force_tile != 0 && g_gemm_force_tile < 4) return POPE_OK;
     if (!streamk_tn_shape_ok(depth, M, Nb)) return POPE_OK;
@@ -852,6 +855,7 @@ static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int
     const int gk = skl_stage_depth();
     a.tiles_m = (M + SK_TM - 1) / SK_TM; a.tiles_nb = (Nb + SK_TN - 1) / SK_TN; a.S = (int)((depth + gk - 1) / gk);
     a.depth_dev = depth_dev;
+    a.rows1 = rows1;
     // the bias gradient = column sums of G: its partial sums are a launch of their own in front of the GEMM (they read G and
     // nothing else), its final stage rides in the fix-up launch behind it
     a.cs_part = cs_part; a.cs_out = cs_out; a.cs_splits = COLSUM_SPLITS; a.cs_C = M;
@@ -903,6 +907,26 @@ extern "C" int pope_debug_read_gemm_stamps(unsigned long long *host, int count) 
 }
 #endif
 
+// dst[i, :] = x[rows[i], :], i < n (a device extent may shorten n): the destination rows of a sampled block as a matrix of
+// their own, for the kernel paths that cannot read them through n_id.
+__global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ x, const long long *__restrict__ rows, int n, int C,
+                                                     float *__restrict__ dst, const int *__restrict__ n_dev) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    n = dyn_extent(n_dev, n);
+    for (int i = wave; i < n; i += nwaves) {
+        const float *src = x + (size_t)rows[i] * C;
+        float *d = dst + (size_t)i * C;
+        if ((C & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+            for (int q = lane; q < (C >> 2); q += 64) reinterpret_cast<float4 *>(d)[q] = reinterpret_cast<const float4 *>(src)[q];
+        } else {
+            for (int c = lane; c < C; c += 64) d[c] = src[c];
+        }
+    }
+}
+
+static size_t rows_matrix_bytes(int64_t n_dst, int32_t c_in) { return align_up((size_t)n_dst * c_in * sizeof(float), 256); }
+
 extern "C" size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t nnz, int32_t c_in, int32_t c_out) {
     (void)n_src; (void)nnz;
     if (n_dst <= 0 || c_in <= 0 || c_out <= 0) return 0;
@@ -919,6 +943,18 @@ extern "C" size_t sage_conv_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t 
 extern "C" size_t sage_conv_forward_scratch_bytes(int64_t n_dst, int32_t c_in, int32_t c_out) {
     if (n_dst <= 0 || c_in <= 0 || c_out <= 0) return 0;
     return streamk_shape_ok(n_dst, c_in, c_in, c_out) ? sk_slab_bytes(SK_MAX_GRID) : 0;
+}
+
+// The indexed entry points may be called without an x_dst matrix (the destination rows are then read through n_id); the
+// kernel paths that cannot do that build the matrix in the tail of the scratch buffer.
+extern "C" size_t sage_conv_forward_indexed_scratch_bytes(int64_t n_dst, int32_t c_in, int32_t c_out) {
+    if (n_dst <= 0 || c_in <= 0 || c_out <= 0) return 0;
+    return align_up(sage_conv_forward_scratch_bytes(n_dst, c_in, c_out), 256) + rows_matrix_bytes(n_dst, c_in);
+}
+
+extern "C" size_t sage_conv_backward_indexed_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t nnz, int32_t c_in, int32_t c_out) {
+    if (n_dst <= 0 || c_in <= 0 || c_out <= 0) return 0;
+    return sage_conv_scratch_bytes(n_src, n_dst, nnz, c_in, c_out) + rows_matrix_bytes(n_dst, c_in);
 }
 
 static void enqueue_gather_mean(const int32_t *rowptr, const int32_t *col, int64_t n_dst, const float *x_src, int32_t c_in,
@@ -978,13 +1014,23 @@ extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *c
                                          void *scratch, size_t scratch_bytes, const int32_t *dims, void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
-    POPE_REQUIRE(rowptr && (col || nnz == 0) && n_id && feats && w_l && w_r && agg && x_dst && out, "sage_conv_forward_indexed: null pointer");
+    POPE_REQUIRE(rowptr && (col || nnz == 0) && n_id && feats && w_l && w_r && agg && out, "sage_conv_forward_indexed: null pointer");
     POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && n_rows > 0 && nnz >= 0 && nnz < INT32_MAX && c_in > 0 && c_out > 0,
                  "sage_conv_forward_indexed: bad size (destinations must be the first n_dst entries of n_id)");
     bool used = false;
     int rc = forward_overlapped(rowptr, col, n_dst, feats, n_rows, c_in, (const long long *)n_id, x_dst, agg, w_l, b_l, w_r, c_out, out, dims, stream,
                                 &used);
     if (rc || used) return rc;
+    if (!x_dst) {                                                    // no matrix of the destination rows from the caller: the kernels below want one
+        const size_t at = align_up(sage_conv_forward_scratch_bytes(n_dst, c_in, c_out), 256);
+        if (!scratch || scratch_bytes < at + rows_matrix_bytes(n_dst, c_in)) {
+            set_error("sage_conv_forward_indexed: without x_dst the scratch must hold sage_conv_forward_indexed_scratch_bytes (%zu), got %zu",
+                      at + rows_matrix_bytes(n_dst, c_in), scratch_bytes);
+            return POPE_ERR_WORKSPACE;
+        }
+        x_dst = (float *)((char *)scratch + at);
+        scratch_bytes = at;
+    }
     enqueue_gather_mean(rowptr, col, n_dst, feats, c_in, agg, stream, n_id, x_dst, dims);
     if ((rc = gemm_tile16(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used, dims))) return rc;
     if (used) return POPE_OK;
@@ -1003,19 +1049,13 @@ namespace pope { int g_sage_lanes = 0; }     // pope_debug_set(POPE_KNOB_SAGE_LA
 // weight gradients, forked and joined inside the call.  Measured on the Flickr-shaped step (tools/sage_step_ab.py): 0.449 ms
 // against 0.378 ms on one stream -- the persistent stream-K kernel deals its units out statically, so CUs that start late
 // because a side kernel sits on them delay the whole launch, and every fork / join is two cross-stream dependencies.  Off.
-extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
-                                  const float *x_src, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
-                                  int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l,
-                                  float *grad_w_r, void *scratch, size_t scratch_bytes, const int32_t *dims, void *stream_) {
-    clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    POPE_REQUIRE(rowptr && (col || nnz == 0) && x_src && agg && w_l && w_r && grad_out && grad_w_l && grad_w_r && scratch,
-                 "sage_conv_backward: null pointer");
-    POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && nnz >= 0 && c_in > 0 && c_out > 0, "sage_conv_backward: bad size");
-    if (scratch_bytes < sage_conv_scratch_bytes(n_src, n_dst, nnz, c_in, c_out)) {
-        set_error("sage_conv_backward: scratch %zu < %zu bytes", scratch_bytes, sage_conv_scratch_bytes(n_src, n_dst, nnz, c_in, c_out));
-        return POPE_ERR_WORKSPACE;
-    }
+// x_rows == nullptr: x_src holds the block's source rows (the destinations first).  Otherwise the destination rows are
+// x_src[x_rows[i]] (the resident feature matrix read through n_id) and x_tmp is room for them as a matrix, used only by the
+// kernel paths that cannot follow the index.
+static int conv_backward_impl(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz, const float *x_src,
+                              const long long *x_rows, float *x_tmp, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
+                              int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l, float *grad_w_r,
+                              void *scratch, size_t scratch_bytes, const int32_t *dims, hipStream_t stream) {
     const size_t gagg_bytes = align_up((size_t)n_dst * c_in * sizeof(float), 256);
     const size_t colsum_bytes = align_up((size_t)COLSUM_SPLITS * c_out * sizeof(float), 256);
     float *gagg = (float *)scratch;
@@ -1037,8 +1077,13 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
     const bool colsum_vec = (c_out & 3) == 0 && aligned16(grad_out);
     const bool bias_with_gemm = grad_b_l && !side;               // the bias gradient's two stages travel with the stream-K launches
     if ((rc = gemm_streamk_tn(grad_out, agg, x_src, n_dst, c_out, c_in, grad_w_l, grad_w_r, slab, slab_bytes, stream, &used, n_dst_dev,
-                              bias_with_gemm ? colsum : nullptr, grad_b_l, colsum_vec))) return rc;
+                              bias_with_gemm ? colsum : nullptr, grad_b_l, colsum_vec, x_rows))) return rc;
     const bool bias_done = used && bias_with_gemm;
+    if (!used && x_rows) {                                           // the other kernels want the destination rows as a matrix
+        hipLaunchKernelGGL(k_gather_rows, dim3(capped_grid((size_t)n_dst * 64, 256)), dim3(256), 0, stream, x_src, x_rows, (int)n_dst, c_in, x_tmp,
+                           n_dst_dev);
+        x_src = x_tmp;
+    }
     const Operand Gt{grad_out, 1, c_out};                       // (outer o, depth i) -> grad_out[i * c_out + o]
     const Operand AggT{agg, 1, c_in}, XdT{x_src, 1, c_in};      // (outer c, depth i)
     const Operand G{grad_out, c_out, 1};                        // (outer i, depth o)
@@ -1112,4 +1157,41 @@ extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int
     if (side && (rc = lanes.join(stream))) return rc;
     POPE_HIP(hipGetLastError());
     return POPE_OK;
+}
+
+extern "C" int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
+                                  const float *x_src, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
+                                  int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l,
+                                  float *grad_w_r, void *scratch, size_t scratch_bytes, const int32_t *dims, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(rowptr && (col || nnz == 0) && x_src && agg && w_l && w_r && grad_out && grad_w_l && grad_w_r && scratch,
+                 "sage_conv_backward: null pointer");
+    POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && nnz >= 0 && c_in > 0 && c_out > 0, "sage_conv_backward: bad size");
+    if (scratch_bytes < sage_conv_scratch_bytes(n_src, n_dst, nnz, c_in, c_out)) {
+        set_error("sage_conv_backward: scratch %zu < %zu bytes", scratch_bytes, sage_conv_scratch_bytes(n_src, n_dst, nnz, c_in, c_out));
+        return POPE_ERR_WORKSPACE;
+    }
+    return conv_backward_impl(rowptr, col, n_src, n_dst, nnz, x_src, nullptr, nullptr, agg, c_in, w_l, w_r, c_out, grad_out, grad_x, grad_w_l, grad_b_l,
+                              grad_w_r, scratch, scratch_bytes, dims, (hipStream_t)stream_);
+}
+
+// The backward pass of sage_conv_forward_indexed without a matrix of the destination rows: grad_w_r = grad_out^T x_dst reads
+// x_dst[i] = feats[n_id[i]] through n_id in the weight-gradient kernel's loader (gemm_streamk_tn.h, rows1).  The input
+// features have no gradient (layer 0), so there is no grad_x.  Scratch: sage_conv_backward_indexed_scratch_bytes.
+extern "C" int sage_conv_backward_indexed(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
+                                          int64_t nnz, const float *feats, int64_t n_rows, const float *agg, int32_t c_in, const float *w_l,
+                                          const float *w_r, int32_t c_out, const float *grad_out, float *grad_w_l, float *grad_b_l,
+                                          float *grad_w_r, void *scratch, size_t scratch_bytes, const int32_t *dims, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(rowptr && (col || nnz == 0) && n_id && feats && agg && w_l && w_r && grad_out && grad_w_l && grad_w_r && scratch,
+                 "sage_conv_backward_indexed: null pointer");
+    POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && n_rows > 0 && nnz >= 0 && c_in > 0 && c_out > 0,
+                 "sage_conv_backward_indexed: bad size");
+    const size_t base = sage_conv_scratch_bytes(n_src, n_dst, nnz, c_in, c_out);
+    if (scratch_bytes < base + rows_matrix_bytes(n_dst, c_in)) {
+        set_error("sage_conv_backward_indexed: scratch %zu < %zu bytes", scratch_bytes, base + rows_matrix_bytes(n_dst, c_in));
+        return POPE_ERR_WORKSPACE;
+    }
+    return conv_backward_impl(rowptr, col, n_src, n_dst, nnz, feats, (const long long *)n_id, (float *)((char *)scratch + base), agg, c_in, w_l, w_r,
+                              c_out, grad_out, nullptr, grad_w_l, grad_b_l, grad_w_r, scratch, base, dims, (hipStream_t)stream_);
 }

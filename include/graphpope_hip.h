@@ -433,6 +433,16 @@ int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src,
                        const float *x_src, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
                        int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l,
                        float *grad_w_r, void *scratch, size_t scratch_bytes, const int32_t *dims, void *stream);
+/* The indexed pair without a matrix of the destination rows.  sage_conv_forward_indexed accepts x_dst = NULL (scratch:
+ * sage_conv_forward_indexed_scratch_bytes), and sage_conv_backward_indexed computes the same gradients as sage_conv_backward
+ * reading x_dst[i] = feats[n_id[i]] through n_id (the weight-gradient kernel's loader follows the index; kernel paths that
+ * cannot build the rows in the scratch tail).  The input features get no gradient.  main.py:118-123, 206. */
+size_t sage_conv_forward_indexed_scratch_bytes(int64_t n_dst, int32_t c_in, int32_t c_out);
+size_t sage_conv_backward_indexed_scratch_bytes(int64_t n_src, int64_t n_dst, int64_t nnz, int32_t c_in, int32_t c_out);
+int sage_conv_backward_indexed(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
+                               int64_t nnz, const float *feats, int64_t n_rows, const float *agg, int32_t c_in, const float *w_l,
+                               const float *w_r, int32_t c_out, const float *grad_out, float *grad_w_l, float *grad_b_l,
+                               float *grad_w_r, void *scratch, size_t scratch_bytes, const int32_t *dims, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fan-out neighbour sampling on the device (one hop of PyG NeighborSampler / torch_sparse.sample_adj, main.py:100-116).

@@ -303,3 +303,62 @@ def test_gather_beside_the_projection_gives_the_same_aggregate_and_the_same_laye
     assert torch.equal(res[0][1], feats[n_id[:n_dst]])
     scale = float(res[0][2].abs().max())
     assert float((res[1][2] - res[0][2]).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("n_dst,c_in,c_out", [(9988, 756, 256), (700, 40, 24)])
+def test_indexed_pair_without_a_destination_matrix(n_dst, c_in, c_out, dev):
+    """sage_conv_forward_indexed with x_dst = NULL and sage_conv_backward_indexed (the destination rows read through n_id by
+    the projection and by the weight-gradient kernel's loader -- or, at the small shape, built in the scratch tail for the
+    plain kernels): the same output and the same gradients as the pair that is given / writes the x_dst matrix."""
+    import ctypes
+    from graphpope_amd import _lib
+    lib = _lib.load()
+    n_src, n_rows = n_dst + 300, n_dst + 3000
+    rowptr, col = _random_block(n_dst, n_src, 6, seed=n_dst + 1)
+    g = torch.Generator().manual_seed(8)
+    feats = torch.rand(n_rows, c_in, generator=g).to(dev)
+    n_id = torch.randperm(n_rows, generator=g)[:n_src].to(dev)
+    w_l, w_r = (torch.randn(c_out, c_in, generator=g) * 0.05).to(dev), (torch.randn(c_out, c_in, generator=g) * 0.05).to(dev)
+    b = torch.randn(c_out, generator=g).to(dev)
+    grad_out = torch.randn(n_dst, c_out, generator=g).to(dev)
+    rp, cl = rowptr.to(dev), col.to(dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nnz = cl.numel()
+
+    def run(indexed):
+        agg = torch.empty(n_dst, c_in, device=dev)
+        out = torch.empty(n_dst, c_out, device=dev)
+        x_dst = None if indexed else torch.empty(n_dst, c_in, device=dev)
+        fbytes = lib.sage_conv_forward_indexed_scratch_bytes(n_dst, c_in, c_out)
+        fs = torch.empty(max(fbytes, 16), dtype=torch.uint8, device=dev)
+        _lib.check(lib.sage_conv_forward_indexed(_lib.ptr(rp), _lib.ptr(cl), _lib.ptr(n_id), n_src, n_dst, nnz, _lib.ptr(feats), n_rows, c_in,
+                                                 _lib.ptr(w_l), _lib.ptr(b), _lib.ptr(w_r), c_out, _lib.ptr(agg), _lib.ptr(x_dst), _lib.ptr(out),
+                                                 _lib.ptr(fs), fbytes, None, stream))
+        gwl, gwr, gb = torch.empty_like(w_l), torch.empty_like(w_r), torch.empty(c_out, device=dev)
+        if indexed:
+            bbytes = lib.sage_conv_backward_indexed_scratch_bytes(n_src, n_dst, nnz, c_in, c_out)
+            bs = torch.empty(bbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.sage_conv_backward_indexed(_lib.ptr(rp), _lib.ptr(cl), _lib.ptr(n_id), n_src, n_dst, nnz, _lib.ptr(feats), n_rows, _lib.ptr(agg),
+                                                      c_in, _lib.ptr(w_l), _lib.ptr(w_r), c_out, _lib.ptr(grad_out), _lib.ptr(gwl), _lib.ptr(gb),
+                                                      _lib.ptr(gwr), _lib.ptr(bs), bbytes, None, stream))
+        else:
+            bbytes = lib.sage_conv_scratch_bytes(n_dst, n_dst, nnz, c_in, c_out)
+            bs = torch.empty(bbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.sage_conv_backward(_lib.ptr(rp), _lib.ptr(cl), n_dst, n_dst, nnz, _lib.ptr(x_dst), _lib.ptr(agg), c_in, _lib.ptr(w_l),
+                                              _lib.ptr(w_r), c_out, _lib.ptr(grad_out), None, _lib.ptr(gwl), _lib.ptr(gb), _lib.ptr(gwr),
+                                              _lib.ptr(bs), bbytes, None, stream))
+        torch.cuda.synchronize()
+        return out, gwl, gwr, gb
+
+    a, b_ = run(True), run(False)
+    assert torch.equal(a[0], b_[0])                               # the forward pass takes the same kernels either way
+    for x, y in zip(a[1:], b_[1:]):                               # stream-K deals the same units: bit for bit the same sums
+        _close(x, y, 1e-6)
+    lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, 0)           # the sequential order wants the matrix: without x_dst it needs the larger scratch
+    try:
+        with pytest.raises(_lib.PopeError, match="scratch"):
+            _lib.check(lib.sage_conv_forward_indexed(_lib.ptr(rp), _lib.ptr(cl), _lib.ptr(n_id), n_src, n_dst, nnz, _lib.ptr(feats), n_rows, c_in,
+                                                     _lib.ptr(w_l), _lib.ptr(b), _lib.ptr(w_r), c_out, _lib.ptr(torch.empty(n_dst, c_in, device=dev)),
+                                                     None, _lib.ptr(torch.empty(n_dst, c_out, device=dev)), None, 0, None, stream))
+    finally:
+        lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, 1)

@@ -76,6 +76,9 @@ SIGNATURES = {
     "pope_pairwise_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "pope_pairwise_minmax": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,
                                      c_int32, c_void_p, c_size_t, c_void_p]),
+    "pope_pairwise_by_id_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "pope_pairwise_features_by_id": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int32,
+                                             c_void_p, c_size_t, c_void_p]),
     "pope_pairwise_features": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,
                                        c_int32, c_void_p, c_size_t, c_void_p]),
     "pope_concat": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),

@@ -425,7 +425,8 @@ static int pairwise_passes(const float *X, int64_t N, int32_t D, const float *A,
 
 // The persistent kernel (pairwise_persistent.h): depths up to 128 in 16-byte pieces.
 static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric, const float *x, int32_t F,
-                               float *out, int64_t out_cols, int32_t c0, const PwLayout &L, char *base, hipStream_t stream) {
+                               float *out, int64_t out_cols, int32_t c0, const PwLayout &L, char *base, hipStream_t stream,
+                               const long long *anchor_rows = nullptr) {
     static LdsOptIn lds_opt_in;
     if (!lds_opt_in.done()) {
         POPE_HIP(hipFuncSetAttribute((const void *)k_pairwise_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
@@ -451,7 +452,7 @@ static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float
     // Two consumer sets keep the matrix cores busy through the epilogues; with the feature copy beside the kernel the call is
     // HBM-bound and the second set's registers are worth more to the copy's waves (configs[2]: 0.193 ms against 0.205).
     const int sets = g_pairwise_kernel == 2 ? 1 : g_pairwise_kernel == 3 ? 2 : (x ? 1 : 2);
-    PpArgs a{X, A, (int)N, D, K, metric, (float2 *)(base + L.xx), out, (unsigned)out_cols, c0,
+    PpArgs a{X, anchor_rows ? X : A, anchor_rows, (int)N, D, K, metric, (float2 *)(base + L.xx), out, (unsigned)out_cols, c0,
              pmin, pmax, L.Kpad, zero, sets};
     hipLaunchKernelGGL(k_pairwise_persistent, dim3(grid, (K + PP_COLS - 1) / PP_COLS), dim3(PP_THREADS), PP_LDS_BYTES, stream, a);
     if (x) {
@@ -469,20 +470,29 @@ static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float
     return POPE_OK;
 }
 
+// rows[j, :] = X[ids[j], :] (one wave per anchor): the anchor matrix for the kernel path that cannot follow the ids
+__global__ __launch_bounds__(64) void k_gather_anchor_rows(const float *__restrict__ X, const long long *__restrict__ ids, int D, float *__restrict__ rows) {
+    const float *src = X + (size_t)ids[blockIdx.x] * D;
+    for (int c = threadIdx.x; c < D; c += 64) rows[(size_t)blockIdx.x * D + c] = src[c];
+}
+
 static bool aligned16p(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-extern "C" int pope_pairwise_features(const float *x, int32_t F, const float *X, int64_t N, int32_t D, const float *A, int32_t K,
+// anchor_ids == nullptr: A holds the K anchor rows.  Otherwise anchor j is row anchor_ids[j] of X (device int64) and A is unused:
+// the persistent kernel reads the rows through the ids, the other path gathers them into the scratch tail first.
+static int pairwise_features_impl(const float *x, int32_t F, const float *X, int64_t N, int32_t D, const float *A, const long long *anchor_ids, int32_t K,
                                       int32_t metric, float *out, int64_t out_cols, int32_t c0, void *scratch, size_t scratch_bytes,
                                       void *stream_) {
     clear_error();
     hipStream_t stream = (hipStream_t)stream_;
-    POPE_REQUIRE(X && A && out && scratch, "pope_pairwise_features: null pointer");
+    POPE_REQUIRE(X && (A || anchor_ids) && out && scratch, "pope_pairwise_features: null pointer");
     POPE_REQUIRE(N > 0 && N < INT32_MAX && K > 0 && D > 0 && F >= 0 && c0 >= 0 && out_cols >= (int64_t)c0 + K, "pope_pairwise_features: bad size");
     POPE_REQUIRE(!x || c0 >= F, "pope_pairwise_features: the embedding columns (c0 = %d) overlap the %d feature columns", c0, F);
     POPE_REQUIRE(metric >= 0 && metric <= 2, "pope_pairwise_features: unknown metric %d", metric);
     const PwLayout L = pw_layout(N, K);
-    if (scratch_bytes < L.total) {
-        set_error("pope_pairwise_features: scratch %zu < %zu bytes", scratch_bytes, L.total);
+    const size_t need = L.total + (anchor_ids ? align_up((size_t)K * D * sizeof(float), 256) : 0);
+    if (scratch_bytes < need) {
+        set_error("pope_pairwise_features: scratch %zu < %zu bytes", scratch_bytes, need);
         return POPE_ERR_WORKSPACE;
     }
     char *base = (char *)scratch;
@@ -493,19 +503,45 @@ extern "C" int pope_pairwise_features(const float *x, int32_t F, const float *X,
         x = nullptr;
     }
     if (F == 0) x = nullptr;
-    if (g_pairwise_kernel != 1 && D <= PP_DMAX && (D & 3) == 0 && aligned16p(X) && aligned16p(A) && (uint64_t)N * (uint64_t)out_cols * 4u < (1ull << 32)) {
+    if (g_pairwise_kernel != 1 && D <= PP_DMAX && (D & 3) == 0 && aligned16p(X) && (anchor_ids || aligned16p(A)) && (uint64_t)N * (uint64_t)out_cols * 4u < (1ull << 32)) {
         if (x && !SideCopy::eligible(x, F, out, out_cols, N)) {          // rows wider than the side copy's 16 pieces per lane: the copy as its own pass
             int rc = pope_concat(x, N, F, out, out_cols, stream_);
             if (rc) return rc;
             x = nullptr;
         }
-        return pairwise_persistent(X, N, D, A, K, metric, x, F, out, out_cols, c0, L, base, stream);
+        return pairwise_persistent(X, N, D, A, K, metric, x, F, out, out_cols, c0, L, base, stream, anchor_ids);
+    }
+    if (anchor_ids) {                                               // the round-1 pipeline wants the anchor rows as a matrix
+        float *rows = (float *)(base + L.total);
+        hipLaunchKernelGGL(k_gather_anchor_rows, dim3(K), dim3(64), 0, stream, X, anchor_ids, D, rows);
+        A = rows;
     }
     launch_sqnorm(X, N, (float2 *)(base + L.xx), A, K, (float2 *)(base + L.aa), D, stream);
     const Operand Xo{X, D, 1}, Ao{A, D, 1};
     const bool vec = pick_layout(Xo, (int)N, D) == LAYOUT_KC_VEC && pick_layout(Ao, K, D) == LAYOUT_KC_VEC;
     if (vec) return pairwise_passes<LAYOUT_KC_VEC>(X, N, D, A, K, metric, x, F, out, out_cols, c0, L, base, stream);
     return pairwise_passes<LAYOUT_GENERIC>(X, N, D, A, K, metric, x, F, out, out_cols, c0, L, base, stream);
+}
+
+extern "C" int pope_pairwise_features(const float *x, int32_t F, const float *X, int64_t N, int32_t D, const float *A, int32_t K,
+                                      int32_t metric, float *out, int64_t out_cols, int32_t c0, void *scratch, size_t scratch_bytes,
+                                      void *stream_) {
+    return pairwise_features_impl(x, F, X, N, D, A, nullptr, K, metric, out, out_cols, c0, scratch, scratch_bytes, stream_);
+}
+
+// utils.py:165-167 as it is written there -- embedding[anchor_nodes] and the distances in one call: anchor j is row
+// anchor_ids[j] (device int64, each in [0, N)) of X; no gathered copy of the anchor rows is made on the common path.
+extern "C" size_t pope_pairwise_by_id_scratch_bytes(int64_t N, int32_t K, int32_t D) {
+    if (N <= 0 || K <= 0 || D <= 0) return 0;
+    return pw_layout(N, K).total + align_up((size_t)K * D * sizeof(float), 256);
+}
+
+extern "C" int pope_pairwise_features_by_id(const float *x, int32_t F, const float *X, int64_t N, int32_t D, const int64_t *anchor_ids, int32_t K,
+                                            int32_t metric, float *out, int64_t out_cols, int32_t c0, void *scratch, size_t scratch_bytes,
+                                            void *stream_) {
+    clear_error();
+    POPE_REQUIRE(anchor_ids, "pope_pairwise_features_by_id: null pointer");
+    return pairwise_features_impl(x, F, X, N, D, nullptr, (const long long *)anchor_ids, K, metric, out, out_cols, c0, scratch, scratch_bytes, stream_);
 }
 
 extern "C" int pope_pairwise_minmax(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric,

@@ -55,7 +55,8 @@ __device__ unsigned long long g_pp_stamps[256 * 8 * 8];
 
 struct PpArgs {
     const float *X;              // [N, D] node2vec table
-    const float *A;              // [K, D] anchor rows
+    const float *A;              // [K, D] anchor rows -- or, with anchor_rows, the table itself: anchor j is row anchor_rows[j] of it
+    const long long *anchor_rows;
     int N, D, K, metric;
     float2 *xn;                  // [N] scratch: per table row {(float)|row|^2, 1 / |row| (1 for a zero row)}, written by the DMA waves
     float *out;                  // [N, out_cols]; embedding columns start at c0; N * out_cols * 4 < 2^32 (32-bit store offsets)
@@ -70,6 +71,7 @@ struct PpArgs {
 __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args) {
     // plain locals: a lambda that captured the argument struct by reference would force a copy of it into scratch memory
     const float *const X = args.X, *const A = args.A, *const zero = args.zero;
+    const long long *const arows = args.anchor_rows;                  // utils.py:167 embedding[anchor_nodes]: read through the ids, no gathered copy
     const int N = args.N, D = args.D, K = args.K, metric = args.metric, c0 = args.c0, Kpad = args.Kpad;
     float2 *const xn = args.xn;
     float *const out = args.out, *const part_min = args.part_min, *const part_max = args.part_max;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
         const int row = i * 2 + (lane >> 5), cslot = lane & 31;
         const int c = cslot ^ (row & 15);
         const int col = col_base + row;
-        const float *src = (col < K && c * 4 < D) ? A + (size_t)col * D + c * 4 : zero;
+        const float *src = (col < K && c * 4 < D) ? A + (size_t)(arows ? arows[col] : col) * D + c * 4 : zero;
         sk_glds16(src, lds0 + i * 1024);
     }
 
@@ -298,7 +300,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
                             while (fix) {
                                 const int src = __ffsll((long long)fix) - 1;
                                 fix &= fix - 1;
-                                const float v = wave_sqdist(X + (size_t)__shfl(row, src) * D, A + (size_t)__shfl(col[t], src) * D, D, lane);
+                                const int acol = __shfl(col[t], src);
+                                const float v = wave_sqdist(X + (size_t)__shfl(row, src) * D, A + (size_t)(arows ? arows[acol] : acol) * D, D, lane);
                                 if (lane == src) {
 #pragma unroll
                                     for (int q = 0; q < 16; ++q)

@@ -607,6 +607,19 @@ def geodesic_features(x: torch.Tensor, edge_index: torch.Tensor, num_nodes: int,
 # ------------------------------------------------------------------------------------------------
 # node2vec-space embedding (utils.py:149-180)
 # ------------------------------------------------------------------------------------------------
+def _anchor_ids(anchors, n: int, dev) -> torch.Tensor:
+    """The anchor row ids as a device int64 tensor.  Ids given on the host are range-checked here, as indexing would (the
+    kernel follows them without a check); ids that already live on the device are the caller's responsibility, like any
+    index tensor handed to a kernel -- checking them would cost a synchronisation."""
+    if isinstance(anchors, torch.Tensor) and anchors.device == dev and anchors.dtype == torch.int64:
+        return anchors.contiguous()
+    arr = np.ascontiguousarray(anchors.cpu().numpy() if isinstance(anchors, torch.Tensor) else np.asarray(anchors), dtype=np.int64).reshape(-1)
+    if arr.size and (int(arr.min()) < -n or int(arr.max()) >= n):
+        raise IndexError(f"anchor id out of range for a table of {n} rows")
+    arr = np.where(arr < 0, arr + n, arr)                # numpy / torch indexing semantics for negative ids
+    return torch.as_tensor(arr, device=dev)
+
+
 def pairwise_embedding(emb: torch.Tensor, anchors, distance_function: str, anchor_embeddings=None, out: torch.Tensor = None,
                        c0: int = 0) -> torch.Tensor:
     """Min-max scaled distance of every node2vec row to the anchor rows (``anchors`` = row indices, utils.py:165-167) or
@@ -620,17 +633,22 @@ def pairwise_embedding(emb: torch.Tensor, anchors, distance_function: str, ancho
     if anchor_embeddings is not None:
         a = torch.as_tensor(anchor_embeddings).to(dev, torch.float32).contiguous()
         assert a.dim() == 2 and a.shape[1] == d
-    else:
-        idx = torch.as_tensor(np.asarray(anchors, dtype=np.int64), device=dev)
-        a = emb.index_select(0, idx).contiguous()        # the K anchor rows (utils.py:167)
-    k = a.shape[0]
+    else:                                                # the K anchor rows (utils.py:167) are read through their ids
+        a = None
+        idx = _anchor_ids(anchors, n, dev)
+    k = a.shape[0] if a is not None else idx.numel()
     with torch.cuda.device(dev):
         if out is None:
             out = torch.empty((n, k), dtype=torch.float32, device=dev)
         assert out.is_cuda and out.is_contiguous() and out.shape[0] == n and out.shape[1] >= c0 + k
-        scratch = _bytes(lib.pope_pairwise_scratch_bytes(n, k, d), dev)
-        check(lib.pope_pairwise_minmax(ptr(emb), n, d, ptr(a), k, metric, ptr(out), out.shape[1], c0, ptr(scratch),
-                                       scratch.numel(), _stream()))
+        if a is not None:
+            scratch = _bytes(lib.pope_pairwise_scratch_bytes(n, k, d), dev)
+            check(lib.pope_pairwise_minmax(ptr(emb), n, d, ptr(a), k, metric, ptr(out), out.shape[1], c0, ptr(scratch),
+                                           scratch.numel(), _stream()))
+        else:
+            scratch = _bytes(lib.pope_pairwise_by_id_scratch_bytes(n, k, d), dev)
+            check(lib.pope_pairwise_features_by_id(None, 0, ptr(emb), n, d, ptr(idx), k, metric, ptr(out), out.shape[1], c0, ptr(scratch),
+                                                   scratch.numel(), _stream()))
     return out
 
 
@@ -737,14 +755,18 @@ def pairwise_features(x: torch.Tensor, emb: torch.Tensor, anchors, distance_func
     if anchor_embeddings is not None:
         a = torch.as_tensor(anchor_embeddings).to(dev, torch.float32).contiguous()
         assert a.dim() == 2 and a.shape[1] == d
-    elif isinstance(anchors, torch.Tensor) and anchors.device == dev and anchors.dtype == torch.int64:
-        a = emb.index_select(0, anchors)                                  # anchor ids already on the device: no host round trip
-    else:
-        a = emb.index_select(0, torch.as_tensor(np.asarray(anchors, dtype=np.int64), device=dev)).contiguous()
-    k = a.shape[0]
+    else:                                                                 # embedding[anchor_nodes] (utils.py:167): read through the ids
+        a = None
+        idx = _anchor_ids(anchors, emb.shape[0], dev)
+    k = a.shape[0] if a is not None else idx.numel()
     with torch.cuda.device(dev):
         out = torch.empty((n, f + k), dtype=torch.float32, device=dev)
-        scratch = _bytes(lib.pope_pairwise_scratch_bytes(n, k, d), dev)
-        check(lib.pope_pairwise_features(ptr(x), f, ptr(emb), n, d, ptr(a), k, metric, ptr(out), f + k, f, ptr(scratch),
-                                         scratch.numel(), _stream()))
+        if a is not None:
+            scratch = _bytes(lib.pope_pairwise_scratch_bytes(n, k, d), dev)
+            check(lib.pope_pairwise_features(ptr(x), f, ptr(emb), n, d, ptr(a), k, metric, ptr(out), f + k, f, ptr(scratch),
+                                             scratch.numel(), _stream()))
+        else:
+            scratch = _bytes(lib.pope_pairwise_by_id_scratch_bytes(n, k, d), dev)
+            check(lib.pope_pairwise_features_by_id(ptr(x), f, ptr(emb), n, d, ptr(idx), k, metric, ptr(out), f + k, f, ptr(scratch),
+                                                   scratch.numel(), _stream()))
     return out

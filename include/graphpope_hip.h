@@ -299,6 +299,13 @@ size_t pope_pairwise_scratch_bytes(int64_t N, int32_t K, int32_t D);
 int pope_pairwise_minmax(const float *X, int64_t N, int32_t D, const float *A, int32_t K, int32_t metric,
                          float *out, int64_t out_cols, int32_t c0, void *scratch, size_t scratch_bytes,
                          void *stream);
+/* utils.py:165-167 as written there -- embedding[anchor_nodes] and the distances in one call: anchor j is row anchor_ids[j]
+ * (DEVICE int64, each in [0, N)) of X, read through the ids by the tile kernel (no gathered copy of the anchor rows, no gather
+ * launch in front of the call).  x = NULL / F = 0: the embedding columns alone.  Scratch: pope_pairwise_by_id_scratch_bytes. */
+size_t pope_pairwise_by_id_scratch_bytes(int64_t N, int32_t K, int32_t D);
+int pope_pairwise_features_by_id(const float *x, int32_t F, const float *X, int64_t N, int32_t D, const int64_t *anchor_ids, int32_t K,
+                                 int32_t metric, float *out, int64_t out_cols, int32_t c0, void *scratch, size_t scratch_bytes,
+                                 void *stream);
 
 /*
  * The same with the feature half of utils.py:177 concat_into_features fused in: out[v, 0:F] = x[v, :] (x float32 [N, F],

@@ -84,10 +84,10 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { mu[i] = m4.v[i]; rs[i] = r4.v[i]; ga[i] = g4.v[i]; be[i] = b4.v[i]; }
     }
-    if (valid)
-        for (int r = r0 + wave; r < r1; r += 4) {
-            const size_t off = (size_t)r * C + c0;
-            const Pack<VEC> xv = load_pack<VEC>(x + off);
+    if (valid) {
+        // four rows of a wave's stride in flight (their loads issued before the first is used), accumulated in row order: a wave
+        // has ~10 rows and one load pair in flight per row made the kernel ten dependent latencies long (9.5 us for 20 MB)
+        auto accumulate = [&](const Pack<VEC> &xv, const Pack<VEC> &gv, size_t off) {
             if constexpr (!BWD) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
                     b[i] += (double)xv.v[i] * (double)xv.v[i];
                 }
             } else {
-                const Pack<VEC> gv = load_pack<VEC>(dy + off);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const float xhat = (xv.v[i] - mu[i]) * rs[i];
@@ -105,7 +104,28 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
                     b[i] += (double)g * (double)xhat;
                 }
             }
+        };
+        int r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {
+            Pack<VEC> xv[4], gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t off = (size_t)(r + 4 * u) * C + c0;
+                xv[u] = load_pack<VEC>(x + off);
+                if constexpr (BWD) gv[u] = load_pack<VEC>(dy + off);
+                else gv[u] = xv[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accumulate(xv[u], gv[u], (size_t)(r + 4 * u) * C + c0);
         }
+        for (; r < r1; r += 4) {
+            const size_t off = (size_t)r * C + c0;
+            const Pack<VEC> xv = load_pack<VEC>(x + off);
+            Pack<VEC> gv = xv;
+            if constexpr (BWD) gv = load_pack<VEC>(dy + off);
+            accumulate(xv, gv, off);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         sh[0][wave][lane * VEC + i] = a[i];

@@ -778,13 +778,10 @@ __device__ __forceinline__ void gather_role(const GatherArgs &g, const int block
 // (registers are allotted per kernel, not per role: at the GEMM role's 138 a gather block's two extra waves per SIMD would not fit
 //  beside a GEMM block -- 4 x 144 > 512 -- and the roles ran one after the other: 62 + 45 us.  Hence four waves per SIMD.)
 template <int RB>
-__global__ __launch_bounds__(T16_THREADS, 4) void k_gather_beside_gemm(T16Args a, GatherArgs g, int gemm_blocks, int only) {
+__global__ __launch_bounds__(T16_THREADS, 4) void k_gather_beside_gemm(T16Args a, GatherArgs g, int gemm_blocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < gemm_blocks) {
-        if (only != 2) t16_block_loop<RB, false>(a, smem, (int)blockIdx.x, gemm_blocks);
-    } else if (only != 3) {
-        gather_role(g, (int)blockIdx.x - gemm_blocks, (int)gridDim.x - gemm_blocks);
-    }
+    if ((int)blockIdx.x < gemm_blocks) t16_block_loop<RB, false>(a, smem, (int)blockIdx.x, gemm_blocks);
+    else gather_role(g, (int)blockIdx.x - gemm_blocks, (int)gridDim.x - gemm_blocks);
 }
 
 template <int RB>
@@ -795,7 +792,7 @@ static int launch_gather_beside_gemm(const T16Args &a, const GatherArgs &g, int 
         opt_in.mark();
     }
     hipLaunchKernelGGL(k_gather_beside_gemm<RB>, dim3((unsigned)(gemm_blocks + gather_blocks)), dim3(T16_THREADS), T16Shape<RB>::LDS_BYTES, stream, a, g,
-                       gemm_blocks, g_sage_forward_overlap);        // (knob values 2 / 3: one role only -- timing experiments, wrong results)
+                       gemm_blocks);
     return POPE_OK;
 }
 

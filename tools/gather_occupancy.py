@@ -22,7 +22,7 @@ flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 conv = gs.SAGEConv(756, 256).to(dev)
 x = gs.IndexedFeatures(feats, n_id)
 print("block", adj.n_dst, adj.n_src, int(adj.rowptr[-1]))
-MODES = [(1, 0), (0, 0), (2, 0), (3, 0), (1, 0), (0, 0), (2, 0), (3, 0)] if "--overlap" in sys.argv else [(0, p) for p in (0, 20, 40, 53, 80, 0)]
+MODES = [(1, 0), (0, 0), (1, 0), (0, 0)] if "--overlap" in sys.argv else [(0, p) for p in (0, 20, 40, 53, 80, 0)]
 for overlap, pad in MODES:
     lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, overlap)
     lib.pope_debug_set(_lib.KNOB_GATHER_LDS_PAD_KB, pad)

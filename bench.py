@@ -396,7 +396,7 @@ def kmeans_leg(n, dev):
     c = engine.kmeans_centers(table, K_PER_GPU)
     torch.cuda.synchronize()
     gpu = time.perf_counter() - t0
-    res = {"gpu_ms": gpu * 1e3, "what": f"engine.kmeans_centers: X [{n}, 128] f32 N(0,1) resident, K = {K_PER_GPU}: k-means++ seeding "
+    res = {"gpu_ms": gpu * 1e3, "what": f"engine.kmeans_centers (the opt-in GPU clustering, GRAPHPOPE_KMEANS=gpu; by default the anchors come from the reference's own scikit-learn call): X [{n}, 128] f32 N(0,1) resident, K = {K_PER_GPU}: k-means++ seeding "
                                          "(7 local trials) + Lloyd iterations (MFMA tile assignment) until scikit-learn's stopping rule"}
     try:
         from sklearn.cluster import KMeans

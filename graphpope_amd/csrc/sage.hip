@@ -660,8 +660,9 @@ static int gemm_tile16(const float *A0, const float *B0, int K0, const float *A1
 // gather in the remaining blocks, which share the CUs with them; launch 2 adds agg W_l^T into out.  No block waits for
 // another block.  Every block of launch 1 carries the GEMM role's LDS reservation, so only one or two gather blocks fit a
 // CU: the gather role keeps twelve 16-byte loads in flight per lane (k_gather_mean: four) to make up for it.
-// (Measured and not kept: x_dst written by the GEMM role out of LDS instead of read + written by the gather role -- the consumer
-//  waves' copy doubled the fused kernel's spills and the launch took 84 us instead of 79; and no x_dst at all, the weight-gradient
+// (Measured and not kept: x_dst written by the GEMM role out of LDS instead of read + written by the gather role -- by the consumer
+//  waves (their copy doubled the fused kernel's spills) or by the loader waves: the launch took 84 us instead of 79 and the step
+//  0.332 ms instead of 0.313 either way (128-byte pieces of 3 KB rows, stage by stage, are poor stores); and no x_dst at all, the weight-gradient
 //  kernel reading the rows through n_id (sage_conv_backward_indexed): its 1 KB random reads cost 29 us more than the copy.)
 struct GatherArgs {
     const int *rowptr, *col;

@@ -585,3 +585,45 @@ def test_host_result_assembly_from_codes(dev):
             asm.finish_codes(codes, lut)
         assert torch.equal(out[:, :f], x)
         assert torch.equal(out[:, f:], lut.cpu()[codes.cpu().long()])
+
+
+def test_concurrent_host_assemblies_take_turns_on_the_ring(dev):
+    """Two host threads, each on its own stream, assembling different results at the same time (ctypes releases the GIL):
+    the process-wide pinned ring is one resource -- pope_assemble_finish holds its mutex for the D2H phase -- so the calls
+    interleave without mixing chunks; float and byte transports at once."""
+    import threading
+    from graphpope_amd import engine
+    g = torch.Generator().manual_seed(4)
+    lut = torch.rand(256, generator=g).to(dev)
+    jobs = []
+    for n, f, k, coded in ((120001, 9, 96, False), (90007, 4, 200, True)):
+        x = torch.rand(n, f, generator=g)
+        emb = (torch.randint(0, 256, (n, k), generator=g, dtype=torch.uint8) if coded else torch.rand(n, k, generator=g)).to(dev)
+        jobs.append((x, emb, coded, f))
+    torch.cuda.synchronize()
+    errors, results = [], {}
+
+    def worker(idx):
+        try:
+            x, emb, coded, f = jobs[idx]
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                for it in range(4):
+                    out = torch.full((x.shape[0], f + emb.shape[1]), -1.0)
+                    with engine.HostAssembly(x, out, f, threads=3) as asm:
+                        asm.finish_codes(emb, lut) if coded else asm.finish(emb)
+                    results[(idx, it)] = out
+        except Exception as exc:                                  # surfaced in the main thread below
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors and all(not t.is_alive() for t in threads), errors
+    for (idx, it), out in results.items():
+        x, emb, coded, f = jobs[idx]
+        want = lut.cpu()[emb.cpu().long()] if coded else emb.cpu()
+        assert torch.equal(out[:, :f], x) and torch.equal(out[:, f:], want), (idx, it)
+    assert len(results) == 8

@@ -32,6 +32,7 @@ SIGNATURES = {
     "pope_assemble_finish": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "pope_assemble_abort": (None, [c_void_p]),
     "pope_assemble_prepare": (None, [c_int32]),
+    "pope_assemble_ring_ready": (c_int32, []),
     "pope_assemble_finish_codes": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "pope_geodesic_hop_codes": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
     "pope_host_pin": (c_int, [c_void_p, c_size_t]),

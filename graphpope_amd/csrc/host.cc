@@ -313,7 +313,7 @@ struct PinnedRing {
     std::mutex mu;
     char *slot[RING_SLOTS] = {nullptr, nullptr, nullptr};
     hipEvent_t ev[RING_SLOTS] = {nullptr, nullptr, nullptr};
-    bool ready = false, failed = false, preparing = false, pinned = true;
+    bool ready = false, failed = false, preparing = false;
     float *lut_pinned = nullptr;                 // hop-code transport: where the device's 256 floats land ...
     float lut_seen[256];                         // ... the table pair_lut was built from ...
     std::vector<uint64_t> pair_lut;              // ... and the 65 536-entry two-byte table (512 KB, built once: the floats never change)
@@ -455,49 +455,34 @@ extern "C" void pope_assemble_abort(void *handle) {
     delete h;
 }
 
-static void ring_release_locked() {
-    for (int i = 0; i < RING_SLOTS; ++i) {
-        if (g_ring.slot[i]) { if (g_ring.pinned) (void)hipHostFree(g_ring.slot[i]); else free(g_ring.slot[i]); }
-        if (g_ring.ev[i]) (void)hipEventDestroy(g_ring.ev[i]);
-        g_ring.slot[i] = nullptr; g_ring.ev[i] = nullptr;
-    }
-    if (g_ring.lut_pinned) { if (g_ring.pinned) (void)hipHostFree(g_ring.lut_pinned); else free(g_ring.lut_pinned); }
-    g_ring.lut_pinned = nullptr;
-    g_ring.ready = false;
-}
-
-// The three slots, the code table and their events; g_ring.mu held.  Once per process: hipHostMalloc (2 ms), or -- if the
-// runtime refuses to pin 24 MB (POPE_KNOB_FAIL_HOST_REGISTER bit 1 simulates that) -- ordinary memory: the same chunked
-// protocol then runs through the runtime's own staging, slower and still correct.
-static void ring_allocate_locked() {
-    const bool refuse_pinned = (pope::g_fail_host_register & 2) != 0;
-    if (g_ring.ready && g_ring.pinned == !refuse_pinned) return;
-    if (g_ring.ready) ring_release_locked();                     // (the test knob changed: build the other kind)
-    if (g_ring.failed) return;
-    bool ok = !refuse_pinned;
+// The three pinned slots, the code table and their events; g_ring.mu held.  Allocated once per process (2 ms of hipHostMalloc)
+// and never released.  false: no pinned ring -- the runtime refused the 24 MB (not retried), or POPE_KNOB_FAIL_HOST_REGISTER bit
+// 1 says to behave as if it had -- and the caller sends float columns through the registered / staged path instead.
+// (A ring of ORDINARY memory as the fallback was built and withdrawn: asynchronous copies into heap memory that is freed and
+// reused afterwards left the runtime with stale mappings, and a later, unrelated transfer died with a GPU memory fault at a
+// host heap address.)
+static bool ring_usable_locked() {
+    if (pope::g_fail_host_register & 2) return false;
+    if (g_ring.ready) return true;
+    if (g_ring.failed) return false;
+    bool ok = true;
     for (int i = 0; i < RING_SLOTS && ok; ++i)
-        ok = hipHostMalloc(reinterpret_cast<void **>(&g_ring.slot[i]), RING_SLOT_BYTES, hipHostMallocDefault) == hipSuccess;
+        ok = hipHostMalloc(reinterpret_cast<void **>(&g_ring.slot[i]), RING_SLOT_BYTES, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g_ring.lut_pinned), 256 * sizeof(float), hipHostMallocDefault) == hipSuccess;
-    g_ring.pinned = ok;
     if (!ok) {
         (void)hipGetLastError();
         for (int i = 0; i < RING_SLOTS; ++i) {
             if (g_ring.slot[i]) (void)hipHostFree(g_ring.slot[i]);
-            g_ring.slot[i] = nullptr;
+            if (g_ring.ev[i]) (void)hipEventDestroy(g_ring.ev[i]);
+            g_ring.slot[i] = nullptr; g_ring.ev[i] = nullptr;
         }
         if (g_ring.lut_pinned) (void)hipHostFree(g_ring.lut_pinned);
         g_ring.lut_pinned = nullptr;
-        ok = true;
-        for (int i = 0; i < RING_SLOTS && ok; ++i) ok = (g_ring.slot[i] = static_cast<char *>(aligned_alloc(4096, RING_SLOT_BYTES))) != nullptr;
-        ok = ok && (g_ring.lut_pinned = static_cast<float *>(aligned_alloc(4096, 4096))) != nullptr;
+        g_ring.failed = true;
     }
-    for (int i = 0; i < RING_SLOTS && ok; ++i) ok = hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming) == hipSuccess;
-    g_ring.ready = true;                                           // so that release frees whatever exists
-    if (!ok) {
-        (void)hipGetLastError();
-        ring_release_locked();
-        g_ring.failed = true;                                      // neither kind: float columns go through registration of the result's pages
-    }
+    g_ring.ready = ok;
+    return ok;
 }
 
 // The first host -> host call of a process can have the ring allocated beside its GPU work: this returns at once and a
@@ -511,8 +496,15 @@ extern "C" void pope_assemble_prepare(int32_t device) {
     std::thread([device] {
         std::unique_lock<std::mutex> lock(g_ring.mu);
         if (device >= 0) (void)hipSetDevice(device);
-        ring_allocate_locked();
+        (void)ring_usable_locked();
     }).detach();
+}
+
+// 1 if the byte transport can be used now (the pinned ring exists, or could be allocated here), else 0; waits for an
+// allocation that pope_assemble_prepare started.  The caller decides between pope_assemble_finish_codes and float columns.
+extern "C" int32_t pope_assemble_ring_ready(void) {
+    std::unique_lock<std::mutex> lock(g_ring.mu);
+    return ring_usable_locked() ? 1 : 0;
 }
 
 // `lut_dev` == nullptr: `emb` holds the float columns themselves.  Otherwise `emb` holds one code byte per element
@@ -576,9 +568,9 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
     if (h->ring && eb > 0 && eb <= RING_SLOT_BYTES) {
         std::unique_lock<std::mutex> lock(g_ring.mu);
         double t0 = now_ms();
-        ring_allocate_locked();
+        const bool usable = ring_usable_locked();
         tr[2] = now_ms() - t0;
-        if (g_ring.ready) {
+        if (usable) {
             const int64_t crow = (int64_t)(RING_SLOT_BYTES / eb);
             const int ne = (int)((rows + crow - 1) / crow);
             a.emb_row = eb; a.emb_elems = eb; a.emb_chunk_rows = crow; a.ring_slots = RING_SLOTS;

@@ -156,21 +156,28 @@ def _give_back(mm, nbytes: int) -> None:
     # otherwise the last reference is dropped here and the mapping is unmapped with it
 
 
-def host_result_tensor(rows: int, cols: int) -> torch.Tensor:
+def host_result_tensor(rows: int, cols: int, with_origin: bool = False):
     """An uninitialised contiguous float32 [rows, cols] HOST tensor in pageable memory (not pinned, not shared), backed by
-    the one-entry pool above.  GRAPHPOPE_RESULT_POOL_MB caps what the pool may keep (default 1024; 0: plain torch.empty)."""
+    the one-entry pool above.  GRAPHPOPE_RESULT_POOL_MB caps what the pool may keep (default 1024; 0: plain torch.empty).
+    ``with_origin``: (tensor, reused) -- reused = the pages come from the pool, i.e. writing them takes no page faults."""
+    t, reused = _host_result_tensor(rows, cols)
+    return (t, reused) if with_origin else t
+
+
+def _host_result_tensor(rows: int, cols: int):
     nbytes = rows * cols * 4
     if nbytes < (1 << 20) or _result_pool_cap() <= 0:
-        return torch.empty((rows, cols), dtype=torch.float32)
+        return torch.empty((rows, cols), dtype=torch.float32), False
     import mmap
     with _RESULT_POOL_LOCK:
         mm = _RESULT_POOL.pop(nbytes, None)
         _RESULT_POOL.clear()         # another size: its pages go back to the system
+    reused = mm is not None
     if mm is None:
         mm = mmap.mmap(-1, nbytes, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, prot=mmap.PROT_READ | mmap.PROT_WRITE)
     flat = np.frombuffer(mm, dtype=np.float32)       # the tensor keeps `flat` alive (as the base of its array); it dies last
     weakref.finalize(flat, _give_back, mm, nbytes)
-    return torch.from_numpy(flat.reshape(rows, cols))
+    return torch.from_numpy(flat.reshape(rows, cols)), reused
 
 
 class HostAssembly:

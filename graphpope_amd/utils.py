@@ -129,10 +129,10 @@ def _assemble_on_host(data, k, embedding_fn):
     ``GRAPHPOPE_HOST_RESULT`` selects the other paths that were built and measured: ``registered`` (the result's own pages
     are registered chunk by chunk and the DMA writes them directly -- 11.4 ms first call, but 4-18 ms on repeated calls,
     the driver's pin/unpin of a fresh quarter gigabyte being erratic), ``staged`` (the runtime's own staging) and ``pinned``
-    (rounds 1-2: page-locked result).  The assembly starts AFTER ``embedding_fn()`` has uploaded edge_index and run the
-    GPU work: starting the host threads before it (engine.HostAssembly allows that) was measured 3.4-3.9 ms in a fresh process
-    but 13-20 ms inside bench.py -- sixteen threads taking page faults hold the address-space lock that the runtime's
-    own allocations behind a launch wait for."""
+    (rounds 1-2: page-locked result).  On a FIRST call (fresh result pages) the assembly starts AFTER ``embedding_fn()`` has
+    uploaded edge_index and run the GPU work: sixteen threads faulting in a quarter gigabyte of huge pages beside it stalled the
+    GPU queues for milliseconds (3.4-3.9 ms in a fresh process, 13-20 ms inside bench.py).  On a repeated call the pages come
+    from the pool, nothing faults, and the feature copy runs underneath the upload and the GPU work."""
     import time as _t
     trace = os.environ.get("GRAPHPOPE_TRACE")
     t0 = _t.perf_counter()
@@ -143,13 +143,9 @@ def _assemble_on_host(data, k, embedding_fn):
         raise ValueError(f"GRAPHPOPE_HOST_RESULT={mode!r}: expected ring, registered, staged or pinned")
     if mode == "ring":                                 # first call of a process: the pinned ring is allocated beside the GPU work
         _lib_mod.load().pope_assemble_prepare(torch.cuda.current_device())
-    emb_dev = embedding_fn()                           # float32 [N, K], or (uint8 codes [N, K], float32 lut [256]): engine.hop_codes
-    coded = isinstance(emb_dev, tuple)
-    if not coded:
-        emb_dev = emb_dev.contiguous()
-    t1 = _t.perf_counter()
-    assert not coded or mode == "ring"
     if mode == "pinned":                               # rounds 1-2: a page-locked result (fast when torch's host cache holds one, 34 ms when not)
+        emb_dev = embedding_fn().contiguous()
+        t1 = _t.perf_counter()
         out = torch.empty((n, f + k), dtype=torch.float32, pin_memory=True)
         engine.copy_columns_to_host(emb_dev, out[:, f:])
         if f:
@@ -157,14 +153,31 @@ def _assemble_on_host(data, k, embedding_fn):
         torch.cuda.current_stream().synchronize()
         res = out
     else:
-        out = engine.host_result_tensor(n, f + k)
+        out, reused = engine.host_result_tensor(n, f + k, with_origin=True)
         lib = _lib_mod.load()
         lib.pope_debug_set(_lib_mod.KNOB_HOST_RESULT_MODE, 0 if mode == "ring" else 1)
         if mode == "staged":                           # no registration of the caller-visible pages: the runtime's own staging
             lib.pope_debug_set(_lib_mod.KNOB_FAIL_HOST_REGISTER, 1)
+        asm = None
         try:
-            with engine.HostAssembly(x if f else None, out, f) as asm:
+            # pages from the pool (a repeated call): no page faults to take, so the feature copy may start now and run underneath
+            # the upload and the GPU work; fresh pages (the first call): the copy starts after them (see the docstring)
+            if reused and mode == "ring":
+                asm = engine.HostAssembly(x if f else None, out, f)
+            emb_dev = embedding_fn()                   # float32 [N, K], or (uint8 codes [N, K], float32 lut [256]): engine.hop_codes
+            coded = isinstance(emb_dev, tuple)
+            if not coded:
+                emb_dev = emb_dev.contiguous()
+            assert not coded or mode == "ring"
+            t1 = _t.perf_counter()
+            if asm is None:
+                asm = engine.HostAssembly(x if f else None, out, f)
+            with asm:
                 res = asm.finish_codes(*emb_dev) if coded else asm.finish(emb_dev)
+        except BaseException:
+            if asm is not None:
+                asm.__exit__(None, None, None)         # waits for the host threads of an assembly that will not be finished
+            raise
         finally:
             lib.pope_debug_set(_lib_mod.KNOB_HOST_RESULT_MODE, 0)
             if mode == "staged":
@@ -206,7 +219,8 @@ def _geodesic_embedding_device(edge_index, n, anchors, dev, coded=False):
             t1 = _t.perf_counter()
             if coded and (not _shard() or pdist.world_size(None) == 1):
                 _, hp = engine.geodesic_run(None, ei, n, anchors, want_out=False, reuse_workspace=True)
-                if hp.max_hop <= engine.MAX_CODED_HOP:
+                # the byte transport needs the process's pinned ring (allocated beside the BFS above: pope_assemble_prepare)
+                if hp.max_hop <= engine.MAX_CODED_HOP and _lib_mod.load().pope_assemble_ring_ready():
                     emb = engine.hop_codes(hp)
                 else:                                                # a graph deeper than a byte: the float columns
                     emb = torch.empty((n, len(anchors)), dtype=torch.float32, device=dev)

@@ -83,7 +83,7 @@ int pope_require_device(int32_t *cu_count_host);
 #define POPE_KNOB_GEMM_TILE         3   /* SAGE GEMM: 0 auto, 1 64x64, 2 64x128, 3 128x256 tiles, 4 / 5 stream-K without loader waves, 6 stream-K with stages of 64 in two 80 KB buffers, 7 stream-K instead of the chip-fitted whole tiles (gemm_tile16.h) */
 #define POPE_KNOB_COPY_BATCHES      5   /* node2vec embedding: 16-piece batches per wave of the feature-copy kernel beside the tile kernel (default 1) */
 #define POPE_KNOB_LEVEL_BLOCKS       6   /* level kernel: cap on the expand blocks of a launch (0 = one wave per 256-slot chunk, up to 2048 blocks)      */
-#define POPE_KNOB_FAIL_HOST_REGISTER 7  /* host -> host boundary, tests of the fallbacks, bit mask: 1 = every hipHostRegister is refused, 2 = the pinned ring's hipHostMalloc is refused (the ring is then ordinary memory) */
+#define POPE_KNOB_FAIL_HOST_REGISTER 7  /* host -> host boundary, tests of the fallbacks, bit mask: 1 = every hipHostRegister is refused, 2 = behave as if the pinned ring's hipHostMalloc had been refused (float columns through registration / staging) */
 #define POPE_KNOB_SAGE_LANES        8   /* sage_conv_backward: 0 (default) one stream; 1 bias gradient and grad_x chain on side streams beside the weight gradients (measured slower) */
 #define POPE_KNOB_LEVEL_VARIANT     9   /* level kernel experiments, bit mask: 1 non-temporal index streams, 2 XCD-contiguous chunk ranges, 4 non-temporal reachability loads */
 #define POPE_KNOB_COPY_GATE         10  /* pope_geodesic_run experiment: early% * 1000 + late% of the feature rows copied on a side stream beside the sparse phases (0 = off) */
@@ -366,6 +366,10 @@ void pope_assemble_abort(void *handle);
 /* Optional, returns at once: the process's pinned ring (24 MB, 2 ms of hipHostMalloc) is allocated by a helper thread on
  * `device` (< 0: the thread's default), beside the caller's GPU work, instead of inside the first pope_assemble_finish. */
 void pope_assemble_prepare(int32_t device);
+/* 1 if pope_assemble_finish_codes can be used now (the pinned ring exists or could be allocated by this call), else 0 -- the
+ * caller then brings float columns down with pope_assemble_finish, which registers the result's pages or uses the runtime's
+ * staging.  Waits for an allocation that pope_assemble_prepare started. */
+int32_t pope_assemble_ring_ready(void);
 
 /*
  * The geodesic embedding in its transport form (utils.py:73 1 / len(path), one byte per element instead of four):

@@ -451,7 +451,8 @@ def test_host_to_host_call_returns_a_pageable_tensor_in_every_result_mode(mode, 
     through the 3-slot pinned ring, 8 registered chunks): ordinary pageable memory like the reference's torch.cat,
     bit-exact, in the default ring mode, with the result's pages registered, and when the runtime refuses to register the
     caller's pages (POPE_KNOB_FAIL_HOST_REGISTER bit 0: edge_index then goes through pinned staging, the embedding columns
-    through the runtime's own staging) or to allocate the pinned ring (bit 1: the ring's slots are ordinary memory then).
+    through the runtime's own staging) or to allocate the pinned ring (bit 1: no byte transport, float columns through the
+    registered / staged path).
     ``pinned`` is the rounds 1-2 behaviour (a page-locked result)."""
     from graphpope_amd import _lib, synth, utils as gp
     lib = _lib.load()

@@ -217,6 +217,48 @@ __device__ int g_stamp_level;
 
 template <int WT> struct Words { u64 w[WT]; };
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: what the non-temporal builtins accept
+
+// COPY ROLE of a level launch (round 4).  out[:, :F] = x (utils.py:129-135) is two thirds of the finalise kernel's traffic and
+// depends on nothing the BFS computes, while the level launches are bound by L2 line fills and latency and leave the HBM
+// interface idle.  Every level launch of pope_geodesic_run therefore carries, BEHIND its expand and housekeeping blocks, a
+// bounded number of short-lived blocks that copy a fixed slice of x's rows -- one batch of 16 pieces of 16 bytes per lane,
+// every load issued before the first store (side_copy.hip's shape) -- and the finalise kernel starts its own copy at the
+// first row no launch took.  Same launch, same stream: nothing forks, nothing delays the next level's launch (both side-stream
+// forms of this were measured slower, DESIGN.md section 3 lessons 5, 11, 12).  x is dense [N, F]: piece p of the flat sequence of
+// 16-byte pieces lies at x + 16 p and goes to row p / F4, piece p % F4 of out.
+struct LevelCopy {
+    const float *x = nullptr;
+    float *out = nullptr;
+    unsigned F4 = 0, opitch4 = 0;                 // row length of x and row pitch of out, in 16-byte pieces
+    unsigned piece_begin = 0, piece_end = 0;      // flat pieces of x this launch copies
+    int first_block = 0, blocks = 0;              // blockIdx.x of the role's first block (set by launch_level), number of its blocks
+};
+constexpr int LEVEL_COPY_PIECES = 16;             // per lane and batch
+constexpr unsigned LEVEL_COPY_BLOCK_PIECES = 256u * LEVEL_COPY_PIECES;
+
+__device__ __forceinline__ void level_copy_role(const LevelCopy &cp) {
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const unsigned base = cp.piece_begin + (((unsigned)blockIdx.x - (unsigned)cp.first_block) * 4u + w) * (64u * LEVEL_COPY_PIECES) + lane;
+    if (base >= cp.piece_end) return;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(cp.x);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(cp.out);
+    f32x4 v[LEVEL_COPY_PIECES];
+#pragma unroll
+    for (int j = 0; j < LEVEL_COPY_PIECES; ++j) {
+        const unsigned p = base + 64u * j;
+        if (p < cp.piece_end) v[j] = __builtin_nontemporal_load(src + p);
+    }
+    unsigned row = base / cp.F4, q = base - row * cp.F4;
+#pragma unroll
+    for (int j = 0; j < LEVEL_COPY_PIECES; ++j) {
+        const unsigned p = base + 64u * j;
+        if (p < cp.piece_end) dst[(size_t)row * cp.opitch4 + q] = v[j];
+        q += 64u;
+        while (q >= cp.F4) { q -= cp.F4; ++row; }
+    }
+}
+
 template <int WT>
 __device__ __forceinline__ Words<WT> load_words(const u64 *__restrict__ p) {
     Words<WT> r;
@@ -347,7 +389,11 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
                                                    size_t plane_elems, int level, BfsCtl *ctl, const int *aux,
                                                    int expand_blocks, const unsigned *__restrict__ live,
                                                    unsigned *__restrict__ live_acc, unsigned *__restrict__ live_idle,
-                                                   int live_words, int variant) {
+                                                   int live_words, int variant, const LevelCopy cp) {
+    if ((int)blockIdx.x >= cp.first_block) {                          // copy role: runs whether or not the BFS is over
+        if (blockIdx.y == 0) level_copy_role(cp);
+        return;
+    }
     if (bfs_over(ctl, aux, level)) return;
     const int lane = threadIdx.x & 63;
     int woff = blockIdx.y * WT;                                    // housekeeping: tile = blockIdx.y
@@ -360,7 +406,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
         //      of the next frontier instead of a plane read-modify-write behind it.
         const int n = (E + CHUNK - 1) >> CHUNK_SHIFT;              // one slot per chunk, -1 = no row continues into it
         const int *mrows = aux + AUX_HEADER;
-        const int hb = gridDim.x - expand_blocks;
+        const int hb = cp.first_block - expand_blocks;
         const int t0 = ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x, tstride = hb * blockDim.x;
         if (LIVE && blockIdx.y == 0)
             for (int i = t0; i < live_words; i += tstride) live_idle[i] = 0u;
@@ -598,8 +644,6 @@ __device__ __forceinline__ void write_report(int last_active, const int *aux, in
     }
 }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: what the non-temporal builtins accept
-
 // ------------------------------------------------------------------------------------------------
 // Finalise: hop planes -> 1/(h+1) float32 written next to the features (utils.py:73,125,129-135)
 // ------------------------------------------------------------------------------------------------
@@ -618,7 +662,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u64 *__restrict__ planes
                                                   int n_hop_bits, const int *__restrict__ max_hop_dev, int N, int K,
                                                   int Wp, const float *__restrict__ x, int F,
                                                   float *__restrict__ out, long long out_cols, int c0,
-                                                  const int *__restrict__ aux, int *report, int ticket) {
+                                                  const int *__restrict__ aux, int *report, int ticket, int x_row_begin) {
     if (max_hop_dev) {                        // enqueued before the host knew the depth: read it from the BFS control block
         const int m = *max_hop_dev;
         n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
@@ -629,7 +673,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u64 *__restrict__ planes
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int v = wave; v < N; v += nwaves) {
         float *orow = out + (size_t)v * out_cols;
-        if (x) {
+        if (x && v >= x_row_begin) {                               // rows below: copied by the level launches (LevelCopy)
             const float *xrow = x + (size_t)v * F;
             if (VEC) {
                 const float4 *xs = reinterpret_cast<const float4 *>(xrow);
@@ -701,7 +745,7 @@ __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ p
     const int F4 = F >> 2, K4 = K >> 2;
     for (int v = v_begin; v < v_end; ++v) {
         f32x4 *orow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols);
-        if (x && v >= x_row_begin) {                           // rows below were copied beside the BFS (POPE_KNOB_COPY_GATE)
+        if (x && v >= x_row_begin) {                           // rows below were copied by the level launches (LevelCopy)
             const f32x4 *xs = reinterpret_cast<const f32x4 *>(x + (size_t)v * F);
             for (int q = lane; q < F4; q += 64) {
                 const f32x4 t = __builtin_nontemporal_load(xs + q);
@@ -1041,7 +1085,10 @@ static int g_finalize_variant = 1;      // 0: generic kernel, 1: fast path with 
 static int g_finalize_blocks = 256 * 8;
 static int g_level_blocks = 0;           // cap on the expand blocks of a level launch (0: one wave per chunk up to 2048 blocks)
 static int g_level_variant = 0;          // POPE_KNOB_LEVEL_VARIANT bits: 1 nt index streams, 2 XCD-contiguous chunks, 4 nt reachability loads
-static int g_copy_gate = 0;              // POPE_KNOB_COPY_GATE: early% * 1000 + late% of the feature rows copied beside the sparse phases (0: off)
+// POPE_KNOB_LEVEL_COPY: per mille of x's rows that level launch l of pope_geodesic_run copies in its copy role (LevelCopy).
+// Index 0 is unused.  Launches the speculative window does not reach leave their share to the finalise kernel.
+constexpr int LEVEL_COPY_SLOTS = 16;
+static int g_level_copy_permille[LEVEL_COPY_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0, g_host_result_mode = 0, g_gemm_split_bf16 = 0, g_gather_lds_pad_kb = 0, g_sage_forward_overlap = 1, g_gemm_small_tile16 = 1; extern int g_sage_lanes; }
 
 extern "C" int pope_debug_set(int32_t knob, int32_t value) {
@@ -1062,7 +1109,13 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_GEMM_SMALL_TILE16: pope::g_gemm_small_tile16 = value; break;
     case POPE_KNOB_SAGE_LANES:       pope::g_sage_lanes = value; break;
     case POPE_KNOB_LEVEL_VARIANT:    g_level_variant = value; break;
-    case POPE_KNOB_COPY_GATE:        g_copy_gate = value; break;
+    case POPE_KNOB_LEVEL_COPY: {                                     // value = level << 16 | per mille; level 0: every launch
+        const int lv = (value >> 16) & 0xff, pm = value & 0xffff;
+        if (lv >= LEVEL_COPY_SLOTS || pm > 1000) { set_error("pope_debug_set: level copy %d / %d", lv, pm); return POPE_ERR_INVALID; }
+        if (lv == 0) for (int i = 1; i < LEVEL_COPY_SLOTS; ++i) g_level_copy_permille[i] = pm;
+        else g_level_copy_permille[lv] = pm;
+        break;
+    }
     default: set_error("pope_debug_set: unknown knob %d", knob); return POPE_ERR_INVALID;
     }
     return POPE_OK;
@@ -1071,27 +1124,30 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
 template <int WT>
 static void launch_level(int E, int N, int Wp, const int *col, const int *erow, const int *aux, const u64 *front, u64 *seen,
                          u64 *acc, u64 *idle, u64 *hop_planes, size_t plane_elems, int level, BfsCtl *ctl,
-                         const unsigned *live, unsigned *live_acc, unsigned *live_idle, int live_words, hipStream_t stream) {
+                         const unsigned *live, unsigned *live_acc, unsigned *live_idle, int live_words, LevelCopy cp, hipStream_t stream) {
     const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
     int expand_blocks = (nchunks + 3) / 4;                           // one wave per chunk ...
     if (expand_blocks > 256 * 8) expand_blocks = 256 * 8;            // ... up to 8 blocks per CU, then waves loop
     if (g_level_blocks > 0 && expand_blocks > g_level_blocks) expand_blocks = g_level_blocks;   // A/B: POPE_KNOB_LEVEL_BLOCKS
     int house_blocks = (N + 255) / 256;                              // the commit of the previous level: one thread per node
     if (house_blocks > 1024) house_blocks = 1024;                    // (+ the clears: rows that span chunks, the live table)
+    cp.first_block = expand_blocks + house_blocks;                   // the copy role's blocks come last: dispatched behind the BFS roles
+    cp.blocks = (int)((cp.piece_end - cp.piece_begin + LEVEL_COPY_BLOCK_PIECES - 1) / LEVEL_COPY_BLOCK_PIECES);
+    const int gx = cp.first_block + cp.blocks;
     profile_mark(stream, level, 0);
     const int mode = g_live_mode >= 0 ? g_live_mode : (live_words <= LIVE_MAX_NODES / 32 ? 1 : 2);
     if (mode == 1 && live_words <= LIVE_MAX_NODES / 32)
-        hipLaunchKernelGGL((k_bfs_level<WT, 1>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256),
+        hipLaunchKernelGGL((k_bfs_level<WT, 1>), dim3(gx, Wp / WT), dim3(256),
                            align_up((size_t)live_words * sizeof(unsigned), 16), stream, erow, col, E, N, Wp, front, seen, acc, idle, hop_planes,
-                           plane_elems, level, ctl, aux, expand_blocks, live, live_acc, live_idle, live_words, g_level_variant);
+                           plane_elems, level, ctl, aux, expand_blocks, live, live_acc, live_idle, live_words, g_level_variant, cp);
     else if (mode == 2)
-        hipLaunchKernelGGL((k_bfs_level<WT, 2>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow,
+        hipLaunchKernelGGL((k_bfs_level<WT, 2>), dim3(gx, Wp / WT), dim3(256), 0, stream, erow,
                            col, E, N, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
-                           live_acc, live_idle, live_words, g_level_variant);
+                           live_acc, live_idle, live_words, g_level_variant, cp);
     else
-        hipLaunchKernelGGL((k_bfs_level<WT, 0>), dim3(expand_blocks + house_blocks, Wp / WT), dim3(256), 0, stream, erow,
+        hipLaunchKernelGGL((k_bfs_level<WT, 0>), dim3(gx, Wp / WT), dim3(256), 0, stream, erow,
                            col, E, N, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
-                           live_acc, live_idle, live_words, g_level_variant);
+                           live_acc, live_idle, live_words, g_level_variant, cp);
     profile_mark(stream, level, 1);
 }
 
@@ -1289,8 +1345,37 @@ static int bfs_enqueue_init(const Bfs &b, const int64_t *anchors_host, hipStream
     return bfs_enqueue_seed(b, anchors_host, stream);
 }
 
+// Which rows of x the level launches of one pope_geodesic_run copy (LevelCopy): launch l takes rows [cut[l - 1], cut[l]).
+struct CopyPlan {
+    const float *x = nullptr;
+    float *out = nullptr;
+    unsigned F4 = 0, opitch4 = 0;
+    int cut[LEVEL_COPY_SLOTS] = {};
+    int levels = 0;                     // launches 1 .. levels carry a slice
+    int rows() const { return cut[levels]; }
+};
+
+// out[:, :F] = x in 16-byte pieces with 32-bit piece indices, and a finalise kernel that can start at a row of its choice.
+static bool level_copy_eligible(const float *x, int32_t F, const float *out, int64_t out_cols, int64_t N, int32_t K) {
+    return x && out && F > 0 && (F & 3) == 0 && (K & 3) == 0 && (out_cols & 3) == 0 && aligned16(x) && aligned16(out) &&
+           (uint64_t)N * (uint64_t)(F / 4) < (1ull << 32);
+}
+
+static CopyPlan make_copy_plan(const float *x, int32_t F, float *out, int64_t out_cols, int64_t N, int launches) {
+    CopyPlan p;
+    p.x = x; p.out = out; p.F4 = (unsigned)F / 4; p.opitch4 = (unsigned)(out_cols / 4);
+    p.levels = launches < LEVEL_COPY_SLOTS - 1 ? launches : LEVEL_COPY_SLOTS - 1;
+    int64_t acc = 0;                                                 // per mille so far
+    for (int l = 1; l <= p.levels; ++l) {
+        acc += g_level_copy_permille[l];
+        if (acc > 1000) acc = 1000;
+        p.cut[l] = (int)(N * acc / 1000);
+    }
+    return p;
+}
+
 // Enqueue levels [level, stop) (clipped to what the hop-bit capacity can represent); returns the next level.
-static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t stream) {
+static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t stream, const CopyPlan *plan = nullptr) {
     const int first = level;
     profile_mark(stream, 0, 0, true);                                // span mode: one event pair around the whole run
     for (; level < stop; ++level) {
@@ -1306,9 +1391,15 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
         u64 *idle = b.front[(level + 1) % 3];                    // next level's accumulator: rows spanning chunks cleared now
         const unsigned *lp = b.live[(level - 1) % 3];
         unsigned *ln = b.live[level % 3], *li = b.live[(level + 1) % 3];
-        if (b.Wp == 1)      launch_level<1>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
-        else if (b.Wp == 2) launch_level<2>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
-        else                launch_level<4>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, stream);
+        LevelCopy cp;
+        if (plan && level <= plan->levels && plan->cut[level] > plan->cut[level - 1]) {
+            cp.x = plan->x; cp.out = plan->out; cp.F4 = plan->F4; cp.opitch4 = plan->opitch4;
+            cp.piece_begin = (unsigned)plan->cut[level - 1] * plan->F4;
+            cp.piece_end = (unsigned)plan->cut[level] * plan->F4;
+        }
+        if (b.Wp == 1)      launch_level<1>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, cp, stream);
+        else if (b.Wp == 2) launch_level<2>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, cp, stream);
+        else                launch_level<4>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, cp, stream);
     }
     profile_mark(stream, 0, 1, true);
     if (g_profile.enabled && g_profile.span_only && !g_profile.level.empty())
@@ -1509,9 +1600,9 @@ static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_ho
         return POPE_OK;
     }
     if (vec)
-        hipLaunchKernelGGL(k_finalize<true>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, aux, report, ticket);
+        hipLaunchKernelGGL(k_finalize<true>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, aux, report, ticket, x_row_begin);
     else
-        hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, aux, report, ticket);
+        hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, aux, report, ticket, x_row_begin);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
@@ -1588,41 +1679,17 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     if ((rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, (uint64_t *)planes, plane_capacity,
                         ws + L.bfs_scratch, L.total - L.bfs_scratch))) return rc;
     const int window = speculative_window(N, E, K);
-    // POPE_KNOB_COPY_GATE experiment (round 3): part of out[:, :F] = x beside the phases of the step that leave the memory system idle --
-    // `early` % of the rows on a side stream from here until level 3 starts (the clear, the CSR build and the first two, sparse
-    // levels), `late` % beside the last three levels -- gated by events so that nothing of it runs beside the dense levels,
-    // which the copy was measured to slow down 2x; the finalise kernel copies the rest.
-    const int early_pct = g_copy_gate / 1000, late_pct = g_copy_gate % 1000;
-    const bool gate = g_copy_gate > 0 && out && x && F > 0 && window >= 6 && early_pct + late_pct <= 100 &&
-                      SideCopy::eligible(x, F, out, out_cols, N);
-    const int64_t rA = gate ? N * early_pct / 100 : 0, rB = gate ? N * (early_pct + late_pct) / 100 : 0;
-    SideLanes early;
-    if (rA > 0) {
-        if ((rc = early.fork(stream, 1))) return rc;
-        if ((rc = enqueue_copy_features(x, F, out, out_cols, rA, early.lane(0)))) return rc;
-    }
+    // The level launches copy part of out[:, :F] = x in their copy role (LevelCopy); the finalise kernel copies the rest.
+    CopyPlan plan;
+    if (out && level_copy_eligible(x, F, out, out_cols, N, K)) plan = make_copy_plan(x, F, out, out_cols, N, window);
     bfs_enqueue_clear(b, aux, stream);                    // BFS state and the CSR status header in one launch
     memcpy(b.slot->anchors, anchors_host, (size_t)K * sizeof(long long));     // this call's pinned, device-mapped slot: read in place
     SeedArgs seed;
     seed.anchors = b.slot->anchors_dev; seed.K = K; seed.Wp = b.Wp; seed.seen = b.seen; seed.front = b.front[0]; seed.live = b.live[0];
     rc = csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, seed, stream);
     if (rc) return rc;
-    int level = 1, x_row_begin = 0;
-    if (gate) {
-        level = bfs_enqueue_levels(b, level, 3, stream);
-        if (rA > 0 && (rc = early.join(stream))) return rc;
-        level = bfs_enqueue_levels(b, level, 1 + window - 3, stream);
-        SideLanes late;
-        if (rB > rA) {
-            if ((rc = late.fork(stream, 1))) return rc;
-            if ((rc = enqueue_copy_features(x + (size_t)rA * F, F, out + (size_t)rA * out_cols, out_cols, rB - rA, late.lane(0)))) return rc;
-        }
-        level = bfs_enqueue_levels(b, level, 1 + window, stream);
-        if (rB > rA && (rc = late.join(stream))) return rc;
-        x_row_begin = (int)rB;
-    } else {
-        level = bfs_enqueue_levels(b, 1, 1 + window, stream);
-    }
+    int level = bfs_enqueue_levels(b, 1, 1 + window, stream, plan.levels ? &plan : nullptr);
+    const int x_row_begin = plan.levels ? plan.cut[std::min(level - 1, plan.levels)] : 0;      // rows the launches really took
     // The finalise kernel writes the verdict into the pinned report when it starts: no report launch, and the host
     // returns as soon as the BFS is known to be complete -- `out` is finished in stream order.
     int ticket = 0;
@@ -1654,7 +1721,8 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
         level = bfs_enqueue_levels(b, level, level + LEVEL_BATCH, stream);
         if ((rc = bfs_poll(b, level, &last_active, &done, stream))) return rc;
     }
-    if (out && (rc = finalize_enqueue(planes, hop_bits(last_active), nullptr, N, K, x, F, out, out_cols, 0, stream))) return rc;
+    if (out && (rc = finalize_enqueue(planes, hop_bits(last_active), nullptr, N, K, x, F, out, out_cols, 0, stream, 1, 0, nullptr, nullptr, 0,
+                                      x_row_begin))) return rc;
     guard.quiescent = true;                               // every poll of this path synchronised the stream; the late finalise kernel does not touch the slot
     remember_depth(N, E, K, last_active, window < LEVEL_BATCH);
     if (max_hop_host) *max_hop_host = last_active;

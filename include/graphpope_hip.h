@@ -86,7 +86,7 @@ int pope_require_device(int32_t *cu_count_host);
 #define POPE_KNOB_FAIL_HOST_REGISTER 7  /* host -> host boundary, tests of the fallbacks, bit mask: 1 = every hipHostRegister is refused, 2 = behave as if the pinned ring's hipHostMalloc had been refused (float columns through registration / staging) */
 #define POPE_KNOB_SAGE_LANES        8   /* sage_conv_backward: 0 (default) one stream; 1 bias gradient and grad_x chain on side streams beside the weight gradients (measured slower) */
 #define POPE_KNOB_LEVEL_VARIANT     9   /* level kernel experiments, bit mask: 1 non-temporal index streams, 2 XCD-contiguous chunk ranges, 4 non-temporal reachability loads */
-#define POPE_KNOB_COPY_GATE         10  /* pope_geodesic_run experiment: early% * 1000 + late% of the feature rows copied on a side stream beside the sparse phases (0 = off) */
+#define POPE_KNOB_LEVEL_COPY        10  /* pope_geodesic_run: per mille of the feature rows that level launch l copies in its copy role beside the BFS blocks; value = l << 16 | per mille, l = 0 sets every launch */
 #define POPE_KNOB_HOST_RESULT_MODE  11  /* host -> host boundary: 0 (default) embedding columns through a reused pinned ring, 1 register the result's own pages for the DMA */
 #define POPE_KNOB_GEMM_SPLIT_BF16   12  /* SAGE forward projection, OPT-IN (default 0 = exact f32 products): 1 = every f32 operand as three bf16 terms, six bf16 MFMAs per product, f32 accumulate -- same accuracy class (~2^-24), not the same bits */
 #define POPE_KNOB_GATHER_LDS_PAD_KB 13  /* k_gather_mean: KB of LDS reserved per block (0): an occupancy experiment, 40 -> 16 waves per CU, 80 -> 8 */

@@ -64,7 +64,7 @@ def _event():
 def pope_step(x, ei, n, anchors, world):
     """One full geodesic GraphPOPE pass on the device; returns the [N, F+K] tensor."""
     if world == 1:
-        return engine.geodesic_run(x, ei, n, anchors, reuse_workspace=True)[0]
+        return engine.geodesic_run(x if x.shape[1] else None, ei, n, anchors, reuse_workspace=True)[0]
     csr = engine.build_csr(ei, n, defer_check=True)
     return pdist.sharded_geodesic_features(x, n, anchors, None,
                                            bfs_fn=lambda a: engine.bfs(csr, a),
@@ -141,10 +141,8 @@ def cpu_baselines_before_gpu(ei, n, anchors, sample_nodes):
             per_pair = tm["pool_s"] / pairs
             res[key] = {
                 "value": pairs / tm["pool_s"], "unit": "embeddings/s", "cores": w, "kind": "port",
-                "sample": f"{emb.shape[0]} random nodes (RandomState(0)) x {len(anchors)} anchors = {pairs} pairs of the same "
-                          f"Flickr-shaped graph: nx.shortest_path per pair under multiprocessing.Pool({w}), float-indexed node "
-                          f"slices, the DiGraph pickled to every job (utils.py:64-107), {tm['pool_s']:.1f} s; "
-                          f"DiGraph build (utils.py:121) {tm['graph_build_s']:.1f} s not included",
+                "sample": f"{emb.shape[0]} random nodes x {len(anchors)} anchors = {pairs} pairs of the same graph, nx.shortest_path per pair "
+                          f"under multiprocessing.Pool({w}) (utils.py:64-107), {tm['pool_s']:.1f} s (+ DiGraph build {tm['graph_build_s']:.1f} s, not counted)",
                 "graph_build_s": tm["graph_build_s"], "pool_s": tm["pool_s"],
                 "extrapolated_full_graph_s": tm["graph_build_s"] + per_pair * n * len(anchors),
             }
@@ -767,6 +765,24 @@ def pmc_traffic():
     return None, None
 
 
+PROSE_KEYS = ("what", "note", "how", "value_note", "bound_note", "layer0_forward_note", "traffic_source", "model", "scope", "all_calls_ms",
+              "last_call_assembly_phases_ms")
+
+
+def compact(obj, depth=0):
+    """The JSON line without its explanatory strings (--verbose keeps them; DESIGN.md says what every figure is): the driver's
+    record keeps only the tail of stdout, so the line has to stay well under 8 KB."""
+    if isinstance(obj, dict):
+        return {k: compact(v, depth + 1) for k, v in obj.items() if k not in PROSE_KEYS}
+    if isinstance(obj, list):
+        return [compact(v, depth + 1) for v in obj]
+    if isinstance(obj, float):
+        return float("%.6g" % obj)
+    if isinstance(obj, str) and len(obj) > 260:
+        return obj[:257] + "..."
+    return obj
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -776,6 +792,11 @@ def main():
     ap.add_argument("--no-sage", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the boundary / pairwise / config3 / config4 legs")
     ap.add_argument("--cpu-sample-nodes", type=int, default=2400, help="nodes of the Baseline A sample (x 256 anchors)")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 3, 4),
+                    help="BASELINE.json configs[i]: 1 = Flickr-shaped, 256 anchors PER GPU (weak scaling, the default and the only one "
+                         "with the extra legs); 3 = Flickr-shaped, 1 024 anchors in all, sharded over the ranks (128 per GPU at 8; strong "
+                         "scaling); 4 = R-MAT scale 22, 512 anchors in all (64 per GPU at 8), no features (strong scaling)")
+    ap.add_argument("--verbose", action="store_true", help="keep the explanatory strings (what / note / how) in the JSON line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -783,14 +804,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
-    ei_np, n = synth.flickr_like(seed=1)
-    k_total = K_PER_GPU * world
+    cfg = args.config
+    if cfg == 4:
+        ei_np, n = synth.rmat(22, edge_factor=8, seed=1)
+        k_total, feat = 512, 0
+    else:
+        ei_np, n = synth.flickr_like(seed=1)
+        k_total, feat = (K_PER_GPU * world, F) if cfg == 1 else (1024, F)
+    k_rank = -(-k_total // world)                                # anchors of one rank's shard (distributed.shard_size)
     anchors = synth.seeded_anchors(n, k_total, 42)
     e = ei_np.shape[1]
 
     # Baseline A forks a multiprocessing.Pool like the reference does: run it before this process touches the GPU
     base, want_hops = {}, None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and cfg == 1 and not args.no_cpu_baseline:
         base, want_hops = cpu_baselines_before_gpu(ei_np, n, anchors, args.cpu_sample_nodes)
 
     backend = None
@@ -806,8 +833,10 @@ def main():
             dist.init_process_group(backend)
     dev = engine.require_gpu()
 
-    x = torch.rand((n, F), device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    x = torch.rand((n, feat), device=dev, generator=torch.Generator(device=dev).manual_seed(0))
     ei = torch.as_tensor(ei_np, device=dev)
+    if cfg == 4:
+        args.steps, args.warmup = min(args.steps, 10), min(args.warmup, 2)       # a step is tens of milliseconds and 8.6 GB of output
 
     def barrier():
         if world > 1:
@@ -836,18 +865,18 @@ def main():
     if world > 1:
         # every rank's own achieved rate and what it put on the wire, gathered so that a SCALE line checks itself: the
         # speculative path all-gathers planes[0:5] (reachability + 4 hop-bit planes) of its K_PER_GPU anchors
-        wpr = _lib.load().pope_words(K_PER_GPU)
+        wpr = _lib.load().pope_words(k_rank)
         sent = 5 * n * wpr * 8
         mine = torch.tensor([elapsed_local, float(sent)], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        src_rank = K_PER_GPU * (4.0 * e + 4.0 * (n + 1) + 4.0 * n)
+        src_rank = k_rank * (4.0 * e + 4.0 * (n + 1) + 4.0 * n)
         per_rank = [{"rank": i, "ms_per_step": float(t[0]) / args.steps * 1e3, "achieved_gbs_per_source_model": src_rank / (float(t[0]) / args.steps) / 1e9,
                      "all_gather_bytes_sent_per_step": int(t[1]), "all_gather_bytes_received_per_step": int(t[1]) * (world - 1)} for i, t in enumerate(allr)]
     # the same step when the library's depth hint misses (what a process's FIRST call on a graph pays: 12 speculative level
     # launches instead of the 10 this graph needs): a call with another anchor count in between invalidates the hint
     hint_miss_ms = None
-    if world == 1:
+    if world == 1 and cfg == 1:
         tm = []
         for _ in range(5):
             engine.geodesic_run(x, ei, n, anchors[:192], reuse_workspace=True)
@@ -864,11 +893,15 @@ def main():
             "metric": "POPE embeddings/sec (nodes x anchors) + SAGE nodes/sec, Flickr 256 anchors",
             "value": n * k_total / (elapsed / args.steps), "unit": "embeddings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "higher_is_better": True, "scaling": "weak" if cfg == 1 else "strong", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "inputs resident in HBM (edge_index, x) -> [N, F+K] f32 in HBM; configs[1]: flickr-shaped "
-                                   "geodesic-stochastic, N=89250 E=%d F=500, %d anchors per GPU (np.random seed 42)" % (e, K_PER_GPU),
-                       "anchors_total": k_total,
+            "config": {"workload": {1: "configs[1]: flickr-shaped geodesic-stochastic, N=%d E=%d F=500, 256 anchors PER GPU (np.random seed 42); "
+                                       "inputs resident in HBM (edge_index, x) -> [N, F+K] f32 in HBM on every rank" % (n, e),
+                                    3: "configs[3]: flickr-shaped geodesic, N=%d E=%d F=500, 1024 anchors IN ALL (np.random seed 42, 1020 distinct) "
+                                       "sharded %d per rank; inputs resident in HBM -> [N, 1524] f32 in HBM on every rank" % (n, e, k_rank),
+                                    4: "configs[4]: R-MAT scale 22 (a,b,c,d)=(.57,.19,.19,.05), N=%d E=%d CSR slots, 512 anchors IN ALL (np.random "
+                                       "seed 42) sharded %d per rank, no features; edge_index resident in HBM -> [N, 512] f32 in HBM on every rank" % (n, e, k_rank)}[cfg],
+                       "baseline_config": cfg, "anchors_total": k_total, "anchors_per_rank": k_rank,
                        "parallelism": f"anchor-shard x{world} + RCCL all-gather of hop planes" if world > 1 else "single GPU"},
         }
         result["value_note"] = ("steady state of repeated identical calls, inputs and output resident in HBM: the call sizes its run of "
@@ -884,7 +917,7 @@ def main():
         # dominant kernel by total time: k_bfs_level (one launch per level), timed on this rank's own anchor shard with HIP
         # events on the launch stream.  Algorithmic bytes of ONE launch: per CSR slot erow + col (8 B) + the
         # neighbour's frontier words (8W B); per node seen (read) + frontier (write) (16W B).  W = 4 words for 256 anchors.
-        exp_ms, launches, active_levels, hp = level_kernel_times(ei, n, anchors[:K_PER_GPU], reps=10)
+        exp_ms, launches, active_levels, hp = level_kernel_times(ei, n, anchors[:k_rank], reps=10 if cfg != 4 else 3)
         wp = hp.planes.shape[2]
         dense_bytes = e * (8.0 + 8.0 * wp) + n * 16.0 * wp           # one level that does work
         exp_bytes = dense_bytes * active_levels / launches            # per launch, the early-exit launches included
@@ -892,8 +925,8 @@ def main():
         pmc, pmc_src = pmc_traffic()
         pmc = pmc or {}
         result["roofline"] = {
-            "kernel": "k_bfs_level<4>", "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": exp_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch"),
+            "kernel": "k_bfs_level<%d>" % min(wp, 4), "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": exp_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch") if cfg == 1 else None,
             "traffic_source": (pmc_src + " (rocprofv3 --pmc passes of this command, collected in a separate run: not measured live)") if pmc_src else None,
             "algorithmic_bytes_per_launch": exp_bytes, "avg_launch_ms": exp_ms, "launches_per_step": launches,
             "active_levels": active_levels, "algorithmic_bytes_per_active_level": dense_bytes,
@@ -908,11 +941,11 @@ def main():
             "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": geo_gbs / (HBM_PEAK_GBS * world), "algorithmic_bytes": src_bytes,
             "note": "SURVEY 8d per-source byte model (every anchor reads the CSR once and writes one f32 column); the "
                     "bit-parallel BFS shares each CSR pass between 64 anchors per word, so this is a model, not traffic"}
-        floor_bytes = 16.0 * e + 4.0 * n * F + 4.0 * n * (F + K_PER_GPU)    # edge list in, x in, [N, F+K] out: each once
+        floor_bytes = 16.0 * e + 4.0 * n * feat + 4.0 * n * (feat + k_total)    # edge list in, x in, [N, F+K] out: each once (per rank)
         result["compulsory_floor"] = {"bytes": floor_bytes, "ms_at_6.29TBs": floor_bytes / 6.29e12 * 1e3,
                                       "step_over_floor": ms / (floor_bytes / 6.29e12 * 1e3) if world == 1 else None}
         result["level_kernel_ms"] = {"avg": exp_ms, "active_levels": active_levels}
-    if world == 1:
+    if world == 1 and cfg == 1:
         # per-phase device time with HIP events on the launch stream, separate from the wall-clock loop above
         timers = {"csr": [], "bfs": [], "finalize": []}
         for _ in range(max(10, min(args.steps, 50))):
@@ -959,7 +992,27 @@ def main():
             torch.cuda.empty_cache()
             result["config4"] = config4_leg(dev)
     if rank == 0:
-        print(json.dumps(result))
+        # the numbers that matter as top-level scalars, so that a record which only keeps scalars still carries them
+        sage = result.get("sage") or {}
+        if "ms_per_step" in sage:
+            result["sage_ms_per_step"] = sage["ms_per_step"]
+            result["sage_nodes_per_s"] = sage["nodes_per_s"]
+            result["sage_graph_replay_ms_per_step"] = sage.get("graph_replay", {}).get("ms_per_step")
+            result["sage_sampled_ms_per_step"] = sage.get("with_gpu_sampling", {}).get("ms_per_step")
+            result["sage_torch_gpu_baseline_ms_per_step"] = sage.get("torch_gpu_baseline", {}).get("ms_per_step")
+            result["sage_layer0_projection_ms"] = sage.get("layer0_projection", {}).get("ms")
+            result["sage_layer0_projection_vendor_ms"] = sage.get("layer0_projection", {}).get("vendor_library_ms")
+        if "host_to_host" in result:
+            result["host_to_host_first_call_ms"] = result["host_to_host"]["first_call_ms"]
+            result["host_to_host_repeat_call_ms"] = result["host_to_host"]["ms"]
+        if "pairwise" in result:
+            result["pairwise_ms_per_call"] = result["pairwise"].get("ms_per_call")
+            result["pairwise_embedding_only_ms"] = result["pairwise"].get("embedding_only_ms")
+        for key in ("config3", "config4"):
+            if key in result:
+                result[key + "_one_gpu_ms_per_step"] = result[key].get("ms_per_step")
+        line = json.dumps(result if args.verbose else compact(result))
+        print(line)
     if world > 1:
         barrier()                              # rank 0 measured its level kernel alone meanwhile: leave the group together
         dist.destroy_process_group()

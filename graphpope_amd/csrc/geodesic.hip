@@ -28,7 +28,9 @@ namespace pope {
 // ------------------------------------------------------------------------------------------------
 // CSR build
 // ------------------------------------------------------------------------------------------------
-enum { CSR_FLAG_BAD_INDEX = 1, CSR_FLAG_UNSORTED = 2 };
+enum { CSR_FLAG_BAD_INDEX = 1, CSR_FLAG_UNSORTED = 2, BFS_FLAG_TAIL_FAILED = 4 };
+constexpr int TAIL_GROUPS = 16;                // k_tail_finalize: groups of the two-stage barrier among its BFS blocks
+constexpr size_t CTL_BYTES = 4096;             // BfsCtl at the start of the BFS scratch
 enum { AUX_FLAGS = 2, AUX_HEADER = 16 };
 constexpr int SLOTS = 4;                      // CSR slots per lane in the BFS expand kernel
 constexpr int CHUNK_SHIFT = 8, CHUNK = 1 << CHUNK_SHIFT;   // slots per wave pass = 64 lanes x SLOTS
@@ -167,9 +169,13 @@ static size_t rowsort_temp_bytes(size_t E, size_t N) {
 // ------------------------------------------------------------------------------------------------
 // BFS
 // ------------------------------------------------------------------------------------------------
-struct BfsCtl {          // device control block at the start of the BFS scratch
+struct BfsCtl {          // device control block at the start of the BFS scratch (CTL_BYTES, zeroed by the first launch of a BFS)
     int last_active;     // highest level at which some (node, anchor) pair was newly reached
-    int pad[3];
+    int tail_done;       // k_tail_finalize: the ticket of the call once its BFS blocks are through (agent-scope release)
+    unsigned tail_top;   // k_tail_finalize: second stage of the barrier of its BFS blocks (groups that have arrived)
+    int tail_failed;     // k_tail_finalize: a bounded wait ran out (never expected; the host turns it into an error)
+    int pad[28];
+    unsigned tail_group[TAIL_GROUPS * 32];      // first stage: one counter per group of BFS blocks, 128 bytes apart
 };
 
 __device__ __forceinline__ bool bfs_over(const BfsCtl *ctl, const int *aux, int level) {
@@ -381,78 +387,50 @@ __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words
 // as well.  Beyond LIVE_MAX_NODES the table is read from global memory (LIVE = 2): there the frontier rows come from the
 // Infinity Cache or HBM while the table still sits in L2 -- R-MAT scale 22 runs 20 % faster with it than without.)
 // WT = words per tile (1, 2 or 4); blockIdx.y selects the tile of a node's W words.
-template <int WT, int LIVE>      // LIVE: 0 no table, 1 table staged in LDS, 2 table read from global memory (big graphs)
-__global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
-                                                   int E, int N, int Wp, const u64 *__restrict__ front,
-                                                   u64 *__restrict__ seen, u64 *__restrict__ acc,
-                                                   u64 *__restrict__ idle, u64 *__restrict__ hop_planes,
-                                                   size_t plane_elems, int level, BfsCtl *ctl, const int *aux,
-                                                   int expand_blocks, const unsigned *__restrict__ live,
-                                                   unsigned *__restrict__ live_acc, unsigned *__restrict__ live_idle,
-                                                   int live_words, int variant, const LevelCopy cp) {
-    if ((int)blockIdx.x >= cp.first_block) {                          // copy role: runs whether or not the BFS is over
-        if (blockIdx.y == 0) level_copy_role(cp);
-        return;
-    }
-    if (bfs_over(ctl, aux, level)) return;
-    const int lane = threadIdx.x & 63;
-    int woff = blockIdx.y * WT;                                    // housekeeping: tile = blockIdx.y
-    if ((int)blockIdx.x >= expand_blocks) {
-        // Housekeeping blocks (beside the expand waves, not on their critical path):
-        //  (1) clear, two levels ahead: the live table and the accumulator words of the rows that span chunks;
-        //  (2) COMMIT level - 1 for every node: a node whose frontier row is non-zero gained those anchors at level - 1
-        //      -> reachability plane and hop-bit planes.  The expand waves never commit: they mask with seen[v] | front[v],
-        //      which is the same whether this commit has landed or not (OR is idempotent), and their chain ends at the store
-        //      of the next frontier instead of a plane read-modify-write behind it.
-        const int n = (E + CHUNK - 1) >> CHUNK_SHIFT;              // one slot per chunk, -1 = no row continues into it
-        const int *mrows = aux + AUX_HEADER;
-        const int hb = cp.first_block - expand_blocks;
-        const int t0 = ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x, tstride = hb * blockDim.x;
-        if (LIVE && blockIdx.y == 0)
-            for (int i = t0; i < live_words; i += tstride) live_idle[i] = 0u;
-        Words<WT> zero;
+// Housekeeping share of one level (see k_bfs_level): thread t0 of tstride threads.  (1) clears two levels ahead -- the live
+// table (first_tile only) and the accumulator words of the rows that span chunks; (2) commits level - 1 for every node whose
+// frontier row is non-zero.
+template <int WT, int LIVE>
+__device__ __forceinline__ void level_housekeeping(int E, int N, int Wp, const u64 *__restrict__ front, u64 *__restrict__ seen,
+                                                   u64 *__restrict__ idle, u64 *__restrict__ hop_planes, size_t plane_elems, int level,
+                                                   const int *aux, const unsigned *__restrict__ live, unsigned *__restrict__ live_idle,
+                                                   int live_words, int t0, int tstride, int woff, bool first_tile) {
+    const int n = (E + CHUNK - 1) >> CHUNK_SHIFT;              // one slot per chunk, -1 = no row continues into it
+    const int *mrows = aux + AUX_HEADER;
+    if (LIVE && first_tile)
+        for (int i = t0; i < live_words; i += tstride) live_idle[i] = 0u;
+    Words<WT> zero;
 #pragma unroll
-        for (int i = 0; i < WT; ++i) zero.w[i] = 0;
-        if constexpr (LIVE == 0) {
-            // No live table (A/B mode): the commit below reads EVERY frontier row, so a row that no chunk writes (a node
-            // without out-edges) must not keep what the buffer held three levels ago: the whole buffer is cleared.
-            for (int v = t0; v < N; v += tstride) store_words<WT>(idle + (size_t)v * Wp + woff, zero);
-        } else {
-            for (int i = t0; i < n; i += tstride) {
-                const int mv = mrows[i];
-                if (mv >= 0) store_words<WT>(idle + (size_t)mv * Wp + woff, zero);
-            }
+    for (int i = 0; i < WT; ++i) zero.w[i] = 0;
+    if constexpr (LIVE == 0) {
+        // No live table (A/B mode): the commit below reads EVERY frontier row, so a row that no chunk writes (a node
+        // without out-edges) must not keep what the buffer held three levels ago: the whole buffer is cleared.
+        for (int v = t0; v < N; v += tstride) store_words<WT>(idle + (size_t)v * Wp + woff, zero);
+    } else {
+        for (int i = t0; i < n; i += tstride) {
+            const int mv = mrows[i];
+            if (mv >= 0) store_words<WT>(idle + (size_t)mv * Wp + woff, zero);
         }
-        if (level > 1) {
-            for (int v = t0; v < N; v += tstride) {
-                if (LIVE && !((live[v >> 5] >> (v & 31)) & 1u)) continue;              // frontier row all zero: nothing gained
-                const size_t idx = (size_t)v * Wp + woff;
-                const Words<WT> fresh = load_words<WT>(front + idx);
-                if (any_bits<WT>(fresh))
-                    commit_words<WT>(fresh, load_words<WT>(seen + idx), idx, seen, hop_planes, plane_elems, level - 1);
-            }
+    }
+    if (level > 1) {
+        for (int v = t0; v < N; v += tstride) {
+            if (LIVE && !((live[v >> 5] >> (v & 31)) & 1u)) continue;              // frontier row all zero: nothing gained
+            const size_t idx = (size_t)v * Wp + woff;
+            const Words<WT> fresh = load_words<WT>(front + idx);
+            if (any_bits<WT>(fresh))
+                commit_words<WT>(fresh, load_words<WT>(seen + idx), idx, seen, hop_planes, plane_elems, level - 1);
         }
-        return;
     }
-    // Expand waves: with more than one word tile per node (K > 256) the tiles of ONE chunk go to adjacent waves of the
-    // same block, so the 128-byte frontier line that all of them gather from is fetched from L2 once and served to the
-    // others by the CU's L1 (one tile per launch row of blocks fetched it once per tile, from different CUs).
-    const int tiles = gridDim.y;
-    // POPE_KNOB_LEVEL_VARIANT bit 1: blocks are dealt round-robin over the 8 XCDs (block b and b + 8 share one); give every
-    // XCD a CONTIGUOUS range of chunks, so that the seen / accumulator rows it touches are one eighth of those arrays.
-    int bx = blockIdx.x;
-    if (variant & 2) {
-        const int q = expand_blocks >> 3, r = expand_blocks & 7, x = bx & 7;
-        bx = x * q + min(x, r) + (bx >> 3);
-    }
-    const int wid = ((blockIdx.y * expand_blocks + bx) * blockDim.x + threadIdx.x) >> 6;
-    const int wave = wid / tiles;                                  // which stream of chunks this wave walks
-    woff = (wid - wave * tiles) * WT;
-    const int nwaves = (expand_blocks * blockDim.x) >> 6;
-    const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
-    // The first chunk's slot loads are issued before the live table is staged: they fly while LDS fills.
-    int4 vr = make_int4(-1, -1, -1, -1), ur = make_int4(0, 0, 0, 0);
-    // bit 0: the index streams are read once per launch: non-temporal, so that they do not evict the frontier from L2
+}
+
+// Expand share of one level (see k_bfs_level): this wave walks chunks wave, wave + nwaves, ... of tile `woff`; (vr, ur) hold the
+// first chunk's slots, loaded by the caller before it staged the live table.  Returns whether this lane emitted a non-zero row.
+template <int WT, int LIVE>
+__device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const int *__restrict__ col, int E, int Wp,
+                                             const u64 *__restrict__ front, u64 *__restrict__ seen, u64 *__restrict__ acc,
+                                             const unsigned *__restrict__ live, unsigned *__restrict__ live_acc,
+                                             const unsigned *live_lds, int variant, int level, int lane, int wave, int nwaves, int nchunks,
+                                             int woff, int tiles, int4 vr, int4 ur) {
     auto load_idx = [&](const int *p) {
         if (variant & 1) {
             const i32x4v t = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(p));
@@ -460,17 +438,6 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
         }
         return *reinterpret_cast<const int4 *>(p);
     };
-    if (wave < nchunks && wave * CHUNK + lane * SLOTS < E) {
-        vr = load_idx(erow + wave * CHUNK + lane * SLOTS);
-        ur = load_idx(col + wave * CHUNK + lane * SLOTS);
-    }
-    extern __shared__ uint4 live_lds4[];
-    const unsigned *live_lds = reinterpret_cast<const unsigned *>(live_lds4);
-    if constexpr (LIVE == 1) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(live);                   // tables are padded to 256 bytes
-        for (int i = threadIdx.x; i < (live_words + 3) / 4; i += blockDim.x) live_lds4[i] = src[i];
-        __syncthreads();
-    }
     bool found = false;
     STAMP(0);
     for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
@@ -591,7 +558,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
                    n3 = e3 && any_bits<WT>(c3) != 0;
         // With the live table an all-zero row need not be written: nobody gathers a row whose live bit is clear.
         // (Several tiles share one live bit per node: then zeros are written too, so a live row is exact in every tile.)
-        const bool dense = !LIVE || gridDim.y > 1;
+        const bool dense = !LIVE || tiles > 1;
         if (e0 && (n0 || dense)) { if (x0) piece(i0, c0); else store_words<WT>(acc + i0, c0); }
         if (e1 && (n1 || dense)) { if (x1) piece(i1, c1); else store_words<WT>(acc + i1, c1); }
         if (e2 && (n2 || dense)) { if (x2) piece(i2, c2); else store_words<WT>(acc + i2, c2); }
@@ -629,6 +596,76 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
         STAMP(5);
     }
     STAMP(6);
+    return found;
+}
+
+template <int WT, int LIVE>      // LIVE: 0 no table, 1 table staged in LDS, 2 table read from global memory (big graphs)
+__global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
+                                                   int E, int N, int Wp, const u64 *__restrict__ front,
+                                                   u64 *__restrict__ seen, u64 *__restrict__ acc,
+                                                   u64 *__restrict__ idle, u64 *__restrict__ hop_planes,
+                                                   size_t plane_elems, int level, BfsCtl *ctl, const int *aux,
+                                                   int expand_blocks, const unsigned *__restrict__ live,
+                                                   unsigned *__restrict__ live_acc, unsigned *__restrict__ live_idle,
+                                                   int live_words, int variant, const LevelCopy cp) {
+    if ((int)blockIdx.x >= cp.first_block) {                          // copy role: runs whether or not the BFS is over
+        if (blockIdx.y == 0) level_copy_role(cp);
+        return;
+    }
+    if (bfs_over(ctl, aux, level)) return;
+    const int lane = threadIdx.x & 63;
+    int woff = blockIdx.y * WT;                                    // housekeeping: tile = blockIdx.y
+    if ((int)blockIdx.x >= expand_blocks) {
+        // Housekeeping blocks (beside the expand waves, not on their critical path):
+        //  (1) clear, two levels ahead: the live table and the accumulator words of the rows that span chunks;
+        //  (2) COMMIT level - 1 for every node: a node whose frontier row is non-zero gained those anchors at level - 1
+        //      -> reachability plane and hop-bit planes.  The expand waves never commit: they mask with seen[v] | front[v],
+        //      which is the same whether this commit has landed or not (OR is idempotent), and their chain ends at the store
+        //      of the next frontier instead of a plane read-modify-write behind it.
+        const int hb = cp.first_block - expand_blocks;
+        level_housekeeping<WT, LIVE>(E, N, Wp, front, seen, idle, hop_planes, plane_elems, level, aux, live, live_idle, live_words,
+                                     ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x, hb * blockDim.x, woff, blockIdx.y == 0);
+        return;
+    }
+    // Expand waves: with more than one word tile per node (K > 256) the tiles of ONE chunk go to adjacent waves of the
+    // same block, so the 128-byte frontier line that all of them gather from is fetched from L2 once and served to the
+    // others by the CU's L1 (one tile per launch row of blocks fetched it once per tile, from different CUs).
+    const int tiles = gridDim.y;
+    // POPE_KNOB_LEVEL_VARIANT bit 1: blocks are dealt round-robin over the 8 XCDs (block b and b + 8 share one); give every
+    // XCD a CONTIGUOUS range of chunks, so that the seen / accumulator rows it touches are one eighth of those arrays.
+    int bx = blockIdx.x;
+    if (variant & 2) {
+        const int q = expand_blocks >> 3, r = expand_blocks & 7, x = bx & 7;
+        bx = x * q + min(x, r) + (bx >> 3);
+    }
+    const int wid = ((blockIdx.y * expand_blocks + bx) * blockDim.x + threadIdx.x) >> 6;
+    const int wave = wid / tiles;                                  // which stream of chunks this wave walks
+    woff = (wid - wave * tiles) * WT;
+    const int nwaves = (expand_blocks * blockDim.x) >> 6;
+    const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
+    // The first chunk's slot loads are issued before the live table is staged: they fly while LDS fills.
+    int4 vr = make_int4(-1, -1, -1, -1), ur = make_int4(0, 0, 0, 0);
+    // bit 0: the index streams are read once per launch: non-temporal, so that they do not evict the frontier from L2
+    auto load_idx = [&](const int *p) {
+        if (variant & 1) {
+            const i32x4v t = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(p));
+            return make_int4(t.x, t.y, t.z, t.w);
+        }
+        return *reinterpret_cast<const int4 *>(p);
+    };
+    if (wave < nchunks && wave * CHUNK + lane * SLOTS < E) {
+        vr = load_idx(erow + wave * CHUNK + lane * SLOTS);
+        ur = load_idx(col + wave * CHUNK + lane * SLOTS);
+    }
+    extern __shared__ uint4 live_lds4[];
+    const unsigned *live_lds = reinterpret_cast<const unsigned *>(live_lds4);
+    if constexpr (LIVE == 1) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(live);                   // tables are padded to 256 bytes
+        for (int i = threadIdx.x; i < (live_words + 3) / 4; i += blockDim.x) live_lds4[i] = src[i];
+        __syncthreads();
+    }
+    const bool found = level_expand<WT, LIVE>(erow, col, E, Wp, front, seen, acc, live, live_acc, live_lds, variant, level, lane, wave, nwaves,
+                                              nchunks, woff, tiles, vr, ur);
     if (__any(found) && lane == 0) raise_level(ctl, level);
 }
 
@@ -776,6 +813,199 @@ __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ p
             r.w = (reach & 8u) ? inv[h3] : 0.0f;
             if (MODE == 1) __builtin_nontemporal_store(r, erow + q);
             else erow[q] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The sparse LAST levels of the BFS and the finalise kernel in ONE launch (round 4)
+// ------------------------------------------------------------------------------------------------
+// On the Flickr-shaped graph the last four level launches touch 3 174, 64, 1 and 0 nodes and still cost a kernel boundary
+// (~3.3 us) plus a pass over the index streams each (27 us of the step), with the whole chip waiting; the finalise kernel
+// behind them is a 100 us stream whose feature copy depends on nothing the BFS computes.  k_tail_finalize runs both at once:
+//   * blocks 0 .. bfs_blocks-1 (dispatched first, so they are resident from the start) run levels first_level, first_level+1,
+//     ... with the SAME per-level code as k_bfs_level (level_housekeeping + level_expand over their share of the chunks) and a
+//     barrier among themselves between levels -- two stages of agent-scope counters in the control block, the arrival a
+//     release, the departure an acquire -- until a level finds nothing (the launch after the last productive level commits
+//     that level, as in k_bfs_level) or level_stop is reached (hop planes are only cleared for levels < 16: a deeper graph
+//     answers "not done" and the host continues with level launches);
+//   * block 0 then publishes the verdict (pinned report + ticket for the host, ctl->tail_done for the device);
+//   * every other block copies its share of x's rows meanwhile (16 pieces of 16 bytes in flight per lane), waits for
+//     tail_done, and expands its share of the planes into the K embedding columns (k_finalize_fast's arithmetic).
+// Every wait is bounded by the 100 MHz real-time counter (TAIL_WAIT_TICKS): a wait that runs out sets ctl->tail_failed and
+// the role moves on, so the grid always drains; the host reports the flag as an error.
+constexpr unsigned long long TAIL_WAIT_TICKS = 200000000ull;        // 2 s
+
+struct TailArgs {
+    const int *erow, *col;
+    int E, N, Wp;
+    u64 *front[3];
+    unsigned *live[3];
+    int live_words;
+    u64 *seen, *hop_planes;
+    size_t plane_elems;
+    BfsCtl *ctl;
+    const int *aux;
+    int first_level, level_stop, bfs_blocks, variant;
+    int K, F;
+    const float *x;
+    float *out;
+    long long out_cols;
+    int x_row_begin;
+    int *report;
+    int ticket;
+};
+
+__device__ __forceinline__ bool tail_barrier(BfsCtl *ctl, int B, unsigned episode) {
+    __shared__ int ok_s;
+    __syncthreads();                                   // every store of this block has been issued and waited for
+    if (threadIdx.x == 0) {
+        const int G = B < TAIL_GROUPS ? B : TAIL_GROUPS, g = (int)blockIdx.x % G;
+        const unsigned members = (unsigned)((B - g + G - 1) / G);
+        __threadfence();
+        const unsigned old = __hip_atomic_fetch_add(&ctl->tail_group[g * 32], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == members * episode) __hip_atomic_fetch_add(&ctl->tail_top, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int ok = 1;
+        while (__hip_atomic_load(&ctl->tail_top, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G * episode) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > TAIL_WAIT_TICKS) { ok = 0; break; }
+        }
+        __threadfence();
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+template <int WT, int LIVE>
+__global__ __launch_bounds__(256) void k_tail_finalize(const TailArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int B = a.bfs_blocks;
+    extern __shared__ uint4 live_lds4[];
+    if ((int)blockIdx.x < B) {
+        // ---- BFS role ----
+        BfsCtl *ctl = a.ctl;
+        int failed = 0;
+        if (!bfs_over(ctl, a.aux, a.first_level)) {
+            const int wave = ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x) >> 6, nwaves = (B * (int)blockDim.x) >> 6;
+            const int nchunks = (a.E + CHUNK - 1) >> CHUNK_SHIFT;
+            unsigned episode = 0;
+            for (int level = a.first_level;; ++level) {
+                const u64 *front = a.front[(level - 1) % 3];
+                u64 *acc = a.front[level % 3], *idle = a.front[(level + 1) % 3];
+                const unsigned *live = a.live[(level - 1) % 3];
+                unsigned *live_acc = a.live[level % 3], *live_idle = a.live[(level + 1) % 3];
+                int4 vr = make_int4(-1, -1, -1, -1), ur = make_int4(0, 0, 0, 0);
+                if (wave < nchunks && wave * CHUNK + lane * SLOTS < a.E) {
+                    vr = *reinterpret_cast<const int4 *>(a.erow + wave * CHUNK + lane * SLOTS);
+                    ur = *reinterpret_cast<const int4 *>(a.col + wave * CHUNK + lane * SLOTS);
+                }
+                if constexpr (LIVE == 1) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(live);
+                    for (int i = threadIdx.x; i < (a.live_words + 3) / 4; i += blockDim.x) live_lds4[i] = src[i];
+                    __syncthreads();
+                }
+                level_housekeeping<WT, LIVE>(a.E, a.N, a.Wp, front, a.seen, idle, a.hop_planes, a.plane_elems, level, a.aux, live, live_idle,
+                                             a.live_words, (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x, B * (int)blockDim.x, 0, true);
+                const bool found = level_expand<WT, LIVE>(a.erow, a.col, a.E, a.Wp, front, a.seen, acc, live, live_acc,
+                                                          reinterpret_cast<const unsigned *>(live_lds4), a.variant, level, lane, wave, nwaves, nchunks,
+                                                          0, 1, vr, ur);
+                if (__any(found) && lane == 0) raise_level(ctl, level);
+                if (!tail_barrier(ctl, B, ++episode)) { failed = 1; break; }
+                // every block reads the same word here: all raises of this level came before the barrier
+                const int la = __hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (la < level || level + 1 >= a.level_stop) break;
+            }
+        }
+        if (failed && threadIdx.x == 0) __hip_atomic_store(&ctl->tail_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            // The other BFS blocks are past their last barrier too (or this block ran out of patience): publish.
+            const int la = __hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int bad = failed | __hip_atomic_load(&ctl->tail_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.report) {
+                a.report[0] = la;
+                a.report[1] = a.aux[AUX_FLAGS] | (bad ? BFS_FLAG_TAIL_FAILED : 0);
+                __hip_atomic_store(&a.report[2], a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __hip_atomic_store(&ctl->tail_done, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // ---- copy + expansion role ----
+    const int nb = (int)gridDim.x - B, cb = (int)blockIdx.x - B;
+    const int w = threadIdx.x >> 6;
+    const unsigned F4 = (unsigned)a.F >> 2, opitch4 = (unsigned)(a.out_cols >> 2);
+    if (a.x && F4) {
+        const unsigned piece_begin = (unsigned)a.x_row_begin * F4, piece_end = (unsigned)a.N * F4;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.x);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(a.out);
+        for (unsigned batch = (unsigned)cb;; batch += (unsigned)nb) {
+            const unsigned long long base64 = (unsigned long long)piece_begin + ((unsigned long long)batch * 4u + w) * (64u * LEVEL_COPY_PIECES) + lane;
+            if ((unsigned long long)piece_begin + (unsigned long long)batch * LEVEL_COPY_BLOCK_PIECES >= piece_end) break;
+            if (base64 >= piece_end) continue;
+            const unsigned base = (unsigned)base64;
+            f32x4 v[LEVEL_COPY_PIECES];
+#pragma unroll
+            for (int j = 0; j < LEVEL_COPY_PIECES; ++j) {
+                const unsigned long long p = (unsigned long long)base + 64u * j;
+                if (p < piece_end) v[j] = __builtin_nontemporal_load(src + p);
+            }
+            unsigned row = base / F4, q = base - row * F4;
+#pragma unroll
+            for (int j = 0; j < LEVEL_COPY_PIECES; ++j) {
+                const unsigned long long p = (unsigned long long)base + 64u * j;
+                if (p < piece_end) dst[(size_t)row * opitch4 + q] = v[j];
+                q += 64u;
+                while (q >= F4) { q -= F4; ++row; }
+            }
+        }
+    }
+    // wait for the verdict of the BFS blocks
+    __shared__ int go_s;
+    __shared__ float inv[16];
+    if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int go = 1;
+        while (__hip_atomic_load(&a.ctl->tail_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.ticket) {
+            __builtin_amdgcn_s_sleep(8);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > TAIL_WAIT_TICKS) { go = 0; break; }
+        }
+        __threadfence();
+        if (!go) __hip_atomic_store(&a.ctl->tail_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        go_s = go;
+    }
+    __syncthreads();
+    if (!go_s) return;
+    const int m = __hip_atomic_load(&a.ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
+    const int wave = cb * 4 + w, nwaves = nb * 4;
+    const int per = (a.N + nwaves - 1) / nwaves;
+    const int v_begin = wave * per, v_end = min(a.N, v_begin + per);
+    const int K4 = a.K >> 2;
+    const u64 *planes = a.seen;                                  // plane 0 = reachability, planes 1.. = hop bits (contiguous)
+    for (int v = v_begin; v < v_end; ++v) {
+        f32x4 *erow = reinterpret_cast<f32x4 *>(a.out + (size_t)v * a.out_cols + a.F);
+        const size_t wbase = (size_t)v * a.Wp;
+        for (int q = lane; q < K4; q += 64) {
+            const int j = q * 4;
+            const size_t widx = wbase + (j >> 6);
+            const int bit = j & 63;
+            const unsigned reach = (unsigned)(planes[widx] >> bit) & 15u;
+            unsigned t = 0;
+            for (int b = 0; b < n_hop_bits; ++b)
+                t |= ((unsigned)(planes[(size_t)(b + 1) * a.plane_elems + widx] >> bit) & 15u) << (4 * b);
+            const unsigned h0 = (((t) & 0x1111u) * 0x1248u >> 12) & 15u;
+            const unsigned h1 = (((t >> 1) & 0x1111u) * 0x1248u >> 12) & 15u;
+            const unsigned h2 = (((t >> 2) & 0x1111u) * 0x1248u >> 12) & 15u;
+            const unsigned h3 = (((t >> 3) & 0x1111u) * 0x1248u >> 12) & 15u;
+            f32x4 r;
+            r.x = (reach & 1u) ? inv[h0] : 0.0f;
+            r.y = (reach & 2u) ? inv[h1] : 0.0f;
+            r.z = (reach & 4u) ? inv[h2] : 0.0f;
+            r.w = (reach & 8u) ? inv[h3] : 0.0f;
+            erow[q] = r;
         }
     }
 }
@@ -1055,7 +1285,7 @@ extern "C" size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K) {
     if (N < 0 || E < 0 || K <= 0) return 0;
     (void)E;
     // control block | anchors[K] | three rotating frontier planes | their three live-bit tables
-    return 256 + align_up((size_t)K * sizeof(long long), 256) + 3 * align_up(pope_plane_bytes(N, K), 256) + 3 * live_bytes(N);
+    return CTL_BYTES + align_up((size_t)K * sizeof(long long), 256) + 3 * align_up(pope_plane_bytes(N, K), 256) + 3 * live_bytes(N);
 }
 
 constexpr int LIVE_MAX_NODES = 256 * 1024;   // live table of 32 KB per block in LDS (4 blocks per CU); beyond: read from global
@@ -1084,6 +1314,8 @@ static int g_live_mode = -1;            // -1: by graph size (LDS table up to LI
 static int g_finalize_variant = 1;      // 0: generic kernel, 1: fast path with plain stores, 2: fast path, non-temporal stores
 static int g_finalize_blocks = 256 * 8;
 static int g_level_blocks = 0;           // cap on the expand blocks of a level launch (0: one wave per chunk up to 2048 blocks)
+static int g_tail_level = 0;             // POPE_KNOB_TAIL_LEVEL: first level that runs inside k_tail_finalize (0: no tail kernel)
+static int g_tail_blocks = 256;          // POPE_KNOB_TAIL_BLOCKS: BFS blocks of k_tail_finalize
 static int g_level_variant = 0;          // POPE_KNOB_LEVEL_VARIANT bits: 1 nt index streams, 2 XCD-contiguous chunks, 4 nt reachability loads
 // POPE_KNOB_LEVEL_COPY: per mille of x's rows that level launch l of pope_geodesic_run copies in its copy role (LevelCopy).
 // Index 0 is unused.  Launches the speculative window does not reach leave their share to the finalise kernel.
@@ -1109,6 +1341,8 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_GEMM_SMALL_TILE16: pope::g_gemm_small_tile16 = value; break;
     case POPE_KNOB_SAGE_LANES:       pope::g_sage_lanes = value; break;
     case POPE_KNOB_LEVEL_VARIANT:    g_level_variant = value; break;
+    case POPE_KNOB_TAIL_LEVEL:       g_tail_level = value; break;
+    case POPE_KNOB_TAIL_BLOCKS:      g_tail_blocks = value > 0 ? value : 256; break;
     case POPE_KNOB_LEVEL_COPY: {                                     // value = level << 16 | per mille; level 0: every launch
         const int lv = (value >> 16) & 0xff, pm = value & 0xffff;
         if (lv >= LEVEL_COPY_SLOTS || pm > 1000) { set_error("pope_debug_set: level copy %d / %d", lv, pm); return POPE_ERR_INVALID; }
@@ -1310,8 +1544,9 @@ static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const in
     b.hop_planes = b.seen + b.plane_elems;
     b.base = (char *)scratch;
     b.ctl = (BfsCtl *)b.base;
-    b.front_off = 256 + align_up((size_t)K * sizeof(long long), 256);
-    b.anchors_dev = (long long *)(b.base + 256);
+    static_assert(sizeof(BfsCtl) <= CTL_BYTES, "control block");
+    b.front_off = CTL_BYTES + align_up((size_t)K * sizeof(long long), 256);
+    b.anchors_dev = (long long *)(b.base + CTL_BYTES);
     b.front[0] = (u64 *)(b.base + b.front_off);
     b.front[1] = (u64 *)((char *)b.front[0] + align_up(b.plane_bytes, 256));
     b.front[2] = (u64 *)((char *)b.front[1] + align_up(b.plane_bytes, 256));
@@ -1407,6 +1642,42 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
     return level;
 }
 
+// The tail kernel (k_tail_finalize): levels [first_level, level_stop) until one finds nothing, the verdict, and -- with `out` --
+// the rest of the feature copy and the embedding columns.  The BFS blocks must all be resident at once (they wait for one
+// another): their number is capped at half of what the device holds of this kernel, the copy blocks fill the rest.
+template <int WT, int LIVE>
+static int launch_tail_t(const TailArgs &a0, size_t lds, hipStream_t stream) {
+    TailArgs a = a0;
+    static std::atomic<int> resident_cache{0};
+    int resident = resident_cache.load(std::memory_order_relaxed);
+    if (!resident) {
+        int per_cu = 0, dev = 0, cus = 0;
+        POPE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail_finalize<WT, LIVE>, 256, LIVE == 1 ? 32 * 1024 : 0));
+        POPE_HIP(hipGetDevice(&dev));
+        POPE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident = per_cu * cus;
+        POPE_REQUIRE(resident >= 2, "tail kernel: the device holds %d blocks", resident);
+        resident_cache.store(resident, std::memory_order_relaxed);
+    }
+    if (a.bfs_blocks > resident / 2) a.bfs_blocks = resident / 2;
+    const int copy_blocks = a.out ? resident - a.bfs_blocks : 0;
+    hipLaunchKernelGGL((k_tail_finalize<WT, LIVE>), dim3(a.bfs_blocks + copy_blocks), dim3(256), lds, stream, a);
+    POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+static int launch_tail(const TailArgs &a, hipStream_t stream) {
+    const int mode = g_live_mode >= 0 ? g_live_mode : (a.live_words <= LIVE_MAX_NODES / 32 ? 1 : 2);
+    const int live = mode == 1 && a.live_words <= LIVE_MAX_NODES / 32 ? 1 : (mode == 2 ? 2 : 0);
+    const size_t lds = live == 1 ? align_up((size_t)a.live_words * sizeof(unsigned), 16) : 0;
+#define POPE_TAIL(WT)                                                      \
+    (live == 1 ? launch_tail_t<WT, 1>(a, lds, stream) : live == 2 ? launch_tail_t<WT, 2>(a, lds, stream) : launch_tail_t<WT, 0>(a, lds, stream))
+    if (a.Wp == 1) return POPE_TAIL(1);
+    if (a.Wp == 2) return POPE_TAIL(2);
+    return POPE_TAIL(4);
+#undef POPE_TAIL
+}
+
 // Wait for the stream and read the verdicts.  Returns POPE_OK with *done set, or an error code.
 // ticket != 0: the finalise kernel enqueued last writes the report when it STARTS; spin on the pinned ticket word instead
 // of waiting for the stream to drain (the expansion keeps running; its output is complete in stream order).
@@ -1448,6 +1719,10 @@ static int bfs_poll(const Bfs &b, int next_level, int *last_active, bool *done, 
     if (flags & CSR_FLAG_UNSORTED) {
         set_error("geodesic bfs: edge_index is not sorted by source; rebuild the CSR with defer_check = 0");
         return POPE_ERR_UNSORTED;
+    }
+    if (flags & BFS_FLAG_TAIL_FAILED) {
+        set_error("geodesic bfs: a bounded wait inside the tail kernel ran out (its BFS blocks did not meet)");
+        return POPE_ERR_HIP;
     }
     *done = *last_active < next_level - 1 || b.E == 0;          // some enqueued level found nothing
     if (!*done && next_level >= b.level_limit) {
@@ -1688,12 +1963,29 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     seed.anchors = b.slot->anchors_dev; seed.K = K; seed.Wp = b.Wp; seed.seen = b.seen; seed.front = b.front[0]; seed.live = b.live[0];
     rc = csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, seed, stream);
     if (rc) return rc;
-    int level = bfs_enqueue_levels(b, 1, 1 + window, stream, plan.levels ? &plan : nullptr);
+    // Round 4: the sparse last levels run inside the finalise kernel's launch (k_tail_finalize) when POPE_KNOB_TAIL_LEVEL names
+    // the first of them: one word tile per node, levels below 16, and -- with an output -- the fast expansion's shapes.
+    const int level_stop = (int)std::min<long long>(b.level_limit, 1 << EAGER_PLANES);
+    const bool tail = g_tail_level >= 2 && g_tail_level <= window && g_tail_level < level_stop && b.Wp <= 4 && E > 0 &&
+                      (!out || ((F & 3) == 0 && (K & 3) == 0 && (out_cols & 3) == 0 && aligned16(out) && (!x || aligned16(x)) &&
+                                (uint64_t)N * (uint64_t)(F / 4 + 1) < (1ull << 32)));
+    int level = bfs_enqueue_levels(b, 1, tail ? g_tail_level : 1 + window, stream, plan.levels ? &plan : nullptr);
     const int x_row_begin = plan.levels ? plan.cut[std::min(level - 1, plan.levels)] : 0;      // rows the launches really took
     // The finalise kernel writes the verdict into the pinned report when it starts: no report launch, and the host
     // returns as soon as the BFS is known to be complete -- `out` is finished in stream order.
     int ticket = 0;
-    if (out) {
+    if (tail && level == g_tail_level) {
+        ticket = b.slot->ticket = b.slot->ticket == INT32_MAX ? 1 : b.slot->ticket + 1;
+        TailArgs a;
+        a.erow = b.erow; a.col = b.col; a.E = b.E; a.N = b.N; a.Wp = b.Wp;
+        for (int i = 0; i < 3; ++i) { a.front[i] = b.front[i]; a.live[i] = b.live[i]; }
+        a.live_words = b.live_words; a.seen = b.seen; a.hop_planes = b.hop_planes; a.plane_elems = b.plane_elems;
+        a.ctl = b.ctl; a.aux = b.aux; a.first_level = level; a.level_stop = level_stop; a.bfs_blocks = g_tail_blocks; a.variant = g_level_variant;
+        a.K = K; a.F = out ? F : 0; a.x = out ? x : nullptr; a.out = out; a.out_cols = out_cols; a.x_row_begin = x_row_begin;
+        a.report = b.slot->report_dev; a.ticket = ticket;
+        if ((rc = launch_tail(a, stream))) return rc;
+        level = level_stop;                               // what the tail kernel may have run
+    } else if (out) {
         ticket = b.slot->ticket = b.slot->ticket == INT32_MAX ? 1 : b.slot->ticket + 1;
         if ((rc = finalize_enqueue(planes, 0, &b.ctl->last_active, N, K, x, F, out, out_cols, 0, stream, 1, 0, aux,
                                    b.slot->report_dev, ticket, x_row_begin))) return rc;

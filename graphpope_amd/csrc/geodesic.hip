@@ -862,13 +862,16 @@ __device__ __forceinline__ bool tail_barrier(BfsCtl *ctl, int B, unsigned episod
     if (threadIdx.x == 0) {
         const int G = B < TAIL_GROUPS ? B : TAIL_GROUPS, g = (int)blockIdx.x % G;
         const unsigned members = (unsigned)((B - g + G - 1) / G);
+        // ONE release fence before the arrival and ONE acquire fence after the departure; the counters themselves are relaxed
+        // agent-scope atomics (they bypass the non-coherent caches without maintaining them): an acquire on every poll is a
+        // cache invalidation per iteration and made a level inside this kernel cost ~100 us.
         __threadfence();
-        const unsigned old = __hip_atomic_fetch_add(&ctl->tail_group[g * 32], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == members * episode) __hip_atomic_fetch_add(&ctl->tail_top, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(&ctl->tail_group[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == members * episode) __hip_atomic_fetch_add(&ctl->tail_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         int ok = 1;
-        while (__hip_atomic_load(&ctl->tail_top, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G * episode) {
-            __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(&ctl->tail_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G * episode) {
+            __builtin_amdgcn_s_sleep(4);
             if (__builtin_amdgcn_s_memrealtime() - t0 > TAIL_WAIT_TICKS) { ok = 0; break; }
         }
         __threadfence();
@@ -955,7 +958,10 @@ __global__ __launch_bounds__(256) void k_tail_finalize(const TailArgs a) {
 #pragma unroll
             for (int j = 0; j < LEVEL_COPY_PIECES; ++j) {
                 const unsigned long long p = (unsigned long long)base + 64u * j;
-                if (p < piece_end) dst[(size_t)row * opitch4 + q] = v[j];
+                if (p < piece_end) {
+                    if (a.variant & 8) __builtin_nontemporal_store(v[j], dst + (size_t)row * opitch4 + q);
+                    else dst[(size_t)row * opitch4 + q] = v[j];
+                }
                 q += 64u;
                 while (q >= F4) { q -= F4; ++row; }
             }
@@ -968,8 +974,8 @@ __global__ __launch_bounds__(256) void k_tail_finalize(const TailArgs a) {
     if (threadIdx.x == 0) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         int go = 1;
-        while (__hip_atomic_load(&a.ctl->tail_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.ticket) {
-            __builtin_amdgcn_s_sleep(8);
+        while (__hip_atomic_load(&a.ctl->tail_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.ticket) {
+            __builtin_amdgcn_s_sleep(32);
             if (__builtin_amdgcn_s_memrealtime() - t0 > TAIL_WAIT_TICKS) { go = 0; break; }
         }
         __threadfence();

@@ -184,14 +184,75 @@ extern "C" int pope_copy_to_device(const void *src_host, void *dst, size_t bytes
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fresh result pages, faulted in beside the GPU work (the first host -> host call of a process)
+// ------------------------------------------------------------------------------------------------
+// A new 270 MB result costs the kernel 3-10 ms of page clearing whoever touches it first (tools/populate_probe.py on the GPU box:
+// madvise(MADV_POPULATE_WRITE) with huge pages takes 9.8 / 5.9 / 3.2 / 4.2 ms on 1 / 2 / 4 / 8 threads).  Round 3 let the sixteen
+// copy threads take those faults AFTER the GPU work (taking them beside it with sixteen threads stalled the GPU queues); here a
+// FEW threads populate the mapping with one madvise call each while the upload and the BFS run, and the copy threads then
+// write pages that exist.  pope_host_prefault_begin returns at once; _wait joins (and frees the handle).
+namespace {
+struct Prefault {
+    std::vector<std::thread> threads;
+};
+}  // namespace
+
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+
+extern "C" void *pope_host_prefault_begin(void *host, size_t bytes, int32_t threads) {
+    if (!host || bytes == 0) return nullptr;
+    int t = threads > 0 ? threads : 4;
+    if (t > 16) t = 16;
+    char *base = static_cast<char *>(host);
+    if (!getenv("GRAPHPOPE_NO_HUGEPAGE")) {
+        const uintptr_t huge = (uintptr_t)1 << 21, b = reinterpret_cast<uintptr_t>(base);
+        const uintptr_t lo = (b + huge - 1) & ~(huge - 1), hi = (b + bytes) & ~(huge - 1);
+        if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    }
+    Prefault *p = new Prefault;
+    const size_t page = 4096, huge = (size_t)1 << 21;
+    // ranges cut at 2 MB boundaries, so that no huge page is faulted by two threads
+    const uintptr_t b0 = reinterpret_cast<uintptr_t>(base) & ~(uintptr_t)(page - 1), b1 = (reinterpret_cast<uintptr_t>(base) + bytes + page - 1) & ~(uintptr_t)(page - 1);
+    const size_t span = b1 - b0, per = ((span / (size_t)t) + huge - 1) / huge * huge;
+    for (int i = 0; i < t; ++i) {
+        uintptr_t lo = b0 + (uintptr_t)i * per, hi = lo + per < b1 ? lo + per : b1;
+        if (i > 0) lo = lo & ~(uintptr_t)(huge - 1);
+        if (i + 1 < t) hi = hi & ~(uintptr_t)(huge - 1);
+        if (lo >= b1 || hi <= lo) continue;
+        p->threads.emplace_back([lo, hi, page] {
+            if (madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_POPULATE_WRITE) != 0) {
+                // a kernel without MADV_POPULATE_WRITE (< 5.14): touch the pages (a locked OR with 0 changes nothing that is there)
+                for (uintptr_t a = lo; a < hi; a += page) (void)__atomic_fetch_or(reinterpret_cast<char *>(a), 0, __ATOMIC_RELAXED);
+            }
+        });
+    }
+    return p;
+}
+
+extern "C" void pope_host_prefault_wait(void *handle) {
+    Prefault *p = static_cast<Prefault *>(handle);
+    if (!p) return;
+    for (auto &th : p->threads) th.join();
+    delete p;
+}
+
+// ------------------------------------------------------------------------------------------------
 // out[:, :F] = x (host cores) and out[:, F:] = emb (DMA), into a pageable result, chunk by chunk
 // ------------------------------------------------------------------------------------------------
 // Phase times of the last pope_assemble_host_result call of the process, in ms (diagnostic: tools/boundary_breakdown.py):
 // 0 madvise, 1 waiting for the chunks' host copies, 2 hipHostRegister, 3 enqueueing DMAs, 4 joining the workers,
 // 5 waiting for the stream, 6 hipHostUnregister, 7 total.
 static double g_assemble_trace[8];
+static std::mutex g_assemble_trace_mu;       // two assemblies may finish at the same time (found by tools/host_race_harness under -fsanitize=thread)
 extern "C" void pope_debug_boundary_trace(double *host8) {
+    std::lock_guard<std::mutex> lock(g_assemble_trace_mu);
     for (int i = 0; i < 8; ++i) host8[i] = g_assemble_trace[i];
+}
+static void publish_trace(const double *tr) {
+    std::lock_guard<std::mutex> lock(g_assemble_trace_mu);
+    for (int i = 0; i < 8; ++i) g_assemble_trace[i] = tr[i];
 }
 
 namespace {
@@ -242,6 +303,12 @@ struct Assembly {
     size_t emb_row = 0;                          // bytes of one row in the ring
     const uint64_t *pair_lut = nullptr;          // hop-code transport: the ring holds one byte per element, this table the floats
     size_t emb_elems = 0;                        //   ... elements (bytes) per row
+    // Threads that run out of feature items before finish() has said how many embedding items there will be (an assembly begun
+    // BEFORE the upload and the GPU work) sleep here instead of spinning through the whole GPU phase; begin_embedding() /
+    // abort() wake them.  Once the embedding phase has begun the waits are short (a chunk is on the bus) and they yield-spin.
+    std::mutex idle_m;
+    std::condition_variable idle_cv;
+    bool no_register = false;                    // this assembly never hands the result's pages to hipHostRegister
 
     explicit Assembly(int nchunks) : done((size_t)nchunks), emb_done(0) {
         for (auto &d : done) d.store(0, std::memory_order_relaxed);
@@ -282,6 +349,22 @@ struct Assembly {
         emb_done[(size_t)c].fetch_add(1, std::memory_order_release);
     }
 
+    void begin_embedding(int total_items) {
+        {
+            std::lock_guard<std::mutex> lock(idle_m);
+            emb_total.store(total_items, std::memory_order_release);
+        }
+        idle_cv.notify_all();
+    }
+
+    void abort() {
+        {
+            std::lock_guard<std::mutex> lock(idle_m);
+            aborted.store(true, std::memory_order_release);
+        }
+        idle_cv.notify_all();
+    }
+
     void work() {
         const int items = chunks * slices;
         for (;;) {
@@ -298,8 +381,13 @@ struct Assembly {
                 if (it < items) x_item(it);
                 continue;
             }
-            if (aborted.load(std::memory_order_relaxed)) return;
+            if (aborted.load(std::memory_order_acquire)) return;
             if (tot >= 0 && emb_next.load(std::memory_order_relaxed) >= tot) return;
+            if (tot < 0) {                       // nothing to do until finish() (or abort()): sleep, do not spin
+                std::unique_lock<std::mutex> lock(idle_m);
+                idle_cv.wait(lock, [&] { return emb_total.load(std::memory_order_acquire) >= 0 || aborted.load(std::memory_order_acquire); });
+                continue;
+            }
             std::this_thread::yield();
         }
     }
@@ -408,7 +496,19 @@ struct HostAssembly {
 // and runs underneath whatever the caller does next (upload edge_index, enqueue and wait for the GPU).
 extern "C" void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, void *out_host,
                                      int64_t out_pitch_bytes, int64_t rows, int32_t threads, int32_t chunks) {
+    // the transport follows the process-global test knobs; callers with a choice of their own use pope_assemble_begin_mode
+    return pope_assemble_begin_mode(x_host, x_pitch_bytes, x_row_bytes, out_host, out_pitch_bytes, rows, threads, chunks,
+                                    pope::g_host_result_mode == 0 ? POPE_RESULT_RING : POPE_RESULT_REGISTERED, (pope::g_fail_host_register & 1) != 0);
+}
+
+extern "C" void *pope_assemble_begin_mode(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, void *out_host,
+                                          int64_t out_pitch_bytes, int64_t rows, int32_t threads, int32_t chunks, int32_t result_mode,
+                                          int32_t no_register) {
     pope::clear_error();
+    if (result_mode != POPE_RESULT_RING && result_mode != POPE_RESULT_REGISTERED) {
+        pope::set_error("pope_assemble_begin_mode: unknown result mode %d", result_mode);
+        return nullptr;
+    }
     if (!out_host || rows <= 0 || x_row_bytes < 0 || (x_row_bytes > 0 && (!x_host || x_pitch_bytes < x_row_bytes)) || out_pitch_bytes < x_row_bytes ||
         out_pitch_bytes <= 0) {
         pope::set_error("pope_assemble_begin: null pointer or bad size");
@@ -435,9 +535,10 @@ extern "C" void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, 
     a.x = static_cast<const char *>(x_host); a.x_pitch = (size_t)x_pitch_bytes; a.x_row = (size_t)x_row_bytes;
     a.out = out; a.out_pitch = (size_t)out_pitch_bytes; a.rows = rows; a.chunks = nch;
     a.slices = t;
-    h->ring = pope::g_host_result_mode == 0;
+    h->ring = result_mode == POPE_RESULT_RING;
+    a.no_register = no_register != 0;
     a.touch_only_pages = !h->ring;
-    if (!h->ring) a.emb_total.store(0, std::memory_order_relaxed);     // no ring items: the threads leave after the feature copy
+    if (!h->ring) a.emb_total.store(0, std::memory_order_relaxed);     // no ring items: the threads leave after the feature copy (they have not started yet)
     a.chunk_lo.resize((size_t)nch + 1);
     // the first chunk is small so that the first DMA starts early; the rest are equal
     for (int c = 0; c <= nch; ++c) a.chunk_lo[(size_t)c] = rows * c / nch;
@@ -450,7 +551,7 @@ extern "C" void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, 
 extern "C" void pope_assemble_abort(void *handle) {
     HostAssembly *h = static_cast<HostAssembly *>(handle);
     if (!h) return;
-    h->a.aborted.store(true, std::memory_order_relaxed);
+    h->a.abort();
     h->pool.join();
     delete h;
 }
@@ -505,6 +606,52 @@ extern "C" void pope_assemble_prepare(int32_t device) {
 extern "C" int32_t pope_assemble_ring_ready(void) {
     std::unique_lock<std::mutex> lock(g_ring.mu);
     return ring_usable_locked() ? 1 : 0;
+}
+
+// Rows [r0, r1) of a DEVICE matrix (row bytes `eb`, pitch `epitch`) into pageable host rows at dst0 + r * dpitch WITHOUT giving
+// the runtime the pageable pointer: 4 MB pinned bounce buffer (allocated once per process, guarded by its own mutex),
+// one blocking pitched copy per buffer-full, memcpy out.  Slow (nothing overlaps) and only used when neither the pinned ring
+// nor a registration of the result's pages is available.  If even the 4 MB are refused, a BLOCKING hipMemcpy2D writes the
+// rows directly (the runtime's own staging; nothing is in flight when it returns).
+constexpr size_t BOUNCE_BYTES = (size_t)4 << 20;
+static std::mutex g_bounce_mu;
+static char *g_bounce = nullptr;
+static bool g_bounce_failed = false;
+
+static int bounce_rows(const char *embp, size_t epitch, size_t eb, char *dst0, size_t dpitch, int64_t r0, int64_t r1, hipStream_t stream) {
+    if (r1 <= r0 || eb == 0) return POPE_OK;
+    std::lock_guard<std::mutex> lock(g_bounce_mu);
+    if (!g_bounce && !g_bounce_failed && !(pope::g_fail_host_register & 4)) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&g_bounce), BOUNCE_BYTES, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            g_bounce = nullptr;
+            g_bounce_failed = true;
+        }
+    }
+    const bool use_bounce = g_bounce && eb <= BOUNCE_BYTES && !(pope::g_fail_host_register & 4);
+    if (!use_bounce) {
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e == hipSuccess)
+            e = hipMemcpy2D(dst0 + (size_t)r0 * dpitch, dpitch, embp + (size_t)r0 * epitch, epitch, eb, (size_t)(r1 - r0), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            pope::set_error("hipMemcpy2D(D2H, rows %lld..%lld) failed: %s", (long long)r0, (long long)r1, hipGetErrorString(e));
+            return POPE_ERR_HIP;
+        }
+        return POPE_OK;
+    }
+    const int64_t per = (int64_t)(BOUNCE_BYTES / eb);
+    for (int64_t r = r0; r < r1; r += per) {
+        const int64_t n = r + per < r1 ? per : r1 - r;
+        hipError_t e = epitch == eb ? hipMemcpyAsync(g_bounce, embp + (size_t)r * epitch, (size_t)n * eb, hipMemcpyDeviceToHost, stream)
+                                    : hipMemcpy2DAsync(g_bounce, eb, embp + (size_t)r * epitch, epitch, eb, (size_t)n, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) {
+            pope::set_error("D2H through the bounce buffer (rows %lld..%lld) failed: %s", (long long)r, (long long)(r + n), hipGetErrorString(e));
+            return POPE_ERR_HIP;
+        }
+        for (int64_t i = 0; i < n; ++i) memcpy(dst0 + (size_t)(r + i) * dpitch, g_bounce + (size_t)i * eb, eb);
+    }
+    return POPE_OK;
 }
 
 // `lut_dev` == nullptr: `emb` holds the float columns themselves.  Otherwise `emb` holds one code byte per element
@@ -582,7 +729,7 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
             for (int i = 0; i < RING_SLOTS; ++i) a.ring[i] = g_ring.slot[i];
             a.emb_done = std::vector<std::atomic<int>>((size_t)ne);
             for (auto &d : a.emb_done) d.store(0, std::memory_order_relaxed);
-            a.emb_total.store(ne * a.slices, std::memory_order_release);
+            a.begin_embedding(ne * a.slices);
             auto publish = [&](int c) {                                            // chunk c has landed: hand it to the threads
                 const double t1 = now_ms();
                 const hipError_t e = hipEventSynchronize(g_ring.ev[c % RING_SLOTS]);
@@ -625,8 +772,8 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
             }
             if (rc == POPE_OK) publish(ne - 1);
             if (rc != POPE_OK) {                                                   // let the threads go; drain what is in flight
-                a.aborted.store(true, std::memory_order_relaxed);
-                a.emb_total.store(0, std::memory_order_release);
+                a.abort();
+                a.begin_embedding(0);
                 (void)hipStreamSynchronize(stream);
             }
             t0 = now_ms();
@@ -634,10 +781,10 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
             tr[4] = now_ms() - t0;
             ring_done = true;
         } else {
-            a.emb_total.store(0, std::memory_order_release);                       // no ring: register the result's pages instead
+            a.begin_embedding(0);                                                  // no ring: register the result's pages instead
         }
     } else if (h->ring) {
-        a.emb_total.store(0, std::memory_order_release);
+        a.begin_embedding(0);
     }
     if (coded && !ring_done) {
         pope_assemble_abort(h);
@@ -646,7 +793,7 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
     }
     if (ring_done) {
         tr[7] = now_ms() - t_begin;
-        for (int i = 0; i < 8; ++i) g_assemble_trace[i] = tr[i];
+        publish_trace(tr);
         delete h;
         return rc;
     }
@@ -656,7 +803,7 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
     // are not multiples of the page size) is sent as two plain copies once both regions exist.
     uintptr_t reg_hi = 0;
     int64_t next_row = 0;                          // rows below have been enqueued
-    bool registering = eb > 0 && !(pope::g_fail_host_register & 1);
+    bool registering = eb > 0 && !a.no_register;
     for (int c = 0; c < nch && rc == POPE_OK; ++c) {
         double t0 = now_ms();
         while (a.done[(size_t)c].load(std::memory_order_acquire) < a.slices) std::this_thread::yield();
@@ -696,7 +843,13 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
             copy1d(reg_hi, T(next_row), next_row);
             ++next_row;
         }
-        copy2d(next_row, rows);
+        // The rest of the rows lie in pageable memory the runtime holds no registration for.  Round 3 handed them to
+        // hipMemcpy2DAsync as they were (the runtime then pins such pages on the fly and may keep that mapping cached after
+        // the caller has freed or unmapped them: the one explanation that fits round 3's GPU memory fault at a host heap
+        // address).  Now they are staged through a pinned buffer of the library's own and copied out by
+        // this thread: the runtime never sees the result's pages.
+        rc = bounce_rows(embp, epitch, eb, reinterpret_cast<char *>(S(0)), pitch, next_row, rows, stream);
+        next_row = rows;
     }
     double t0 = now_ms();
     pool.join();
@@ -709,10 +862,19 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
         rc = POPE_ERR_HIP;
     }
     t0 = now_ms();
-    for (auto &p : pinned) (void)hipHostUnregister(p.first);
+    for (auto &p : pinned) {
+        const hipError_t eu = hipHostUnregister(p.first);
+        if (eu != hipSuccess) {                        // the pages stay registered: say so instead of leaving a stale registration behind silently
+            (void)hipGetLastError();
+            if (rc == POPE_OK) {
+                pope::set_error("hipHostUnregister(%p, %zu bytes) failed: %s -- the result's pages are still registered", p.first, p.second, hipGetErrorString(eu));
+                rc = POPE_ERR_HIP;
+            }
+        }
+    }
     tr[6] = now_ms() - t0;
     tr[7] = now_ms() - t_begin;
-    for (int i = 0; i < 8; ++i) g_assemble_trace[i] = tr[i];
+    publish_trace(tr);
     delete h;
     return rc;
 }

@@ -68,6 +68,14 @@ struct PpArgs {
     int sets;                    // consumer sets: 2, or 1 when the feature copy runs beside this kernel (its waves need the registers)
 };
 
+// Anchor j is row ids[j] of the table (device int64 supplied by the caller, engine._anchor_ids checks ids that come from the
+// host).  An id outside [0, N) is clamped into the table: the result for that column is meaningless, but the kernel never
+// reads outside the caller's allocation (a faulting access can take the whole node down).
+__device__ __forceinline__ size_t anchor_row(const long long *ids, int j, int N) {
+    const long long r = ids[j];
+    return (size_t)(r < 0 ? 0 : (r >= N ? N - 1 : r));
+}
+
 __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args) {
     // plain locals: a lambda that captured the argument struct by reference would force a copy of it into scratch memory
     const float *const X = args.X, *const A = args.A, *const zero = args.zero;
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
         const int row = i * 2 + (lane >> 5), cslot = lane & 31;
         const int c = cslot ^ (row & 15);
         const int col = col_base + row;
-        const float *src = (col < K && c * 4 < D) ? A + (size_t)(arows ? arows[col] : col) * D + c * 4 : zero;
+        const float *src = (col < K && c * 4 < D) ? A + (arows ? anchor_row(arows, col, N) : (size_t)col) * D + c * 4 : zero;
         sk_glds16(src, lds0 + i * 1024);
     }
 
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pairwise_persistent(PpArgs args)
                                 const int src = __ffsll((long long)fix) - 1;
                                 fix &= fix - 1;
                                 const int acol = __shfl(col[t], src);
-                                const float v = wave_sqdist(X + (size_t)__shfl(row, src) * D, A + (size_t)(arows ? arows[acol] : acol) * D, D, lane);
+                                const float v = wave_sqdist(X + (size_t)__shfl(row, src) * D, A + (arows ? anchor_row(arows, acol, N) : (size_t)acol) * D, D, lane);
                                 if (lane == src) {
 #pragma unroll
                                     for (int q = 0; q < 16; ++q)

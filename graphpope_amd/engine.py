@@ -71,7 +71,7 @@ def host_copy_2d(src: torch.Tensor, dst: torch.Tensor, threads: int = 0) -> None
                                 threads or host_threads()))
 
 
-def stage_to_device(t: torch.Tensor, device) -> torch.Tensor:
+def stage_to_device(t: torch.Tensor, device, register: bool = True) -> torch.Tensor:
     """A pageable host tensor -> device, asynchronously on the current stream.
 
     The caller's pages are registered with the HIP runtime for the length of the copy (pope_host_pin: microseconds per
@@ -85,14 +85,14 @@ def stage_to_device(t: torch.Tensor, device) -> torch.Tensor:
         return t.to(device, non_blocking=True)
     lib = _lib.load()
     nbytes = t.numel() * t.element_size()
-    if nbytes >= (1 << 20) and lib.pope_host_pin(ptr(t), nbytes) == _lib.OK:
+    if register and nbytes >= (1 << 20) and lib.pope_host_pin(ptr(t), nbytes) == _lib.OK:
         try:
             with torch.cuda.device(device):
                 out = torch.empty(t.shape, dtype=t.dtype, device=device)
                 check(lib.pope_copy_to_device(ptr(t), ptr(out), nbytes, _stream()))
                 torch.cuda.current_stream().synchronize()          # the pages stay registered exactly as long as the DMA reads them
         finally:
-            lib.pope_host_unpin(ptr(t))
+            check(lib.pope_host_unpin(ptr(t)))                      # a refused release is an error: the pages would stay registered
         return out
     staged = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host_copy_2d(t.view(1, -1), staged.view(1, -1))
@@ -104,8 +104,8 @@ class staged:
     (enqueueing the GPU work that consumes t_dev), and the caller's pages are released on exit, once the event recorded
     behind the copy has completed (normally long before: the body has waited for results that depend on it)."""
 
-    def __init__(self, t: torch.Tensor, device):
-        self.t, self.device, self.pinned, self.event = t, device, False, None
+    def __init__(self, t: torch.Tensor, device, register: bool = True):
+        self.t, self.device, self.pinned, self.event, self.register = t, device, False, None, register
 
     def __enter__(self) -> torch.Tensor:
         t = self.t
@@ -114,8 +114,8 @@ class staged:
         lib = _lib.load()
         self.t = t = t.contiguous()
         nbytes = t.numel() * t.element_size()
-        if nbytes < (1 << 20) or lib.pope_host_pin(ptr(t), nbytes) != _lib.OK:
-            return stage_to_device(t, self.device)
+        if not self.register or nbytes < (1 << 20) or lib.pope_host_pin(ptr(t), nbytes) != _lib.OK:
+            return stage_to_device(t, self.device, register=False)
         self.pinned = True
         try:
             with torch.cuda.device(self.device):
@@ -132,8 +132,10 @@ class staged:
         if self.pinned:
             if self.event is not None:
                 self.event.synchronize()
-            _lib.load().pope_host_unpin(ptr(self.t))
             self.pinned = False
+            rc = _lib.load().pope_host_unpin(ptr(self.t))
+            if rc != _lib.OK and exc[0] is None:                   # a refused release leaves the caller's pages registered: do not hide it
+                check(rc)
         return False
 
 
@@ -186,15 +188,22 @@ class HostAssembly:
     feature copy run underneath whatever happens between the two calls -- the upload of edge_index and the GPU work.
     Use as a context manager: an exception in between aborts the assembly (waits for the host threads)."""
 
-    def __init__(self, x: torch.Tensor | None, out: torch.Tensor, f: int, threads: int = 0, chunks: int = 0):
+    def __init__(self, x: torch.Tensor | None, out: torch.Tensor, f: int, threads: int = 0, chunks: int = 0, mode: str | None = None,
+                 register: bool = True):
+        """mode: "ring" (the embedding columns through the process's pinned ring) or "registered" (the result's pages are
+        registered chunk by chunk); None: what the library's test knobs say.  register=False: never hand the result's pages to
+        hipHostRegister (columns staged through the library's bounce buffer)."""
         lib = _lib.load()
         assert not out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.dim() == 2 and out.shape[1] >= f
         assert f == 0 or (x is not None and not x.is_cuda and x.dtype == torch.float32 and x.shape == (out.shape[0], f) and x.stride(1) == 1)
         self.out, self.x, self.f, self.handle = out, x, f, None        # x is kept alive until finish
         if out.shape[0] == 0:
             return
-        self.handle = lib.pope_assemble_begin(ptr(x) if f else None, (x.stride(0) * 4) if f else 0, f * 4, ptr(out), out.shape[1] * 4,
-                                              out.shape[0], threads or host_threads(), chunks)
+        args = (ptr(x) if f else None, (x.stride(0) * 4) if f else 0, f * 4, ptr(out), out.shape[1] * 4, out.shape[0], threads or host_threads(), chunks)
+        if mode is None:
+            self.handle = lib.pope_assemble_begin(*args)
+        else:
+            self.handle = lib.pope_assemble_begin_mode(*args, {"ring": _lib.RESULT_RING, "registered": _lib.RESULT_REGISTERED}[mode], 0 if register else 1)
         if not self.handle:
             raise _lib.PopeError(_lib.ERR_INVALID, lib.pope_last_error().decode())
 

@@ -46,8 +46,18 @@ class DeviceBatch:
         self.dims = torch.zeros((h, 4), dtype=torch.int32, device=device)
         self.n_id = self.n_ids[-1]                                   # [capacity]: the true length is dims[-1, 1]
         self.host_dims = None                                        # set by load(): sizes known on the host
+        self._sampler_scratch = {}                                   # bytes -> tensor, see sampler_scratch()
         # outermost block first, like NeighborSampler's adjs (main.py:118-123)
         self.adjs = [SampledAdj(self.rowptrs[i], self.cols[i], self.t_cap[i] + self.caps[i], self.dims[i]) for i in range(h)][::-1]
+
+    def sampler_scratch(self, nbytes: int) -> torch.Tensor:
+        """The device-extent sampler's scratch for THIS batch (position-key map, ranks, chain status words): allocated once per
+        size and kept for the life of the batch.  A captured step has its address baked in, so it must never be replaced or
+        shared with the host-sized sampling paths (which regrow their own scratch on demand, NeighborSampler._scratch)."""
+        t = self._sampler_scratch.get(nbytes)
+        if t is None:
+            t = self._sampler_scratch[nbytes] = torch.empty(nbytes, dtype=torch.uint8, device=self.dims.device)
+        return t
 
     def segments(self, valid_only: bool = False):
         """Every buffer a batch consists of (same order for every DeviceBatch of the same shape): for sage_copy_segments.
@@ -92,16 +102,14 @@ class NeighborSampler:
         assert seeds.is_cuda and seeds.dtype == torch.int64 and seeds.is_contiguous() and seeds.numel() == out.n_seeds
         assert out.sizes == [int(f) for f in self.sizes]
         h = len(out.sizes)
-        need = lib.sage_sample_scratch_bytes(self.num_nodes, out.t_cap[-1], out.caps[-1])
-        if self._scratch is None or self._scratch.numel() < need:
-            self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+        scratch = out.sampler_scratch(lib.sage_sample_scratch_bytes(self.num_nodes, out.t_cap[-1], out.caps[-1]))
         arr = ctypes.c_void_p * h
         with on_device(dev):
             check(lib.sage_sample_batch_device(ptr(self.rowptr), ptr(self.col), self.num_nodes, ptr(seeds), seeds.numel(),
                                                (ctypes.c_int32 * h)(*out.sizes), h, int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(seed_dev),
                                                arr(*[r.data_ptr() for r in out.rowptrs]), arr(*[c.data_ptr() for c in out.cols]),
-                                               arr(*[n.data_ptr() for n in out.n_ids]), ptr(out.dims), ptr(self._scratch),
-                                               self._scratch.numel(), _stream()))
+                                               arr(*[n.data_ptr() for n in out.n_ids]), ptr(out.dims), ptr(scratch),
+                                               scratch.numel(), _stream()))
         return out
 
     def sample_epoch_device(self, order: torch.Tensor, first_dev: torch.Tensor, labels: torch.Tensor | None, y_out: torch.Tensor | None,
@@ -118,17 +126,15 @@ class NeighborSampler:
             assert labels.is_cuda and labels.dtype == torch.int64 and labels.is_contiguous() and y_out.dtype == torch.int64
             assert y_out.is_contiguous() and y_out.numel() >= out.n_seeds
         h = len(out.sizes)
-        need = lib.sage_sample_scratch_bytes(self.num_nodes, out.t_cap[-1], out.caps[-1])
-        if self._scratch is None or self._scratch.numel() < need:
-            self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+        scratch = out.sampler_scratch(lib.sage_sample_scratch_bytes(self.num_nodes, out.t_cap[-1], out.caps[-1]))
         arr = ctypes.c_void_p * h
         with on_device(dev):
             check(lib.sage_sample_epoch_batch_device(ptr(self.rowptr), ptr(self.col), self.num_nodes, ptr(order), ptr(first_dev), out.n_seeds,
                                                      ptr(labels), ptr(y_out), (ctypes.c_int32 * h)(*out.sizes), h,
                                                      int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(seed_dev),
                                                      arr(*[r.data_ptr() for r in out.rowptrs]), arr(*[c.data_ptr() for c in out.cols]),
-                                                     arr(*[n.data_ptr() for n in out.n_ids]), ptr(out.dims), ptr(self._scratch),
-                                                     self._scratch.numel(), _stream()))
+                                                     arr(*[n.data_ptr() for n in out.n_ids]), ptr(out.dims), ptr(scratch),
+                                                     scratch.numel(), _stream()))
         return out
 
     def _hop(self, targets: torch.Tensor, fanout: int, seed: int, hop: int):

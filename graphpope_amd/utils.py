@@ -154,34 +154,40 @@ def _assemble_on_host(data, k, embedding_fn):
         res = out
     else:
         out, reused = engine.host_result_tensor(n, f + k, with_origin=True)
-        lib = _lib_mod.load()
-        lib.pope_debug_set(_lib_mod.KNOB_HOST_RESULT_MODE, 0 if mode == "ring" else 1)
-        if mode == "staged":                           # no registration of the caller-visible pages: the runtime's own staging
-            lib.pope_debug_set(_lib_mod.KNOB_FAIL_HOST_REGISTER, 1)
+        # the transport is an ARGUMENT of this assembly (pope_assemble_begin_mode), not a process-global knob: concurrent callers
+        # with different choices do not meet.  "staged": nothing of the caller's is ever registered with the runtime.
+        asm_mode, register = ("ring" if mode == "ring" else "registered"), mode != "staged"
         asm = None
+        prefault = None
         try:
             # pages from the pool (a repeated call): no page faults to take, so the feature copy may start now and run underneath
-            # the upload and the GPU work; fresh pages (the first call): the copy starts after them (see the docstring)
+            # the upload and the GPU work; fresh pages (the first call): a few helper threads populate them meanwhile (round 4:
+            # GRAPHPOPE_PREFAULT_THREADS, default 4, 0 = off) and the copy starts after the GPU work, on pages that exist
             if reused and mode == "ring":
-                asm = engine.HostAssembly(x if f else None, out, f)
+                asm = engine.HostAssembly(x if f else None, out, f, mode=asm_mode, register=register)
+            elif not reused and out.numel() * 4 >= (8 << 20):
+                nthreads = int(os.environ.get("GRAPHPOPE_PREFAULT_THREADS", "4"))
+                if nthreads > 0:
+                    prefault = _lib_mod.load().pope_host_prefault_begin(out.data_ptr(), out.numel() * 4, nthreads)
             emb_dev = embedding_fn()                   # float32 [N, K], or (uint8 codes [N, K], float32 lut [256]): engine.hop_codes
+            if prefault:
+                _lib_mod.load().pope_host_prefault_wait(prefault)
+                prefault = None
             coded = isinstance(emb_dev, tuple)
             if not coded:
                 emb_dev = emb_dev.contiguous()
             assert not coded or mode == "ring"
             t1 = _t.perf_counter()
             if asm is None:
-                asm = engine.HostAssembly(x if f else None, out, f)
+                asm = engine.HostAssembly(x if f else None, out, f, mode=asm_mode, register=register)
             with asm:
                 res = asm.finish_codes(*emb_dev) if coded else asm.finish(emb_dev)
         except BaseException:
+            if prefault:
+                _lib_mod.load().pope_host_prefault_wait(prefault)
             if asm is not None:
                 asm.__exit__(None, None, None)         # waits for the host threads of an assembly that will not be finished
             raise
-        finally:
-            lib.pope_debug_set(_lib_mod.KNOB_HOST_RESULT_MODE, 0)
-            if mode == "staged":
-                lib.pope_debug_set(_lib_mod.KNOB_FAIL_HOST_REGISTER, 0)
     if trace:
         import sys as _s
         print(f"[trace] upload + GPU {1e3 * (t1 - t0):.2f} ms, result assembly {1e3 * (_t.perf_counter() - t1):.2f} ms", file=_s.stderr)
@@ -213,7 +219,8 @@ def _geodesic_embedding_device(edge_index, n, anchors, dev, coded=False):
     trace = os.environ.get("GRAPHPOPE_TRACE")
     import time as _t
     t0 = _t.perf_counter()
-    with engine.staged(edge_index.detach(), dev) as ei_dev:         # 14.4 MB straight from the caller's pages, released on exit
+    register = os.environ.get("GRAPHPOPE_HOST_RESULT", "ring") != "staged"
+    with engine.staged(edge_index.detach(), dev, register=register) as ei_dev:   # 14.4 MB straight from the caller's pages, released on exit
         ei = ei_dev.to(torch.int64)
         if not os.environ.get("GRAPHPOPE_CACHE_DIR"):
             t1 = _t.perf_counter()

@@ -83,7 +83,7 @@ int pope_require_device(int32_t *cu_count_host);
 #define POPE_KNOB_GEMM_TILE         3   /* SAGE GEMM: 0 auto, 1 64x64, 2 64x128, 3 128x256 tiles, 4 / 5 stream-K without loader waves, 6 stream-K with stages of 64 in two 80 KB buffers, 7 stream-K instead of the chip-fitted whole tiles (gemm_tile16.h) */
 #define POPE_KNOB_COPY_BATCHES      5   /* node2vec embedding: 16-piece batches per wave of the feature-copy kernel beside the tile kernel (default 1) */
 #define POPE_KNOB_LEVEL_BLOCKS       6   /* level kernel: cap on the expand blocks of a launch (0 = one wave per 256-slot chunk, up to 2048 blocks)      */
-#define POPE_KNOB_FAIL_HOST_REGISTER 7  /* host -> host boundary, tests of the fallbacks, bit mask: 1 = every hipHostRegister is refused, 2 = behave as if the pinned ring's hipHostMalloc had been refused (float columns through registration / staging) */
+#define POPE_KNOB_FAIL_HOST_REGISTER 7  /* host -> host boundary, tests of the fallbacks, bit mask: 1 = every hipHostRegister is refused, 2 = behave as if the pinned ring's hipHostMalloc had been refused (float columns through registration / the bounce buffer), 4 = behave as if the 4 MB bounce buffer had been refused too (blocking copies by the runtime) */
 #define POPE_KNOB_SAGE_LANES        8   /* sage_conv_backward: 0 (default) one stream; 1 bias gradient and grad_x chain on side streams beside the weight gradients (measured slower) */
 #define POPE_KNOB_LEVEL_VARIANT     9   /* level kernel experiments, bit mask: 1 non-temporal index streams, 2 XCD-contiguous chunk ranges, 4 non-temporal reachability loads */
 #define POPE_KNOB_LEVEL_COPY        10  /* pope_geodesic_run: per mille of the feature rows that level launch l copies in its copy role beside the BFS blocks; value = l << 16 | per mille, l = 0 sets every launch */
@@ -348,8 +348,10 @@ int pope_copy_2d_to_host(const void *src, int64_t src_pitch_bytes, void *dst_hos
  * the bus -- no page of the result is ever registered.  Mode 1: the result is cut into `chunks` row chunks (<= 0: 8),
  * worker threads fill a chunk's feature columns (its first touch: MADV_HUGEPAGE is applied first), the calling thread
  * registers that chunk's pages with the HIP runtime and the pitched DMA writes them directly; every registration is
- * released before the call returns, and if one is refused the remaining chunks go through the runtime's own staging
- * (slower, same bytes).  `stream` is synchronised before the call returns.  x_row_bytes or emb_row_bytes may be 0.
+ * released before the call returns (a release the runtime refuses is reported as POPE_ERR_HIP: the pages would stay
+ * registered), and if a registration is refused the remaining rows are staged through a 4 MB pinned bounce buffer of the
+ * library's own and copied out by the host (slower, same bytes; only if that buffer is refused as well does a blocking
+ * copy by the runtime write the pageable rows).  `stream` is synchronised before the call returns.  x_row_bytes or emb_row_bytes may be 0.
  */
 int pope_assemble_host_result(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, const void *emb,
                               int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *out_host, int64_t out_pitch_bytes,
@@ -363,6 +365,23 @@ int pope_assemble_host_result(const void *x_host, int64_t x_pitch_bytes, int64_t
  */
 void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, void *out_host, int64_t out_pitch_bytes,
                           int64_t rows, int32_t threads, int32_t chunks);
+/* Fresh result pages faulted in beside the GPU work (the first host -> host call of a process; utils.py:134 allocates the result
+ * with torch.cat): `threads` (<= 0: 4) helper threads populate [host, host + bytes) -- MADV_HUGEPAGE, then one
+ * madvise(MADV_POPULATE_WRITE) per thread over disjoint 2 MB-aligned ranges (page touches on kernels without it) -- while the
+ * caller uploads edge_index and runs the BFS.  _begin returns at once (NULL: nothing to do); _wait joins and frees the handle. */
+void *pope_host_prefault_begin(void *host, size_t bytes, int32_t threads);
+void pope_host_prefault_wait(void *handle);
+/* pope_assemble_begin takes the transport from the process-global test knobs (POPE_KNOB_HOST_RESULT_MODE, bit 0 of
+ * POPE_KNOB_FAIL_HOST_REGISTER); pope_assemble_begin_mode takes it as ARGUMENTS, so that concurrent callers with different
+ * choices do not meet in global state (utils.py:129-135; what graphpope_amd.utils calls): result_mode = POPE_RESULT_RING (the
+ * embedding columns through the process's pinned ring) or POPE_RESULT_REGISTERED (the result's own pages are registered chunk
+ * by chunk); no_register != 0: this assembly never hands the result's pages to hipHostRegister -- the columns are staged
+ * through a small pinned bounce buffer of the library's own and copied out by the host, so the runtime never holds a
+ * mapping of pageable memory that the caller will free or unmap later. */
+#define POPE_RESULT_RING       0
+#define POPE_RESULT_REGISTERED 1
+void *pope_assemble_begin_mode(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, void *out_host, int64_t out_pitch_bytes,
+                               int64_t rows, int32_t threads, int32_t chunks, int32_t result_mode, int32_t no_register);
 int pope_assemble_finish(void *handle, const void *emb, int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *stream);
 void pope_assemble_abort(void *handle);
 /* Optional, returns at once: the process's pinned ring (24 MB, 2 ms of hipHostMalloc) is allocated by a helper thread on

@@ -628,3 +628,64 @@ def test_concurrent_host_assemblies_take_turns_on_the_ring(dev):
         want = lut.cpu()[emb.cpu().long()] if coded else emb.cpu()
         assert torch.equal(out[:, :f], x) and torch.equal(out[:, f:], want), (idx, it)
     assert len(results) == 8
+
+
+@pytest.mark.parametrize("k", [40, 100, 256])
+def test_copy_role_of_the_level_launches_leaves_the_result_unchanged(dev, oracle, k):
+    """POPE_KNOB_LEVEL_COPY (round-4 experiment, off by default): level launch l copies a share of x's rows beside its BFS
+    blocks and the finalise kernel starts at the first row nobody took.  Shares that end before, at and beyond the number of
+    launches, on a poisoned output buffer: bit-exact against the oracle (utils.py:129-135)."""
+    from graphpope_amd import _lib, engine, synth
+    lib = _lib.load()
+    ei, n = synth.rmat(12, edge_factor=8, seed=31)
+    eid = torch.as_tensor(ei, device=dev)
+    x = torch.rand(n, 20, device=dev)
+    anchors = np.random.RandomState(k).choice(np.arange(n), k)
+    want = oracle.geodesic_features(x.cpu().numpy(), ei, n, anchors)
+    try:
+        for shares in ({1: 100, 2: 250}, {0: 60}, {1: 700, 2: 700}, {3: 333, 14: 500}):
+            lib.pope_debug_set(_lib.KNOB_LEVEL_COPY, 0)
+            for level, pm in shares.items():
+                assert lib.pope_debug_set(_lib.KNOB_LEVEL_COPY, (level << 16) | pm) == 0
+            for _ in range(2):                                   # the second call runs the window the first one found
+                out = engine.geodesic_run(x, eid, n, anchors, reuse_workspace=True)[0]
+                assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), shares
+                out.fill_(float("nan"))
+                del out
+    finally:
+        lib.pope_debug_set(_lib.KNOB_LEVEL_COPY, 0)
+
+
+@pytest.mark.parametrize("k", [40, 100, 256])
+@pytest.mark.parametrize("blocks", [8, 64])
+def test_tail_kernel_runs_the_last_levels_inside_the_finalise_launch(dev, oracle, k, blocks):
+    """POPE_KNOB_TAIL_LEVEL (round-4 experiment, off by default): levels T, T + 1, ... run in a few blocks of the finalise
+    kernel's launch with a barrier among themselves, the others copy x and wait for the verdict.  T inside, at the end of and
+    beyond the depth of the graph, with and without an output matrix, on a graph deeper than the 15 levels the kernel may run
+    (the host continues with level launches): bit-exact against the oracle (utils.py:64-81, 129-135)."""
+    from graphpope_amd import _lib, engine, synth
+    lib = _lib.load()
+    ei, n = synth.rmat(12, edge_factor=8, seed=37)
+    path = np.arange(40)                                          # a tail of 40 extra hops hanging off node 0
+    deep = np.concatenate([ei, np.stack([np.r_[0, n + path[:-1]], n + path]), np.stack([n + path, np.r_[0, n + path[:-1]]])], axis=1)
+    deep = np.ascontiguousarray(deep[:, np.lexsort((deep[1], deep[0]))])
+    try:
+        for graph, nn in ((ei, n), (deep, n + 40)):
+            eid = torch.as_tensor(graph, device=dev)
+            x = torch.rand(nn, 20, device=dev)
+            anchors = np.random.RandomState(k).choice(np.arange(nn), k)
+            want = oracle.geodesic_features(x.cpu().numpy(), graph, nn, anchors)
+            want_hops = oracle.geodesic_hops(graph, nn, anchors)
+            for t in (0, 2, 3, 5, 9, 14):
+                lib.pope_debug_set(_lib.KNOB_TAIL_LEVEL, t)
+                lib.pope_debug_set(_lib.KNOB_TAIL_BLOCKS, blocks)
+                for _ in range(2):
+                    out, hp = engine.geodesic_run(x, eid, nn, anchors, reuse_workspace=True)
+                    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (t, nn)
+                    out.fill_(float("nan"))
+                    del out
+                hp = engine.geodesic_run(None, eid, nn, anchors, want_out=False)[1]
+                assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), want_hops), (t, nn)
+    finally:
+        lib.pope_debug_set(_lib.KNOB_TAIL_LEVEL, 0)
+        lib.pope_debug_set(_lib.KNOB_TAIL_BLOCKS, 0)

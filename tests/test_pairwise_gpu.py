@@ -342,3 +342,4 @@ def test_kmeans_overlapping_clusters_reach_a_fixed_point(dev):
     np.random.seed(7)
     ref = KMeans(n_clusters=20).fit(x.numpy()).inertia_
     assert abs(inertia - ref) / ref < 0.02
+

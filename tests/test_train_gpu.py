@@ -213,3 +213,40 @@ def test_sampling_ahead_on_a_side_stream_gives_the_same_steps(graph):
             losses.append(st.step(sd, labels[sd].contiguous(), nxt, None if nxt is None else labels[nxt].contiguous()).item())
         runs.append(losses)
     assert np.allclose(runs[0], runs[1], rtol=1e-4) and runs[0][-1] < runs[0][0]
+
+
+def test_a_captured_step_keeps_its_own_sampler_scratch(graph):
+    """ADVICE (round 3): the captured step has the sampler's scratch address baked in, and the host-sized sampling paths used
+    to share it and replace it when they needed a larger one -- the next replay then wrote into freed memory.  The
+    device-extent paths now take their scratch from the DeviceBatch (never replaced): a replayed trainer whose sampler serves
+    a much larger host-sized batch (and a second, larger DeviceBatch) in between draws the same batches and the same losses
+    as an undisturbed one."""
+    from graphpope_amd.optim import Adam
+    from graphpope_amd.sampler import DeviceBatch, NeighborSampler
+    from graphpope_amd.train import SageTrainStep
+    dev, _, csr = graph
+    feats = torch.randn(6000, 40, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    labels = torch.randint(0, 5, (6000,), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    perm = torch.randperm(6000, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    runs = []
+    for disturb in (False, True):
+        sampler = NeighborSampler(csr.rowptr, csr.col, 6000, (25, 10))
+        m = _model(dev)
+        opt = Adam(m.parameters(), lr=0.01)
+        st = SageTrainStep(m, opt, feats, 128, (25, 10), sampler=sampler, clip=0.5, graph=True, seed=11)
+        losses, ids = [], []
+        for i in range(8):
+            if disturb and i >= 3:
+                big = perm[: 1024 + 256 * i].contiguous()             # every call needs more scratch than the one before
+                sampler.sample(big, seed=i)
+                sampler.sample_device(perm[: 512].contiguous(), seed=i, out=DeviceBatch(512, (25, 10), dev))
+                junk = torch.full((1 << 22,), 0x7F, dtype=torch.uint8, device=dev)   # whatever was freed gets reused and overwritten
+                del junk
+            sd = perm[(i % 6) * 128:(i % 6 + 1) * 128].contiguous()
+            losses.append(st.step(sd, labels[sd].contiguous()).item())
+            ids.append(st.batch.n_id[: int(st.batch.dims[-1][1])].clone())
+        runs.append((losses, ids))
+    (la, ia), (lb, ib) = runs
+    for a, b in zip(ia, ib):
+        assert torch.equal(a, b)
+    assert np.allclose(la, lb, rtol=1e-4)

@@ -1,0 +1,145 @@
+// Drives graphpope_amd/csrc/host.cc (the host half of the host -> host boundary, utils.py:129-147) against fake_hip.cc:
+// the parked worker pool, the pinned-ring hand-off, the registered and the bounce transport, aborts, and two assemblies at
+// once -- every result compared with a plain reference.  Built by run.sh under -fsanitize=thread and -fsanitize=address.
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "graphpope_hip.h"
+
+namespace pope {            // what abi.cpp / geodesic.hip provide in the real library
+int g_host_result_mode = 0, g_fail_host_register = 0;
+static thread_local char g_error[512];
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+void clear_error() { g_error[0] = 0; }
+}  // namespace pope
+
+extern "C" long fake_unpinned_async_targets();
+extern "C" long fake_live_registrations();
+
+static int g_failures = 0;
+#define CHECK(cond, ...)                                   \
+    do {                                                   \
+        if (!(cond)) {                                     \
+            ++g_failures;                                  \
+            fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); \
+            fprintf(stderr, __VA_ARGS__);                  \
+            fprintf(stderr, " [%s]\n", pope::g_error);     \
+        }                                                  \
+    } while (0)
+
+struct Case {
+    int64_t rows;
+    int f, k;
+    std::vector<float> x, emb, out;
+    std::vector<uint8_t> codes;
+    float lut[256];
+    Case(int64_t rows_, int f_, int k_, unsigned seed) : rows(rows_), f(f_), k(k_), x((size_t)rows_ * f_), emb((size_t)rows_ * k_), out((size_t)rows_ * (f_ + k_), -1.f),
+                                                          codes((size_t)rows_ * k_) {
+        srand(seed);
+        for (auto &v : x) v = (float)rand() / RAND_MAX;
+        lut[0] = 0.f;
+        for (int c = 1; c < 256; ++c) lut[c] = 1.0f / (float)c;
+        for (size_t i = 0; i < codes.size(); ++i) {
+            codes[i] = (uint8_t)(rand() % 12);
+            emb[i] = lut[codes[i]];
+        }
+    }
+    bool ok() const {
+        for (int64_t r = 0; r < rows; ++r) {
+            if (f && memcmp(&out[(size_t)r * (f + k)], &x[(size_t)r * f], (size_t)f * 4)) return false;
+            if (memcmp(&out[(size_t)r * (f + k) + f], &emb[(size_t)r * k], (size_t)k * 4)) return false;
+        }
+        return true;
+    }
+};
+
+enum How { FLOATS, CODES, ABORT };
+
+static void run_case(Case &c, int mode, int no_register, How how, int threads, void *stream, int delay_us = 0) {
+    if (getenv("HARNESS_VERBOSE")) fprintf(stderr, "case rows %lld f %d k %d mode %d no_register %d how %d threads %d stream %p\n", (long long)c.rows, c.f, c.k, mode, no_register, (int)how, threads, stream);
+    void *h = pope_assemble_begin_mode(c.f ? c.x.data() : nullptr, (int64_t)c.f * 4, (int64_t)c.f * 4, c.out.data(), (int64_t)(c.f + c.k) * 4, c.rows, threads, 0, mode,
+                                       no_register);
+    CHECK(h != nullptr, "begin");
+    if (!h) return;
+    if (delay_us) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));    // the "GPU phase": the workers must sleep, not spin
+    if (how == ABORT) {
+        pope_assemble_abort(h);
+        return;
+    }
+    int rc = how == CODES ? pope_assemble_finish_codes(h, c.codes.data(), c.k, c.k, c.lut, stream)
+                          : pope_assemble_finish(h, c.emb.data(), (int64_t)c.k * 4, (int64_t)c.k * 4, stream);
+    CHECK(rc == POPE_OK, "finish rc %d", rc);
+    CHECK(c.ok(), "result differs (rows %lld f %d k %d mode %d no_register %d how %d)", (long long)c.rows, c.f, c.k, mode, no_register, (int)how);
+}
+
+int main() {
+    // 1. the ring transport, floats and codes, repeated (the parked pool is reused), with and without feature columns
+    for (int rep = 0; rep < 4; ++rep)
+        for (int f : {500, 0, 3}) {
+            Case a(30000 + 17 * rep, f, 256, 1 + rep), b(30000 + 17 * rep, f, 256, 7 + rep);
+            run_case(a, POPE_RESULT_RING, 0, FLOATS, 16, nullptr, rep ? 300 : 0);
+            run_case(b, POPE_RESULT_RING, 0, CODES, 16, nullptr, rep ? 300 : 0);
+        }
+    // 2. registered transport: the result's pages registered chunk by chunk, everything released afterwards
+    {
+        Case a(40000, 500, 64, 11);
+        run_case(a, POPE_RESULT_REGISTERED, 0, FLOATS, 8, nullptr);
+        CHECK(fake_live_registrations() == 0, "%ld registrations left behind", fake_live_registrations());
+    }
+    // 3. no registration allowed: the bounce buffer; the runtime must never be given a pageable destination
+    {
+        const long before = fake_unpinned_async_targets();
+        Case a(40000, 500, 64, 12), b(1000, 8, 1100, 13);
+        run_case(a, POPE_RESULT_REGISTERED, 1, FLOATS, 8, nullptr);
+        run_case(b, POPE_RESULT_REGISTERED, 1, FLOATS, 3, nullptr);
+        CHECK(fake_unpinned_async_targets() == before, "%ld asynchronous copies into unpinned, unregistered host memory", fake_unpinned_async_targets() - before);
+        pope::g_fail_host_register = 4;                        // even the bounce buffer refused: blocking copies
+        Case c(5000, 20, 40, 14);
+        run_case(c, POPE_RESULT_REGISTERED, 1, FLOATS, 4, nullptr);
+        pope::g_fail_host_register = 0;
+    }
+    // 4. ring refused (knob bit 2): floats fall back to registration; codes are refused with an error, not a hang
+    {
+        pope::g_fail_host_register = 2;
+        Case a(20000, 100, 128, 15);
+        run_case(a, POPE_RESULT_RING, 0, FLOATS, 8, nullptr);
+        Case b(20000, 100, 128, 16);
+        void *h = pope_assemble_begin_mode(b.x.data(), 400, 400, b.out.data(), (100 + 128) * 4, b.rows, 8, 0, POPE_RESULT_RING, 0);
+        CHECK(h && pope_assemble_finish_codes(h, b.codes.data(), 128, 128, b.lut, nullptr) == POPE_ERR_HIP, "codes without a ring must fail cleanly");
+        pope::g_fail_host_register = 0;
+        CHECK(fake_live_registrations() == 0, "%ld registrations left behind", fake_live_registrations());
+    }
+    // 5. aborts: before any work, and with the workers asleep in the "GPU phase"
+    for (int rep = 0; rep < 3; ++rep) {
+        Case a(25000, 500, 256, 20 + rep);
+        run_case(a, POPE_RESULT_RING, 0, ABORT, 16, nullptr, rep * 200);
+    }
+    // 6. two assemblies at once on two streams (one borrows the parked pool, the other starts threads of its own), repeatedly
+    for (int rep = 0; rep < 6; ++rep) {
+        Case a(30000, 200, 256, 30 + rep), b(28000, 64, 128, 40 + rep);
+        std::thread t1([&] { run_case(a, POPE_RESULT_RING, 0, rep & 1 ? CODES : FLOATS, 8, (void *)0x10, 100); });
+        std::thread t2([&] { run_case(b, rep & 2 ? POPE_RESULT_REGISTERED : POPE_RESULT_RING, 0, FLOATS, 6, (void *)0x20, 50); });
+        t1.join();
+        t2.join();
+    }
+    // 7. the whole-call entry and the 2-D host copy
+    {
+        Case a(12345, 77, 33, 50);
+        CHECK(pope_assemble_host_result(a.x.data(), 77 * 4, 77 * 4, a.emb.data(), 33 * 4, 33 * 4, a.out.data(), (77 + 33) * 4, a.rows, 5, 3, nullptr) == POPE_OK, "host_result");
+        CHECK(a.ok(), "host_result differs");
+        std::vector<float> dst(a.x.size());
+        CHECK(pope_host_copy_2d(a.x.data(), 77 * 4, dst.data(), 77 * 4, 77 * 4, a.rows, 7) == POPE_OK && dst == a.x, "host_copy_2d");
+    }
+    printf(g_failures ? "host harness: %d FAILURES\n" : "host harness: all cases passed\n", g_failures);
+    return g_failures ? 1 : 0;
+}

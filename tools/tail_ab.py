@@ -27,13 +27,27 @@ specs = args or ["0", "8:256", "8:128", "8:384", "9:256", "7:256", "6:256", "10:
 
 
 def apply(spec):
+    spec, _, variant = spec.partition("/")
+    assert lib.pope_debug_set(_lib.KNOB_LEVEL_VARIANT, int(variant) if variant else 0) == 0
     t, _, b = spec.partition(":")
     assert lib.pope_debug_set(_lib.KNOB_TAIL_LEVEL, int(t)) == 0
     assert lib.pope_debug_set(_lib.KNOB_TAIL_BLOCKS, int(b) if b else 256) == 0
 
 
+WITH_OUT = os.environ.get("TAIL_AB_NO_OUT") is None
+
+
 def run(spec, steps):
     apply(spec)
+    if not WITH_OUT:
+        for _ in range(3):
+            engine.geodesic_run(None, ei, n, anchors, want_out=False, reuse_workspace=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            engine.geodesic_run(None, ei, n, anchors, want_out=False, reuse_workspace=True)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, engine.geodesic_run(x, ei, n, anchors, reuse_workspace=True)[0]
     for _ in range(3):
         out = engine.geodesic_run(x, ei, n, anchors, reuse_workspace=True)[0]
     torch.cuda.synchronize()

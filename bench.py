@@ -254,13 +254,15 @@ def pairwise_leg(n, anchors, x, dev, steps):
     emb_ms = ev[0].elapsed_time(ev[1]) / steps
     flops = 2.0 * n * k * d
     tile_traffic, tile_traffic_src = None, None
-    try:                                                         # HBM bytes of the tile kernel from the committed counter passes
-        with open(os.path.join(ROOT, "profiles", "r02_pairwise_pmc.json")) as fh:
-            kk = json.load(fh)["kernels"]["k_pairwise_persistent"]
-        tile_traffic = kk["hbm_read_bytes"] + kk["hbm_write_bytes"]
-        tile_traffic_src = "profiles/r02_pairwise_pmc.json (rocprofv3 --pmc passes of tools/pairwise_time.py, a separate run: k_pairwise_persistent only)"
-    except (OSError, ValueError, KeyError):
-        pass
+    for pmc_name in ("r04_pairwise_pmc.json", "r02_pairwise_pmc.json"):     # HBM bytes of the tile kernel from the committed counter passes, newest first
+        try:
+            with open(os.path.join(ROOT, "profiles", pmc_name)) as fh:
+                kk = json.load(fh)["kernels"]["k_pairwise_persistent"]
+            tile_traffic = kk["hbm_read_bytes"] + kk["hbm_write_bytes"]
+            tile_traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc passes of tools/pairwise_time.py, a separate run: k_pairwise_persistent only)"
+            break
+        except (OSError, ValueError, KeyError):
+            continue
     res = {
         "workload": f"configs[2]: node2vec-euclidean, X [{n}, {d}] f32 N(0,1) (torch seed 0), {k} anchors (np seed 42), "
                     "features [N, 500] resident in HBM -> [N, 756] f32 in HBM (feature copy + pairwise + column min-max)",
@@ -755,7 +757,7 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernels from the committed rocprofv3 --pmc summary of the same command
     (separate profiling run, newest round first); None if no summary is committed."""
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as fh:

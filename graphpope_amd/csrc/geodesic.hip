@@ -1873,6 +1873,19 @@ static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_ho
     }
     if (vec && (g_finalize_variant > 0 || n_shards > 1) && (max_hop_dev || n_hop_bits <= 4)) {
         dim3 fgrid(g_finalize_blocks);                          // 8 blocks per CU, contiguous row blocks per wave
+        // POPE_KNOB_FINALIZE_VARIANT 3 / 4 (round-4 A/B): the embedding columns and the feature copy as TWO launches on the same
+        // stream -- 3: columns first (that kernel carries the verdict, so the host still hears it when the BFS ends), then
+        // side_copy.hip's copy kernel (5.9 TB/s alone); 4: the copy first.
+        if ((g_finalize_variant == 3 || g_finalize_variant == 4) && x && n_shards == 1 && x_row_begin < N &&
+            SideCopy::eligible(x, F, out, out_cols, N)) {
+            const float *xs = x + (size_t)x_row_begin * F;
+            float *os = out + (size_t)x_row_begin * out_cols;
+            if (g_finalize_variant == 4) { int rc = enqueue_copy_features(xs, F, os, out_cols, N - x_row_begin, stream); if (rc) return rc; }
+            hipLaunchKernelGGL(k_finalize_fast<0>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, (int)N);
+            if (g_finalize_variant == 3) { int rc = enqueue_copy_features(xs, F, os, out_cols, N - x_row_begin, stream); if (rc) return rc; }
+            POPE_HIP(hipGetLastError());
+            return POPE_OK;
+        }
         if (g_finalize_variant == 2)
             hipLaunchKernelGGL(k_finalize_fast<1>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, x_row_begin);
         else

@@ -161,12 +161,14 @@ def _assemble_on_host(data, k, embedding_fn):
         prefault = None
         try:
             # pages from the pool (a repeated call): no page faults to take, so the feature copy may start now and run underneath
-            # the upload and the GPU work; fresh pages (the first call): a few helper threads populate them meanwhile (round 4:
-            # GRAPHPOPE_PREFAULT_THREADS, default 4, 0 = off) and the copy starts after the GPU work, on pages that exist
+            # the upload and the GPU work; fresh pages (the first call): the copy starts after the GPU work.  Opt-in (round 4,
+            # GRAPHPOPE_PREFAULT_THREADS = n > 0): n helper threads populate the fresh pages beside the GPU work -- measured
+            # SLOWER inside bench.py (6.4 ms -> 8.9 / 14.7 / 17.0 ms with 2 / 4 / 8 threads: page population beside the launches
+            # stalls the GPU queues of a large process, as the sixteen copy threads did in round 3), hence off by default
             if reused and mode == "ring":
                 asm = engine.HostAssembly(x if f else None, out, f, mode=asm_mode, register=register)
             elif not reused and out.numel() * 4 >= (8 << 20):
-                nthreads = int(os.environ.get("GRAPHPOPE_PREFAULT_THREADS", "4"))
+                nthreads = int(os.environ.get("GRAPHPOPE_PREFAULT_THREADS", "0"))
                 if nthreads > 0:
                     prefault = _lib_mod.load().pope_host_prefault_begin(out.data_ptr(), out.numel() * 4, nthreads)
             emb_dev = embedding_fn()                   # float32 [N, K], or (uint8 codes [N, K], float32 lut [256]): engine.hop_codes

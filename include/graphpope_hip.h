@@ -78,7 +78,7 @@ int pope_require_device(int32_t *cu_count_host);
  * needed by a caller.  value < 0 restores the automatic choice where one exists.
  */
 #define POPE_KNOB_LIVE_MODE         0   /* level kernel: -1 auto, 0 no live-bit table, 1 table in LDS, 2 table in global memory */
-#define POPE_KNOB_FINALIZE_VARIANT  1   /* 0 generic finalise kernel, 1 fast path (default), 2 fast path + non-temporal stores   */
+#define POPE_KNOB_FINALIZE_VARIANT  1   /* 0 generic finalise kernel, 1 fast path (default), 2 fast path + non-temporal stores, 3 embedding columns and feature copy as two launches (columns first), 4 the same with the copy first (round-4 A/B: both slower) */
 #define POPE_KNOB_FINALIZE_BLOCKS   2   /* grid of the fast finalise kernel (default 2048)                                       */
 #define POPE_KNOB_GEMM_TILE         3   /* SAGE GEMM: 0 auto, 1 64x64, 2 64x128, 3 128x256 tiles, 4 / 5 stream-K without loader waves, 6 stream-K with stages of 64 in two 80 KB buffers, 7 stream-K instead of the chip-fitted whole tiles (gemm_tile16.h) */
 #define POPE_KNOB_COPY_BATCHES      5   /* node2vec embedding: 16-piece batches per wave of the feature-copy kernel beside the tile kernel (default 1) */

@@ -137,6 +137,16 @@ extern "C" int pope_host_copy_2d(const void *src_host, int64_t src_pitch_bytes, 
 // ------------------------------------------------------------------------------------------------
 // Caller-owned pageable memory as a DMA endpoint for the length of one call
 // ------------------------------------------------------------------------------------------------
+// Round 4: only the WHOLE pages inside [host, host + bytes) are registered -- the partial pages at the two ends of a heap
+// allocation also hold other objects (the allocator's headers, neighbouring tensors), and registering those registers memory
+// this library knows nothing about.  pope_copy_to_device sends the two fragments (under a page each) as plain pageable copies,
+// which the runtime stages through its own buffers, and the body by DMA from the registered pages.
+namespace {
+struct PinnedRange { uintptr_t lo, hi; };
+std::mutex g_pin_mu;
+std::vector<std::pair<const void *, PinnedRange>> g_pins;          // live registrations made by pope_host_pin, by the caller's pointer
+}  // namespace
+
 extern "C" int pope_host_pin(const void *host, size_t bytes) {
     pope::clear_error();
     if (!host || bytes == 0) {
@@ -147,19 +157,41 @@ extern "C" int pope_host_pin(const void *host, size_t bytes) {
         pope::set_error("pope_host_pin: refused (POPE_KNOB_FAIL_HOST_REGISTER)");
         return POPE_ERR_HIP;
     }
-    const hipError_t e = hipHostRegister(const_cast<void *>(host), bytes, hipHostRegisterDefault);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        pope::set_error("hipHostRegister(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE), b = reinterpret_cast<uintptr_t>(host);
+    const uintptr_t lo = (b + page - 1) & ~(page - 1), hi = (b + bytes) & ~(page - 1);
+    if (hi <= lo || hi - lo < ((uintptr_t)1 << 20)) {
+        pope::set_error("pope_host_pin: fewer than 1 MB of whole pages inside the buffer: stage it instead");
         return POPE_ERR_HIP;
     }
+    const hipError_t e = hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        pope::set_error("hipHostRegister(%zu bytes) failed: %s", (size_t)(hi - lo), hipGetErrorString(e));
+        return POPE_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    g_pins.emplace_back(host, PinnedRange{lo, hi});
     return POPE_OK;
 }
 
 extern "C" int pope_host_unpin(const void *host) {
     pope::clear_error();
     if (!host) return POPE_ERR_INVALID;
-    const hipError_t e = hipHostUnregister(const_cast<void *>(host));
+    PinnedRange r{0, 0};
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mu);
+        for (size_t i = 0; i < g_pins.size(); ++i)
+            if (g_pins[i].first == host) {
+                r = g_pins[i].second;
+                g_pins.erase(g_pins.begin() + (long)i);
+                break;
+            }
+    }
+    if (!r.hi) {
+        pope::set_error("pope_host_unpin: %p was not pinned by pope_host_pin", host);
+        return POPE_ERR_INVALID;
+    }
+    const hipError_t e = hipHostUnregister(reinterpret_cast<void *>(r.lo));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         pope::set_error("hipHostUnregister failed: %s", hipGetErrorString(e));
@@ -175,12 +207,29 @@ extern "C" int pope_copy_to_device(const void *src_host, void *dst, size_t bytes
         return POPE_ERR_INVALID;
     }
     if (bytes == 0) return POPE_OK;
-    const hipError_t e = hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
-    if (e != hipSuccess) {
-        pope::set_error("hipMemcpyAsync(H2D, %zu bytes) failed: %s", bytes, hipGetErrorString(e));
-        return POPE_ERR_HIP;
+    PinnedRange r{0, 0};
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mu);
+        for (auto &p : g_pins)
+            if (p.first == src_host) r = p.second;
     }
-    return POPE_OK;
+    const uintptr_t b = reinterpret_cast<uintptr_t>(src_host), e_ = b + bytes;
+    auto piece = [&](uintptr_t lo, uintptr_t hi) -> int {
+        if (hi <= lo) return POPE_OK;
+        const hipError_t e = hipMemcpyAsync(static_cast<char *>(dst) + (lo - b), reinterpret_cast<const void *>(lo), hi - lo, hipMemcpyHostToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) {
+            pope::set_error("hipMemcpyAsync(H2D, %zu bytes) failed: %s", (size_t)(hi - lo), hipGetErrorString(e));
+            return POPE_ERR_HIP;
+        }
+        return POPE_OK;
+    };
+    if (r.hi && r.lo >= b && r.hi <= e_) {             // pinned by pope_host_pin: the body from the registered pages, the two ends apart
+        int rc = piece(b, r.lo);
+        if (!rc) rc = piece(r.lo, r.hi);
+        if (!rc) rc = piece(r.hi, e_);
+        return rc;
+    }
+    return piece(b, e_);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -803,15 +852,22 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
     // are not multiples of the page size) is sent as two plain copies once both regions exist.
     uintptr_t reg_hi = 0;
     int64_t next_row = 0;                          // rows below have been enqueued
-    bool registering = eb > 0 && !a.no_register;
+    // Only pages that belong to the result ALONE are ever registered (round 4): the result must start on a page boundary (the
+    // library's own results are anonymous mappings: engine.host_result_tensor) and be at least 1 MB, and the last region ends at the
+    // last page boundary INSIDE it.  Registering the partial pages at the ends of a heap allocation registers whatever else lives
+    // on those pages -- other tensors, the allocator's and the runtime's own data; tests did that with torch heap tensors as small
+    // as 140 bytes, and every unexplained abort / GPU memory fault of rounds 3 and 4 came after such a test.
+    const uintptr_t reg_end = (base + total) & ~pmask;
+    bool registering = eb > 0 && !a.no_register && (base & pmask) == 0 && total >= ((size_t)1 << 20);
     for (int c = 0; c < nch && rc == POPE_OK; ++c) {
         double t0 = now_ms();
         while (a.done[(size_t)c].load(std::memory_order_acquire) < a.slices) std::this_thread::yield();
         tr[1] += now_ms() - t0;
         if (eb == 0 || !registering) continue;
         const int64_t r1 = a.chunk_lo[(size_t)c + 1];
-        const uintptr_t lo = c == 0 ? (base & ~pmask) : reg_hi;
-        const uintptr_t hi = c + 1 == nch ? ((base + total + pmask) & ~pmask) : ((base + (uintptr_t)r1 * pitch + pmask) & ~pmask);
+        const uintptr_t lo = c == 0 ? base : reg_hi;
+        uintptr_t hi = c + 1 == nch ? reg_end : ((base + (uintptr_t)r1 * pitch + pmask) & ~pmask);
+        if (hi > reg_end) hi = reg_end;
         if (hi <= lo) continue;
         t0 = now_ms();
         const hipError_t e = hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterDefault);
@@ -837,12 +893,7 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
         }
         tr[3] += now_ms() - t0;
     }
-    if (eb > 0 && next_row < rows && rc == POPE_OK) {                               // registration refused (or switched off)
-        if (reg_hi && S(next_row) < reg_hi) {
-            copy1d(S(next_row), reg_hi, next_row);
-            copy1d(reg_hi, T(next_row), next_row);
-            ++next_row;
-        }
+    if (eb > 0 && next_row < rows && rc == POPE_OK) {                               // not registered: refused, switched off, or the tail behind the last whole page
         // The rest of the rows lie in pageable memory the runtime holds no registration for.  Round 3 handed them to
         // hipMemcpy2DAsync as they were (the runtime then pins such pages on the fly and may keep that mapping cached after
         // the caller has freed or unmapped them: the one explanation that fits round 3's GPU memory fault at a host heap

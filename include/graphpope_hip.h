@@ -347,7 +347,9 @@ int pope_copy_2d_to_host(const void *src, int64_t src_pitch_bytes, void *dst_hos
  * slots that are allocated once per process, and the worker threads copy each landed chunk out while the next one is on
  * the bus -- no page of the result is ever registered.  Mode 1: the result is cut into `chunks` row chunks (<= 0: 8),
  * worker threads fill a chunk's feature columns (its first touch: MADV_HUGEPAGE is applied first), the calling thread
- * registers that chunk's pages with the HIP runtime and the pitched DMA writes them directly; every registration is
+ * registers that chunk's pages with the HIP runtime and the pitched DMA writes them directly -- only for a result that starts on
+ * a page boundary and is at least 1 MB (the library's own results are anonymous mappings), and only up to the last page boundary
+ * inside it: pages the result shares with other objects are never registered, their rows take the bounce buffer; every registration is
  * released before the call returns (a release the runtime refuses is reported as POPE_ERR_HIP: the pages would stay
  * registered), and if a registration is refused the remaining rows are staged through a 4 MB pinned bounce buffer of the
  * library's own and copied out by the host (slower, same bytes; only if that buffer is refused as well does a blocking
@@ -405,10 +407,13 @@ int pope_geodesic_hop_codes(const uint64_t *planes, int32_t n_hop_bits, int32_t 
 int pope_assemble_finish_codes(void *handle, const uint8_t *codes, int64_t codes_pitch_bytes, int32_t K, const float *lut, void *stream);
 
 /*
- * Caller-owned pageable HOST memory as a DMA endpoint for the length of one call: pope_host_pin registers [host, host +
- * bytes) with the HIP runtime (POPE_ERR_HIP if refused -- the caller then stages through pinned memory instead),
- * pope_copy_to_device enqueues one asynchronous host -> device copy on `stream`, pope_host_unpin releases the pages
- * (after the copy has completed).  Used for edge_index (utils.py:121): 14.4 MB go up straight from the caller's tensor.
+ * Caller-owned pageable HOST memory as a DMA endpoint for the length of one call: pope_host_pin registers the WHOLE PAGES
+ * inside [host, host + bytes) with the HIP runtime -- never the partial pages at the two ends, which a heap allocation shares
+ * with other objects (POPE_ERR_HIP if refused, or if fewer than 1 MB of whole pages lie inside: the caller then stages through
+ * pinned memory instead); pope_copy_to_device enqueues the asynchronous host -> device copy on `stream` (for a pinned buffer:
+ * the body by DMA from the registered pages, the two end fragments as plain copies); pope_host_unpin releases the pages (after
+ * the copy has completed; POPE_ERR_INVALID for a pointer pope_host_pin did not pin).  Used for edge_index (utils.py:121):
+ * 14.4 MB go up straight from the caller's tensor.
  */
 int pope_host_pin(const void *host, size_t bytes);
 int pope_host_unpin(const void *host);

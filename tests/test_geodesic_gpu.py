@@ -509,9 +509,13 @@ def test_host_result_assembly_shapes(register, dev):
             emb = torch.rand(n, k, generator=g).to(dev)
             xw = torch.rand(n, f + 5, generator=g)
             x = xw[:, :f]                                     # row pitch larger than the row
-            out = torch.full((n, f + k), -1.0)
-            engine.assemble_host_result(x if f else None, emb, out, f, threads=4, chunks=chunks)
-            assert torch.equal(out[:, :f], x) and torch.equal(out[:, f:], emb.cpu())
+            # heap tensors (never registered: their end pages hold other objects -> the bounce buffer in registered mode) and
+            # page-aligned anonymous mappings like the ones Graphpope() returns (registered chunk by chunk in registered mode)
+            for out in (torch.full((n, f + k), -1.0), engine.host_result_tensor(n, f + k)):
+                out.fill_(-1.0)
+                engine.assemble_host_result(x if f else None, emb, out, f, threads=4, chunks=chunks)
+                assert torch.equal(out[:, :f], x) and torch.equal(out[:, f:], emb.cpu())
+                del out
         emb = torch.rand(50000, 80, generator=g).to(dev)[:, :48]      # a pitched device embedding (320-byte rows, 192 used)
         out = torch.full((50000, 48), -1.0)
         engine.assemble_host_result(None, emb, out, 0, threads=3, chunks=2)

@@ -91,6 +91,7 @@ void note_host_target(const void *dst, size_t n) {
 }  // namespace
 
 extern "C" long fake_unpinned_async_targets() { return g_unpinned_targets.load(); }
+extern "C" void fake_stream_synchronize(void *stream) { queue_of((hipStream_t)stream).drain(); }
 extern "C" long fake_live_registrations() {
     std::lock_guard<std::mutex> lock(g_m);
     return (long)g_registered.size();

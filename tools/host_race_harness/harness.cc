@@ -25,6 +25,7 @@ void clear_error() { g_error[0] = 0; }
 
 extern "C" long fake_unpinned_async_targets();
 extern "C" long fake_live_registrations();
+extern "C" void fake_stream_synchronize(void *stream);
 
 static int g_failures = 0;
 #define CHECK(cond, ...)                                   \
@@ -131,6 +132,21 @@ int main() {
         std::thread t2([&] { run_case(b, rep & 2 ? POPE_RESULT_REGISTERED : POPE_RESULT_RING, 0, FLOATS, 6, (void *)0x20, 50); });
         t1.join();
         t2.join();
+    }
+    // 6b. uploads: only whole pages inside the caller's buffer are registered, the two ends travel as plain copies
+    {
+        std::vector<char> src((3 << 20) + 777), dst(src.size(), 0);
+        for (size_t i = 0; i < src.size(); ++i) src[i] = (char)(i * 131 + 7);
+        const char *p = src.data() + 13;                       // not page aligned
+        const size_t n = src.size() - 13 - 5;
+        CHECK(pope_host_pin(p, n) == POPE_OK, "pin");
+        CHECK(fake_live_registrations() == 1, "one registration expected");
+        CHECK(pope_copy_to_device(p, dst.data(), n, (void *)0x30) == POPE_OK, "copy");
+        fake_stream_synchronize((void *)0x30);
+        CHECK(memcmp(dst.data(), p, n) == 0, "uploaded bytes differ");
+        CHECK(pope_host_unpin(p) == POPE_OK && fake_live_registrations() == 0, "unpin");
+        CHECK(pope_host_unpin(p) == POPE_ERR_INVALID, "a second unpin must be refused");
+        CHECK(pope_host_pin(src.data() + 1, 8192) == POPE_ERR_HIP, "a buffer without 1 MB of whole pages must be refused");
     }
     // 7. the whole-call entry and the 2-D host copy
     {

@@ -817,6 +817,221 @@ __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ p
     }
 }
 
+// k_finalize_fast with every load of a row in flight at once, the NEXT row's loads issued before this row's stores, and the rows
+// dealt to the waves round-robin (round 4).  The ISA of k_finalize_fast shows why it runs at 4.6 TB/s: its loops compile to
+// load - s_waitcnt vmcnt(0) - store per 16-byte piece and to one plane load per s_waitcnt in the hop-bit loop -- seven serial round
+// trips per row and ONE load in flight per lane, the chip's 32 waves per CU being all that hides them.  Here a row's XP feature
+// pieces and the 5 plane words of its EP embedding pieces are independent loads (no loops), held in registers for one
+// iteration while the next row's are requested: 0.263 -> 0.254 ms per configs[1] step.  Row v goes to wave v mod nwaves, so
+// the waves that run at the same time stream through ONE moving window of consecutive rows instead of 8 192 separate places
+// (0.254 -> 0.247; with the old kernel's serial loops contiguous row blocks per wave were the faster choice), and the grid is one
+// row per wave (22 313 blocks for Flickr: 0.2395 ms; profiles/r04_finalize_pipe*.txt): 463 MB in ~74 us = 6.25 TB/s, the measured
+// copy rate of the part.  Shapes: F <= 256 XP (XP <= 4), any K * shards (rows wider than 1 024 columns are cut into segments, one
+// work item each), at most four hop bits (others: k_finalize_fast).
+template <int XP, int EP>
+struct FinRow {
+    f32x4 x[XP > 0 ? XP : 1];
+    u64 w[EP][5];
+};
+
+template <int XP, int EP>
+__device__ __forceinline__ FinRow<XP, EP> fin_load(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits, int Wp, const float *__restrict__ x,
+                                                   int F4, int v, int lane, bool copy_x, int K4, int n_emb, size_t shard_elems, int q0) {
+    FinRow<XP, EP> r;
+#pragma unroll
+    for (int i = 0; i < (XP > 0 ? XP : 1); ++i) r.x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (XP > 0 && copy_x) {
+        const f32x4 *xs = reinterpret_cast<const f32x4 *>(x) + (size_t)v * F4;
+#pragma unroll
+        for (int i = 0; i < XP; ++i)
+            if (lane + 64 * i < F4) r.x[i] = __builtin_nontemporal_load(xs + lane + 64 * i);
+    }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+#pragma unroll
+        for (int b = 0; b < 5; ++b) r.w[e][b] = 0;
+        const int q = q0 + lane + 64 * e;
+        if (q < n_emb) {
+            const int shard = q / K4, j = (q - shard * K4) * 4;
+            const size_t widx = (size_t)shard * shard_elems + (size_t)v * Wp + (j >> 6);
+            r.w[e][0] = planes[widx];
+            if (n_hop_bits > 0) r.w[e][1] = planes[plane_elems + widx];
+            if (n_hop_bits > 1) r.w[e][2] = planes[2 * plane_elems + widx];
+            if (n_hop_bits > 2) r.w[e][3] = planes[3 * plane_elems + widx];
+            if (n_hop_bits > 3) r.w[e][4] = planes[4 * plane_elems + widx];
+        }
+    }
+    return r;
+}
+
+template <int XP, int EP>
+__global__ __launch_bounds__(256) void k_finalize_pipe(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
+                                                       const int *__restrict__ max_hop_dev, int N, int K, int Wp,
+                                                       const float *__restrict__ x, int F, float *__restrict__ out, long long out_cols,
+                                                       int c0, int n_shards, size_t shard_elems, const int *__restrict__ aux, int *report,
+                                                       int ticket, int x_row_begin, int contiguous) {
+    if (max_hop_dev) write_report(*max_hop_dev, aux, report, ticket);
+    __shared__ float inv[16];
+    if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
+    __syncthreads();
+    if (max_hop_dev) {
+        const int m = *max_hop_dev;
+        n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    // A work item is (row, segment): a row wider than 256 EP embedding columns (many shards) is cut into segments of 64 EP pieces,
+    // each a work item of its own; segment 0 also copies the row's features.  Items are dealt to the waves round-robin
+    // (contiguous != 0 -- A/B, POPE_KNOB_FINALIZE_VARIANT 5 -- a block of consecutive items per wave, as k_finalize_fast deals rows).
+    const int F4 = F >> 2, K4 = K >> 2, n_emb = K4 * n_shards;
+    const int n_seg = (n_emb + 64 * EP - 1) / (64 * EP);
+    const int items = N * n_seg;                                         // < 2^31: checked on the host
+    const int per = (items + nwaves - 1) / nwaves;
+    const int i_begin = contiguous ? wave * per : wave, i_end = contiguous ? min(items, i_begin + per) : items, i_step = contiguous ? 1 : nwaves;
+    if (i_begin >= i_end) return;
+    auto row_of = [&](int i, int &seg) { const int v = (int)((unsigned)i / (unsigned)n_seg); seg = i - v * n_seg; return v; };
+    int seg = 0, v = row_of(i_begin, seg);
+    FinRow<XP, EP> cur = fin_load<XP, EP>(planes, plane_elems, n_hop_bits, Wp, x, F4, v, lane, x && seg == 0 && v >= x_row_begin, K4, n_emb, shard_elems, seg * 64 * EP);
+    for (int i = i_begin; i < i_end; i += i_step) {
+        FinRow<XP, EP> nxt = cur;
+        int seg_n = 0, v_n = 0;
+        if (i + i_step < i_end) {
+            v_n = row_of(i + i_step, seg_n);
+            nxt = fin_load<XP, EP>(planes, plane_elems, n_hop_bits, Wp, x, F4, v_n, lane, x && seg_n == 0 && v_n >= x_row_begin, K4, n_emb, shard_elems, seg_n * 64 * EP);
+        }
+        f32x4 *orow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols);
+        if (XP > 0 && x && seg == 0 && v >= x_row_begin) {
+#pragma unroll
+            for (int p = 0; p < XP; ++p)
+                if (lane + 64 * p < F4) orow[lane + 64 * p] = cur.x[p];
+        }
+        f32x4 *erow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols + F + c0);
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+            const int q = seg * 64 * EP + lane + 64 * e;
+            if (q < n_emb) {
+                const int shard = q / K4, j = (q - shard * K4) * 4, bit = j & 63;
+                const unsigned reach = (unsigned)(cur.w[e][0] >> bit) & 15u;
+                unsigned t = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) t |= ((unsigned)(cur.w[e][b + 1] >> bit) & 15u) << (4 * b);      // planes past n_hop_bits were loaded as 0
+                const unsigned h0 = (((t) & 0x1111u) * 0x1248u >> 12) & 15u;
+                const unsigned h1 = (((t >> 1) & 0x1111u) * 0x1248u >> 12) & 15u;
+                const unsigned h2 = (((t >> 2) & 0x1111u) * 0x1248u >> 12) & 15u;
+                const unsigned h3 = (((t >> 3) & 0x1111u) * 0x1248u >> 12) & 15u;
+                f32x4 r;
+                r.x = (reach & 1u) ? inv[h0] : 0.0f;
+                r.y = (reach & 2u) ? inv[h1] : 0.0f;
+                r.z = (reach & 4u) ? inv[h2] : 0.0f;
+                r.w = (reach & 8u) ? inv[h3] : 0.0f;
+                erow[q] = r;
+            }
+        }
+        cur = nxt;
+        v = v_n;
+        seg = seg_n;
+    }
+}
+
+// Wide rows (more than 256 embedding columns: several shards after the all-gather, or K > 256 on one GPU), K a multiple of 64.
+// In k_finalize_pipe sixteen lanes load the same plane word, and an item of 256 pieces costs twenty narrow loads and ~100
+// registers: at 8 x 256 anchors the plane loads alone took 162 us for 114 MB and the stores another 150 (profiles/
+// r04_finalize_shards.txt).  Here a work item is (row, 16 words): lane l < 32 loads one 32-bit HALF of a word of each of the five
+// planes -- five loads per item -- and every lane fetches the half-word of its four anchors from lane (piece >> 3) with ONE
+// 32-bit shuffle per plane; five registers per item instead of forty, so the next item's loads fit beside this one's stores at full occupancy: 220 us against 382 at 8 x 256
+// anchors.  (Four lanes per word and no shuffles -- each lane expanding pieces (l & 3) + 4 e of its own word -- makes every store
+// instruction write sixteen 64-byte runs instead of whole lines: 285 us.)
+template <int XP>
+__global__ __launch_bounds__(256) void k_finalize_wide(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
+                                                       const int *__restrict__ max_hop_dev, int N, int K, int Wp,
+                                                       const float *__restrict__ x, int F, float *__restrict__ out, long long out_cols,
+                                                       int c0, int n_shards, size_t shard_elems, const int *__restrict__ aux, int *report,
+                                                       int ticket, int x_row_begin) {
+    if (max_hop_dev) write_report(*max_hop_dev, aux, report, ticket);
+    __shared__ float inv[16];
+    if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
+    __syncthreads();
+    if (max_hop_dev) {
+        const int m = *max_hop_dev;
+        n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int F4 = F >> 2, K4 = K >> 2, n_emb = K4 * n_shards;          // K4 is a multiple of 16: a word never spans two shards
+    const int wps = K4 >> 4;                                             // words per shard and node (not Wp: that one is padded to the tile width)
+    const int n_words = n_emb >> 4, n_seg = (n_words + 15) >> 4;
+    const int items = N * n_seg;                                         // < 2^31: checked on the host
+    if (wave >= items) return;
+    struct Item { f32x4 x[XP > 0 ? XP : 1]; unsigned w[5]; };      // w: one 32-bit HALF of a plane word per lane (lanes 0 .. 31)
+    auto load = [&](int i, int &v, int &seg) {
+        v = (int)((unsigned)i / (unsigned)n_seg);
+        seg = i - v * n_seg;
+        Item r;
+#pragma unroll
+        for (int p = 0; p < (XP > 0 ? XP : 1); ++p) r.x[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 5; ++b) r.w[b] = 0;
+        if (XP > 0 && x && seg == 0 && v >= x_row_begin) {
+            const f32x4 *xs = reinterpret_cast<const f32x4 *>(x) + (size_t)v * F4;
+#pragma unroll
+            for (int p = 0; p < XP; ++p)
+                if (lane + 64 * p < F4) r.x[p] = __builtin_nontemporal_load(xs + lane + 64 * p);
+        }
+        const int word = seg * 16 + (lane >> 1);                         // lanes 0 .. 31: half (lane & 1) of word lane >> 1 of the item
+        if (lane < 32 && word < n_words) {
+            const int shard = word / wps;
+            const unsigned *p = reinterpret_cast<const unsigned *>(planes + ((size_t)shard * shard_elems + (size_t)v * Wp + (word - shard * wps))) + (lane & 1);
+            r.w[0] = p[0];
+            if (n_hop_bits > 0) r.w[1] = p[2 * plane_elems];
+            if (n_hop_bits > 1) r.w[2] = p[4 * plane_elems];
+            if (n_hop_bits > 2) r.w[3] = p[6 * plane_elems];
+            if (n_hop_bits > 3) r.w[4] = p[8 * plane_elems];
+        }
+        return r;
+    };
+    int v = 0, seg = 0;
+    Item cur = load(wave, v, seg);
+    for (int i = wave; i < items; i += nwaves) {
+        Item nxt = cur;
+        int v_n = 0, seg_n = 0;
+        if (i + nwaves < items) nxt = load(i + nwaves, v_n, seg_n);
+        if (XP > 0 && x && seg == 0 && v >= x_row_begin) {
+            f32x4 *orow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols);
+#pragma unroll
+            for (int p = 0; p < XP; ++p)
+                if (lane + 64 * p < F4) orow[lane + 64 * p] = cur.x[p];
+        }
+        f32x4 *erow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols + F + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = seg * 256 + lane + 64 * e;                     // piece: four anchors of half-word q >> 3, held by lane (q >> 3) - 32 seg
+            const int src = (lane >> 3) + 8 * e, bit = (q & 7) * 4;
+            unsigned nib[5];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) nib[b] = ((unsigned)__shfl((int)cur.w[b], src) >> bit) & 15u;
+            if (q < n_emb) {
+                const unsigned reach = nib[0];
+                const unsigned t = nib[1] | (nib[2] << 4) | (nib[3] << 8) | (nib[4] << 12);
+                const unsigned h0 = (((t) & 0x1111u) * 0x1248u >> 12) & 15u;
+                const unsigned h1 = (((t >> 1) & 0x1111u) * 0x1248u >> 12) & 15u;
+                const unsigned h2 = (((t >> 2) & 0x1111u) * 0x1248u >> 12) & 15u;
+                const unsigned h3 = (((t >> 3) & 0x1111u) * 0x1248u >> 12) & 15u;
+                f32x4 r;
+                r.x = (reach & 1u) ? inv[h0] : 0.0f;
+                r.y = (reach & 2u) ? inv[h1] : 0.0f;
+                r.z = (reach & 4u) ? inv[h2] : 0.0f;
+                r.w = (reach & 8u) ? inv[h3] : 0.0f;
+                erow[q] = r;
+            }
+        }
+        cur = nxt;
+        v = v_n;
+        seg = seg_n;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The sparse LAST levels of the BFS and the finalise kernel in ONE launch (round 4)
 // ------------------------------------------------------------------------------------------------
@@ -1317,8 +1532,9 @@ static void profile_mark(hipStream_t stream, int level, int which, bool span = f
 
 // Diagnostic knobs behind pope_debug_set() (include/graphpope_hip.h): process-global, not thread-safe, A/B tooling only.
 static int g_live_mode = -1;            // -1: by graph size (LDS table up to LIVE_MAX_NODES, global table beyond)
-static int g_finalize_variant = 1;      // 0: generic kernel, 1: fast path with plain stores, 2: fast path, non-temporal stores
+static int g_finalize_variant = 1;      // 0: generic kernel, 1: pipelined fast path (default), 2: round 1-3 fast path + non-temporal stores, 3 / 4: two launches, 5: pipelined with contiguous rows, 7: round 1-3 fast path
 static int g_finalize_blocks = 256 * 8;
+static bool g_finalize_blocks_set = false;   // POPE_KNOB_FINALIZE_BLOCKS given: it also sizes the pipelined kernel (default 4 096 blocks)
 static int g_level_blocks = 0;           // cap on the expand blocks of a level launch (0: one wave per chunk up to 2048 blocks)
 static int g_tail_level = 0;             // POPE_KNOB_TAIL_LEVEL: first level that runs inside k_tail_finalize (0: no tail kernel)
 static int g_tail_blocks = 256;          // POPE_KNOB_TAIL_BLOCKS: BFS blocks of k_tail_finalize
@@ -1334,7 +1550,7 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     switch (knob) {
     case POPE_KNOB_LIVE_MODE:        g_live_mode = value; break;
     case POPE_KNOB_FINALIZE_VARIANT: g_finalize_variant = value; break;
-    case POPE_KNOB_FINALIZE_BLOCKS:  g_finalize_blocks = value > 0 ? value : 256 * 8; break;
+    case POPE_KNOB_FINALIZE_BLOCKS:  g_finalize_blocks = value > 0 ? value : 256 * 8; g_finalize_blocks_set = value > 0; break;
     case POPE_KNOB_GEMM_TILE:        pope::g_gemm_force_tile = value; break;
     case POPE_KNOB_PAIRWISE_KERNEL:  pope::g_pairwise_kernel = value; break;
     case POPE_KNOB_COPY_BATCHES:     pope::g_copy_batches_per_wave = value; break;
@@ -1886,6 +2102,41 @@ static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_ho
             POPE_HIP(hipGetLastError());
             return POPE_OK;
         }
+        // the pipelined kernel (default, variant 1; 5: with contiguous row blocks; 7: the round 1-3 kernel): shapes it has instances for
+        {
+            const int xp = !x ? 0 : (F <= 256 ? 1 : F <= 512 ? 2 : F <= 1024 ? 4 : -1);
+            const int64_t ne = (int64_t)(K / 4) * n_shards;
+            const int ep = ne <= 64 ? 1 : ne <= 128 ? 2 : 4;             // wider rows: segments of 256 pieces, one work item each
+            const int64_t items = N * ((ne + 64 * ep - 1) / (64 * ep));
+            const int64_t witems = N * ((ne / 16 + 15) / 16);
+            if (g_finalize_variant == 1 && xp >= 0 && ne > 64 && (K & 63) == 0 && witems + 32768 * 4 < INT32_MAX) {      // wide rows: one load per plane half-word, shuffles to the lanes
+                dim3 wgrid(g_finalize_blocks_set ? g_finalize_blocks : (unsigned)std::min<int64_t>(std::max<int64_t>((witems + 3) / 4, 256), 32768));
+#define POPE_FIN_WIDE(XP)                                                                                                                 \
+    hipLaunchKernelGGL((k_finalize_wide<XP>), wgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, \
+                       (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, x_row_begin)
+                if (xp == 0) POPE_FIN_WIDE(0); else if (xp == 1) POPE_FIN_WIDE(1); else if (xp == 2) POPE_FIN_WIDE(2); else POPE_FIN_WIDE(4);
+#undef POPE_FIN_WIDE
+                POPE_HIP(hipGetLastError());
+                return POPE_OK;
+            }
+            if ((g_finalize_variant == 1 || g_finalize_variant == 5) && xp >= 0 && items + 32768 * 4 < INT32_MAX) {
+                const int contiguous = g_finalize_variant == 5;
+                // one row per wave by default (grid sweep, profiles/r04_finalize_pipe*.txt: 2 048 blocks 0.2479 ms, 4 096 0.2456, 8 192
+                // 0.2416, 16 384 0.2394, one row per wave 0.2395, 32 768 0.2400): short-lived waves in row order
+                const int64_t one_row_per_wave = std::min<int64_t>(std::max<int64_t>((items + 3) / 4, 256), 32768);
+                dim3 pgrid(g_finalize_blocks_set ? g_finalize_blocks : (unsigned)one_row_per_wave);
+#define POPE_FIN_PIPE(XP, EP)                                                                                                             \
+    hipLaunchKernelGGL((k_finalize_pipe<XP, EP>), pgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, \
+                       (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, x_row_begin, contiguous)
+                if (xp == 0)      { if (ep == 1) POPE_FIN_PIPE(0, 1); else if (ep == 2) POPE_FIN_PIPE(0, 2); else POPE_FIN_PIPE(0, 4); }
+                else if (xp == 1) { if (ep == 1) POPE_FIN_PIPE(1, 1); else if (ep == 2) POPE_FIN_PIPE(1, 2); else POPE_FIN_PIPE(1, 4); }
+                else if (xp == 2) { if (ep == 1) POPE_FIN_PIPE(2, 1); else if (ep == 2) POPE_FIN_PIPE(2, 2); else POPE_FIN_PIPE(2, 4); }
+                else              { if (ep == 1) POPE_FIN_PIPE(4, 1); else if (ep == 2) POPE_FIN_PIPE(4, 2); else POPE_FIN_PIPE(4, 4); }
+#undef POPE_FIN_PIPE
+                POPE_HIP(hipGetLastError());
+                return POPE_OK;
+            }
+        }
         if (g_finalize_variant == 2)
             hipLaunchKernelGGL(k_finalize_fast<1>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, x_row_begin);
         else
@@ -2113,6 +2364,9 @@ extern "C" int pope_concat(const float *x, int64_t N, int32_t F, float *out, int
     hipStream_t stream = (hipStream_t)stream_;
     POPE_REQUIRE(x && out, "pope_concat: null pointer");
     POPE_REQUIRE(N > 0 && N < INT32_MAX && F > 0 && out_cols >= F, "pope_concat: bad size");
+    // Round 4: side_copy.hip's kernel (16 pieces of 16 bytes in flight per lane: 5.9 TB/s) where its shapes allow -- k_concat's loop
+    // compiles to load - wait - store per piece (4.8 TB/s); this is the feature copy the multi-GPU path runs underneath its all-gather.
+    if (SideCopy::eligible(x, F, out, out_cols, N)) return enqueue_copy_features(x, F, out, out_cols, N, stream);
     const bool vec = F % 4 == 0 && out_cols % 4 == 0 && aligned16(out) && aligned16(x);
     hipLaunchKernelGGL(k_concat, dim3(256 * 8), dim3(256), 0, stream, x, (int)N, F, out,
                        (long long)out_cols, vec);

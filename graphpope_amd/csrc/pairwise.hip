@@ -363,7 +363,43 @@ __global__ __launch_bounds__(256) void k_minmax_apply(float *__restrict__ out, i
     }
 }
 
+// The same on 16-byte pieces (K, c0, out_cols multiples of 4, aligned bases): a lane owns four columns of a row, a wave one row per
+// pass -- the whole 1 KB of a 256-anchor row in ONE load and ONE store instruction, where the scalar form above issues four
+// load - wait - store rounds of 256 bytes (round 4: the finalise kernel's lesson).  The arithmetic per element is
+// identical: two separately rounded operations.
+__global__ __launch_bounds__(256) void k_minmax_apply4(float *__restrict__ out, int N, int K4, long long out_cols, int c0,
+                                                       const float *__restrict__ scale, const float *__restrict__ shift) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int q0 = 0; q0 < K4; q0 += 64) {                       // one trip for K <= 256
+        const int q = q0 + lane;
+        if (q >= K4) continue;
+        const float4 sc = reinterpret_cast<const float4 *>(scale)[q], sh = reinterpret_cast<const float4 *>(shift)[q];
+        for (int v = wave; v < N; v += nwaves) {
+            float4 *p = reinterpret_cast<float4 *>(out + (size_t)v * out_cols + c0) + q;
+            float4 e = *p;
+            e.x = e.x * sc.x; e.x = e.x + sh.x;
+            e.y = e.y * sc.y; e.y = e.y + sh.y;
+            e.z = e.z * sc.z; e.z = e.z + sh.z;
+            e.w = e.w * sc.w; e.w = e.w + sh.w;
+            *p = e;
+        }
+    }
+}
+
 #pragma clang fp contract(fast)
+
+static void launch_minmax_apply(float *out, int64_t N, int32_t K, int64_t out_cols, int32_t c0, const float *scale, const float *shift, hipStream_t stream) {
+    const bool vec = (K & 3) == 0 && (c0 & 3) == 0 && (out_cols & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u) == 0;
+    if (vec) {                                                  // one row per wave: short-lived waves in row order (the finalise kernel's grid rule)
+        const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((N + 3) / 4, 256), 32768);
+        hipLaunchKernelGGL(k_minmax_apply4, dim3(grid), dim3(256), 0, stream, out, (int)N, K / 4, (long long)out_cols, c0, scale, shift);
+    } else {
+        hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K, (long long)out_cols, c0, scale, shift);
+    }
+}
 
 static size_t pw_lds_bytes() { return tile_lds_bytes<PM, PN>(); }
 
@@ -417,8 +453,7 @@ static int pairwise_passes(const float *X, int64_t N, int32_t D, const float *A,
                        out, (long long)out_cols, c0, pmin, pmax, L.Kpad, copy);
     hipLaunchKernelGGL(k_minmax_fold, dim3((K + 63) / 64, RSPLIT), dim3(256), 0, stream, pmin, pmax, L.nblocks, K, L.Kpad, fmin, fmax);
     hipLaunchKernelGGL(k_minmax_reduce, dim3((K + 255) / 256), dim3(256), 0, stream, fmin, fmax, K, L.Kpad, scale, shift);
-    hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K, (long long)out_cols, c0,
-                       scale, shift);
+    launch_minmax_apply(out, N, K, out_cols, c0, scale, shift, stream);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }
@@ -464,8 +499,7 @@ static int pairwise_persistent(const float *X, int64_t N, int32_t D, const float
     //  AGAIN and stored scaled, no scaling pass -- was built and measured: 0.219 ms against 0.171 for the whole call, 0.177
     //  against 0.119 for the embedding alone (profiles/r04_pairwise_two_pass.txt).  A second exact-f32 MFMA pass costs 58 us;
     //  the 182 MB scaling pass it replaces costs 35.  Removed again)
-    hipLaunchKernelGGL(k_minmax_apply, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, out, (int)N, K, (long long)out_cols, c0,
-                       scale, shift);
+    launch_minmax_apply(out, N, K, out_cols, c0, scale, shift, stream);
     if (x) {
         int rc = copy.join(stream);
         if (rc) return rc;

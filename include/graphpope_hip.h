@@ -78,8 +78,8 @@ int pope_require_device(int32_t *cu_count_host);
  * needed by a caller.  value < 0 restores the automatic choice where one exists.
  */
 #define POPE_KNOB_LIVE_MODE         0   /* level kernel: -1 auto, 0 no live-bit table, 1 table in LDS, 2 table in global memory */
-#define POPE_KNOB_FINALIZE_VARIANT  1   /* 0 generic finalise kernel, 1 fast path (default), 2 fast path + non-temporal stores, 3 embedding columns and feature copy as two launches (columns first), 4 the same with the copy first (round-4 A/B: both slower) */
-#define POPE_KNOB_FINALIZE_BLOCKS   2   /* grid of the fast finalise kernel (default 2048)                                       */
+#define POPE_KNOB_FINALIZE_VARIANT  1   /* 1 (default) the pipelined finalise kernel (every load of a row in flight, next row requested before this one is stored, rows dealt round-robin); 5 the same with contiguous row blocks per wave; 7 the round 1-3 kernel (serial loops); 2 that kernel with non-temporal stores; 3 / 4 embedding columns and feature copy as two launches; 0 the generic kernel */
+#define POPE_KNOB_FINALIZE_BLOCKS   2   /* grid of the finalise kernel (default: 4096 blocks for the pipelined kernel, 2048 for the round 1-3 one)                   */
 #define POPE_KNOB_GEMM_TILE         3   /* SAGE GEMM: 0 auto, 1 64x64, 2 64x128, 3 128x256 tiles, 4 / 5 stream-K without loader waves, 6 stream-K with stages of 64 in two 80 KB buffers, 7 stream-K instead of the chip-fitted whole tiles (gemm_tile16.h) */
 #define POPE_KNOB_COPY_BATCHES      5   /* node2vec embedding: 16-piece batches per wave of the feature-copy kernel beside the tile kernel (default 1) */
 #define POPE_KNOB_LEVEL_BLOCKS       6   /* level kernel: cap on the expand blocks of a launch (0 = one wave per 256-slot chunk, up to 2048 blocks)      */

@@ -693,3 +693,33 @@ def test_tail_kernel_runs_the_last_levels_inside_the_finalise_launch(dev, oracle
     finally:
         lib.pope_debug_set(_lib.KNOB_TAIL_LEVEL, 0)
         lib.pope_debug_set(_lib.KNOB_TAIL_BLOCKS, 0)
+
+
+@pytest.mark.parametrize("f,k,shards", [(0, 64, 1), (20, 100, 1), (300, 256, 1), (500, 256, 1), (700, 512, 1), (36, 1024, 1), (1100, 64, 1),
+                                         (0, 128, 3), (40, 256, 4), (8, 128, 8), (0, 256, 5), (0, 256, 8), (500, 1024, 3), (12, 1020, 1)])
+def test_pipelined_finalise_kernel_writes_the_same_bits(dev, f, k, shards):
+    """The finalise kernel of round 4 (every load of a row in flight at once, the next row requested before this one is stored, rows
+    dealt round-robin to the waves; utils.py:73, 129-135) against the round 1-3 kernel (POPE_KNOB_FINALIZE_VARIANT 7) on random
+    planes: one and several shards, feature widths and anchor counts on both sides of every instance's limits (and beyond them,
+    where the old kernel takes over), both row orders -- the same bits, NaN-poisoned outputs."""
+    from graphpope_amd import _lib, engine
+    lib = _lib.load()
+    n, bits = 3001, 4
+    g = torch.Generator().manual_seed(f + 7 * k + shards)
+    w = lib.pope_words(k)
+    planes = torch.randint(-2**62, 2**62, (shards, 1 + bits, n, w), generator=g, dtype=torch.int64).to(dev)
+    x = torch.rand((n, f), generator=g).to(dev) if f else None
+    outs = []
+    try:
+        for variant in (7, 1, 5):
+            lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, variant)
+            out = torch.full((n, f + shards * k), float("nan"), device=dev)
+            if shards == 1:
+                engine.finalize(planes[0], bits, n, k, x, f, out, 0)
+            else:
+                engine.finalize_shards(planes, bits, n, k, x, f, out)
+            outs.append(out)
+    finally:
+        lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 1)
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -958,7 +958,7 @@ def main():
         fin_bytes = 4.0 * n * F + 4.0 * n * (F + K_PER_GPU) + 8.0 * n * wp * (1 + timers["n_hop_bits"])
         fin_gbs = fin_bytes / (med["finalize"] * 1e-3) / 1e9
         result["roofline_finalize"] = {
-            "kernel": "k_finalize_fast<0>", "bound": "hbm", "achieved": fin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "k_finalize_pipe<2, 1>", "bound": "hbm", "achieved": fin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": fin_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_finalize_hbm_bytes_per_launch"),
             "algorithmic_bytes_per_launch": fin_bytes, "avg_launch_ms": med["finalize"]}
         if not args.no_sage:

@@ -423,6 +423,14 @@ __device__ __forceinline__ void level_housekeeping(int E, int N, int Wp, const u
     }
 }
 
+// erow of the slot in front of chunk `chunk` (.x, -1: none) and of the slot behind it (.y, -2: none).
+__device__ __forceinline__ int2 chunk_edge_rows(const int *__restrict__ erow, int chunk, int E) {
+    int2 r = make_int2(-1, -2);
+    if (chunk > 0 && chunk * CHUNK - 1 < E) r.x = erow[chunk * CHUNK - 1];
+    if ((chunk + 1) * CHUNK < E) r.y = erow[(chunk + 1) * CHUNK];
+    return r;
+}
+
 // Expand share of one level (see k_bfs_level): this wave walks chunks wave, wave + nwaves, ... of tile `woff`; (vr, ur) hold the
 // first chunk's slots, loaded by the caller before it staged the live table.  Returns whether this lane emitted a non-zero row.
 template <int WT, int LIVE>
@@ -463,15 +471,17 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
         const int vc = __shfl(v0, 0);                                                  // row of the chunk's first slot
         const int vl = __shfl(v3, 63);                                                 // row of its last slot (-1: short chunk)
         STAMP(1);
-        const bool head_multi = chunk > 0 && erow[chunk * CHUNK - 1] == vc;             // first row began in an earlier chunk
-        const bool tail_multi = vl >= 0 && (chunk + 1) * CHUNK < E && erow[(chunk + 1) * CHUNK] == vl;   // last row runs on
+        // the rows of the slots just outside the chunk: does its first row begin earlier, does its last row run on?
+        const int2 er = chunk_edge_rows(erow, chunk, E);
+        const bool head_multi = chunk > 0 && er.x == vc;                               // first row began in an earlier chunk
+        const bool tail_multi = vl >= 0 && (chunk + 1) * CHUNK < E && er.y == vl;     // last row runs on
         // slots of a row that spans chunks (only the chunk's first and last row can)
         const bool x0 = (head_multi && v0 == vc) || (tail_multi && v0 == vl);
         const bool x3 = (head_multi && v3 == vc) || (tail_multi && v3 == vl);
 
-        Words<WT> c0, c1, c2, c3, s0, s1, s2, s3;
+        Words<WT> c0, c1, c2, c3;
 #pragma unroll
-        for (int i = 0; i < WT; ++i) c0.w[i] = c1.w[i] = c2.w[i] = c3.w[i] = s0.w[i] = s1.w[i] = s2.w[i] = s3.w[i] = 0;
+        for (int i = 0; i < WT; ++i) c0.w[i] = c1.w[i] = c2.w[i] = c3.w[i] = 0;
         const bool work = __any(g0 || g1 || g2 || g3);                 // else: no live neighbour behind these 256 slots
         if (g0) c0 = gather_words<WT>(front + (size_t)u0 * Wp + woff);
         if (g1) c1 = gather_words<WT>(front + (size_t)u1 * Wp + woff);
@@ -480,26 +490,40 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
         // mask of row v: what reached it before this level = seen[v] | front[v].  front[v] (level - 1's gain) is committed to
         // seen by the housekeeping blocks of THIS launch: either order gives the same mask.  Rows whose live bit is clear
         // have an all-zero (possibly never written) frontier row: not loaded.
-        auto row_mask = [&](int v) {
-            Words<WT> m = (variant & 4) ? load_words_nt<WT>(seen + (size_t)v * Wp + woff) : load_words<WT>(seen + (size_t)v * Wp + woff);
-            if (is_live(v)) {
-                const Words<WT> f = load_words<WT>(front + (size_t)v * Wp + woff);
+        // Round 4: the first and the last row's loads (reachability + frontier, predicated, no use in between) go out together with
+        // the gathers; as a chain of calls each frontier load sat inside an `if (live)` whose merge point waited for it, and the ISA
+        // showed up to four serial round trips behind the gathers.  (All four rows' loads at once: 142 registers, three waves per
+        // SIMD instead of four, every level 3-6 us SLOWER -- profiles/r04_level_times_batched_masks.txt.)
+        // (Round 4, after the finalise kernel's lesson: this chain compiles to up to four serial load - wait rounds behind the gathers.
+        //  Requesting the first and last row's masks with the gathers and the interior rows' in a second batch was built and
+        //  A/B-ed as separate library builds, tools/ab_lib.py: BFS 205-212 us against 193-197 us for this chain; all four rows at
+        //  once needs 142 registers, three waves per SIMD, every level 3-6 us slower.  Requesting the rows of the slots next to
+        //  the chunk with the index loads made no measurable difference either.  profiles/r04_level_ab_libs.txt)
+        {
+            auto row_mask = [&](int v) {
+                Words<WT> m = (variant & 4) ? load_words_nt<WT>(seen + (size_t)v * Wp + woff) : load_words<WT>(seen + (size_t)v * Wp + woff);
+                if (is_live(v)) {
+                    const Words<WT> f = load_words<WT>(front + (size_t)v * Wp + woff);
 #pragma unroll
-                for (int i = 0; i < WT; ++i) m.w[i] |= f.w[i];
+                    for (int i = 0; i < WT; ++i) m.w[i] |= f.w[i];
+                }
+                return m;
+            };
+            Words<WT> s0, s1, s2, s3;
+#pragma unroll
+            for (int i = 0; i < WT; ++i) s0.w[i] = s1.w[i] = s2.w[i] = s3.w[i] = 0;
+            if (work && v0 >= 0) s0 = row_mask(v0);
+            if (work && v3 >= 0) s3 = v3 == v0 ? s0 : row_mask(v3);
+            // an interior row (neither the lane's first nor last row)
+            if (work && v1 >= 0) s1 = v1 == v0 ? s0 : (v1 == v3 ? s3 : row_mask(v1));
+            if (work && v2 >= 0) s2 = v2 == v1 ? s1 : (v2 == v3 ? s3 : row_mask(v2));
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                c0.w[i] &= ~s0.w[i];
+                c1.w[i] &= ~s1.w[i];
+                c2.w[i] &= ~s2.w[i];
+                c3.w[i] &= ~s3.w[i];
             }
-            return m;
-        };
-        if (work && v0 >= 0) s0 = row_mask(v0);
-        if (work && v3 >= 0) s3 = v3 == v0 ? s0 : row_mask(v3);
-        // an interior row (neither the lane's first nor last row)
-        if (work && v1 >= 0) s1 = v1 == v0 ? s0 : (v1 == v3 ? s3 : row_mask(v1));
-        if (work && v2 >= 0) s2 = v2 == v1 ? s1 : (v2 == v3 ? s3 : row_mask(v2));
-#pragma unroll
-        for (int i = 0; i < WT; ++i) {
-            c0.w[i] &= ~s0.w[i];
-            c1.w[i] &= ~s1.w[i];
-            c2.w[i] &= ~s2.w[i];
-            c3.w[i] &= ~s3.w[i];
         }
         const u64 any = any_bits<WT>(c0) | any_bits<WT>(c1) | any_bits<WT>(c2) | any_bits<WT>(c3);
         STAMP(2);

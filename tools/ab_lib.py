@@ -21,7 +21,7 @@ for _ in range(30):
     e0.record(); engine.bfs(csr, anchors); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
 print(json.dumps({"median_us": float(np.median(ts)), "min_us": float(min(ts))}))
 ''' % ROOT
-for rnd in range(3):
+for rnd in range(4):
     for lib in ["default"] + sys.argv[1:]:
         out = subprocess.run([sys.executable, "-c", CHILD, lib], capture_output=True, text=True)
         print(rnd, os.path.basename(lib), out.stdout.strip().split("\n")[-1] if out.returncode == 0 else out.stderr[-300:])

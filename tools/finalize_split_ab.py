@@ -30,7 +30,7 @@ def run(v, steps=40):
 
 
 ref = run(7, 5)[1].clone()
-times = {v: [] for v in (7, 1, (1, 8192), (1, 12288), (1, 16384), (1, 22400), (1, 32768), (5, 16384), (5, 22400))}
+times = {v: [] for v in (7, 1)}
 for rnd in range(5):
     for v in times:
         ms, out = run(v)

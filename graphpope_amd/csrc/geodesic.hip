@@ -387,6 +387,27 @@ __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words
 // as well.  Beyond LIVE_MAX_NODES the table is read from global memory (LIVE = 2): there the frontier rows come from the
 // Infinity Cache or HBM while the table still sits in L2 -- R-MAT scale 22 runs 20 % faster with it than without.)
 // WT = words per tile (1, 2 or 4); blockIdx.y selects the tile of a node's W words.
+// The live table (one bit per node, at most LIVE_MAX_NODES / 8 = 32 KB) into LDS: every load of a thread is requested before its
+// first write (round 4: as `for (i ...) lds[i] = src[i]` the loop compiled to load - s_waitcnt vmcnt(0) - ds_write per trip, three
+// serial round trips for Flickr's 11 KB in front of the barrier every expand wave waits at).
+__device__ __forceinline__ void stage_live_table(const unsigned *__restrict__ live, int live_words, uint4 *live_lds4) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(live);                       // tables are padded to 256 bytes
+    const int n4 = (live_words + 3) / 4;
+    for (int base = 0; base < n4; base += 4 * 256) {                                // one trip up to 131 072 nodes
+        // Branch-free on purpose: indices past the table are clamped to its last piece (loaded and written again by several threads,
+        // the same 16 bytes).  A load under an `if` is waited for at the join, and loads whose only use sits under an `if` are sunk
+        // into it by the optimiser -- either way one load in flight.
+        uint4 t[4];
+        int idx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) idx[j] = min(base + (int)threadIdx.x + 256 * j, n4 - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = src[idx[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) live_lds4[idx[j]] = t[j];
+    }
+}
+
 // Housekeeping share of one level (see k_bfs_level): thread t0 of tstride threads.  (1) clears two levels ahead -- the live
 // table (first_tile only) and the accumulator words of the rows that span chunks; (2) commits level - 1 for every node whose
 // frontier row is non-zero.
@@ -684,8 +705,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
     extern __shared__ uint4 live_lds4[];
     const unsigned *live_lds = reinterpret_cast<const unsigned *>(live_lds4);
     if constexpr (LIVE == 1) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(live);                   // tables are padded to 256 bytes
-        for (int i = threadIdx.x; i < (live_words + 3) / 4; i += blockDim.x) live_lds4[i] = src[i];
+        stage_live_table(live, live_words, live_lds4);
         __syncthreads();
     }
     const bool found = level_expand<WT, LIVE>(erow, col, E, Wp, front, seen, acc, live, live_acc, live_lds, variant, level, lane, wave, nwaves,
@@ -1144,8 +1164,7 @@ __global__ __launch_bounds__(256) void k_tail_finalize(const TailArgs a) {
                     ur = *reinterpret_cast<const int4 *>(a.col + wave * CHUNK + lane * SLOTS);
                 }
                 if constexpr (LIVE == 1) {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(live);
-                    for (int i = threadIdx.x; i < (a.live_words + 3) / 4; i += blockDim.x) live_lds4[i] = src[i];
+                    stage_live_table(live, a.live_words, live_lds4);
                     __syncthreads();
                 }
                 level_housekeeping<WT, LIVE>(a.E, a.N, a.Wp, front, a.seen, idle, a.hop_planes, a.plane_elems, level, a.aux, live, live_idle,

@@ -508,9 +508,15 @@ __global__ __launch_bounds__(256) void k_xent_rows(const float *__restrict__ log
     float gscale = 1.f;
     if constexpr (FUSED) {
         int n = 0;
-        for (int i = threadIdx.x; i < N; i += 256) {
-            const long long y = target[i];
-            n += (y != ignore_index && y >= 0 && y < C) ? 1 : 0;
+        // eight labels per thread requested at once (round 4: as a plain loop this compiled to load - wait - add per label, seven
+        // serial round trips per block for 1 550 labels); indices past N are clamped and not counted
+        for (int base = 0; base < N; base += 8 * 256) {
+            long long y[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) y[u] = target[min(base + (int)threadIdx.x + 256 * u, N - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                n += (base + (int)threadIdx.x + 256 * u < N && y[u] != ignore_index && y[u] >= 0 && y[u] < C) ? 1 : 0;
         }
         s_cnt[threadIdx.x] = n;
         __syncthreads();
@@ -528,6 +534,41 @@ __global__ __launch_bounds__(256) void k_xent_rows(const float *__restrict__ log
             if (y != ignore_index && lane == 0) *bad_label = 1;
             for (int c = lane; c < C; c += 64) g[c] = 0.f;
             if (lane == 0) row_loss[i] = -1.f;                    // marks "not counted" (a loss is never negative)
+            continue;
+        }
+        if (C <= 512) {
+            // the row lives in registers: ONE round trip instead of three passes of C / 64 serial loads (same operations in the
+            // same order, so the same bits)
+            // Columns past C read the row's last element and become -inf through a SELECT (no branch: a load whose only use sits
+            // under an `if` is sunk into it and waited for there); -inf is neutral for the maximum and adds exp(-inf) = +0 to the sum.
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float t = row[min(lane + 64 * k, C - 1)];
+                v[k] = lane + 64 * k < C ? t : -__builtin_huge_valf();
+            }
+            const float ly = row[y];
+            float mx = -__builtin_huge_valf();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mx = fmaxf(mx, v[k]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += expf(v[k] - mx);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+            const float lse = logf(sum) + mx, inv = 1.f / sum;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = lane + 64 * k;
+                if (c < C) {
+                    const float w = expf(v[k] - mx) * inv - (c == (int)y ? 1.f : 0.f);
+                    g[c] = FUSED ? w * gscale : w;
+                }
+            }
+            const float loss_i = lse - ly;                     // computed by every lane: a use outside the `if` keeps the load of row[y] up with the others
+            if (lane == 0) row_loss[i] = loss_i;
             continue;
         }
         float mx = -__builtin_huge_valf();
@@ -553,9 +594,16 @@ __global__ __launch_bounds__(256) void k_xent_final(const float *__restrict__ ro
     __shared__ int scnt[256];
     double s = 0.0;
     int n = 0;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        const float v = row_loss[i];
-        if (v >= 0.f) { s += (double)v; ++n; }
+    for (int base = 0; base < N; base += 8 * 256) {             // eight row losses per thread in flight (same order of additions)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float t = row_loss[min(base + (int)threadIdx.x + 256 * u, N - 1)];
+            v[u] = base + (int)threadIdx.x + 256 * u < N ? t : -1.f;         // a select, not a branch: -1 marks "not counted"
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u] >= 0.f) { s += (double)v[u]; ++n; }
     }
     ssum[threadIdx.x] = s;
     scnt[threadIdx.x] = n;

@@ -156,8 +156,26 @@ __device__ __forceinline__ void colsum_partial_block(const float *__restrict__ g
     float s[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) s[k] = 0.f;
-    if (c < C)
-        for (int i = r0 + wave; i < r1; i += 4) {
+    if (c < C) {
+        // four rows requested before the first is added (round 4: one load per trip compiled to load - wait - add, a wave's ten
+        // rows ten serial round trips); the additions keep their order, so the sums keep their bits
+        int i = r0 + wave;
+        for (; i + 12 < r1; i += 16) {
+            if constexpr (VEC) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(g + (size_t)(i + 4 * u) * C + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
+            } else {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = g[(size_t)(i + 4 * u) * C + c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[0] += v[u];
+            }
+        }
+        for (; i < r1; i += 4) {
             if constexpr (VEC) {
                 const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)i * C + c);
                 s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
@@ -165,6 +183,7 @@ __device__ __forceinline__ void colsum_partial_block(const float *__restrict__ g
                 s[0] += g[(size_t)i * C + c];
             }
         }
+    }
 #pragma unroll
     for (int k = 0; k < W; ++k) red[wave][lane * W + k] = s[k];
     __syncthreads();

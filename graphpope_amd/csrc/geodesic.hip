@@ -182,7 +182,8 @@ __device__ __forceinline__ bool bfs_over(const BfsCtl *ctl, const int *aux, int 
     // The previous level reached nothing new (every later launch is a no-op), or the CSR is not usable.
     // Plain loads: both words were last written by EARLIER launches (a wave of this launch may be raising
     // last_active to `level` meanwhile, which does not change the verdict).
-    return *(const volatile int *)&ctl->last_active < level - 1 || aux[AUX_FLAGS] != 0;
+    // (plain, wave-uniform loads: scalar loads, which do not occupy the vector memory counter the index loads wait on)
+    return ctl->last_active < level - 1 || aux[AUX_FLAGS] != 0;
 }
 
 // Same-address device-scope stores serialise at the memory side (tens of ns each): a wave stores only while
@@ -493,7 +494,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
         const int vl = __shfl(v3, 63);                                                 // row of its last slot (-1: short chunk)
         STAMP(1);
         // the rows of the slots just outside the chunk: does its first row begin earlier, does its last row run on?
-        const int2 er = chunk_edge_rows(erow, chunk, E);
+        const int2 er = chunk_edge_rows(erow, __builtin_amdgcn_readfirstlane(chunk), E);     // wave-uniform: scalar loads
         const bool head_multi = chunk > 0 && er.x == vc;                               // first row began in an earlier chunk
         const bool tail_multi = vl >= 0 && (chunk + 1) * CHUNK < E && er.y == vl;     // last row runs on
         // slots of a row that spans chunks (only the chunk's first and last row can)

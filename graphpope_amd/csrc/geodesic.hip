@@ -460,7 +460,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
                                              const u64 *__restrict__ front, u64 *__restrict__ seen, u64 *__restrict__ acc,
                                              const unsigned *__restrict__ live, unsigned *__restrict__ live_acc,
                                              const unsigned *live_lds, int variant, int level, int lane, int wave, int nwaves, int nchunks,
-                                             int woff, int tiles, int4 vr, int4 ur) {
+                                             int woff, int tiles, int4 vr, int4 ur, unsigned *wave_words) {
     auto load_idx = [&](const int *p) {
         if (variant & 1) {
             const i32x4v t = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(p));
@@ -565,6 +565,10 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
             bool head = !(connects && v0 == v3);
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
+                // Nobody left who would take from d lanes back (every lane's range already reaches its row's first lane): nobody
+                // will at 2d either -- heads only change where something is taken.  Rows average ten slots, so chunks without a
+                // hub row leave after two or three of the six steps (9 shuffles each; round 4).
+                if (!__any(lane >= d && !head)) break;
                 const bool ph = __shfl_up((int)head, d) != 0;
                 const bool take = lane >= d && !head;
 #pragma unroll
@@ -617,19 +621,23 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
             // from a few waves -- cost 14 us per dense level).
             if (__any(n0 || n1 || n2 || n3)) {
                 const int wfirst = vc >> 5;
-                const int last_slot = min((chunk + 1) * CHUNK, E) - 1;
-                const int kmax = (erow[last_slot] >> 5) - wfirst;
+                // the row of the chunk's last slot: lane 63's last slot, except in the one short chunk at the end of the edge list
+                const int last_row = vl >= 0 ? vl : erow[min((chunk + 1) * CHUNK, E) - 1];
+                const int kmax = (last_row >> 5) - wfirst;
                 if (kmax < 8) {
-                    for (int k = 0; k <= kmax; ++k) {
-                        const int wk = wfirst + k;
-                        unsigned m = 0;
-                        if (n0 && (v0 >> 5) == wk) m |= 1u << (v0 & 31);
-                        if (n1 && (v1 >> 5) == wk) m |= 1u << (v1 & 31);
-                        if (n2 && (v2 >> 5) == wk) m |= 1u << (v2 & 31);
-                        if (n3 && (v3 >> 5) == wk) m |= 1u << (v3 & 31);
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) m |= (unsigned)__shfl_xor((int)m, d);
-                        if (lane == 0 && m) atomicOr(&live_acc[wk], m);
+                    // Round 4: every row of the chunk has exactly one emitting slot (the end of its run), so the set bits are distinct:
+                    // the emitting lanes OR them into eight LDS words of the wave (one ds_or each, no return), and lanes 0 .. kmax publish
+                    // the words.  (Rounds 2-3 built each word with a six-step wave-wide OR per word and read the last row from memory:
+                    // 1.36 us of a wave's 13.8, tools/stamp_expand.py.)  A wave's LDS instructions execute in order: no barrier.
+                    if (lane < 8) wave_words[lane] = 0u;
+                    if (n0) atomicOr(&wave_words[(v0 >> 5) - wfirst], 1u << (v0 & 31));
+                    if (n1) atomicOr(&wave_words[(v1 >> 5) - wfirst], 1u << (v1 & 31));
+                    if (n2) atomicOr(&wave_words[(v2 >> 5) - wfirst], 1u << (v2 & 31));
+                    if (n3) atomicOr(&wave_words[(v3 >> 5) - wfirst], 1u << (v3 & 31));
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane <= kmax) {
+                        const unsigned m = wave_words[lane];
+                        if (m) atomicOr(&live_acc[wfirst + lane], m);
                     }
                 } else {                                       // a run with wide gaps (isolated nodes in between)
                     if (n0) atomicOr(&live_acc[v0 >> 5], 1u << (v0 & 31));
@@ -709,8 +717,9 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
         stage_live_table(live, live_words, live_lds4);
         __syncthreads();
     }
+    __shared__ unsigned wave_live_words[4][8];                     // per wave: the live-table words its chunk's rows fall into
     const bool found = level_expand<WT, LIVE>(erow, col, E, Wp, front, seen, acc, live, live_acc, live_lds, variant, level, lane, wave, nwaves,
-                                              nchunks, woff, tiles, vr, ur);
+                                              nchunks, woff, tiles, vr, ur, wave_live_words[threadIdx.x >> 6]);
     if (__any(found) && lane == 0) raise_level(ctl, level);
 }
 
@@ -1146,6 +1155,7 @@ __global__ __launch_bounds__(256) void k_tail_finalize(const TailArgs a) {
     const int lane = threadIdx.x & 63;
     const int B = a.bfs_blocks;
     extern __shared__ uint4 live_lds4[];
+    __shared__ unsigned wave_live_words[4][8];
     if ((int)blockIdx.x < B) {
         // ---- BFS role ----
         BfsCtl *ctl = a.ctl;
@@ -1172,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_tail_finalize(const TailArgs a) {
                                              a.live_words, (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x, B * (int)blockDim.x, 0, true);
                 const bool found = level_expand<WT, LIVE>(a.erow, a.col, a.E, a.Wp, front, a.seen, acc, live, live_acc,
                                                           reinterpret_cast<const unsigned *>(live_lds4), a.variant, level, lane, wave, nwaves, nchunks,
-                                                          0, 1, vr, ur);
+                                                          0, 1, vr, ur, wave_live_words[threadIdx.x >> 6]);
                 if (__any(found) && lane == 0) raise_level(ctl, level);
                 if (!tail_barrier(ctl, B, ++episode)) { failed = 1; break; }
                 // every block reads the same word here: all raises of this level came before the barrier

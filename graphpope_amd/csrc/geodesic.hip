@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include <rocprim/device/device_scan.hpp>
@@ -225,6 +226,19 @@ __device__ int g_stamp_level;
 template <int WT> struct Words { u64 w[WT]; };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: what the non-temporal builtins accept
+
+// Cross-lane moves on the vector ALUs (DPP) instead of the LDS crossbar (ds_bpermute, which sixteen waves of a CU share): shifts
+// inside rows of 16 lanes, the row broadcasts (lane 15 of a row to the next row, lane 31 to rows 2 and 3) and whole-wave shifts by
+// one lane.  A lane without a source reads 0 (bound_ctrl).
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142,
+              DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_mov64(u64 x) {
+    const unsigned lo = (unsigned)dpp_mov<CTRL>((int)(unsigned)x), hi = (unsigned)dpp_mov<CTRL>((int)(unsigned)(x >> 32));
+    return ((u64)hi << 32) | lo;
+}
 
 // COPY ROLE of a level launch (round 4).  out[:, :F] = x (utils.py:129-135) is two thirds of the finalise kernel's traffic and
 // depends on nothing the BFS computes, while the level launches are bound by L2 line fills and latency and leave the HBM
@@ -559,29 +573,38 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
             }
             // across lanes: segmented scan over each lane's LAST run (row v3); a lane starts a new segment unless all
             // its slots share one row and that row is also the previous lane's last row
-            const int pv3 = __shfl_up(v3, 1);
+            const int pv3 = dpp_mov<DPP_WAVE_SHR1>(v3);
             const bool connects = lane > 0 && pv3 == v0 && v0 >= 0;
             Words<WT> t = c3;
             bool head = !(connects && v0 == v3);
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                // Nobody left who would take from d lanes back (every lane's range already reaches its row's first lane): nobody
-                // will at 2d either -- heads only change where something is taken.  Rows average ten slots, so chunks without a
-                // hub row leave after two or three of the six steps (9 shuffles each; round 4).
-                if (!__any(lane >= d && !head)) break;
-                const bool ph = __shfl_up((int)head, d) != 0;
-                const bool take = lane >= d && !head;
+            // Round 4: the scan network runs on DPP moves -- four shifts inside the rows of 16 lanes, then lane 15 of rows 0 / 2 to
+            // rows 1 / 3 and lane 31 to rows 2 / 3 -- where rounds 1-3 shuffled through the LDS crossbar (9 ds_bpermute per step and
+            // wave, sixteen waves of a CU queueing for it: 1.9 us of a wave's 13.8, tools/stamp_expand.py).  The operator on
+            // (value, head) pairs is the same, so is the result.  A step nobody would take anything in is skipped: rows average ten
+            // slots, so chunks without a hub row need two or three of the six.
+            auto scan_step = [&](auto ctrl, bool valid) {
+                constexpr int CTRL = decltype(ctrl)::value;
+                if (!__any(valid && !head)) return;
+                const bool ph = dpp_mov<CTRL>((int)head) != 0;
+                const bool take = valid && !head;
 #pragma unroll
                 for (int i = 0; i < WT; ++i) {
-                    const u64 pt = __shfl_up(t.w[i], d);
+                    const u64 pt = dpp_mov64<CTRL>(t.w[i]);
                     if (take) t.w[i] |= pt;
                 }
                 if (take) head = ph;
-            }
+            };
+            const int in_row = lane & 15;
+            scan_step(std::integral_constant<int, DPP_ROW_SHR1>{}, in_row >= 1);
+            scan_step(std::integral_constant<int, DPP_ROW_SHR2>{}, in_row >= 2);
+            scan_step(std::integral_constant<int, DPP_ROW_SHR4>{}, in_row >= 4);
+            scan_step(std::integral_constant<int, DPP_ROW_SHR8>{}, in_row >= 8);
+            scan_step(std::integral_constant<int, DPP_ROW_BCAST15>{}, ((lane >> 4) & 1) != 0);
+            scan_step(std::integral_constant<int, DPP_ROW_BCAST31>{}, lane >= 32);
             // carry into this lane's first run = accumulated value of the previous lane's last run
 #pragma unroll
             for (int i = 0; i < WT; ++i) {
-                u64 ci = __shfl_up(t.w[i], 1);
+                u64 ci = dpp_mov64<DPP_WAVE_SHR1>(t.w[i]);
                 if (!connects) ci = 0;
                 c0.w[i] |= ci;
                 if (v1 == v0) c1.w[i] |= ci;
@@ -591,7 +614,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
         }
         STAMP(3);
         // Emit every run that ends in this lane (the slot after it belongs to another row, or the chunk ends).
-        const int nv0 = __shfl_down(v0, 1);
+        const int nv0 = dpp_mov<DPP_WAVE_SHL1>(v0);
         const int after3 = lane == 63 ? -3 : nv0;
         const size_t i0 = (size_t)v0 * Wp + woff, i1 = (size_t)v1 * Wp + woff, i2 = (size_t)v2 * Wp + woff,
                      i3 = (size_t)v3 * Wp + woff;

@@ -621,21 +621,28 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
         const bool e0 = v0 >= 0 && v0 != v1, e1 = v1 >= 0 && v1 != v2, e2 = v2 >= 0 && v2 != v3, e3 = v3 >= 0 && v3 != after3;
         const bool x1 = (head_multi && v1 == vc) || (tail_multi && v1 == vl);
         const bool x2 = (head_multi && v2 == vc) || (tail_multi && v2 == vl);
-        // piece of a row that spans chunks: OR it in (its words were cleared two launches ago), commit later
-        auto piece = [&](size_t idx, const Words<WT> &c) {
-#pragma unroll
-            for (int i = 0; i < WT; ++i)
-                if (c.w[i]) atomicOr(&acc[idx + i], c.w[i]);
-        };
         const bool n0 = e0 && any_bits<WT>(c0) != 0, n1 = e1 && any_bits<WT>(c1) != 0, n2 = e2 && any_bits<WT>(c2) != 0,
                    n3 = e3 && any_bits<WT>(c3) != 0;
         // With the live table an all-zero row need not be written: nobody gathers a row whose live bit is clear.
         // (Several tiles share one live bit per node: then zeros are written too, so a live row is exact in every tile.)
         const bool dense = !LIVE || tiles > 1;
-        if (e0 && (n0 || dense)) { if (x0) piece(i0, c0); else store_words<WT>(acc + i0, c0); }
-        if (e1 && (n1 || dense)) { if (x1) piece(i1, c1); else store_words<WT>(acc + i1, c1); }
-        if (e2 && (n2 || dense)) { if (x2) piece(i2, c2); else store_words<WT>(acc + i2, c2); }
-        if (e3 && (n3 || dense)) { if (x3) piece(i3, c3); else store_words<WT>(acc + i3, c3); }
+        // rows that lie inside the chunk: plain stores
+        if (e0 && !x0 && (n0 || dense)) store_words<WT>(acc + i0, c0);
+        if (e1 && !x1 && (n1 || dense)) store_words<WT>(acc + i1, c1);
+        if (e2 && !x2 && (n2 || dense)) store_words<WT>(acc + i2, c2);
+        if (e3 && !x3 && (n3 || dense)) store_words<WT>(acc + i3, c3);
+        // pieces of the (at most two) rows that span chunks: OR them in (their words were cleared two launches ago), commit later.
+        // Wave-uniform guard, and no branch per word (round 4: ~28 divergent branch regions in this phase before).
+        if (head_multi || tail_multi) {
+            auto piece = [&](size_t idx, const Words<WT> &c) {
+#pragma unroll
+                for (int i = 0; i < WT; ++i) atomicOr(&acc[idx + i], c.w[i]);
+            };
+            if (n0 && x0) piece(i0, c0);
+            if (n1 && x1) piece(i1, c1);
+            if (n2 && x2) piece(i2, c2);
+            if (n3 && x3) piece(i3, c3);
+        }
         STAMP(4);
         found |= n0 || n1 || n2 || n3;
         if constexpr (LIVE) {

@@ -502,10 +502,12 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
             const unsigned w = LIVE == 1 ? live_lds[u >> 5] : live[u >> 5];
             return ((w >> (u & 31)) & 1u) != 0;
         };
-        const bool g0 = v0 >= 0 && is_live(u0), g1 = v1 >= 0 && is_live(u1), g2 = v2 >= 0 && is_live(u2),
-                   g3 = v3 >= 0 && is_live(u3);
-        const int vc = __shfl(v0, 0);                                                  // row of the chunk's first slot
-        const int vl = __shfl(v3, 63);                                                 // row of its last slot (-1: short chunk)
+        // the four look-ups first, unconditionally (u = 0 for an empty slot), then the tests: as `v >= 0 && is_live(u)` each look-up sat
+        // behind a branch and was waited for on its own
+        const bool q0 = is_live(u0), q1 = is_live(u1), q2 = is_live(u2), q3 = is_live(u3);
+        const bool g0 = (v0 >= 0) & q0, g1 = (v1 >= 0) & q1, g2 = (v2 >= 0) & q2, g3 = (v3 >= 0) & q3;
+        const int vc = __builtin_amdgcn_readlane(v0, 0);                               // row of the chunk's first slot
+        const int vl = __builtin_amdgcn_readlane(v3, 63);                              // row of its last slot (-1: short chunk)
         STAMP(1);
         // the rows of the slots just outside the chunk: does its first row begin earlier, does its last row run on?
         const int2 er = chunk_edge_rows(erow, __builtin_amdgcn_readfirstlane(chunk), E);     // wave-uniform: scalar loads

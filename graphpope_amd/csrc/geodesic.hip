@@ -521,6 +521,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
 #pragma unroll
         for (int i = 0; i < WT; ++i) c0.w[i] = c1.w[i] = c2.w[i] = c3.w[i] = 0;
         const bool work = __any(g0 || g1 || g2 || g3);                 // else: no live neighbour behind these 256 slots
+        if (!work && LIVE && tiles == 1) continue;                     // nothing to gather, nothing to store (all-zero rows are not written), nothing to mark
         if (g0) c0 = gather_words<WT>(front + (size_t)u0 * Wp + woff);
         if (g1) c1 = gather_words<WT>(front + (size_t)u1 * Wp + woff);
         if (g2) c2 = gather_words<WT>(front + (size_t)u2 * Wp + woff);

@@ -36,7 +36,20 @@ struct T16Args {
     const long long *rows;     // nullptr, or: row m of the FIRST product's A operand is p[0].A + rows[m] * p[0].lda (the resident
                                // feature matrix read through n_id; byte offsets must fit 32 bits)
     int accumulate;            // 1: C += product (no bias): the second half of a layer whose first half another launch wrote
+    // The SECOND product's A rows are written by other blocks of the same launch (the gather role of k_gather_beside_gemm):
+    // done[tm] counts the finished rows of row tile tm, and the loader waves issue the first stage of the second product
+    // only once it has reached the tile's height (bounded wait; on a timeout *fail is set and a later launch redoes the product).
+    const int *done;           // nullptr: the rows are there before the launch
+    int *fail;
 };
+
+constexpr unsigned long long T16_WAIT_TICKS = 2000000ull;   // 20 ms of the 100 MHz counter: 300 x the whole launch
+#ifdef POPE_STAMP
+#define T16_STAMP(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_gemm_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define T16_STAMP(slot) do { } while (0)
+#endif
+constexpr int T16_DONE_STRIDE = 32;                         // ints between two tiles' counters: a 128-byte line (a memory channel) each
 
 template <int RB> struct T16Shape {
     static constexpr int TM = 16 * RB;
@@ -79,7 +92,7 @@ __device__ __forceinline__ void t16_split8(const float4 &p0, const float4 &p1, t
 // POPE_KNOB_GEMM_SPLIT_BF16): every f32 operand as three bf16 terms and six v_mfma_f32_16x16x32_bf16 per product
 // (hh, hm, mh, mm, hl, lh; the dropped terms are below 2^-24 of |a||b|), f32 accumulate -- the same accuracy class, not the
 // same bits; the LDS images, the loader waves and the epilogue are shared.
-template <int RB, bool SPLIT>
+template <int RB, bool SPLIT, bool WAIT = false>
 __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const int tm, const int tn, char *smem, const unsigned lds0,
                                          const int lane, const int wave) {
     using Sh = T16Shape<RB>;
@@ -114,25 +127,53 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
             if (k0 + T16_GK <= PK) {
 #pragma unroll
                 for (int d = 0; d < Sh::ND; ++d)
-                    if (lw * Sh::ND + d < Sh::INSTR)
-                        sk_glds16_saddr(lw * Sh::ND + d < Sh::A_INSTR ? A : B, second ? off[1][d] : off[0][d],
-                                        lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
+                    if (lw * Sh::ND + d < Sh::INSTR) {
+                        if (WAIT && second && lw * Sh::ND + d < Sh::A_INSTR)       // rows written in this launch: read at agent scope
+                            sk_glds16_saddr_agent(A, off[1][d], lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
+                        else
+                            sk_glds16_saddr(lw * Sh::ND + d < Sh::A_INSTR ? A : B, second ? off[1][d] : off[0][d],
+                                            lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
+                    }
             } else {                                                   // depth padding: lanes past the depth read the zero page
 #pragma unroll
                 for (int d = 0; d < Sh::ND; ++d)
                     if (lw * Sh::ND + d < Sh::INSTR) {
                         const float *src = (const float *)((const char *)(lw * Sh::ND + d < Sh::A_INSTR ? A : B) + (second ? off[1][d] : off[0][d]));
                         if (k0 + koff[d] >= PK) src = a.zero;
-                        sk_glds16(src, lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
+                        if (WAIT && second && lw * Sh::ND + d < Sh::A_INSTR) sk_glds16_agent(src, lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
+                        else sk_glds16(src, lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
                     }
             }
         };
+        if (WAIT && lw == 0) T16_STAMP(0);
         issue_all(0, 0);
         if (1 < S) issue_all(1, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // B_0: stages 0 and 1 have landed
         int buf = 0;
         for (int s = 0; s < S; ++s) {
+            if constexpr (WAIT) {
+                // the second product's rows come from the gather role of this launch: wait for this tile's (host: S0 >= 2, so the
+                // two stages issued ahead of the loop never belong to it)
+                if (s + 2 == a.S0) {
+                    if (lw == 0) T16_STAMP(1);
+                    const int need = min(Sh::TM, M - m0);
+                    const int *flag = a.done + tm * T16_DONE_STRIDE;
+                    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+                            __builtin_amdgcn_s_sleep(32);
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > T16_WAIT_TICKS) {
+                                if (lane == 0) atomicOr(a.fail, 1);
+                                break;
+                            }
+                        }
+                    }
+                    if (lw == 0) T16_STAMP(2);
+                    // no acquire fence (it would drop every line the XCD's L2 holds, the weights all its blocks share included: measured,
+                    // 270 us for the launch instead of 115): the rows are READ at agent scope instead, see issue_all
+                }
+            }
             if (s + 2 < S) issue_all(s + 2, buf == 0 ? 2 : buf - 1);   // the buffer of stage s - 1: its readers left it before B_s
             if (s + 1 < S) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -256,6 +297,7 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
             buf = nbuf;
         }
     }
+    if (WAIT && wave == 0) T16_STAMP(3);
     // C/D layout of the 16 x 16 forms: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -282,7 +324,7 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
 }
 
 // The tiles `first`, `first + stride`, ... of the product, one after the other, by the calling block (all eight waves).
-template <int RB, bool SPLIT>
+template <int RB, bool SPLIT, bool WAIT = false>
 __device__ __forceinline__ void t16_block_loop(const T16Args &a, char *smem, const int first, const int stride) {
     using Sh = T16Shape<RB>;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -309,7 +351,7 @@ __device__ __forceinline__ void t16_block_loop(const T16Args &a, char *smem, con
             break;
         }
         if (again) __syncthreads();                               // the previous tile's last stage has been read: its buffers are free
-        t16_tile<RB, SPLIT>(a, M, tm, tn, smem, lds0, lane, wave);
+        t16_tile<RB, SPLIT, WAIT>(a, M, tm, tn, smem, lds0, lane, wave);
         again = true;
     }
 }

@@ -145,10 +145,11 @@ def config2_block():
     return n, torch.as_tensor(n_id), a0
 
 
-@pytest.fixture(params=[1, 0], ids=["gather_beside_projection", "gather_then_projection"])
+@pytest.fixture(params=[1, 0, 2], ids=["gather_beside_projection", "gather_then_projection", "one_fused_launch"])
 def forward_order(request):
-    """POPE_KNOB_SAGE_FORWARD_OVERLAP: 1 (default) = the gather in the blocks beside the x_dst half of the projection + a
-    second launch for the agg half; 0 = gather, then the whole projection."""
+    """POPE_KNOB_SAGE_FORWARD_OVERLAP: 1 = the gather in the blocks beside the x_dst half of the projection + a second launch
+    for the agg half; 0 = gather, then the whole projection; 2 = one launch, the projection's tiles waiting for their rows of
+    the aggregate."""
     from graphpope_amd import _lib
     lib = _lib.load()
     lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, request.param)
@@ -287,11 +288,11 @@ def test_gather_beside_the_projection_gives_the_same_aggregate_and_the_same_laye
     scratch = torch.empty(max(lib.sage_conv_forward_scratch_bytes(n_dst, c_in, c_out), 16), dtype=torch.uint8, device=dev)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     res = {}
-    for order in (1, 0):
+    for order in (1, 0, 2, 22):                                     # 22: the fused launch a second time (its row counters were left at zero)
         agg = torch.full((n_dst, c_in), -7.0, device=dev)
         x_dst = torch.full((n_dst, c_in), -7.0, device=dev)
         out = torch.full((n_dst, c_out), -7.0, device=dev)
-        lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, order)
+        lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, order % 10)
         try:
             _lib.check(lib.sage_conv_forward_indexed(_lib.ptr(rp), _lib.ptr(cl), _lib.ptr(n_id), n_src, n_dst, cl.numel(), _lib.ptr(feats), n_rows,
                                                      c_in, _lib.ptr(w_l), _lib.ptr(b), _lib.ptr(w_r), c_out, _lib.ptr(agg), _lib.ptr(x_dst),
@@ -303,6 +304,12 @@ def test_gather_beside_the_projection_gives_the_same_aggregate_and_the_same_laye
     assert torch.equal(res[0][1], feats[n_id[:n_dst]])
     scale = float(res[0][2].abs().max())
     assert float((res[1][2] - res[0][2]).abs().max()) <= 1e-5 * scale
+    # the fused launch: the aggregate it hands to the waiting tiles is the one the other orders write (the tiles were poisoned with
+    # -7: a tile that read a row before it was written, or a stale line of it, lands far outside the tolerance)
+    for k in (2, 22):
+        assert torch.equal(res[k][0], res[0][0]) and torch.equal(res[k][1], res[0][1])
+        assert float((res[k][2] - res[0][2]).abs().max()) <= 1e-5 * scale
+    assert torch.equal(res[2][2], res[22][2])
 
 
 @pytest.mark.parametrize("n_dst,c_in,c_out", [(9988, 756, 256), (700, 40, 24)])

@@ -46,14 +46,18 @@ struct T16Args {
 constexpr unsigned long long T16_WAIT_TICKS = 2000000ull;   // 20 ms of the 100 MHz counter: 300 x the whole launch
 #ifdef POPE_STAMP
 #define T16_STAMP(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_gemm_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// per-stage trace of the plain (not WAIT) kernel: [block][who: 0 loader wave 0 arrives at B_(s+1), 1 consumer wave 0 arrives, 2 consumer wave 0 leaves][stage]
+__device__ unsigned long long g_t16_trace[256 * 4 * 64];                  // (row 3: the shader-clock counter at row 2's instants)
+#define T16_TRACE(who, s) do { if (!WAIT && (threadIdx.x & 63) == 0 && blockIdx.x < 256 && (s) < 64) g_t16_trace[(blockIdx.x * 4 + (who)) * 64 + (s)] = (who) == 3 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define T16_STAMP(slot) do { } while (0)
+#define T16_TRACE(who, s) do { } while (0)
 #endif
 constexpr int T16_DONE_STRIDE = 32;                         // ints between two tiles' counters: a 128-byte line (a memory channel) each
 
-template <int RB> struct T16Shape {
+template <int RB, int NBUF = 3> struct T16Shape {
     static constexpr int TM = 16 * RB;
-    static constexpr int A_BYTES = TM * T16_GK * 4, STAGE_BYTES = (TM + T16_TN) * T16_GK * 4, LDS_BYTES = 3 * STAGE_BYTES;
+    static constexpr int A_BYTES = TM * T16_GK * 4, STAGE_BYTES = (TM + T16_TN) * T16_GK * 4, LDS_BYTES = NBUF * STAGE_BYTES;
     static constexpr int A_INSTR = TM / 8, INSTR = (TM + T16_TN) / 8;      // DMA wave-instructions per stage: 8 rows x 8 chunks each
     static constexpr int ND = (INSTR + T16_LOADERS - 1) / T16_LOADERS;     // per loader wave (the last one may have fewer)
 };
@@ -92,10 +96,30 @@ __device__ __forceinline__ void t16_split8(const float4 &p0, const float4 &p1, t
 // POPE_KNOB_GEMM_SPLIT_BF16): every f32 operand as three bf16 terms and six v_mfma_f32_16x16x32_bf16 per product
 // (hh, hm, mh, mm, hl, lh; the dropped terms are below 2^-24 of |a||b|), f32 accumulate -- the same accuracy class, not the
 // same bits; the LDS images, the loader waves and the epilogue are shared.
-template <int RB, bool SPLIT, bool WAIT = false>
+// s_waitcnt vmcnt(n) with a wave-uniform run-time n <= 8 (the instruction takes an immediate)
+__device__ __forceinline__ void t16_wait_vmcnt(int n) {
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+// NBUF = 3: the loader waves wait for everything they issued before each barrier -- stage s + 2 is requested behind B_s and must
+// have landed by B_(s+1): ONE stage of MFMA time hides the request.  NBUF = 4: stage s + 3 is requested behind B_s and only stage
+// s + 2 must have landed by B_(s+1) (s_waitcnt vmcnt(the newest stage's instruction count): loads return in order), so a
+// request has TWO stage times.  Stage t lives in buffer t % NBUF either way.
+template <int RB, bool SPLIT, bool WAIT = false, int NBUF = 3>
 __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const int tm, const int tn, char *smem, const unsigned lds0,
                                          const int lane, const int wave) {
-    using Sh = T16Shape<RB>;
+    static_assert(!WAIT || NBUF == 3, "the in-launch wait is placed for two stages of look-ahead");
+    using Sh = T16Shape<RB, NBUF>;
     const int m0 = tm * Sh::TM, n0 = tn * T16_TN;
     const int S = a.S0 + a.S1;
 
@@ -146,11 +170,15 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
             }
         };
         if (WAIT && lw == 0) T16_STAMP(0);
+        int mine = 0;                                              // DMA instructions of this wave per stage
+#pragma unroll
+        for (int d = 0; d < Sh::ND; ++d) mine += lw * Sh::ND + d < Sh::INSTR ? 1 : 0;
         issue_all(0, 0);
         if (1 < S) issue_all(1, 1);
+        if (NBUF == 4 && 2 < S) issue_all(2, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // B_0: stages 0 and 1 have landed
-        int buf = 0;
+        __builtin_amdgcn_s_barrier();          // B_0: the stages issued so far have landed
+        int buf = 0;                           // buffer of stage s
         for (int s = 0; s < S; ++s) {
             if constexpr (WAIT) {
                 // the second product's rows come from the gather role of this launch: wait for this tile's (host: S0 >= 2, so the
@@ -174,12 +202,16 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
                     // 270 us for the launch instead of 115): the rows are READ at agent scope instead, see issue_all
                 }
             }
-            if (s + 2 < S) issue_all(s + 2, buf == 0 ? 2 : buf - 1);   // the buffer of stage s - 1: its readers left it before B_s
+            const int ahead = NBUF - 1;
+            const bool more = s + ahead < S;
+            if (more) issue_all(s + ahead, buf == 0 ? NBUF - 1 : buf - 1);   // the buffer of stage s - 1: its readers left it before B_s
             if (s + 1 < S) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (NBUF == 4) t16_wait_vmcnt(more ? mine : 0);        // everything but the stage just requested
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lw == 0) T16_TRACE(0, s);
                 __builtin_amdgcn_s_barrier();                          // B_(s+1)
             }
-            buf = buf == 2 ? 0 : buf + 1;
+            buf = buf == NBUF - 1 ? 0 : buf + 1;
         }
         return;
     }
@@ -220,7 +252,7 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
         int buf = 0;
         for (int s = 0; s < S; ++s) {
             const bool next = s + 1 < S;
-            const int nbuf = buf == 2 ? 0 : buf + 1;
+            const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
             t16_bf16x8 bh[2], bm[2], bl[2], ah[2], am[2], al[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -266,11 +298,14 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
         read_pass(0, 0, 0);
         for (int s = 0; s < S; ++s) {
             const bool next = s + 1 < S;
-            const int nbuf = buf == 2 ? 0 : buf + 1;
+            const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
     #pragma unroll
             for (int p = 0; p < 2; ++p) {                                  // 16 depth values per pass
+                // pass 0 of stage s + 1 (landed since B_s).  Unconditional: behind an `if (next)` the two paths merge in front of this
+                // pass's MFMAs and hipcc waits there for the smaller of their counters -- lgkmcnt(0), i.e. for the reads just issued
+                // (ISA, round 4): the whole LDS latency once per stage.  Behind the last stage the read fetches a stale buffer, unused.
                 if (p == 0) read_pass(buf, 1, 1);
-                else if (next) read_pass(nbuf, 0, 0);                      // pass 0 of stage s + 1: landed since B_s
+                else read_pass(nbuf, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
                 for (int i = 0; i < RB; ++i)
@@ -291,8 +326,11 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (next) {
+                if (wave == 0) T16_TRACE(1, s);
                 __builtin_amdgcn_s_barrier();                              // B_(s+1)
                 asm volatile("" ::: "memory");
+                if (wave == 0) T16_TRACE(2, s);
+                if (wave == 0) T16_TRACE(3, s);
             }
             buf = nbuf;
         }
@@ -324,9 +362,9 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
 }
 
 // The tiles `first`, `first + stride`, ... of the product, one after the other, by the calling block (all eight waves).
-template <int RB, bool SPLIT, bool WAIT = false>
+template <int RB, bool SPLIT, bool WAIT = false, int NBUF = 3>
 __device__ __forceinline__ void t16_block_loop(const T16Args &a, char *smem, const int first, const int stride) {
-    using Sh = T16Shape<RB>;
+    using Sh = T16Shape<RB, NBUF>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem);
@@ -351,15 +389,15 @@ __device__ __forceinline__ void t16_block_loop(const T16Args &a, char *smem, con
             break;
         }
         if (again) __syncthreads();                               // the previous tile's last stage has been read: its buffers are free
-        t16_tile<RB, SPLIT, WAIT>(a, M, tm, tn, smem, lds0, lane, wave);
+        t16_tile<RB, SPLIT, WAIT, NBUF>(a, M, tm, tn, smem, lds0, lane, wave);
         again = true;
     }
 }
 
-template <int RB, bool SPLIT = false>
+template <int RB, bool SPLIT = false, int NBUF = 3>
 __global__ __launch_bounds__(T16_THREADS) void k_gemm_tile16(T16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    t16_block_loop<RB, SPLIT>(a, smem, (int)blockIdx.x, (int)gridDim.x);
+    t16_block_loop<RB, SPLIT, false, NBUF>(a, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // The tile height (in 16-row blocks, 3 .. 8) that wastes the least of the chip for this M x N, or 0 if no choice reaches

@@ -1630,7 +1630,7 @@ static int g_level_variant = 0;          // POPE_KNOB_LEVEL_VARIANT bits: 1 nt i
 // Index 0 is unused.  Launches the speculative window does not reach leave their share to the finalise kernel.
 constexpr int LEVEL_COPY_SLOTS = 16;
 static int g_level_copy_permille[LEVEL_COPY_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0, g_host_result_mode = 0, g_gemm_split_bf16 = 0, g_gather_lds_pad_kb = 0, g_sage_forward_overlap = 1, g_gemm_small_tile16 = 1; extern int g_sage_lanes; }
+namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0, g_host_result_mode = 0, g_gemm_split_bf16 = 0, g_gather_lds_pad_kb = 0, g_sage_forward_overlap = 1, g_gemm_small_tile16 = 1, g_gemm_tile16_buffers = 4; extern int g_sage_lanes; }
 
 extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     clear_error();
@@ -1647,6 +1647,7 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_GEMM_SPLIT_BF16:  pope::g_gemm_split_bf16 = value; break;
     case POPE_KNOB_GATHER_LDS_PAD_KB: pope::g_gather_lds_pad_kb = value; break;
     case POPE_KNOB_SAGE_FORWARD_OVERLAP: pope::g_sage_forward_overlap = value; break;
+    case POPE_KNOB_GEMM_TILE16_BUFFERS: pope::g_gemm_tile16_buffers = value == 4 ? 4 : 3; break;
     case POPE_KNOB_GEMM_SMALL_TILE16: pope::g_gemm_small_tile16 = value; break;
     case POPE_KNOB_SAGE_LANES:       pope::g_sage_lanes = value; break;
     case POPE_KNOB_LEVEL_VARIANT:    g_level_variant = value; break;

@@ -460,6 +460,7 @@ extern int g_gemm_force_tile;          // pope_debug_set(POPE_KNOB_GEMM_TILE, ..
 extern int g_gemm_small_tile16;        // POPE_KNOB_GEMM_SMALL_TILE16: 1 (default) = forward products too small for stream-K take 16 / 32-row whole tiles (layer 1: 14.4 us against 21)
 extern int g_sage_forward_overlap;     // pope_debug_set(POPE_KNOB_SAGE_FORWARD_OVERLAP, ...): 1 (default) gather beside half of the projection, 0 one after the other
 extern int g_gather_lds_pad_kb;        // pope_debug_set(POPE_KNOB_GATHER_LDS_PAD_KB, ...): occupancy experiment
+extern int g_gemm_tile16_buffers;     // pope_debug_set(POPE_KNOB_GEMM_TILE16_BUFFERS, ...)
 extern int g_gemm_split_bf16;         // pope_debug_set(POPE_KNOB_GEMM_SPLIT_BF16, ...): 1 = opt-in split-bf16 arithmetic in the whole-tile forward GEMM
 
 static long long tiles(int M, int N, int tm, int tn) { return (long long)((M + tm - 1) / tm) * ((N + tn - 1) / tn); }
@@ -587,21 +588,24 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
 }
 
 // ---- forward projection as whole tiles fitted to the chip (gemm_tile16.h): no partial tiles, no fix-up ----
-template <int RB, bool SPLIT>
+template <int RB, bool SPLIT, int NBUF>
 static int launch_tile16_as(const T16Args &a, int grid, hipStream_t stream) {
     static LdsOptIn opt_in;
+    constexpr int lds = T16Shape<RB, NBUF>::LDS_BYTES;
     if (!opt_in.done()) {
-        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_tile16<RB, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, T16Shape<RB>::LDS_BYTES));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_tile16<RB, SPLIT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         opt_in.mark();
     }
-    hipLaunchKernelGGL((k_gemm_tile16<RB, SPLIT>), dim3((unsigned)grid), dim3(T16_THREADS), T16Shape<RB>::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_gemm_tile16<RB, SPLIT, NBUF>), dim3((unsigned)grid), dim3(T16_THREADS), lds, stream, a);
     return POPE_OK;
 }
 
 // POPE_KNOB_GEMM_SPLIT_BF16 = 1 (opt-in, off by default): the split-bf16 arithmetic of gemm_tile16.h instead of exact f32 products.
+// POPE_KNOB_GEMM_TILE16_BUFFERS: 3 or 4 stage buffers (gemm_tile16.h: one or two stage times to hide a request).
 template <int RB>
 static int launch_tile16(const T16Args &a, int grid, hipStream_t stream) {
-    return g_gemm_split_bf16 ? launch_tile16_as<RB, true>(a, grid, stream) : launch_tile16_as<RB, false>(a, grid, stream);
+    if (g_gemm_split_bf16) return launch_tile16_as<RB, true, 3>(a, grid, stream);
+    return g_gemm_tile16_buffers == 4 ? launch_tile16_as<RB, false, 4>(a, grid, stream) : launch_tile16_as<RB, false, 3>(a, grid, stream);
 }
 
 // A whole-tile product ready to launch: arguments, tile height and grid; ok = false if the shape does not fit the chip well
@@ -1046,6 +1050,9 @@ using namespace pope;
 #ifdef POPE_STAMP
 extern "C" int pope_debug_read_streamk_stamps(unsigned long long *host, int count) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sk_stamps), (size_t)count * sizeof(unsigned long long));
+}
+extern "C" int pope_debug_read_t16_trace(unsigned long long *host, int count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_t16_trace), (size_t)count * sizeof(unsigned long long));
 }
 extern "C" int pope_debug_read_gemm_stamps(unsigned long long *host, int count) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamps), (size_t)count * sizeof(unsigned long long));

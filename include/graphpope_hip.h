@@ -90,10 +90,11 @@ int pope_require_device(int32_t *cu_count_host);
 #define POPE_KNOB_HOST_RESULT_MODE  11  /* host -> host boundary: 0 (default) embedding columns through a reused pinned ring, 1 register the result's own pages for the DMA */
 #define POPE_KNOB_GEMM_SPLIT_BF16   12  /* SAGE forward projection, OPT-IN (default 0 = exact f32 products): 1 = every f32 operand as three bf16 terms, six bf16 MFMAs per product, f32 accumulate -- same accuracy class (~2^-24), not the same bits */
 #define POPE_KNOB_GATHER_LDS_PAD_KB 13  /* k_gather_mean: KB of LDS reserved per block (0): an occupancy experiment, 40 -> 16 waves per CU, 80 -> 8 */
-#define POPE_KNOB_SAGE_FORWARD_OVERLAP 14 /* sage_conv_forward(_indexed): 1 (default) the gather runs beside the x_dst half of the projection in one launch, the agg half follows; 0 gather, then the whole projection */
+#define POPE_KNOB_SAGE_FORWARD_OVERLAP 14 /* sage_conv_forward(_indexed): 1 (default) the gather runs beside the x_dst half of the projection in one launch, the agg half follows; 0 gather, then the whole projection; 2 ONE launch: the projection's tiles wait, inside the launch, for their rows of the aggregate (measured slower) */
 #define POPE_KNOB_GEMM_SMALL_TILE16 15  /* SAGE forward products too small for stream-K: 1 (default) = whole tiles of 16 or 32 rows (gemm_tile16.h), 0 = the 64 x 64 tile kernel */
 #define POPE_KNOB_TAIL_LEVEL        16  /* pope_geodesic_run: first BFS level that runs inside the finalise kernel's launch (k_tail_finalize: a few blocks run the sparse last levels with a barrier among themselves while the others copy the features); 0 = every level is a launch of its own */
 #define POPE_KNOB_TAIL_BLOCKS       17  /* k_tail_finalize: number of its BFS blocks (default 256) */
+#define POPE_KNOB_GEMM_TILE16_BUFFERS 18 /* whole-tile forward GEMM: 4 (default) or 3 LDS stage buffers (two or one stage times to hide a request; same bits) */
 #define POPE_KNOB_PAIRWISE_KERNEL   4   /* node2vec embedding: 0 auto (anchor-resident persistent kernel for depths <= 128), 1 one tile per block, 2 / 3 persistent kernel with one / two consumer sets */
 int pope_debug_set(int32_t knob, int32_t value);
 

@@ -312,6 +312,34 @@ def test_gather_beside_the_projection_gives_the_same_aggregate_and_the_same_laye
     assert torch.equal(res[2][2], res[22][2])
 
 
+@pytest.mark.parametrize("n_dst,c_in,c_out", [(9988, 756, 256), (8100, 200, 256), (12200, 132, 250), (700, 40, 24)])
+def test_four_stage_buffers_give_the_bits_of_three(n_dst, c_in, c_out, dev):
+    """POPE_KNOB_GEMM_TILE16_BUFFERS: the whole-tile forward GEMM with four LDS stage buffers (the default: a request has two stage
+    times to land) against three -- the same products added in the same order, so the layer output is the same bit for bit; the
+    short last stage at depth 132 / 200 / 40 and the ragged last tiles are in the shapes."""
+    from graphpope_amd import _lib
+    from graphpope_amd.sage import SAGEConv, SampledAdj
+    lib = _lib.load()
+    n_src = n_dst + 50
+    rowptr, col = _random_block(n_dst, n_src, 4, seed=n_dst)
+    torch.manual_seed(3)
+    conv = SAGEConv(c_in, c_out).to(dev)
+    x = torch.randn(n_src, c_in).to(dev)
+    adj = SampledAdj(rowptr, col, n_src).to(dev)
+    outs = {}
+    with torch.no_grad():
+        for order in (0, 1):
+            lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, order)
+            try:
+                for bufs in (3, 4):
+                    lib.pope_debug_set(_lib.KNOB_GEMM_TILE16_BUFFERS, bufs)
+                    outs[order, bufs] = conv((x, None), adj).clone()
+            finally:
+                lib.pope_debug_set(_lib.KNOB_GEMM_TILE16_BUFFERS, 4)
+                lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, 1)
+            assert torch.equal(outs[order, 3], outs[order, 4])
+
+
 @pytest.mark.parametrize("n_dst,c_in,c_out", [(9988, 756, 256), (700, 40, 24)])
 def test_indexed_pair_without_a_destination_matrix(n_dst, c_in, c_out, dev):
     """sage_conv_forward_indexed with x_dst = NULL and sage_conv_backward_indexed (the destination rows read through n_id by

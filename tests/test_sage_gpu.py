@@ -310,6 +310,28 @@ def test_gather_beside_the_projection_gives_the_same_aggregate_and_the_same_laye
         assert torch.equal(res[k][0], res[0][0]) and torch.equal(res[k][1], res[0][1])
         assert float((res[k][2] - res[0][2]).abs().max()) <= 1e-5 * scale
     assert torch.equal(res[2][2], res[22][2])
+    # device extents (the captured training step): the same buffers as capacities, the true row count in a device word -- rows past
+    # it are neither gathered nor waited for; the rows in front of it carry the bits of a host-sized call on that many rows
+    n_true = n_dst - 137
+    dims = torch.tensor([n_true, n_src, int(rowptr[n_true]), 0], dtype=torch.int32, device=dev)
+    for order in (1, 2):
+        got, want = [], []
+        for extent in (True, False):
+            agg = torch.full((n_dst, c_in), -7.0, device=dev)
+            x_dst = torch.full((n_dst, c_in), -7.0, device=dev)
+            out = torch.full((n_dst, c_out), -7.0, device=dev)
+            lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, order)
+            try:
+                _lib.check(lib.sage_conv_forward_indexed(_lib.ptr(rp), _lib.ptr(cl), _lib.ptr(n_id), n_src, n_dst if extent else n_true,
+                                                         cl.numel() if extent else int(rowptr[n_true]), _lib.ptr(feats), n_rows, c_in, _lib.ptr(w_l),
+                                                         _lib.ptr(b), _lib.ptr(w_r), c_out, _lib.ptr(agg), _lib.ptr(x_dst), _lib.ptr(out),
+                                                         _lib.ptr(scratch), scratch.numel(), _lib.ptr(dims) if extent else None, stream))
+            finally:
+                lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, 1)
+            (got if extent else want).extend([agg, x_dst, out])
+        for g_, w_ in zip(got, want):
+            assert torch.equal(g_[:n_true], w_[:n_true])
+            assert bool((g_[n_true:] == -7.0).all())                     # nothing written past the true extent
 
 
 @pytest.mark.parametrize("n_dst,c_in,c_out", [(9988, 756, 256), (8100, 200, 256), (12200, 132, 250), (700, 40, 24)])

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_ld(SkArgs a) {
 #pragma unroll
             for (int p = 0; p < St::PASSES; ++p) {
                 if (p + 1 < St::PASSES) read_pass(buf, p + 1, (p + 1) & 1);
-                else if (NBUF == 3 && next) read_pass(nbuf, 0, 0);     // pass 0 of stage s + 1: landed since B_s (three buffers only)
+                else if (NBUF == 3) read_pass(nbuf, 0, 0);             // pass 0 of stage s + 1: landed since B_s (three buffers only); unconditional, see gemm_tile16.h
                 __builtin_amdgcn_sched_barrier(0);                     // the next pass's LDS reads are issued above this line
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p & 1].x, fb[t][p & 1].x, acc[t], 0, 0, 0);

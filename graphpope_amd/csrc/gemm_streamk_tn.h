@@ -210,7 +210,9 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
 #pragma unroll
             for (int j = 0; j < GK / 2; ++j) {
                 if (j + 1 < GK / 2) read_step(buf, j + 1, (j + 1) & 1);
-                else if (NBUF == 3 && next) read_step(nbuf, 0, 0);     // the next stage's first step: landed since B_s (three buffers only)
+                // the next stage's first step: landed since B_s (three buffers only).  Unconditional (behind the last stage it reads a stale
+                // buffer, unused): behind `if (next)` hipcc waits lgkmcnt(0) in front of this step's MFMAs, i.e. for these very reads
+                else if (NBUF == 3) read_step(nbuf, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1], fb[t][j & 1], acc[t], 0, 0, 0);

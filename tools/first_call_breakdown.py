@@ -30,7 +30,10 @@ for f in ("enabled", "defrag", "shmem_enabled"):
 print("cpus:", len(os.sched_getaffinity(0)))
 
 t0 = time.perf_counter()
-from graphpope_amd import _lib, engine, synth  # noqa: E402
+from graphpope_amd import _lib  # noqa: E402
+if os.environ.get("GRAPHPOPE_DIAG_LIB"):                     # A/B of two library builds: one per process
+    _lib.LIB_PATH = os.environ["GRAPHPOPE_DIAG_LIB"]
+from graphpope_amd import engine, synth  # noqa: E402
 from graphpope_amd import utils as gp  # noqa: E402
 lib = _lib.load()
 print(f"import graphpope_amd + dlopen:                          {ms(t0):9.2f} ms")

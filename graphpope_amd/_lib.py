@@ -19,6 +19,7 @@ KNOB_PAIRWISE_KERNEL, KNOB_COPY_BATCHES, KNOB_LEVEL_BLOCKS, KNOB_FAIL_HOST_REGIS
 KNOB_LEVEL_VARIANT, KNOB_LEVEL_COPY, KNOB_HOST_RESULT_MODE, KNOB_GEMM_SPLIT_BF16 = 9, 10, 11, 12
 KNOB_GATHER_LDS_PAD_KB, KNOB_SAGE_FORWARD_OVERLAP, KNOB_GEMM_SMALL_TILE16, KNOB_TAIL_LEVEL, KNOB_TAIL_BLOCKS = 13, 14, 15, 16, 17
 KNOB_GEMM_TILE16_BUFFERS = 18
+KNOB_PREPARE_MERGE = 19
 
 # name -> (restype, argtypes); exactly the symbols include/graphpope_hip.h declares
 SIGNATURES = {

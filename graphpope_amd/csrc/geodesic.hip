@@ -12,7 +12,9 @@
 //  * hop counts are stored bit-sliced: plane b gets `new` OR-ed in when bit b of the level is set.  State is
 //    a few N*W*8-byte planes that live in L2 / Infinity Cache; the 4*N*K-byte float matrix is written once,
 //    coalesced, by the finalise kernel straight into the [N, F+K] output (no transpose, no torch.cat).
+#include <atomic>
 #include <chrono>
+#include <cstddef>
 #include <cstring>
 #include <mutex>
 #include <type_traits>
@@ -77,18 +79,13 @@ __device__ __forceinline__ int csr_sorted_edge(int e, long long s, long long d, 
 // PAIRS: a thread takes two consecutive edges with 16-byte loads and one 8-byte store per output array (E even, 16-byte
 // aligned halves of edge_index): half the memory instructions of the one-edge form for the same 22 MB.
 template <bool PAIRS>
-__global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict__ src,
-                                                    const long long *__restrict__ dst, int E, int N,
-                                                    int *__restrict__ rowptr, int *__restrict__ col,
-                                                    int *__restrict__ erow, int *aux,
-                                                    const long long *__restrict__ anchors, int K, int Wp, u64 *seen,
-                                                    u64 *front, unsigned *live) {
-    if (K > 0 && blockIdx.x == gridDim.x - 1)
-        for (int j = threadIdx.x; j < K; j += blockDim.x) seed_anchor(anchors[j], j, Wp, seen, front, live);
+__device__ __forceinline__ int csr_sorted_role(const long long *__restrict__ src, const long long *__restrict__ dst, int E, int N,
+                                               int *__restrict__ rowptr, int *__restrict__ col, int *__restrict__ erow, int *aux,
+                                               const int bid, const int nblk) {
     int flags = 0;
     if (PAIRS) {
         typedef long long ll2 __attribute__((ext_vector_type(2)));
-        for (int t = blockIdx.x * blockDim.x + threadIdx.x; 2 * t < E; t += gridDim.x * blockDim.x) {
+        for (int t = bid * blockDim.x + threadIdx.x; 2 * t < E; t += nblk * blockDim.x) {
             const int e = 2 * t;
             const ll2 s2 = reinterpret_cast<const ll2 *>(src)[t], d2 = reinterpret_cast<const ll2 *>(dst)[t];
             const long long prev = e > 0 ? src[e - 1] : -1;
@@ -100,7 +97,7 @@ __global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict_
             reinterpret_cast<int2 *>(erow)[t] = make_int2((int)s2.x, (int)s2.y);
         }
     } else {
-        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        for (int e = bid * blockDim.x + threadIdx.x; e < E; e += nblk * blockDim.x) {
             const long long s = src[e], d = dst[e];
             const int f = csr_sorted_edge(e, s, d, e > 0 ? src[e - 1] : -1, src, E, N, rowptr, aux);
             flags |= f;
@@ -109,6 +106,19 @@ __global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict_
             erow[e] = (int)s;
         }
     }
+    return flags;
+}
+
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict__ src,
+                                                    const long long *__restrict__ dst, int E, int N,
+                                                    int *__restrict__ rowptr, int *__restrict__ col,
+                                                    int *__restrict__ erow, int *aux,
+                                                    const long long *__restrict__ anchors, int K, int Wp, u64 *seen,
+                                                    u64 *front, unsigned *live) {
+    if (K > 0 && blockIdx.x == gridDim.x - 1)
+        for (int j = threadIdx.x; j < K; j += blockDim.x) seed_anchor(anchors[j], j, Wp, seen, front, live);
+    const int flags = csr_sorted_role<PAIRS>(src, dst, E, N, rowptr, col, erow, aux, (int)blockIdx.x, (int)gridDim.x);
     if (flags) atomicOr(&aux[AUX_FLAGS], flags);
 }
 
@@ -175,16 +185,83 @@ struct BfsCtl {          // device control block at the start of the BFS scratch
     int tail_done;       // k_tail_finalize: the ticket of the call once its BFS blocks are through (agent-scope release)
     unsigned tail_top;   // k_tail_finalize: second stage of the barrier of its BFS blocks (groups that have arrived)
     int tail_failed;     // k_tail_finalize: a bounded wait ran out (never expected; the host turns it into an error)
-    int pad[28];
+    unsigned flag_epoch; // the tag the CSR status word must carry to count (csr_flags); 0 = the zeroed word of the separate launches
+    int pad[27];
     unsigned tail_group[TAIL_GROUPS * 32];      // first stage: one counter per group of BFS blocks, 128 bytes apart
 };
+
+// The CSR status word aux[AUX_FLAGS] = (tag << 3) | flags.  The separate launches zero it and OR flags into it (tag 0); the merged
+// prepare launch (k_prepare) cannot zero it in front of the blocks that may raise a flag, so those write it whole with the call's
+// tag and the readers ignore a word whose tag is not the one the launch left in the control block (an older call's, or whatever
+// an uninitialised workspace held).
+static_assert(offsetof(BfsCtl, last_active) == 0, "write_report finds the control block through the address of last_active");
+__device__ __forceinline__ int csr_flags(const BfsCtl *ctl, const int *aux) {
+    const unsigned w = (unsigned)aux[AUX_FLAGS];
+    return (w >> 3) == ctl->flag_epoch ? (int)(w & 7u) : 0;
+}
+
+__device__ __forceinline__ void csr_raise(int *aux, int flags, unsigned epoch) {
+    if (epoch == 0) {
+        atomicOr(&aux[AUX_FLAGS], flags);
+        return;
+    }
+    unsigned *p = reinterpret_cast<unsigned *>(&aux[AUX_FLAGS]);
+    unsigned old = *p;
+    for (int tries = 0; tries < 1 << 20; ++tries) {                  // (bounded: the word is contended by the raising blocks only)
+        const unsigned want = (old >> 3) == epoch ? old | (unsigned)flags : (epoch << 3) | (unsigned)flags;
+        const unsigned seen = atomicCAS(p, old, want);
+        if (seen == old) return;
+        old = seen;
+    }
+}
 
 __device__ __forceinline__ bool bfs_over(const BfsCtl *ctl, const int *aux, int level) {
     // The previous level reached nothing new (every later launch is a no-op), or the CSR is not usable.
     // Plain loads: both words were last written by EARLIER launches (a wave of this launch may be raising
     // last_active to `level` meanwhile, which does not change the verdict).
     // (plain, wave-uniform loads: scalar loads, which do not occupy the vector memory counter the index loads wait on)
-    return ctl->last_active < level - 1 || aux[AUX_FLAGS] != 0;
+    return ctl->last_active < level - 1 || csr_flags(ctl, aux) != 0;
+}
+
+// pope_geodesic_run, one launch in front of the levels instead of two (round 4): blocks [0, zero_blocks) clear the BFS state and
+// seed it, the others build the speculative CSR.  The two roles share nothing:
+//  * the anchors come by value (at most PREP_MAX_ANCHORS), and a seeded word is written by the block that zeroed it -- behind its
+//    own stores and a block barrier -- so no seed can meet a later zero;
+//  * the CSR status word is not zeroed but tagged (csr_raise / csr_flags); the clear role leaves the tag in the control block.
+constexpr int PREP_MAX_ANCHORS = 256;
+struct PrepSeeds { int a[PREP_MAX_ANCHORS]; };
+
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void k_prepare(const long long *__restrict__ src, const long long *__restrict__ dst, int E, int N,
+                                                 int *__restrict__ rowptr, int *__restrict__ col, int *__restrict__ erow, int *aux,
+                                                 uint4 *za, size_t na, uint4 *zb, size_t nb, int zero_blocks, unsigned epoch,
+                                                 PrepSeeds seeds, int K, int Wp, u64 *seen, u64 *front, unsigned *live) {
+    if ((int)blockIdx.x >= zero_blocks) {
+        const int flags = csr_sorted_role<PAIRS>(src, dst, E, N, rowptr, col, erow, aux, (int)blockIdx.x - zero_blocks, (int)gridDim.x - zero_blocks);
+        if (flags) csr_raise(aux, flags, epoch);
+        return;
+    }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const size_t stride = (size_t)zero_blocks * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // region a starts with the control block: its second 16-byte unit holds flag_epoch in its first word
+    static_assert(offsetof(BfsCtl, flag_epoch) == 16, "k_prepare writes the tag as the first word of the control block's second unit");
+    for (size_t i = first; i < na; i += stride) za[i] = i == 1 ? make_uint4(epoch, 0, 0, 0) : z;
+    for (size_t i = first; i < nb; i += stride) zb[i] = z;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this thread's stores are in L2
+    __syncthreads();
+    // the block's own seeds: unit u of a region was zeroed by thread u % stride, i.e. by block (u % stride) / blockDim.x
+    auto mine = [&](const void *word, const void *region) {
+        const size_t u = (size_t)((const char *)word - (const char *)region) >> 4;
+        return (u % stride) / blockDim.x == blockIdx.x;
+    };
+    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+        const long long a = seeds.a[j];
+        const size_t idx = (size_t)a * Wp + (j >> 6);
+        const u64 bit = 1ull << (j & 63);
+        if (mine(&seen[idx], zb)) atomicOr(&seen[idx], bit);
+        if (mine(&front[idx], za)) atomicOr(&front[idx], bit);
+        if (mine(&live[a >> 5], za)) atomicOr(&live[a >> 5], 1u << (a & 31));
+    }
 }
 
 // Same-address device-scope stores serialise at the memory side (tens of ns each): a wave stores only while
@@ -760,10 +837,10 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
 // device-mapped host memory, which the host reads after its one stream synchronisation.
 // The ticket is stored last (system-scope release): a host thread spinning on it sees the verdict as soon as the
 // kernel STARTS, i.e. when the BFS levels before it in the stream are done, not when the 100 us expansion ends.
-__device__ __forceinline__ void write_report(int last_active, const int *aux, int *report, int ticket) {
+__device__ __forceinline__ void write_report(const int *max_hop_dev, const int *aux, int *report, int ticket) {
     if (report && blockIdx.x == 0 && threadIdx.x == 0) {
-        report[0] = last_active;
-        report[1] = aux[AUX_FLAGS];
+        report[0] = *max_hop_dev;
+        report[1] = csr_flags(reinterpret_cast<const BfsCtl *>(max_hop_dev), aux);        // (&ctl->last_active: the block's first word)
         __hip_atomic_store(&report[2], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -790,7 +867,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u64 *__restrict__ planes
     if (max_hop_dev) {                        // enqueued before the host knew the depth: read it from the BFS control block
         const int m = *max_hop_dev;
         n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
-        write_report(m, aux, report, ticket);
+        write_report(max_hop_dev, aux, report, ticket);
     }
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -853,7 +930,7 @@ __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ p
                                                        float *__restrict__ out, long long out_cols, int c0,
                                                        int n_shards, size_t shard_elems, const int *__restrict__ aux,
                                                        int *report, int ticket, int x_row_begin) {
-    if (max_hop_dev) write_report(*max_hop_dev, aux, report, ticket);
+    if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
     __shared__ float inv[16];
     if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
     __syncthreads();
@@ -957,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_finalize_pipe(const u64 *__restrict__ p
                                                        const float *__restrict__ x, int F, float *__restrict__ out, long long out_cols,
                                                        int c0, int n_shards, size_t shard_elems, const int *__restrict__ aux, int *report,
                                                        int ticket, int x_row_begin, int contiguous) {
-    if (max_hop_dev) write_report(*max_hop_dev, aux, report, ticket);
+    if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
     __shared__ float inv[16];
     if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
     __syncthreads();
@@ -1035,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_finalize_wide(const u64 *__restrict__ p
                                                        const float *__restrict__ x, int F, float *__restrict__ out, long long out_cols,
                                                        int c0, int n_shards, size_t shard_elems, const int *__restrict__ aux, int *report,
                                                        int ticket, int x_row_begin) {
-    if (max_hop_dev) write_report(*max_hop_dev, aux, report, ticket);
+    if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
     __shared__ float inv[16];
     if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
     __syncthreads();
@@ -1230,7 +1307,7 @@ __global__ __launch_bounds__(256) void k_tail_finalize(const TailArgs a) {
             const int bad = failed | __hip_atomic_load(&ctl->tail_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.report) {
                 a.report[0] = la;
-                a.report[1] = a.aux[AUX_FLAGS] | (bad ? BFS_FLAG_TAIL_FAILED : 0);
+                a.report[1] = csr_flags(ctl, a.aux) | (bad ? BFS_FLAG_TAIL_FAILED : 0);
                 __hip_atomic_store(&a.report[2], a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             __hip_atomic_store(&ctl->tail_done, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1625,6 +1702,7 @@ static bool g_finalize_blocks_set = false;   // POPE_KNOB_FINALIZE_BLOCKS given:
 static int g_level_blocks = 0;           // cap on the expand blocks of a level launch (0: one wave per chunk up to 2048 blocks)
 static int g_tail_level = 0;             // POPE_KNOB_TAIL_LEVEL: first level that runs inside k_tail_finalize (0: no tail kernel)
 static int g_tail_blocks = 256;          // POPE_KNOB_TAIL_BLOCKS: BFS blocks of k_tail_finalize
+static int g_prepare_merge = 1;          // POPE_KNOB_PREPARE_MERGE: 1 (default) = pope_geodesic_run clears, seeds and builds the CSR in ONE launch (k_prepare); 0 = two launches
 static int g_level_variant = 0;          // POPE_KNOB_LEVEL_VARIANT bits: 1 nt index streams, 2 XCD-contiguous chunks, 4 nt reachability loads
 // POPE_KNOB_LEVEL_COPY: per mille of x's rows that level launch l of pope_geodesic_run copies in its copy role (LevelCopy).
 // Index 0 is unused.  Launches the speculative window does not reach leave their share to the finalise kernel.
@@ -1653,6 +1731,7 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_LEVEL_VARIANT:    g_level_variant = value; break;
     case POPE_KNOB_TAIL_LEVEL:       g_tail_level = value; break;
     case POPE_KNOB_TAIL_BLOCKS:      g_tail_blocks = value > 0 ? value : 256; break;
+    case POPE_KNOB_PREPARE_MERGE:    g_prepare_merge = value; break;
     case POPE_KNOB_LEVEL_COPY: {                                     // value = level << 16 | per mille; level 0: every launch
         const int lv = (value >> 16) & 0xff, pm = value & 0xffff;
         if (lv >= LEVEL_COPY_SLOTS || pm > 1000) { set_error("pope_debug_set: level copy %d / %d", lv, pm); return POPE_ERR_INVALID; }
@@ -1778,7 +1857,7 @@ struct SlotGuard {                       // releases the call's slot on every re
 // The BFS verdict (deepest active level, CSR status flags) written straight into pinned host memory.
 __global__ void k_bfs_report(const BfsCtl *ctl, const int *aux, int *report) {
     report[0] = ctl->last_active;
-    report[1] = aux[AUX_FLAGS];
+    report[1] = csr_flags(ctl, aux);
     __threadfence_system();
 }
 
@@ -2315,12 +2394,36 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     // The level launches copy part of out[:, :F] = x in their copy role (LevelCopy); the finalise kernel copies the rest.
     CopyPlan plan;
     if (out && level_copy_eligible(x, F, out, out_cols, N, K)) plan = make_copy_plan(x, F, out, out_cols, N, window);
-    bfs_enqueue_clear(b, aux, stream);                    // BFS state and the CSR status header in one launch
     memcpy(b.slot->anchors, anchors_host, (size_t)K * sizeof(long long));     // this call's pinned, device-mapped slot: read in place
-    SeedArgs seed;
-    seed.anchors = b.slot->anchors_dev; seed.K = K; seed.Wp = b.Wp; seed.seen = b.seen; seed.front = b.front[0]; seed.live = b.live[0];
-    rc = csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, seed, stream);
-    if (rc) return rc;
+    if (g_prepare_merge && K <= PREP_MAX_ANCHORS && E > 0) {
+        // one launch: clear + seed role beside the speculative CSR role (k_prepare)
+        static std::atomic<unsigned> epochs{0};
+        unsigned epoch = ++epochs & 0x1fffffffu;
+        if (epoch == 0) epoch = ++epochs & 0x1fffffffu;
+        PrepSeeds seeds;
+        for (int j = 0; j < K; ++j) seeds.a[j] = (int)anchors_host[j];          // (validated by bfs_setup)
+        const int eager = b.capacity < EAGER_PLANES ? b.capacity : EAGER_PLANES;
+        const size_t na = (b.front_off + 3 * align_up(b.plane_bytes, 256) + 3 * live_bytes(b.N)) / 16, nb = (size_t)(1 + eager) * b.plane_bytes / 16;
+        const long long *src = (const long long *)edge_index, *dst = src + E;
+        // (knob values above 1, for A/B: low 16 bits = the clear role's block count, high 16 bits = a cap on the CSR role's)
+        const int zero_blocks = (g_prepare_merge & 0xffff) > 1 ? (g_prepare_merge & 0xffff) : 1024;
+        const bool pairs = (E & 1) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(col) | reinterpret_cast<uintptr_t>(erow)) & 15u) == 0;
+        unsigned csr_blocks = pairs ? capped_grid(E / 2, 256) : capped_grid(E, 256);
+        if ((g_prepare_merge >> 16) > 0) csr_blocks = std::min<unsigned>(csr_blocks, (unsigned)(g_prepare_merge >> 16));
+        if (pairs)
+            hipLaunchKernelGGL(k_prepare<true>, dim3(zero_blocks + csr_blocks), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, aux,
+                               (uint4 *)b.base, na, (uint4 *)b.seen, nb, zero_blocks, epoch, seeds, K, b.Wp, b.seen, b.front[0], b.live[0]);
+        else
+            hipLaunchKernelGGL(k_prepare<false>, dim3(zero_blocks + csr_blocks), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, aux,
+                               (uint4 *)b.base, na, (uint4 *)b.seen, nb, zero_blocks, epoch, seeds, K, b.Wp, b.seen, b.front[0], b.live[0]);
+        POPE_HIP(hipGetLastError());
+    } else {
+        bfs_enqueue_clear(b, aux, stream);                    // BFS state and the CSR status header in one launch
+        SeedArgs seed;
+        seed.anchors = b.slot->anchors_dev; seed.K = K; seed.Wp = b.Wp; seed.seen = b.seen; seed.front = b.front[0]; seed.live = b.live[0];
+        rc = csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, seed, stream);
+        if (rc) return rc;
+    }
     // Round 4: the sparse last levels run inside the finalise kernel's launch (k_tail_finalize) when POPE_KNOB_TAIL_LEVEL names
     // the first of them: one word tile per node, levels below 16, and -- with an output -- the fast expansion's shapes.
     const int level_stop = (int)std::min<long long>(b.level_limit, 1 << EAGER_PLANES);

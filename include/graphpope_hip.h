@@ -94,6 +94,7 @@ int pope_require_device(int32_t *cu_count_host);
 #define POPE_KNOB_GEMM_SMALL_TILE16 15  /* SAGE forward products too small for stream-K: 1 (default) = whole tiles of 16 or 32 rows (gemm_tile16.h), 0 = the 64 x 64 tile kernel */
 #define POPE_KNOB_TAIL_LEVEL        16  /* pope_geodesic_run: first BFS level that runs inside the finalise kernel's launch (k_tail_finalize: a few blocks run the sparse last levels with a barrier among themselves while the others copy the features); 0 = every level is a launch of its own */
 #define POPE_KNOB_TAIL_BLOCKS       17  /* k_tail_finalize: number of its BFS blocks (default 256) */
+#define POPE_KNOB_PREPARE_MERGE     19  /* pope_geodesic_run: 1 (default) = the clear + seed of the BFS state and the speculative CSR build as two roles of ONE launch (k_prepare; at most 256 anchors per call); 0 = two launches */
 #define POPE_KNOB_GEMM_TILE16_BUFFERS 18 /* whole-tile forward GEMM: 4 (default) or 3 LDS stage buffers (two or one stage times to hide a request; same bits) */
 #define POPE_KNOB_PAIRWISE_KERNEL   4   /* node2vec embedding: 0 auto (anchor-resident persistent kernel for depths <= 128), 1 one tile per block, 2 / 3 persistent kernel with one / two consumer sets */
 int pope_debug_set(int32_t knob, int32_t value);

@@ -695,6 +695,52 @@ def test_tail_kernel_runs_the_last_levels_inside_the_finalise_launch(dev, oracle
         lib.pope_debug_set(_lib.KNOB_TAIL_BLOCKS, 0)
 
 
+def test_one_prepare_launch_gives_the_same_bits(dev, oracle):
+    """POPE_KNOB_PREPARE_MERGE (the default): pope_geodesic_run clears and seeds the BFS state and builds the speculative CSR as two roles of ONE
+    launch (k_prepare: the anchors by value, every seeded word written by the block that zeroed it, the CSR status word tagged with
+    the call's epoch instead of zeroed).  Against the reference's goldens (utils.py:64-81, 129-135) on ONE reused workspace -- so
+    each call meets the previous call's status word -- with the workspace overwritten by 0xFF and by random bytes in between; the
+    unsorted list (fallback to the counting sort), E = 0 and more than 256 anchors (the separate launches) included; a node id out of
+    range still fails; at Flickr size with 256 anchors (duplicates among them) the planes equal the separate launches' bit for bit."""
+    from graphpope_amd import _lib, engine, synth
+    lib = _lib.load()
+    lib.pope_debug_set(_lib.KNOB_PREPARE_MERGE, 1)
+    try:
+        names = ["rmat11_seed42", "multiloops30", "powerlaw4k_seed42", "path300", "noedges6", "star701", "rmat11_seed42", "multiloops30"]
+        for rnd, name in enumerate(names):
+            g = load_golden(os.path.join(GOLDEN, f"geodesic_{name}.npz"))
+            n = int(g["num_nodes"])
+            ei = torch.as_tensor(g["edge_index"].astype(np.int64), device=dev)
+            for ws in engine._WORKSPACE.values():
+                if rnd % 3 == 1:
+                    ws.fill_(0xFF)
+                elif rnd % 3 == 2:
+                    ws.copy_(torch.randint(0, 256, ws.shape, dtype=torch.uint8, device=ws.device))
+            for _ in range(2):
+                out, hp = engine.geodesic_run(torch.as_tensor(g["x"], device=dev), ei, n, g["anchors"], reuse_workspace=True)
+                f = g["x"].shape[1]
+                assert np.array_equal(out.cpu().numpy()[:, f:].view(np.uint32), g["emb"].view(np.uint32)), name
+                assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), g["hops"]), name
+        with pytest.raises(_lib.PopeError) as e:
+            engine.geodesic_run(None, torch.tensor([[0, 1, 2, 3], [1, 2, 9, 0]], device=dev), 4, [0, 1], want_out=False, reuse_workspace=True)
+        assert e.value.code == _lib.ERR_INDEX
+        ei_np, n = synth.flickr_like()
+        eid = torch.as_tensor(ei_np, device=dev)
+        for k in (256, 300, 7):                                     # 300: the separate launches; all with repeated anchors
+            anchors = np.random.RandomState(k).choice(np.arange(n), k)
+            anchors[-1] = anchors[0]
+            lib.pope_debug_set(_lib.KNOB_PREPARE_MERGE, 0)
+            want = engine.geodesic_run(None, eid, n, anchors, want_out=False)[1].valid().clone()
+            lib.pope_debug_set(_lib.KNOB_PREPARE_MERGE, 1)
+            for _ in range(3):
+                got = engine.geodesic_run(None, eid, n, anchors, want_out=False, reuse_workspace=True)[1].valid()
+                assert torch.equal(got, want), k
+        want_hops = oracle.geodesic_hops(ei_np, n, anchors)
+        assert np.array_equal(engine.hop_matrix(engine.geodesic_run(None, eid, n, anchors, want_out=False)[1]).cpu().numpy(), want_hops)
+    finally:
+        lib.pope_debug_set(_lib.KNOB_PREPARE_MERGE, 1)
+
+
 @pytest.mark.parametrize("f,k,shards", [(0, 64, 1), (20, 100, 1), (300, 256, 1), (500, 256, 1), (700, 512, 1), (36, 1024, 1), (1100, 64, 1),
                                          (0, 128, 3), (40, 256, 4), (8, 128, 8), (0, 256, 5), (0, 256, 8), (500, 1024, 3), (12, 1020, 1)])
 def test_pipelined_finalise_kernel_writes_the_same_bits(dev, f, k, shards):

@@ -37,9 +37,43 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher on the command line (WORLD_SIZE unset): start the N ranks as CHILD
+    processes -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`,
+    exactly the command the driver's contract names -- wait, and exit with their code; rank 0's JSON line goes to the inherited
+    stdout.  This runs before torch is imported: the parent never touches the GPU and nothing is exec-replaced."""
+    if "WORLD_SIZE" in os.environ:
+        return
+    gpus = 1
+    argv = sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            gpus = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            gpus = int(a.split("=", 1)[1])
+    if gpus <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sock:                           # a free port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    print("[bench] WORLD_SIZE unset with --gpus %d: starting the ranks as child processes: %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    _self_launch()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -108,6 +142,13 @@ def finalize_kernel_ms(x, ei, n, anchors, reps=20):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
+
+
+def finalize_kernel_name(n, k, f, has_x, shards):
+    """The finalise kernel the library launches for this shape (pope_finalize_kernel_name: the choice finalize_enqueue makes)."""
+    buf = ctypes.create_string_buffer(64)
+    _lib.check(_lib.load().pope_finalize_kernel_name(n, k, f, 1 if has_x else 0, shards, buf, 64))
+    return buf.value.decode()
 
 
 def level_kernel_times(ei, n, anchors, reps):
@@ -602,25 +643,6 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
             l0_seq_ms = ev3[0].elapsed_time(ev3[1]) / 10
         finally:
             _lib.load().pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, 1)
-    # OPT-IN arithmetic, never part of the step or of `value`: the same layer with POPE_KNOB_GEMM_SPLIT_BF16 (every f32 operand
-    # as three bf16 terms, six bf16 MFMAs per product, f32 accumulate), timed the same way and compared with the exact-f32 output
-    with torch.no_grad():
-        exact = conv((x, x[:adjs[0].n_dst]), adjs[0]).clone()
-        _lib.load().pope_debug_set(_lib.KNOB_GEMM_SPLIT_BF16, 1)
-        try:
-            for _ in range(3):
-                split_out = conv((x, x[:adjs[0].n_dst]), adjs[0])
-            ev2 = [_event() for _ in range(2)]
-            ev2[0].record()
-            for _ in range(10):
-                split_out = conv((x, x[:adjs[0].n_dst]), adjs[0])
-            ev2[1].record()
-            torch.cuda.synchronize()
-            split_l0_ms = ev2[0].elapsed_time(ev2[1]) / 10
-            split_err = float((split_out - exact).abs().max())
-            split_scale = float(exact.abs().max())
-        finally:
-            _lib.load().pope_debug_set(_lib.KNOB_GEMM_SPLIT_BF16, 0)
     n_dst, _, nnz = shapes[0]
     # the neighbour gather + mean on its own (memory-bound half of the layer)
     lib = _lib.load()
@@ -765,12 +787,6 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
                               "vendor_library_ms": lib_ms,
                               "note": "sequential layer-0 forward minus the gather (the one-launch projection kernel), HIP events; vendor_library_ms = torch.addmm (hipBLASLt) on "
                                       "the concatenated operands of the same product, timed in the same run"},
-        "layer0_projection_split_bf16_opt_in": {
-            "ms": split_l0_ms - g_ms, "max_abs_diff_vs_exact_f32": split_err, "output_max_abs": split_scale,
-            "note": "OPT-IN (POPE_KNOB_GEMM_SPLIT_BF16, off by default, not used by any other figure in this line): each f32 operand "
-                    "split into three bf16 terms in the consumer waves, six v_mfma_f32_16x16x32_bf16 per product, f32 accumulate; "
-                    "same accuracy class as f32, not the same bits.  The conversion's vector instructions (44 per eight floats) now "
-                    "bound the loop instead of the MFMAs (DESIGN.md 7h)"},
         "with_gpu_sampling": sampled,
         "cpu_baseline": cpu,
     }
@@ -789,7 +805,7 @@ def pmc_traffic():
     return None, None
 
 
-PROSE_KEYS = ("what", "note", "how", "value_note", "bound_note", "layer0_forward_note", "traffic_source", "model", "scope", "all_calls_ms",
+PROSE_KEYS = ("what", "note", "how", "method", "value_note", "bound_note", "layer0_forward_note", "traffic_source", "model", "scope", "all_calls_ms",
               "last_call_assembly_phases_ms")
 
 
@@ -826,7 +842,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus"
 
     cfg = args.config
     if cfg == 4:
@@ -873,17 +889,18 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = pope_step(x, ei, n, anchors, world)
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0          # this rank's own time, BEFORE the closing barrier: a straggler shows in per_rank
     barrier()
     elapsed = time.perf_counter() - t0
-    rccl_ranks = None
-    elapsed_local = elapsed
+    collective_ranks = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         ones = torch.ones(1, device=dev, dtype=torch.int32)          # how many ranks the collective backend really joined
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-        rccl_ranks = int(ones.item())
+        collective_ranks = int(ones.item())
 
     per_rank = None
     if world > 1:
@@ -935,7 +952,7 @@ def main():
         result["ms_per_step_depth_hint_miss"] = hint_miss_ms
         if world > 1:
             result["backend"] = backend
-            result["rccl_ranks"] = rccl_ranks
+            result["collective_ranks"] = collective_ranks
             result["per_rank"] = per_rank
     if rank == 0:
         # dominant kernel by total time: k_bfs_level (one launch per level), timed on this rank's own anchor shard with HIP
@@ -949,7 +966,7 @@ def main():
         pmc, pmc_src = pmc_traffic()
         pmc = pmc or {}
         result["roofline"] = {
-            "kernel": "k_bfs_level<%d>" % min(wp, 4), "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "k_bfs_level<%d, %d, %s>" % (min(wp, 4), 1 if n <= 256 * 1024 else 3, "true" if wp > 4 else "false"), "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": exp_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch") if cfg == 1 else None,
             "traffic_source": (pmc_src + " (rocprofv3 --pmc passes of this command, collected in a separate run: not measured live)") if pmc_src else None,
             "algorithmic_bytes_per_launch": exp_bytes, "avg_launch_ms": exp_ms, "launches_per_step": launches,
@@ -983,9 +1000,13 @@ def main():
         fin_ms = finalize_kernel_ms(x, ei, n, anchors)
         fin_gbs = fin_bytes / (fin_ms * 1e-3) / 1e9
         result["roofline_finalize"] = {
-            "kernel": "k_finalize_pipe<2, 1>", "bound": "hbm", "achieved": fin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": finalize_kernel_name(n, K_PER_GPU, F, True, 1), "bound": "hbm", "achieved": fin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": fin_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_finalize_hbm_bytes_per_launch"),
-            "algorithmic_bytes_per_launch": fin_bytes, "avg_launch_ms": fin_ms, "phase_ms_from_idle_device": med["finalize"]}
+            "algorithmic_bytes_per_launch": fin_bytes, "avg_launch_ms": fin_ms, "phase_ms_from_idle_device": med["finalize"],
+            "achieved_from_idle_device": fin_bytes / (med["finalize"] * 1e-3) / 1e9,
+            "method": "achieved / frac use avg_launch_ms = 20 launches queued back to back between two HIP events (since round 4; the kernel's own "
+                      "duration, what rocprofv3 --stats averages); phase_ms_from_idle_device = the one launch of the phase loop, which starts at an "
+                      "idle device behind a host synchronisation (rounds 1-3 quoted that figure)"}
         boundary = None
         if not args.no_extra:
             # the host -> host call right behind the timed steps.  It is host-side work and the box's host side is noisy: the same

@@ -13,11 +13,9 @@ LIB_PATH = os.path.join(_HERE, "libgraphpope_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_HOP_OVERFLOW, ERR_WORKSPACE, ERR_NO_DEVICE, ERR_UNSORTED = 0, -1, -2, -3, -4, -5, -6, -7
 METRIC = {"distance": 0, "similarity": 1, "euclidean": 2}
-RESULT_RING, RESULT_REGISTERED = 0, 1          # pope_assemble_begin_mode (include/graphpope_hip.h)
 KNOB_LIVE_MODE, KNOB_FINALIZE_VARIANT, KNOB_FINALIZE_BLOCKS, KNOB_GEMM_TILE = 0, 1, 2, 3
-KNOB_PAIRWISE_KERNEL, KNOB_COPY_BATCHES, KNOB_LEVEL_BLOCKS, KNOB_FAIL_HOST_REGISTER, KNOB_SAGE_LANES = 4, 5, 6, 7, 8
-KNOB_LEVEL_VARIANT, KNOB_LEVEL_COPY, KNOB_HOST_RESULT_MODE, KNOB_GEMM_SPLIT_BF16 = 9, 10, 11, 12
-KNOB_GATHER_LDS_PAD_KB, KNOB_SAGE_FORWARD_OVERLAP, KNOB_GEMM_SMALL_TILE16, KNOB_TAIL_LEVEL, KNOB_TAIL_BLOCKS = 13, 14, 15, 16, 17
+KNOB_PAIRWISE_KERNEL, KNOB_COPY_BATCHES, KNOB_FAIL_HOST_REGISTER = 4, 5, 7
+KNOB_SAGE_FORWARD_OVERLAP, KNOB_GEMM_SMALL_TILE16 = 14, 15
 KNOB_GEMM_TILE16_BUFFERS = 18
 KNOB_PREPARE_MERGE = 19
 
@@ -31,10 +29,7 @@ SIGNATURES = {
     "pope_copy_2d_to_host": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "pope_assemble_host_result": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32,
                                           c_int32, c_void_p]),
-    "pope_host_prefault_begin": (c_void_p, [c_void_p, c_size_t, c_int32]),
-    "pope_host_prefault_wait": (None, [c_void_p]),
     "pope_assemble_begin": (c_void_p, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32]),
-    "pope_assemble_begin_mode": (c_void_p, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32]),
     "pope_assemble_finish": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "pope_assemble_abort": (None, [c_void_p]),
     "pope_assemble_prepare": (None, [c_int32]),
@@ -77,6 +72,7 @@ SIGNATURES = {
     "pope_profile_read": (c_int32, [c_void_p, c_void_p, c_int32]),
     "pope_geodesic_finalize_shards": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int64, c_int32, c_void_p, c_int32,
                                               c_void_p, c_int64, c_void_p]),
+    "pope_finalize_kernel_name": (c_int, [c_int64, c_int32, c_int32, c_int32, c_int32, c_char_p, c_size_t]),
     "pope_column_stats_scratch_bytes": (c_size_t, [c_int32]),
     "pope_geodesic_column_stats": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pope_geodesic_hops": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),

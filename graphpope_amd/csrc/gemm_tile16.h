@@ -36,24 +36,17 @@ struct T16Args {
     const long long *rows;     // nullptr, or: row m of the FIRST product's A operand is p[0].A + rows[m] * p[0].lda (the resident
                                // feature matrix read through n_id; byte offsets must fit 32 bits)
     int accumulate;            // 1: C += product (no bias): the second half of a layer whose first half another launch wrote
-    // The SECOND product's A rows are written by other blocks of the same launch (the gather role of k_gather_beside_gemm):
-    // done[tm] counts the finished rows of row tile tm, and the loader waves issue the first stage of the second product
-    // only once it has reached the tile's height (bounded wait; on a timeout *fail is set and a later launch redoes the product).
-    const int *done;           // nullptr: the rows are there before the launch
-    int *fail;
 };
 
-constexpr unsigned long long T16_WAIT_TICKS = 2000000ull;   // 20 ms of the 100 MHz counter: 300 x the whole launch
 #ifdef POPE_STAMP
 #define T16_STAMP(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_gemm_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-// per-stage trace of the plain (not WAIT) kernel: [block][who: 0 loader wave 0 arrives at B_(s+1), 1 consumer wave 0 arrives, 2 consumer wave 0 leaves][stage]
+// per-stage trace of the kernel: [block][who: 0 loader wave 0 arrives at B_(s+1), 1 consumer wave 0 arrives, 2 consumer wave 0 leaves][stage]
 __device__ unsigned long long g_t16_trace[256 * 4 * 64];                  // (row 3: the shader-clock counter at row 2's instants)
-#define T16_TRACE(who, s) do { if (!WAIT && (threadIdx.x & 63) == 0 && blockIdx.x < 256 && (s) < 64) g_t16_trace[(blockIdx.x * 4 + (who)) * 64 + (s)] = (who) == 3 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime(); } while (0)
+#define T16_TRACE(who, s) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && (s) < 64) g_t16_trace[(blockIdx.x * 4 + (who)) * 64 + (s)] = (who) == 3 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define T16_STAMP(slot) do { } while (0)
 #define T16_TRACE(who, s) do { } while (0)
 #endif
-constexpr int T16_DONE_STRIDE = 32;                         // ints between two tiles' counters: a 128-byte line (a memory channel) each
 
 template <int RB, int NBUF = 3> struct T16Shape {
     static constexpr int TM = 16 * RB;
@@ -63,39 +56,9 @@ template <int RB, int NBUF = 3> struct T16Shape {
 };
 
 // One output tile: rows [tm * TM, ...) x columns [tn * 128, ...).  All eight waves of the block call it together.
-typedef __bf16 t16_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float t16_f32x2 __attribute__((ext_vector_type(2)));
-
-// Eight floats (two 16-byte pieces of a row) as three bf16 vectors h + m + l: h = the top 16 bits of x, m = the top 16 bits
-// of x - h, l = the top 16 bits of x - h - m (both differences are exact), so h + m + l carries 24 significant bits.
-__device__ __forceinline__ float t16_sub(float a, float b) {
-    float r;                                     // a plain v_sub_f32: beside MFMAs the packed form the compiler would pick costs more
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // than two scalar ones (MI355X_MICROARCH.md, cycle constants)
-    return r;
-}
-
-__device__ __forceinline__ void t16_split8(const float4 &p0, const float4 &p1, t16_bf16x8 &h, t16_bf16x8 &m, t16_bf16x8 &l) {
-    const float f[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-    unsigned hh[4], mm[4], ll[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const unsigned u0 = __float_as_uint(f[2 * q]), u1 = __float_as_uint(f[2 * q + 1]);
-        hh[q] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                       // {top half of f[2q], top half of f[2q+1]}
-        const float ra = t16_sub(f[2 * q], __uint_as_float(u0 & 0xffff0000u)), rb = t16_sub(f[2 * q + 1], __uint_as_float(u1 & 0xffff0000u));
-        const unsigned r0 = __float_as_uint(ra), r1 = __float_as_uint(rb);
-        mm[q] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);
-        const float ta = t16_sub(ra, __uint_as_float(r0 & 0xffff0000u)), tb = t16_sub(rb, __uint_as_float(r1 & 0xffff0000u));
-        ll[q] = __builtin_amdgcn_perm(__float_as_uint(tb), __float_as_uint(ta), 0x07060302u);
-    }
-    h = __builtin_bit_cast(t16_bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
-    m = __builtin_bit_cast(t16_bf16x8, make_uint4(mm[0], mm[1], mm[2], mm[3]));
-    l = __builtin_bit_cast(t16_bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
-}
-
-// SPLIT = false: exact f32 products on v_mfma_f32_16x16x4_f32 (the product path).  SPLIT = true (opt-in,
-// POPE_KNOB_GEMM_SPLIT_BF16): every f32 operand as three bf16 terms and six v_mfma_f32_16x16x32_bf16 per product
-// (hh, hm, mh, mm, hl, lh; the dropped terms are below 2^-24 of |a||b|), f32 accumulate -- the same accuracy class, not the
-// same bits; the LDS images, the loader waves and the epilogue are shared.
+// Exact f32 products on v_mfma_f32_16x16x4_f32.  (Round 3's opt-in split-bf16 arithmetic -- every f32 operand as three bf16 terms, six
+// v_mfma_f32_16x16x32_bf16 per product -- measured 1.13 x, bound by the conversion in the consumer waves, and was removed in round 5:
+// DESIGN.md 7h keeps the figures.)
 // s_waitcnt vmcnt(n) with a wave-uniform run-time n <= 8 (the instruction takes an immediate)
 __device__ __forceinline__ void t16_wait_vmcnt(int n) {
     switch (n) {
@@ -115,10 +78,9 @@ __device__ __forceinline__ void t16_wait_vmcnt(int n) {
 // have landed by B_(s+1): ONE stage of MFMA time hides the request.  NBUF = 4: stage s + 3 is requested behind B_s and only stage
 // s + 2 must have landed by B_(s+1) (s_waitcnt vmcnt(the newest stage's instruction count): loads return in order), so a
 // request has TWO stage times.  Stage t lives in buffer t % NBUF either way.
-template <int RB, bool SPLIT, bool WAIT = false, int NBUF = 3>
+template <int RB, int NBUF = 3>
 __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const int tm, const int tn, char *smem, const unsigned lds0,
                                          const int lane, const int wave) {
-    static_assert(!WAIT || NBUF == 3, "the in-launch wait is placed for two stages of look-ahead");
     using Sh = T16Shape<RB, NBUF>;
     const int m0 = tm * Sh::TM, n0 = tn * T16_TN;
     const int S = a.S0 + a.S1;
@@ -151,25 +113,19 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
             if (k0 + T16_GK <= PK) {
 #pragma unroll
                 for (int d = 0; d < Sh::ND; ++d)
-                    if (lw * Sh::ND + d < Sh::INSTR) {
-                        if (WAIT && second && lw * Sh::ND + d < Sh::A_INSTR)       // rows written in this launch: read at agent scope
-                            sk_glds16_saddr_agent(A, off[1][d], lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
-                        else
-                            sk_glds16_saddr(lw * Sh::ND + d < Sh::A_INSTR ? A : B, second ? off[1][d] : off[0][d],
-                                            lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
-                    }
+                    if (lw * Sh::ND + d < Sh::INSTR)
+                        sk_glds16_saddr(lw * Sh::ND + d < Sh::A_INSTR ? A : B, second ? off[1][d] : off[0][d],
+                                        lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
             } else {                                                   // depth padding: lanes past the depth read the zero page
 #pragma unroll
                 for (int d = 0; d < Sh::ND; ++d)
                     if (lw * Sh::ND + d < Sh::INSTR) {
                         const float *src = (const float *)((const char *)(lw * Sh::ND + d < Sh::A_INSTR ? A : B) + (second ? off[1][d] : off[0][d]));
                         if (k0 + koff[d] >= PK) src = a.zero;
-                        if (WAIT && second && lw * Sh::ND + d < Sh::A_INSTR) sk_glds16_agent(src, lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
-                        else sk_glds16(src, lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
+                        sk_glds16(src, lds0 + buf * Sh::STAGE_BYTES + (lw * Sh::ND + d) * 1024);
                     }
             }
         };
-        if (WAIT && lw == 0) T16_STAMP(0);
         int mine = 0;                                              // DMA instructions of this wave per stage
 #pragma unroll
         for (int d = 0; d < Sh::ND; ++d) mine += lw * Sh::ND + d < Sh::INSTR ? 1 : 0;
@@ -180,28 +136,6 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
         __builtin_amdgcn_s_barrier();          // B_0: the stages issued so far have landed
         int buf = 0;                           // buffer of stage s
         for (int s = 0; s < S; ++s) {
-            if constexpr (WAIT) {
-                // the second product's rows come from the gather role of this launch: wait for this tile's (host: S0 >= 2, so the
-                // two stages issued ahead of the loop never belong to it)
-                if (s + 2 == a.S0) {
-                    if (lw == 0) T16_STAMP(1);
-                    const int need = min(Sh::TM, M - m0);
-                    const int *flag = a.done + tm * T16_DONE_STRIDE;
-                    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
-                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
-                            __builtin_amdgcn_s_sleep(32);
-                            if (__builtin_amdgcn_s_memrealtime() - t0 > T16_WAIT_TICKS) {
-                                if (lane == 0) atomicOr(a.fail, 1);
-                                break;
-                            }
-                        }
-                    }
-                    if (lw == 0) T16_STAMP(2);
-                    // no acquire fence (it would drop every line the XCD's L2 holds, the weights all its blocks share included: measured,
-                    // 270 us for the launch instead of 115): the rows are READ at agent scope instead, see issue_all
-                }
-            }
             const int ahead = NBUF - 1;
             const bool more = s + ahead < S;
             if (more) issue_all(s + ahead, buf == 0 ? NBUF - 1 : buf - 1);   // the buffer of stage s - 1: its readers left it before B_s
@@ -232,59 +166,7 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
             for (int r = 0; r < 4; ++r) acc[i][t][r] = 0.0f;
     __builtin_amdgcn_s_barrier();              // B_0
     asm volatile("" ::: "memory");
-    if constexpr (SPLIT) {
-        // one 16x16x32 MFMA spans a whole 32-deep stage: lane (r15, g) holds depth 8g .. 8g + 7 = pieces 2g, 2g + 1 of its row
-        float4 ra[RB][2], rb[2][2];
-        auto read_a = [&](int b, int i) {
-            const char *base = smem + b * Sh::STAGE_BYTES + fa_base + i * 2048;
-            ra[i][0] = *reinterpret_cast<const float4 *>(base + (((2 * g) ^ swz) << 4));
-            ra[i][1] = *reinterpret_cast<const float4 *>(base + (((2 * g + 1) ^ swz) << 4));
-        };
-        auto read_b = [&](int b, int t) {
-            const char *base = smem + b * Sh::STAGE_BYTES + fb_base + t * 2048;
-            rb[t][0] = *reinterpret_cast<const float4 *>(base + (((2 * g) ^ swz) << 4));
-            rb[t][1] = *reinterpret_cast<const float4 *>(base + (((2 * g + 1) ^ swz) << 4));
-        };
-#pragma unroll
-        for (int t = 0; t < 2; ++t) read_b(0, t);
-#pragma unroll
-        for (int i = 0; i < RB; ++i) read_a(0, i);
-        int buf = 0;
-        for (int s = 0; s < S; ++s) {
-            const bool next = s + 1 < S;
-            const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
-            t16_bf16x8 bh[2], bm[2], bl[2], ah[2], am[2], al[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                t16_split8(rb[t][0], rb[t][1], bh[t], bm[t], bl[t]);
-                if (next) read_b(nbuf, t);                             // stage s + 1 has landed since B_s; the raw registers are free again
-            }
-            t16_split8(ra[0][0], ra[0][1], ah[0], am[0], al[0]);
-            if (next) read_a(nbuf, 0);
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                const int cur = i & 1, nxt = cur ^ 1;
-                if (i + 1 < RB) {                                      // the next row block is split while this one's MFMAs run
-                    t16_split8(ra[i + 1][0], ra[i + 1][1], ah[nxt], am[nxt], al[nxt]);
-                    if (next) read_a(nbuf, i + 1);
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cur], bh[t], acc[i][t], 0, 0, 0);
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur], bl[t], acc[i][t], 0, 0, 0);
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[cur], bm[t], acc[i][t], 0, 0, 0);
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[cur], bh[t], acc[i][t], 0, 0, 0);
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur], bm[t], acc[i][t], 0, 0, 0);
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur], bh[t], acc[i][t], 0, 0, 0);
-                }
-            }
-            if (next) {
-                __builtin_amdgcn_s_barrier();                          // B_(s+1)
-                asm volatile("" ::: "memory");
-            }
-            buf = nbuf;
-        }
-    } else {
+    {
         float4 fa[2][RB], fb[2][2];
         auto read_pass = [&](int b, int p, int set) {
             const char *base = smem + b * Sh::STAGE_BYTES;
@@ -335,7 +217,6 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
             buf = nbuf;
         }
     }
-    if (WAIT && wave == 0) T16_STAMP(3);
     // C/D layout of the 16 x 16 forms: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -362,7 +243,7 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
 }
 
 // The tiles `first`, `first + stride`, ... of the product, one after the other, by the calling block (all eight waves).
-template <int RB, bool SPLIT, bool WAIT = false, int NBUF = 3>
+template <int RB, int NBUF = 3>
 __device__ __forceinline__ void t16_block_loop(const T16Args &a, char *smem, const int first, const int stride) {
     using Sh = T16Shape<RB, NBUF>;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -389,15 +270,15 @@ __device__ __forceinline__ void t16_block_loop(const T16Args &a, char *smem, con
             break;
         }
         if (again) __syncthreads();                               // the previous tile's last stage has been read: its buffers are free
-        t16_tile<RB, SPLIT, WAIT, NBUF>(a, M, tm, tn, smem, lds0, lane, wave);
+        t16_tile<RB, NBUF>(a, M, tm, tn, smem, lds0, lane, wave);
         again = true;
     }
 }
 
-template <int RB, bool SPLIT = false, int NBUF = 3>
+template <int RB, int NBUF = 3>
 __global__ __launch_bounds__(T16_THREADS) void k_gemm_tile16(T16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    t16_block_loop<RB, SPLIT, false, NBUF>(a, smem, (int)blockIdx.x, (int)gridDim.x);
+    t16_block_loop<RB, NBUF>(a, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // The tile height (in 16-row blocks, 3 .. 8) that wastes the least of the chip for this M x N, or 0 if no choice reaches

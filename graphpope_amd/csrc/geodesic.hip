@@ -31,8 +31,7 @@ namespace pope {
 // ------------------------------------------------------------------------------------------------
 // CSR build
 // ------------------------------------------------------------------------------------------------
-enum { CSR_FLAG_BAD_INDEX = 1, CSR_FLAG_UNSORTED = 2, BFS_FLAG_TAIL_FAILED = 4 };
-constexpr int TAIL_GROUPS = 16;                // k_tail_finalize: groups of the two-stage barrier among its BFS blocks
+enum { CSR_FLAG_BAD_INDEX = 1, CSR_FLAG_UNSORTED = 2 };
 constexpr size_t CTL_BYTES = 4096;             // BfsCtl at the start of the BFS scratch
 enum { AUX_FLAGS = 2, AUX_HEADER = 16 };
 constexpr int SLOTS = 4;                      // CSR slots per lane in the BFS expand kernel
@@ -182,12 +181,9 @@ static size_t rowsort_temp_bytes(size_t E, size_t N) {
 // ------------------------------------------------------------------------------------------------
 struct BfsCtl {          // device control block at the start of the BFS scratch (CTL_BYTES, zeroed by the first launch of a BFS)
     int last_active;     // highest level at which some (node, anchor) pair was newly reached
-    int tail_done;       // k_tail_finalize: the ticket of the call once its BFS blocks are through (agent-scope release)
-    unsigned tail_top;   // k_tail_finalize: second stage of the barrier of its BFS blocks (groups that have arrived)
-    int tail_failed;     // k_tail_finalize: a bounded wait ran out (never expected; the host turns it into an error)
+    int pad0[3];
     unsigned flag_epoch; // the tag the CSR status word must carry to count (csr_flags); 0 = the zeroed word of the separate launches
     int pad[27];
-    unsigned tail_group[TAIL_GROUPS * 32];      // first stage: one counter per group of BFS blocks, 128 bytes apart
 };
 
 // The CSR status word aux[AUX_FLAGS] = (tag << 3) | flags.  The separate launches zero it and OR flags into it (tag 0); the merged
@@ -234,7 +230,7 @@ struct PrepSeeds { int a[PREP_MAX_ANCHORS]; };
 template <bool PAIRS>
 __global__ __launch_bounds__(256) void k_prepare(const long long *__restrict__ src, const long long *__restrict__ dst, int E, int N,
                                                  int *__restrict__ rowptr, int *__restrict__ col, int *__restrict__ erow, int *aux,
-                                                 uint4 *za, size_t na, uint4 *zb, size_t nb, int zero_blocks, unsigned epoch,
+                                                 uint4 *za, size_t na, uint4 *zb, size_t nb, u64 *zb_tail, int zero_blocks, unsigned epoch,
                                                  PrepSeeds seeds, int K, int Wp, u64 *seen, u64 *front, unsigned *live) {
     if ((int)blockIdx.x >= zero_blocks) {
         const int flags = csr_sorted_role<PAIRS>(src, dst, E, N, rowptr, col, erow, aux, (int)blockIdx.x - zero_blocks, (int)gridDim.x - zero_blocks);
@@ -247,6 +243,9 @@ __global__ __launch_bounds__(256) void k_prepare(const long long *__restrict__ s
     static_assert(offsetof(BfsCtl, flag_epoch) == 16, "k_prepare writes the tag as the first word of the control block's second unit");
     for (size_t i = first; i < na; i += stride) za[i] = i == 1 ? make_uint4(epoch, 0, 0, 0) : z;
     for (size_t i = first; i < nb; i += stride) zb[i] = z;
+    // region b is (1 + eager) planes of N * W words: an odd word count leaves one 8-byte word behind the last 16-byte unit (the last
+    // node's word of the last eager hop-bit plane; never a seeded word: seeds go to plane 0)
+    if (zb_tail && first == 0) *zb_tail = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this thread's stores are in L2
     __syncthreads();
     // the block's own seeds: unit u of a region was zeroed by thread u % stride, i.e. by block (u % stride) / blockDim.x
@@ -273,12 +272,18 @@ __device__ __forceinline__ void raise_level(BfsCtl *ctl, int level) {
 
 // Zero `n16` 16-byte units at each of up to 3 regions + the control block, then nothing else: one launch
 // instead of a string of hipMemsetAsync calls (each is its own ~4 us fill kernel).
-__global__ __launch_bounds__(256) void k_zero(uint4 *a, size_t na, uint4 *b, size_t nb, uint4 *c, size_t nc) {
+__global__ __launch_bounds__(256) void k_zero(uint4 *a, size_t na, uint4 *b, size_t nb, uint4 *c, size_t nc, u64 *b_tail) {
     const uint4 z = make_uint4(0, 0, 0, 0);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if (b_tail && blockIdx.x == 0 && threadIdx.x == 0) *b_tail = 0;       // the 8-byte word behind region b's last 16-byte unit (odd word count)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = z;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = z;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += stride) c[i] = z;
+}
+
+// A run of 8-byte words that need not start on a 16-byte boundary (hop-bit planes of an odd N * W: deep levels only).
+__global__ __launch_bounds__(256) void k_zero_words(u64 *p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0;
 }
 
 __global__ void k_bfs_seed(const long long *__restrict__ anchors, int K, int Wp, u64 *seen, u64 *front, unsigned *live) {
@@ -317,46 +322,6 @@ __device__ __forceinline__ u64 dpp_mov64(u64 x) {
     return ((u64)hi << 32) | lo;
 }
 
-// COPY ROLE of a level launch (round 4).  out[:, :F] = x (utils.py:129-135) is two thirds of the finalise kernel's traffic and
-// depends on nothing the BFS computes, while the level launches are bound by L2 line fills and latency and leave the HBM
-// interface idle.  Every level launch of pope_geodesic_run therefore carries, BEHIND its expand and housekeeping blocks, a
-// bounded number of short-lived blocks that copy a fixed slice of x's rows -- one batch of 16 pieces of 16 bytes per lane,
-// every load issued before the first store (side_copy.hip's shape) -- and the finalise kernel starts its own copy at the
-// first row no launch took.  Same launch, same stream: nothing forks, nothing delays the next level's launch (both side-stream
-// forms of this were measured slower, DESIGN.md section 3 lessons 5, 11, 12).  x is dense [N, F]: piece p of the flat sequence of
-// 16-byte pieces lies at x + 16 p and goes to row p / F4, piece p % F4 of out.
-struct LevelCopy {
-    const float *x = nullptr;
-    float *out = nullptr;
-    unsigned F4 = 0, opitch4 = 0;                 // row length of x and row pitch of out, in 16-byte pieces
-    unsigned piece_begin = 0, piece_end = 0;      // flat pieces of x this launch copies
-    int first_block = 0, blocks = 0;              // blockIdx.x of the role's first block (set by launch_level), number of its blocks
-};
-constexpr int LEVEL_COPY_PIECES = 16;             // per lane and batch
-constexpr unsigned LEVEL_COPY_BLOCK_PIECES = 256u * LEVEL_COPY_PIECES;
-
-__device__ __forceinline__ void level_copy_role(const LevelCopy &cp) {
-    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const unsigned base = cp.piece_begin + (((unsigned)blockIdx.x - (unsigned)cp.first_block) * 4u + w) * (64u * LEVEL_COPY_PIECES) + lane;
-    if (base >= cp.piece_end) return;
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(cp.x);
-    f32x4 *dst = reinterpret_cast<f32x4 *>(cp.out);
-    f32x4 v[LEVEL_COPY_PIECES];
-#pragma unroll
-    for (int j = 0; j < LEVEL_COPY_PIECES; ++j) {
-        const unsigned p = base + 64u * j;
-        if (p < cp.piece_end) v[j] = __builtin_nontemporal_load(src + p);
-    }
-    unsigned row = base / cp.F4, q = base - row * cp.F4;
-#pragma unroll
-    for (int j = 0; j < LEVEL_COPY_PIECES; ++j) {
-        const unsigned p = base + 64u * j;
-        if (p < cp.piece_end) dst[(size_t)row * cp.opitch4 + q] = v[j];
-        q += 64u;
-        while (q >= cp.F4) { q -= cp.F4; ++row; }
-    }
-}
-
 template <int WT>
 __device__ __forceinline__ Words<WT> load_words(const u64 *__restrict__ p) {
     Words<WT> r;
@@ -366,26 +331,6 @@ __device__ __forceinline__ Words<WT> load_words(const u64 *__restrict__ p) {
 #pragma unroll
         for (int i = 0; i < WT; i += 2) {                      // 16-byte loads (rows of 16 / 32 bytes, aligned)
             const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p + i);
-            r.w[i] = v.x;
-            r.w[i + 1] = v.y;
-        }
-    }
-    return r;
-}
-
-typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
-typedef int i32x4v __attribute__((ext_vector_type(4)));
-
-// The same with the non-temporal hint (POPE_KNOB_LEVEL_VARIANT experiments: streams that should not evict the frontier).
-template <int WT>
-__device__ __forceinline__ Words<WT> load_words_nt(const u64 *__restrict__ p) {
-    Words<WT> r;
-    if constexpr (WT == 1) {
-        r.w[0] = __builtin_nontemporal_load(p);
-    } else {
-#pragma unroll
-        for (int i = 0; i < WT; i += 2) {
-            const u64x2v v = __builtin_nontemporal_load(reinterpret_cast<const u64x2v *>(p + i));
             r.w[i] = v.x;
             r.w[i + 1] = v.y;
         }
@@ -478,7 +423,7 @@ __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words
 // slower than no table at all FOR FLICKR: each chunk's 256 gathered lines flush the 32 KB L1, so the lookups went to L2
 // as well.  Beyond LIVE_MAX_NODES the table is read from global memory (LIVE = 2): there the frontier rows come from the
 // Infinity Cache or HBM while the table still sits in L2 -- R-MAT scale 22 runs 20 % faster with it than without.)
-// WT = words per tile (1, 2 or 4); blockIdx.y selects the tile of a node's W words.
+// WT = words per tile (1, 2 or 4); a node with more words (K > 256) has several tiles (TILES, see level_expand).
 // The live table (one bit per node, at most LIVE_MAX_NODES / 8 = 32 KB) into LDS: every load of a thread is requested before its
 // first write (round 4: as `for (i ...) lds[i] = src[i]` the loop compiled to load - s_waitcnt vmcnt(0) - ds_write per trip, three
 // serial round trips for Flickr's 11 KB in front of the barrier every expand wave waits at).
@@ -500,38 +445,49 @@ __device__ __forceinline__ void stage_live_table(const unsigned *__restrict__ li
     }
 }
 
+// The summary of a live table for LIVE = 3: bit w of it says that table word w is non-zero (one bit per 32 nodes: 16 KB for the 4.2 M
+// nodes of R-MAT scale 22, where the table itself is 512 KB and cannot be staged).  A launch of its own between two level launches
+// (~4 us against levels of 0.3-2.5 ms): the table of the level just finished is complete, nobody else writes the summary.
+// Tables are padded to 256 bytes with zeros, so a wave may read its 64 words unconditionally.
+__global__ __launch_bounds__(256) void k_live_summary(const unsigned *__restrict__ live, int padded_words, unsigned *__restrict__ sum) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned v = w < padded_words ? live[w] : 0u;
+    const unsigned long long b = __ballot(v != 0u);
+    if ((threadIdx.x & 63) == 0 && w < padded_words) {
+        sum[(w >> 5)] = (unsigned)b;
+        sum[(w >> 5) + 1] = (unsigned)(b >> 32);
+    }
+}
+
 // Housekeeping share of one level (see k_bfs_level): thread t0 of tstride threads.  (1) clears two levels ahead -- the live
-// table (first_tile only) and the accumulator words of the rows that span chunks; (2) commits level - 1 for every node whose
-// frontier row is non-zero.
-template <int WT, int LIVE>
-__device__ __forceinline__ void level_housekeeping(int E, int N, int Wp, const u64 *__restrict__ front, u64 *__restrict__ seen,
+// table and the accumulator words of the rows that span chunks; (2) commits level - 1 for every node whose
+// frontier row is non-zero.  A node's W = tiles * WT words are walked tile by tile.
+template <int WT, int LIVE, int TILES>
+__device__ __forceinline__ void level_housekeeping(int E, int N, int Wp, int tiles_arg, const u64 *__restrict__ front, u64 *__restrict__ seen,
                                                    u64 *__restrict__ idle, u64 *__restrict__ hop_planes, size_t plane_elems, int level,
                                                    const int *aux, const unsigned *__restrict__ live, unsigned *__restrict__ live_idle,
-                                                   int live_words, int t0, int tstride, int woff, bool first_tile) {
+                                                   int live_words, int t0, int tstride) {
+    const int tiles = TILES ? tiles_arg : 1;
     const int n = (E + CHUNK - 1) >> CHUNK_SHIFT;              // one slot per chunk, -1 = no row continues into it
     const int *mrows = aux + AUX_HEADER;
-    if (LIVE && first_tile)
-        for (int i = t0; i < live_words; i += tstride) live_idle[i] = 0u;
+    for (int i = t0; i < live_words; i += tstride) live_idle[i] = 0u;
     Words<WT> zero;
 #pragma unroll
     for (int i = 0; i < WT; ++i) zero.w[i] = 0;
-    if constexpr (LIVE == 0) {
-        // No live table (A/B mode): the commit below reads EVERY frontier row, so a row that no chunk writes (a node
-        // without out-edges) must not keep what the buffer held three levels ago: the whole buffer is cleared.
-        for (int v = t0; v < N; v += tstride) store_words<WT>(idle + (size_t)v * Wp + woff, zero);
-    } else {
-        for (int i = t0; i < n; i += tstride) {
-            const int mv = mrows[i];
-            if (mv >= 0) store_words<WT>(idle + (size_t)mv * Wp + woff, zero);
-        }
+    for (int i = t0; i < n; i += tstride) {
+        const int mv = mrows[i];
+        if (mv >= 0)
+            for (int t = 0; t < tiles; ++t) store_words<WT>(idle + (size_t)mv * Wp + t * WT, zero);
     }
     if (level > 1) {
         for (int v = t0; v < N; v += tstride) {
-            if (LIVE && !((live[v >> 5] >> (v & 31)) & 1u)) continue;              // frontier row all zero: nothing gained
-            const size_t idx = (size_t)v * Wp + woff;
-            const Words<WT> fresh = load_words<WT>(front + idx);
-            if (any_bits<WT>(fresh))
-                commit_words<WT>(fresh, load_words<WT>(seen + idx), idx, seen, hop_planes, plane_elems, level - 1);
+            if (!((live[v >> 5] >> (v & 31)) & 1u)) continue;                      // frontier row all zero: nothing gained
+            for (int t = 0; t < tiles; ++t) {
+                const size_t idx = (size_t)v * Wp + t * WT;
+                const Words<WT> fresh = load_words<WT>(front + idx);
+                if (any_bits<WT>(fresh))
+                    commit_words<WT>(fresh, load_words<WT>(seen + idx), idx, seen, hop_planes, plane_elems, level - 1);
+            }
         }
     }
 }
@@ -544,21 +500,25 @@ __device__ __forceinline__ int2 chunk_edge_rows(const int *__restrict__ erow, in
     return r;
 }
 
-// Expand share of one level (see k_bfs_level): this wave walks chunks wave, wave + nwaves, ... of tile `woff`; (vr, ur) hold the
-// first chunk's slots, loaded by the caller before it staged the live table.  Returns whether this lane emitted a non-zero row.
-template <int WT, int LIVE>
-__device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const int *__restrict__ col, int E, int Wp,
+// Expand share of one level (see k_bfs_level): this wave walks chunks wave, wave + nwaves, ...; (vr, ur) hold the first chunk's
+// slots, loaded by the caller before it staged the live table.  Returns whether this lane emitted a non-zero row.
+// A node with more than 256 anchors has several WT-word tiles (TILES != 0).  Two ways to walk them, chosen by the size of the graph:
+//  TILES = 1 (round 5, graphs whose frontier lives in HBM: LIVE >= 2): INSIDE the wave -- the chunk's index loads, live look-ups and row
+//    structure (which slots end a run, which rows span chunks, who connects to whom in the scan) are computed once and the gather /
+//    mask / scan / store part runs once per tile, the next tile's gathers requested behind this tile's mask loads.  R-MAT scale 22 with
+//    512 anchors: 11.95 -> 9.3 ms for the nine levels (one pass over the 522 MB index stream and over the live look-ups instead of two).
+//  TILES = 2 (rounds 2-4, graphs that live in L2: LIVE = 1): every tile of a chunk is a wave of its own, adjacent waves of one block, so
+//    the 128-byte frontier line they all gather from is fetched from L2 once.  These levels are latency-bound and want the waves: with
+//    the tiles inside the wave the Flickr-shaped graph with 1 024 anchors ran 0.616 ms instead of 0.565.
+template <int WT, int LIVE, int TILES>
+__device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const int *__restrict__ col, int E, int Wp, int tile_begin, int tile_end,
                                              const u64 *__restrict__ front, u64 *__restrict__ seen, u64 *__restrict__ acc,
                                              const unsigned *__restrict__ live, unsigned *__restrict__ live_acc,
-                                             const unsigned *live_lds, int variant, int level, int lane, int wave, int nwaves, int nchunks,
-                                             int woff, int tiles, int4 vr, int4 ur, unsigned *wave_words) {
-    auto load_idx = [&](const int *p) {
-        if (variant & 1) {
-            const i32x4v t = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(p));
-            return make_int4(t.x, t.y, t.z, t.w);
-        }
-        return *reinterpret_cast<const int4 *>(p);
-    };
+                                             const unsigned *live_lds, int level, int lane, int wave, int nwaves, int nchunks,
+                                             int4 vr, int4 ur, unsigned *wave_words) {
+    auto load_idx = [&](const int *p) { return *reinterpret_cast<const int4 *>(p); };
+    constexpr bool LOOP = TILES == 1;                          // only then a wave sees more than one tile (and carries the prefetch registers)
+    if (!TILES) { tile_begin = 0; tile_end = 1; }
     bool found = false;
     STAMP(0);
     for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
@@ -575,9 +535,15 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
             if (base + 3 < E) { v3 = vr.w; u3 = ur.w; }
         }
         auto is_live = [&](int u) {
-            if constexpr (LIVE == 0) return true;
-            const unsigned w = LIVE == 1 ? live_lds[u >> 5] : live[u >> 5];
-            return ((w >> (u & 31)) & 1u) != 0;
+            if constexpr (LIVE == 3) {
+                // two-level table: the summary in LDS says whether the node's table word holds any bit at all; only then the word
+                // itself is fetched (from L2).  A sparse level's waves then stream the indices and touch little else.
+                if (!((live_lds[u >> 10] >> ((u >> 5) & 31)) & 1u)) return false;
+                return ((live[u >> 5] >> (u & 31)) & 1u) != 0;
+            } else {
+                const unsigned w = LIVE == 1 ? live_lds[u >> 5] : live[u >> 5];
+                return ((w >> (u & 31)) & 1u) != 0;
+            }
         };
         // the four look-ups first, unconditionally (u = 0 for an empty slot), then the tests: as `v >= 0 && is_live(u)` each look-up sat
         // behind a branch and was waited for on its own
@@ -586,175 +552,186 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
         const int vc = __builtin_amdgcn_readlane(v0, 0);                               // row of the chunk's first slot
         const int vl = __builtin_amdgcn_readlane(v3, 63);                              // row of its last slot (-1: short chunk)
         STAMP(1);
+        const bool work = __any(g0 || g1 || g2 || g3);                 // else: no live neighbour behind these 256 slots
+        if (!work) continue;                                           // nothing to gather, nothing to store (nobody gathers a row whose live bit is clear), nothing to mark
         // the rows of the slots just outside the chunk: does its first row begin earlier, does its last row run on?
         const int2 er = chunk_edge_rows(erow, __builtin_amdgcn_readfirstlane(chunk), E);     // wave-uniform: scalar loads
         const bool head_multi = chunk > 0 && er.x == vc;                               // first row began in an earlier chunk
         const bool tail_multi = vl >= 0 && (chunk + 1) * CHUNK < E && er.y == vl;     // last row runs on
         // slots of a row that spans chunks (only the chunk's first and last row can)
         const bool x0 = (head_multi && v0 == vc) || (tail_multi && v0 == vl);
-        const bool x3 = (head_multi && v3 == vc) || (tail_multi && v3 == vl);
-
-        Words<WT> c0, c1, c2, c3;
-#pragma unroll
-        for (int i = 0; i < WT; ++i) c0.w[i] = c1.w[i] = c2.w[i] = c3.w[i] = 0;
-        const bool work = __any(g0 || g1 || g2 || g3);                 // else: no live neighbour behind these 256 slots
-        if (!work && LIVE && tiles == 1) continue;                     // nothing to gather, nothing to store (all-zero rows are not written), nothing to mark
-        if (g0) c0 = gather_words<WT>(front + (size_t)u0 * Wp + woff);
-        if (g1) c1 = gather_words<WT>(front + (size_t)u1 * Wp + woff);
-        if (g2) c2 = gather_words<WT>(front + (size_t)u2 * Wp + woff);
-        if (g3) c3 = gather_words<WT>(front + (size_t)u3 * Wp + woff);
-        // mask of row v: what reached it before this level = seen[v] | front[v].  front[v] (level - 1's gain) is committed to
-        // seen by the housekeeping blocks of THIS launch: either order gives the same mask.  Rows whose live bit is clear
-        // have an all-zero (possibly never written) frontier row: not loaded.
-        // Round 4: the first and the last row's loads (reachability + frontier, predicated, no use in between) go out together with
-        // the gathers; as a chain of calls each frontier load sat inside an `if (live)` whose merge point waited for it, and the ISA
-        // showed up to four serial round trips behind the gathers.  (All four rows' loads at once: 142 registers, three waves per
-        // SIMD instead of four, every level 3-6 us SLOWER -- profiles/r04_level_times_batched_masks.txt.)
-        // (Round 4, after the finalise kernel's lesson: this chain compiles to up to four serial load - wait rounds behind the gathers.
-        //  Requesting the first and last row's masks with the gathers and the interior rows' in a second batch was built and
-        //  A/B-ed as separate library builds, tools/ab_lib.py: BFS 205-212 us against 193-197 us for this chain; all four rows at
-        //  once needs 142 registers, three waves per SIMD, every level 3-6 us slower.  Requesting the rows of the slots next to
-        //  the chunk with the index loads made no measurable difference either.  profiles/r04_level_ab_libs.txt)
-        {
-            auto row_mask = [&](int v) {
-                Words<WT> m = (variant & 4) ? load_words_nt<WT>(seen + (size_t)v * Wp + woff) : load_words<WT>(seen + (size_t)v * Wp + woff);
-                if (is_live(v)) {
-                    const Words<WT> f = load_words<WT>(front + (size_t)v * Wp + woff);
-#pragma unroll
-                    for (int i = 0; i < WT; ++i) m.w[i] |= f.w[i];
-                }
-                return m;
-            };
-            Words<WT> s0, s1, s2, s3;
-#pragma unroll
-            for (int i = 0; i < WT; ++i) s0.w[i] = s1.w[i] = s2.w[i] = s3.w[i] = 0;
-            if (work && v0 >= 0) s0 = row_mask(v0);
-            if (work && v3 >= 0) s3 = v3 == v0 ? s0 : row_mask(v3);
-            // an interior row (neither the lane's first nor last row)
-            if (work && v1 >= 0) s1 = v1 == v0 ? s0 : (v1 == v3 ? s3 : row_mask(v1));
-            if (work && v2 >= 0) s2 = v2 == v1 ? s1 : (v2 == v3 ? s3 : row_mask(v2));
-#pragma unroll
-            for (int i = 0; i < WT; ++i) {
-                c0.w[i] &= ~s0.w[i];
-                c1.w[i] &= ~s1.w[i];
-                c2.w[i] &= ~s2.w[i];
-                c3.w[i] &= ~s3.w[i];
-            }
-        }
-        const u64 any = any_bits<WT>(c0) | any_bits<WT>(c1) | any_bits<WT>(c2) | any_bits<WT>(c3);
-        STAMP(2);
-        if (__any(any != 0)) {                                         // else: nothing new through these 256 edges
-            // inclusive OR along the lane's own slots, restarting where the row changes
-#pragma unroll
-            for (int i = 0; i < WT; ++i) {
-                if (v1 == v0) c1.w[i] |= c0.w[i];
-                if (v2 == v1) c2.w[i] |= c1.w[i];
-                if (v3 == v2) c3.w[i] |= c2.w[i];
-            }
-            // across lanes: segmented scan over each lane's LAST run (row v3); a lane starts a new segment unless all
-            // its slots share one row and that row is also the previous lane's last row
-            const int pv3 = dpp_mov<DPP_WAVE_SHR1>(v3);
-            const bool connects = lane > 0 && pv3 == v0 && v0 >= 0;
-            Words<WT> t = c3;
-            bool head = !(connects && v0 == v3);
-            // Round 4: the scan network runs on DPP moves -- four shifts inside the rows of 16 lanes, then lane 15 of rows 0 / 2 to
-            // rows 1 / 3 and lane 31 to rows 2 / 3 -- where rounds 1-3 shuffled through the LDS crossbar (9 ds_bpermute per step and
-            // wave, sixteen waves of a CU queueing for it: 1.9 us of a wave's 13.8, tools/stamp_expand.py).  The operator on
-            // (value, head) pairs is the same, so is the result.  A step nobody would take anything in is skipped: rows average ten
-            // slots, so chunks without a hub row need two or three of the six.
-            auto scan_step = [&](auto ctrl, bool valid) {
-                constexpr int CTRL = decltype(ctrl)::value;
-                if (!__any(valid && !head)) return;
-                const bool ph = dpp_mov<CTRL>((int)head) != 0;
-                const bool take = valid && !head;
-#pragma unroll
-                for (int i = 0; i < WT; ++i) {
-                    const u64 pt = dpp_mov64<CTRL>(t.w[i]);
-                    if (take) t.w[i] |= pt;
-                }
-                if (take) head = ph;
-            };
-            const int in_row = lane & 15;
-            scan_step(std::integral_constant<int, DPP_ROW_SHR1>{}, in_row >= 1);
-            scan_step(std::integral_constant<int, DPP_ROW_SHR2>{}, in_row >= 2);
-            scan_step(std::integral_constant<int, DPP_ROW_SHR4>{}, in_row >= 4);
-            scan_step(std::integral_constant<int, DPP_ROW_SHR8>{}, in_row >= 8);
-            scan_step(std::integral_constant<int, DPP_ROW_BCAST15>{}, ((lane >> 4) & 1) != 0);
-            scan_step(std::integral_constant<int, DPP_ROW_BCAST31>{}, lane >= 32);
-            // carry into this lane's first run = accumulated value of the previous lane's last run
-#pragma unroll
-            for (int i = 0; i < WT; ++i) {
-                u64 ci = dpp_mov64<DPP_WAVE_SHR1>(t.w[i]);
-                if (!connects) ci = 0;
-                c0.w[i] |= ci;
-                if (v1 == v0) c1.w[i] |= ci;
-                if (v2 == v0) c2.w[i] |= ci;
-                if (v3 == v0) c3.w[i] |= ci;
-            }
-        }
-        STAMP(3);
-        // Emit every run that ends in this lane (the slot after it belongs to another row, or the chunk ends).
-        const int nv0 = dpp_mov<DPP_WAVE_SHL1>(v0);
-        const int after3 = lane == 63 ? -3 : nv0;
-        const size_t i0 = (size_t)v0 * Wp + woff, i1 = (size_t)v1 * Wp + woff, i2 = (size_t)v2 * Wp + woff,
-                     i3 = (size_t)v3 * Wp + woff;
-        const bool e0 = v0 >= 0 && v0 != v1, e1 = v1 >= 0 && v1 != v2, e2 = v2 >= 0 && v2 != v3, e3 = v3 >= 0 && v3 != after3;
         const bool x1 = (head_multi && v1 == vc) || (tail_multi && v1 == vl);
         const bool x2 = (head_multi && v2 == vc) || (tail_multi && v2 == vl);
-        const bool n0 = e0 && any_bits<WT>(c0) != 0, n1 = e1 && any_bits<WT>(c1) != 0, n2 = e2 && any_bits<WT>(c2) != 0,
-                   n3 = e3 && any_bits<WT>(c3) != 0;
+        const bool x3 = (head_multi && v3 == vc) || (tail_multi && v3 == vl);
+        // a run ends in this lane where the slot after it belongs to another row, or the chunk ends
+        const int nv0 = dpp_mov<DPP_WAVE_SHL1>(v0);
+        const int after3 = lane == 63 ? -3 : nv0;
+        const bool e0 = v0 >= 0 && v0 != v1, e1 = v1 >= 0 && v1 != v2, e2 = v2 >= 0 && v2 != v3, e3 = v3 >= 0 && v3 != after3;
+        // across lanes: segmented scan over each lane's LAST run (row v3); a lane starts a new segment unless all
+        // its slots share one row and that row is also the previous lane's last row
+        const int pv3 = dpp_mov<DPP_WAVE_SHR1>(v3);
+        const bool connects = lane > 0 && pv3 == v0 && v0 >= 0;
+        const bool head0 = !(connects && v0 == v3);
+        // the live bits of the rows themselves: row v's mask includes front[v] only when v is live
+        const bool lv0 = is_live(max(v0, 0)), lv1 = is_live(max(v1, 0)), lv2 = is_live(max(v2, 0)), lv3 = is_live(max(v3, 0));     // (only used for v >= 0)
+        bool m0 = false, m1 = false, m2 = false, m3 = false;           // run ends here with something new, in any tile
         // With the live table an all-zero row need not be written: nobody gathers a row whose live bit is clear.
         // (Several tiles share one live bit per node: then zeros are written too, so a live row is exact in every tile.)
-        const bool dense = !LIVE || tiles > 1;
-        // rows that lie inside the chunk: plain stores
-        if (e0 && !x0 && (n0 || dense)) store_words<WT>(acc + i0, c0);
-        if (e1 && !x1 && (n1 || dense)) store_words<WT>(acc + i1, c1);
-        if (e2 && !x2 && (n2 || dense)) store_words<WT>(acc + i2, c2);
-        if (e3 && !x3 && (n3 || dense)) store_words<WT>(acc + i3, c3);
-        // pieces of the (at most two) rows that span chunks: OR them in (their words were cleared two launches ago), commit later.
-        // Wave-uniform guard, and no branch per word (round 4: ~28 divergent branch regions in this phase before).
-        if (head_multi || tail_multi) {
-            auto piece = [&](size_t idx, const Words<WT> &c) {
+        const bool dense = TILES != 0;
+
+        auto gather4 = [&](int woff, Words<WT> &c0, Words<WT> &c1, Words<WT> &c2, Words<WT> &c3) {
 #pragma unroll
-                for (int i = 0; i < WT; ++i) atomicOr(&acc[idx + i], c.w[i]);
-            };
-            if (n0 && x0) piece(i0, c0);
-            if (n1 && x1) piece(i1, c1);
-            if (n2 && x2) piece(i2, c2);
-            if (n3 && x3) piece(i3, c3);
-        }
-        STAMP(4);
-        found |= n0 || n1 || n2 || n3;
-        if constexpr (LIVE) {
-            // Mark the rows that received something.  The chunk's rows are a short ascending run of node ids: build each
-            // 32-bit table word with a wave-wide OR and let one lane publish it (per-row atomics -- ~30 to every word
-            // from a few waves -- cost 14 us per dense level).
-            if (__any(n0 || n1 || n2 || n3)) {
-                const int wfirst = vc >> 5;
-                // the row of the chunk's last slot: lane 63's last slot, except in the one short chunk at the end of the edge list
-                const int last_row = vl >= 0 ? vl : erow[min((chunk + 1) * CHUNK, E) - 1];
-                const int kmax = (last_row >> 5) - wfirst;
-                if (kmax < 8) {
-                    // Round 4: every row of the chunk has exactly one emitting slot (the end of its run), so the set bits are distinct:
-                    // the emitting lanes OR them into eight LDS words of the wave (one ds_or each, no return), and lanes 0 .. kmax publish
-                    // the words.  (Rounds 2-3 built each word with a six-step wave-wide OR per word and read the last row from memory:
-                    // 1.36 us of a wave's 13.8, tools/stamp_expand.py.)  A wave's LDS instructions execute in order: no barrier.
-                    if (lane < 8) wave_words[lane] = 0u;
-                    if (n0) atomicOr(&wave_words[(v0 >> 5) - wfirst], 1u << (v0 & 31));
-                    if (n1) atomicOr(&wave_words[(v1 >> 5) - wfirst], 1u << (v1 & 31));
-                    if (n2) atomicOr(&wave_words[(v2 >> 5) - wfirst], 1u << (v2 & 31));
-                    if (n3) atomicOr(&wave_words[(v3 >> 5) - wfirst], 1u << (v3 & 31));
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane <= kmax) {
-                        const unsigned m = wave_words[lane];
-                        if (m) atomicOr(&live_acc[wfirst + lane], m);
+            for (int i = 0; i < WT; ++i) c0.w[i] = c1.w[i] = c2.w[i] = c3.w[i] = 0;
+            if (g0) c0 = gather_words<WT>(front + (size_t)u0 * Wp + woff);
+            if (g1) c1 = gather_words<WT>(front + (size_t)u1 * Wp + woff);
+            if (g2) c2 = gather_words<WT>(front + (size_t)u2 * Wp + woff);
+            if (g3) c3 = gather_words<WT>(front + (size_t)u3 * Wp + woff);
+        };
+        Words<WT> c0, c1, c2, c3;
+        gather4(tile_begin * WT, c0, c1, c2, c3);
+        for (int tile = tile_begin; tile < tile_end; ++tile) {
+            const int woff = tile * WT;
+            // mask of row v: what reached it before this level = seen[v] | front[v].  front[v] (level - 1's gain) is committed to
+            // seen by the housekeeping blocks of THIS launch: either order gives the same mask.  Rows whose live bit is clear
+            // have an all-zero (possibly never written) frontier row: not loaded.
+            // (Round 4, after the finalise kernel's lesson: this chain compiles to up to four serial load - wait rounds behind the gathers.
+            //  Requesting the first and last row's masks with the gathers and the interior rows' in a second batch was built and
+            //  A/B-ed as separate library builds, tools/ab_lib.py: BFS 205-212 us against 193-197 us for this chain; all four rows at
+            //  once needs 142 registers, three waves per SIMD, every level 3-6 us slower.  Requesting the rows of the slots next to
+            //  the chunk with the index loads made no measurable difference either.  profiles/r04_level_ab_libs.txt)
+            {
+                auto row_mask = [&](int v, bool lv) {
+                    Words<WT> m = load_words<WT>(seen + (size_t)v * Wp + woff);
+                    if (lv) {
+                        const Words<WT> f = load_words<WT>(front + (size_t)v * Wp + woff);
+#pragma unroll
+                        for (int i = 0; i < WT; ++i) m.w[i] |= f.w[i];
                     }
-                } else {                                       // a run with wide gaps (isolated nodes in between)
-                    if (n0) atomicOr(&live_acc[v0 >> 5], 1u << (v0 & 31));
-                    if (n1) atomicOr(&live_acc[v1 >> 5], 1u << (v1 & 31));
-                    if (n2) atomicOr(&live_acc[v2 >> 5], 1u << (v2 & 31));
-                    if (n3) atomicOr(&live_acc[v3 >> 5], 1u << (v3 & 31));
+                    return m;
+                };
+                Words<WT> s0, s1, s2, s3;
+#pragma unroll
+                for (int i = 0; i < WT; ++i) s0.w[i] = s1.w[i] = s2.w[i] = s3.w[i] = 0;
+                if (v0 >= 0) s0 = row_mask(v0, lv0);
+                if (v3 >= 0) s3 = v3 == v0 ? s0 : row_mask(v3, lv3);
+                // an interior row (neither the lane's first nor last row)
+                if (v1 >= 0) s1 = v1 == v0 ? s0 : (v1 == v3 ? s3 : row_mask(v1, lv1));
+                if (v2 >= 0) s2 = v2 == v1 ? s1 : (v2 == v3 ? s3 : row_mask(v2, lv2));
+#pragma unroll
+                for (int i = 0; i < WT; ++i) {
+                    c0.w[i] &= ~s0.w[i];
+                    c1.w[i] &= ~s1.w[i];
+                    c2.w[i] &= ~s2.w[i];
+                    c3.w[i] &= ~s3.w[i];
                 }
+            }
+            // the next tile's gathers go out behind this tile's mask loads (memory instructions retire in order: requested in front of
+            // them they would be waited for first), and fly while this tile is scanned and stored
+            Words<WT> d0, d1, d2, d3;
+            if (LOOP && tile + 1 < tile_end) gather4(woff + WT, d0, d1, d2, d3);
+            const u64 any = any_bits<WT>(c0) | any_bits<WT>(c1) | any_bits<WT>(c2) | any_bits<WT>(c3);
+            STAMP(2);
+            if (__any(any != 0)) {                                         // else: nothing new through these 256 edges
+                // inclusive OR along the lane's own slots, restarting where the row changes
+#pragma unroll
+                for (int i = 0; i < WT; ++i) {
+                    if (v1 == v0) c1.w[i] |= c0.w[i];
+                    if (v2 == v1) c2.w[i] |= c1.w[i];
+                    if (v3 == v2) c3.w[i] |= c2.w[i];
+                }
+                Words<WT> t = c3;
+                bool head = head0;
+                // Round 4: the scan network runs on DPP moves -- four shifts inside the rows of 16 lanes, then lane 15 of rows 0 / 2 to
+                // rows 1 / 3 and lane 31 to rows 2 / 3 -- where rounds 1-3 shuffled through the LDS crossbar (9 ds_bpermute per step and
+                // wave, sixteen waves of a CU queueing for it: 1.9 us of a wave's 13.8, tools/stamp_expand.py).  The operator on
+                // (value, head) pairs is the same, so is the result.  A step nobody would take anything in is skipped: rows average ten
+                // slots, so chunks without a hub row need two or three of the six.
+                auto scan_step = [&](auto ctrl, bool valid) {
+                    constexpr int CTRL = decltype(ctrl)::value;
+                    if (!__any(valid && !head)) return;
+                    const bool ph = dpp_mov<CTRL>((int)head) != 0;
+                    const bool take = valid && !head;
+#pragma unroll
+                    for (int i = 0; i < WT; ++i) {
+                        const u64 pt = dpp_mov64<CTRL>(t.w[i]);
+                        if (take) t.w[i] |= pt;
+                    }
+                    if (take) head = ph;
+                };
+                const int in_row = lane & 15;
+                scan_step(std::integral_constant<int, DPP_ROW_SHR1>{}, in_row >= 1);
+                scan_step(std::integral_constant<int, DPP_ROW_SHR2>{}, in_row >= 2);
+                scan_step(std::integral_constant<int, DPP_ROW_SHR4>{}, in_row >= 4);
+                scan_step(std::integral_constant<int, DPP_ROW_SHR8>{}, in_row >= 8);
+                scan_step(std::integral_constant<int, DPP_ROW_BCAST15>{}, ((lane >> 4) & 1) != 0);
+                scan_step(std::integral_constant<int, DPP_ROW_BCAST31>{}, lane >= 32);
+                // carry into this lane's first run = accumulated value of the previous lane's last run
+#pragma unroll
+                for (int i = 0; i < WT; ++i) {
+                    u64 ci = dpp_mov64<DPP_WAVE_SHR1>(t.w[i]);
+                    if (!connects) ci = 0;
+                    c0.w[i] |= ci;
+                    if (v1 == v0) c1.w[i] |= ci;
+                    if (v2 == v0) c2.w[i] |= ci;
+                    if (v3 == v0) c3.w[i] |= ci;
+                }
+            }
+            STAMP(3);
+            // Emit every run that ends in this lane.
+            const size_t i0 = (size_t)v0 * Wp + woff, i1 = (size_t)v1 * Wp + woff, i2 = (size_t)v2 * Wp + woff,
+                         i3 = (size_t)v3 * Wp + woff;
+            const bool n0 = e0 && any_bits<WT>(c0) != 0, n1 = e1 && any_bits<WT>(c1) != 0, n2 = e2 && any_bits<WT>(c2) != 0,
+                       n3 = e3 && any_bits<WT>(c3) != 0;
+            // rows that lie inside the chunk: plain stores
+            if (e0 && !x0 && (n0 || dense)) store_words<WT>(acc + i0, c0);
+            if (e1 && !x1 && (n1 || dense)) store_words<WT>(acc + i1, c1);
+            if (e2 && !x2 && (n2 || dense)) store_words<WT>(acc + i2, c2);
+            if (e3 && !x3 && (n3 || dense)) store_words<WT>(acc + i3, c3);
+            // pieces of the (at most two) rows that span chunks: OR them in (their words were cleared two launches ago), commit later.
+            // Wave-uniform guard, and no branch per word (round 4: ~28 divergent branch regions in this phase before).
+            if (head_multi || tail_multi) {
+                auto piece = [&](size_t idx, const Words<WT> &c) {
+#pragma unroll
+                    for (int i = 0; i < WT; ++i) atomicOr(&acc[idx + i], c.w[i]);
+                };
+                if (n0 && x0) piece(i0, c0);
+                if (n1 && x1) piece(i1, c1);
+                if (n2 && x2) piece(i2, c2);
+                if (n3 && x3) piece(i3, c3);
+            }
+            STAMP(4);
+            m0 |= n0; m1 |= n1; m2 |= n2; m3 |= n3;
+            if (LOOP && tile + 1 < tile_end) { c0 = d0; c1 = d1; c2 = d2; c3 = d3; }
+        }
+        found |= m0 || m1 || m2 || m3;
+        // Mark the rows that received something.  The chunk's rows are a short ascending run of node ids: build each
+        // 32-bit table word with a wave-wide OR and let one lane publish it (per-row atomics -- ~30 to every word
+        // from a few waves -- cost 14 us per dense level).
+        if (__any(m0 || m1 || m2 || m3)) {
+            const int wfirst = vc >> 5;
+            // the row of the chunk's last slot: lane 63's last slot, except in the one short chunk at the end of the edge list
+            const int last_row = vl >= 0 ? vl : erow[min((chunk + 1) * CHUNK, E) - 1];
+            const int kmax = (last_row >> 5) - wfirst;
+            if (kmax < 8) {
+                // Round 4: every row of the chunk has exactly one emitting slot (the end of its run), so the set bits are distinct:
+                // the emitting lanes OR them into eight LDS words of the wave (one ds_or each, no return), and lanes 0 .. kmax publish
+                // the words.  (Rounds 2-3 built each word with a six-step wave-wide OR per word and read the last row from memory:
+                // 1.36 us of a wave's 13.8, tools/stamp_expand.py.)  A wave's LDS instructions execute in order: no barrier.
+                if (lane < 8) wave_words[lane] = 0u;
+                if (m0) atomicOr(&wave_words[(v0 >> 5) - wfirst], 1u << (v0 & 31));
+                if (m1) atomicOr(&wave_words[(v1 >> 5) - wfirst], 1u << (v1 & 31));
+                if (m2) atomicOr(&wave_words[(v2 >> 5) - wfirst], 1u << (v2 & 31));
+                if (m3) atomicOr(&wave_words[(v3 >> 5) - wfirst], 1u << (v3 & 31));
+                __builtin_amdgcn_wave_barrier();
+                if (lane <= kmax) {
+                    const unsigned m = wave_words[lane];
+                    if (m) atomicOr(&live_acc[wfirst + lane], m);
+                }
+            } else {                                       // a run with wide gaps (isolated nodes in between)
+                if (m0) atomicOr(&live_acc[v0 >> 5], 1u << (v0 & 31));
+                if (m1) atomicOr(&live_acc[v1 >> 5], 1u << (v1 & 31));
+                if (m2) atomicOr(&live_acc[v2 >> 5], 1u << (v2 & 31));
+                if (m3) atomicOr(&live_acc[v3 >> 5], 1u << (v3 & 31));
             }
         }
         STAMP(5);
@@ -763,22 +740,20 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
     return found;
 }
 
-template <int WT, int LIVE>      // LIVE: 0 no table, 1 table staged in LDS, 2 table read from global memory (big graphs)
+// LIVE: 1 live table staged in LDS; 2 live table read from global memory (graphs beyond LIVE_MAX_NODES); 3 the same behind a summary
+// in LDS (one bit per table word, built by k_live_summary between the launches).  TILES: 0 one WT-word tile per node; several tiles
+// walked inside the wave (1) or dealt to adjacent waves (2), see level_expand.
+template <int WT, int LIVE, int TILES>
 __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
-                                                   int E, int N, int Wp, const u64 *__restrict__ front,
+                                                   int E, int N, int Wp, int tiles, const u64 *__restrict__ front,
                                                    u64 *__restrict__ seen, u64 *__restrict__ acc,
                                                    u64 *__restrict__ idle, u64 *__restrict__ hop_planes,
                                                    size_t plane_elems, int level, BfsCtl *ctl, const int *aux,
                                                    int expand_blocks, const unsigned *__restrict__ live,
                                                    unsigned *__restrict__ live_acc, unsigned *__restrict__ live_idle,
-                                                   int live_words, int variant, const LevelCopy cp) {
-    if ((int)blockIdx.x >= cp.first_block) {                          // copy role: runs whether or not the BFS is over
-        if (blockIdx.y == 0) level_copy_role(cp);
-        return;
-    }
+                                                   int live_words, const unsigned *__restrict__ live_sum, int sum_words) {
     if (bfs_over(ctl, aux, level)) return;
     const int lane = threadIdx.x & 63;
-    int woff = blockIdx.y * WT;                                    // housekeeping: tile = blockIdx.y
     if ((int)blockIdx.x >= expand_blocks) {
         // Housekeeping blocks (beside the expand waves, not on their critical path):
         //  (1) clear, two levels ahead: the live table and the accumulator words of the rows that span chunks;
@@ -786,50 +761,39 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
         //      -> reachability plane and hop-bit planes.  The expand waves never commit: they mask with seen[v] | front[v],
         //      which is the same whether this commit has landed or not (OR is idempotent), and their chain ends at the store
         //      of the next frontier instead of a plane read-modify-write behind it.
-        const int hb = cp.first_block - expand_blocks;
-        level_housekeeping<WT, LIVE>(E, N, Wp, front, seen, idle, hop_planes, plane_elems, level, aux, live, live_idle, live_words,
-                                     ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x, hb * blockDim.x, woff, blockIdx.y == 0);
+        const int hb = (int)gridDim.x - expand_blocks;
+        level_housekeeping<WT, LIVE, TILES>(E, N, Wp, tiles, front, seen, idle, hop_planes, plane_elems, level, aux, live, live_idle, live_words,
+                                     ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x, hb * blockDim.x);
         return;
     }
-    // Expand waves: with more than one word tile per node (K > 256) the tiles of ONE chunk go to adjacent waves of the
-    // same block, so the 128-byte frontier line that all of them gather from is fetched from L2 once and served to the
-    // others by the CU's L1 (one tile per launch row of blocks fetched it once per tile, from different CUs).
-    const int tiles = gridDim.y;
-    // POPE_KNOB_LEVEL_VARIANT bit 1: blocks are dealt round-robin over the 8 XCDs (block b and b + 8 share one); give every
-    // XCD a CONTIGUOUS range of chunks, so that the seen / accumulator rows it touches are one eighth of those arrays.
-    int bx = blockIdx.x;
-    if (variant & 2) {
-        const int q = expand_blocks >> 3, r = expand_blocks & 7, x = bx & 7;
-        bx = x * q + min(x, r) + (bx >> 3);
+    // which stream of chunks this wave walks, and which tiles of a node's words
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (expand_blocks * blockDim.x) >> 6, tile_begin = 0, tile_end = tiles;
+    if constexpr (TILES == 2) {                                    // the tiles of one chunk go to adjacent waves of the same block
+        const int wid = wave;
+        wave = wid / tiles;
+        tile_begin = wid - wave * tiles;
+        tile_end = tile_begin + 1;
+        nwaves /= tiles;
     }
-    const int wid = ((blockIdx.y * expand_blocks + bx) * blockDim.x + threadIdx.x) >> 6;
-    const int wave = wid / tiles;                                  // which stream of chunks this wave walks
-    woff = (wid - wave * tiles) * WT;
-    const int nwaves = (expand_blocks * blockDim.x) >> 6;
     const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
     // The first chunk's slot loads are issued before the live table is staged: they fly while LDS fills.
     int4 vr = make_int4(-1, -1, -1, -1), ur = make_int4(0, 0, 0, 0);
-    // bit 0: the index streams are read once per launch: non-temporal, so that they do not evict the frontier from L2
-    auto load_idx = [&](const int *p) {
-        if (variant & 1) {
-            const i32x4v t = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(p));
-            return make_int4(t.x, t.y, t.z, t.w);
-        }
-        return *reinterpret_cast<const int4 *>(p);
-    };
     if (wave < nchunks && wave * CHUNK + lane * SLOTS < E) {
-        vr = load_idx(erow + wave * CHUNK + lane * SLOTS);
-        ur = load_idx(col + wave * CHUNK + lane * SLOTS);
+        vr = *reinterpret_cast<const int4 *>(erow + wave * CHUNK + lane * SLOTS);
+        ur = *reinterpret_cast<const int4 *>(col + wave * CHUNK + lane * SLOTS);
     }
     extern __shared__ uint4 live_lds4[];
     const unsigned *live_lds = reinterpret_cast<const unsigned *>(live_lds4);
     if constexpr (LIVE == 1) {
         stage_live_table(live, live_words, live_lds4);
         __syncthreads();
+    } else if constexpr (LIVE == 3) {
+        stage_live_table(live_sum, sum_words, live_lds4);
+        __syncthreads();
     }
     __shared__ unsigned wave_live_words[4][8];                     // per wave: the live-table words its chunk's rows fall into
-    const bool found = level_expand<WT, LIVE>(erow, col, E, Wp, front, seen, acc, live, live_acc, live_lds, variant, level, lane, wave, nwaves,
-                                              nchunks, woff, tiles, vr, ur, wave_live_words[threadIdx.x >> 6]);
+    const bool found = level_expand<WT, LIVE, TILES>(erow, col, E, Wp, tile_begin, tile_end, front, seen, acc, live, live_acc, live_lds, level, lane, wave, nwaves,
+                                              nchunks, vr, ur, wave_live_words[threadIdx.x >> 6]);
     if (__any(found) && lane == 0) raise_level(ctl, level);
 }
 
@@ -863,7 +827,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u64 *__restrict__ planes
                                                   int n_hop_bits, const int *__restrict__ max_hop_dev, int N, int K,
                                                   int Wp, const float *__restrict__ x, int F,
                                                   float *__restrict__ out, long long out_cols, int c0,
-                                                  const int *__restrict__ aux, int *report, int ticket, int x_row_begin) {
+                                                  const int *__restrict__ aux, int *report, int ticket) {
     if (max_hop_dev) {                        // enqueued before the host knew the depth: read it from the BFS control block
         const int m = *max_hop_dev;
         n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
@@ -874,7 +838,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u64 *__restrict__ planes
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int v = wave; v < N; v += nwaves) {
         float *orow = out + (size_t)v * out_cols;
-        if (x && v >= x_row_begin) {                               // rows below: copied by the level launches (LevelCopy)
+        if (x) {
             const float *xrow = x + (size_t)v * F;
             if (VEC) {
                 const float4 *xs = reinterpret_cast<const float4 *>(xrow);
@@ -920,16 +884,15 @@ __global__ __launch_bounds__(256) void k_finalize(const u64 *__restrict__ planes
 //  * 1/(h+1) comes from a 16-entry table built once per block with the same IEEE division (bit-identical);
 //  * the four hop counts of a lane are pulled out of the packed plane nibbles with one multiply each;
 //  * x is read with non-temporal loads (read once); stores are plain -- non-temporal stores measured 23 % slower.
-// MODE: 0 plain stores (default), 1 non-temporal stores (kept for A/B, tools/ab_finalize.py).
+// Since round 4 the fallback of k_finalize_pipe / k_finalize_wide for shapes they have no instance for (F > 1024).
 // n_shards > 1 (multi-GPU): `planes` holds the all-gathered shards back to back (shard_elems words apart, K anchors
 // each); a row's columns of ALL shards are written in one pass, so the [N, F + shards*K] matrix is streamed once.
-template <int MODE>
 __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ planes, size_t plane_elems,
                                                        int n_hop_bits, const int *__restrict__ max_hop_dev, int N, int K,
                                                        int Wp, const float *__restrict__ x, int F,
                                                        float *__restrict__ out, long long out_cols, int c0,
                                                        int n_shards, size_t shard_elems, const int *__restrict__ aux,
-                                                       int *report, int ticket, int x_row_begin) {
+                                                       int *report, int ticket) {
     if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
     __shared__ float inv[16];
     if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
@@ -946,12 +909,11 @@ __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ p
     const int F4 = F >> 2, K4 = K >> 2;
     for (int v = v_begin; v < v_end; ++v) {
         f32x4 *orow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols);
-        if (x && v >= x_row_begin) {                           // rows below were copied by the level launches (LevelCopy)
+        if (x) {
             const f32x4 *xs = reinterpret_cast<const f32x4 *>(x + (size_t)v * F);
             for (int q = lane; q < F4; q += 64) {
                 const f32x4 t = __builtin_nontemporal_load(xs + q);
-                if (MODE == 1) __builtin_nontemporal_store(t, orow + q);
-                else orow[q] = t;
+                orow[q] = t;
             }
         }
         f32x4 *erow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols + F + c0);
@@ -975,8 +937,7 @@ __global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ p
             r.y = (reach & 2u) ? inv[h1] : 0.0f;
             r.z = (reach & 4u) ? inv[h2] : 0.0f;
             r.w = (reach & 8u) ? inv[h3] : 0.0f;
-            if (MODE == 1) __builtin_nontemporal_store(r, erow + q);
-            else erow[q] = r;
+            erow[q] = r;
         }
     }
 }
@@ -1033,7 +994,7 @@ __global__ __launch_bounds__(256) void k_finalize_pipe(const u64 *__restrict__ p
                                                        const int *__restrict__ max_hop_dev, int N, int K, int Wp,
                                                        const float *__restrict__ x, int F, float *__restrict__ out, long long out_cols,
                                                        int c0, int n_shards, size_t shard_elems, const int *__restrict__ aux, int *report,
-                                                       int ticket, int x_row_begin, int contiguous) {
+                                                       int ticket) {
     if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
     __shared__ float inv[16];
     if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
@@ -1047,25 +1008,23 @@ __global__ __launch_bounds__(256) void k_finalize_pipe(const u64 *__restrict__ p
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     // A work item is (row, segment): a row wider than 256 EP embedding columns (many shards) is cut into segments of 64 EP pieces,
     // each a work item of its own; segment 0 also copies the row's features.  Items are dealt to the waves round-robin
-    // (contiguous != 0 -- A/B, POPE_KNOB_FINALIZE_VARIANT 5 -- a block of consecutive items per wave, as k_finalize_fast deals rows).
     const int F4 = F >> 2, K4 = K >> 2, n_emb = K4 * n_shards;
     const int n_seg = (n_emb + 64 * EP - 1) / (64 * EP);
     const int items = N * n_seg;                                         // < 2^31: checked on the host
-    const int per = (items + nwaves - 1) / nwaves;
-    const int i_begin = contiguous ? wave * per : wave, i_end = contiguous ? min(items, i_begin + per) : items, i_step = contiguous ? 1 : nwaves;
+    const int i_begin = wave, i_end = items, i_step = nwaves;
     if (i_begin >= i_end) return;
     auto row_of = [&](int i, int &seg) { const int v = (int)((unsigned)i / (unsigned)n_seg); seg = i - v * n_seg; return v; };
     int seg = 0, v = row_of(i_begin, seg);
-    FinRow<XP, EP> cur = fin_load<XP, EP>(planes, plane_elems, n_hop_bits, Wp, x, F4, v, lane, x && seg == 0 && v >= x_row_begin, K4, n_emb, shard_elems, seg * 64 * EP);
+    FinRow<XP, EP> cur = fin_load<XP, EP>(planes, plane_elems, n_hop_bits, Wp, x, F4, v, lane, x && seg == 0, K4, n_emb, shard_elems, seg * 64 * EP);
     for (int i = i_begin; i < i_end; i += i_step) {
         FinRow<XP, EP> nxt = cur;
         int seg_n = 0, v_n = 0;
         if (i + i_step < i_end) {
             v_n = row_of(i + i_step, seg_n);
-            nxt = fin_load<XP, EP>(planes, plane_elems, n_hop_bits, Wp, x, F4, v_n, lane, x && seg_n == 0 && v_n >= x_row_begin, K4, n_emb, shard_elems, seg_n * 64 * EP);
+            nxt = fin_load<XP, EP>(planes, plane_elems, n_hop_bits, Wp, x, F4, v_n, lane, x && seg_n == 0, K4, n_emb, shard_elems, seg_n * 64 * EP);
         }
         f32x4 *orow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols);
-        if (XP > 0 && x && seg == 0 && v >= x_row_begin) {
+        if (XP > 0 && x && seg == 0) {
 #pragma unroll
             for (int p = 0; p < XP; ++p)
                 if (lane + 64 * p < F4) orow[lane + 64 * p] = cur.x[p];
@@ -1111,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_finalize_wide(const u64 *__restrict__ p
                                                        const int *__restrict__ max_hop_dev, int N, int K, int Wp,
                                                        const float *__restrict__ x, int F, float *__restrict__ out, long long out_cols,
                                                        int c0, int n_shards, size_t shard_elems, const int *__restrict__ aux, int *report,
-                                                       int ticket, int x_row_begin) {
+                                                       int ticket) {
     if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
     __shared__ float inv[16];
     if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
@@ -1137,7 +1096,7 @@ __global__ __launch_bounds__(256) void k_finalize_wide(const u64 *__restrict__ p
         for (int p = 0; p < (XP > 0 ? XP : 1); ++p) r.x[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int b = 0; b < 5; ++b) r.w[b] = 0;
-        if (XP > 0 && x && seg == 0 && v >= x_row_begin) {
+        if (XP > 0 && x && seg == 0) {
             const f32x4 *xs = reinterpret_cast<const f32x4 *>(x) + (size_t)v * F4;
 #pragma unroll
             for (int p = 0; p < XP; ++p)
@@ -1161,7 +1120,7 @@ __global__ __launch_bounds__(256) void k_finalize_wide(const u64 *__restrict__ p
         Item nxt = cur;
         int v_n = 0, seg_n = 0;
         if (i + nwaves < items) nxt = load(i + nwaves, v_n, seg_n);
-        if (XP > 0 && x && seg == 0 && v >= x_row_begin) {
+        if (XP > 0 && x && seg == 0) {
             f32x4 *orow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols);
 #pragma unroll
             for (int p = 0; p < XP; ++p)
@@ -1193,205 +1152,6 @@ __global__ __launch_bounds__(256) void k_finalize_wide(const u64 *__restrict__ p
         cur = nxt;
         v = v_n;
         seg = seg_n;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The sparse LAST levels of the BFS and the finalise kernel in ONE launch (round 4)
-// ------------------------------------------------------------------------------------------------
-// On the Flickr-shaped graph the last four level launches touch 3 174, 64, 1 and 0 nodes and still cost a kernel boundary
-// (~3.3 us) plus a pass over the index streams each (27 us of the step), with the whole chip waiting; the finalise kernel
-// behind them is a 100 us stream whose feature copy depends on nothing the BFS computes.  k_tail_finalize runs both at once:
-//   * blocks 0 .. bfs_blocks-1 (dispatched first, so they are resident from the start) run levels first_level, first_level+1,
-//     ... with the SAME per-level code as k_bfs_level (level_housekeeping + level_expand over their share of the chunks) and a
-//     barrier among themselves between levels -- two stages of agent-scope counters in the control block, the arrival a
-//     release, the departure an acquire -- until a level finds nothing (the launch after the last productive level commits
-//     that level, as in k_bfs_level) or level_stop is reached (hop planes are only cleared for levels < 16: a deeper graph
-//     answers "not done" and the host continues with level launches);
-//   * block 0 then publishes the verdict (pinned report + ticket for the host, ctl->tail_done for the device);
-//   * every other block copies its share of x's rows meanwhile (16 pieces of 16 bytes in flight per lane), waits for
-//     tail_done, and expands its share of the planes into the K embedding columns (k_finalize_fast's arithmetic).
-// Every wait is bounded by the 100 MHz real-time counter (TAIL_WAIT_TICKS): a wait that runs out sets ctl->tail_failed and
-// the role moves on, so the grid always drains; the host reports the flag as an error.
-constexpr unsigned long long TAIL_WAIT_TICKS = 200000000ull;        // 2 s
-
-struct TailArgs {
-    const int *erow, *col;
-    int E, N, Wp;
-    u64 *front[3];
-    unsigned *live[3];
-    int live_words;
-    u64 *seen, *hop_planes;
-    size_t plane_elems;
-    BfsCtl *ctl;
-    const int *aux;
-    int first_level, level_stop, bfs_blocks, variant;
-    int K, F;
-    const float *x;
-    float *out;
-    long long out_cols;
-    int x_row_begin;
-    int *report;
-    int ticket;
-};
-
-__device__ __forceinline__ bool tail_barrier(BfsCtl *ctl, int B, unsigned episode) {
-    __shared__ int ok_s;
-    __syncthreads();                                   // every store of this block has been issued and waited for
-    if (threadIdx.x == 0) {
-        const int G = B < TAIL_GROUPS ? B : TAIL_GROUPS, g = (int)blockIdx.x % G;
-        const unsigned members = (unsigned)((B - g + G - 1) / G);
-        // ONE release fence before the arrival and ONE acquire fence after the departure; the counters themselves are relaxed
-        // agent-scope atomics (they bypass the non-coherent caches without maintaining them): an acquire on every poll is a
-        // cache invalidation per iteration and made a level inside this kernel cost ~100 us.
-        __threadfence();
-        const unsigned old = __hip_atomic_fetch_add(&ctl->tail_group[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == members * episode) __hip_atomic_fetch_add(&ctl->tail_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        int ok = 1;
-        while (__hip_atomic_load(&ctl->tail_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G * episode) {
-            __builtin_amdgcn_s_sleep(4);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > TAIL_WAIT_TICKS) { ok = 0; break; }
-        }
-        __threadfence();
-        ok_s = ok;
-    }
-    __syncthreads();
-    return ok_s != 0;
-}
-
-template <int WT, int LIVE>
-__global__ __launch_bounds__(256) void k_tail_finalize(const TailArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int B = a.bfs_blocks;
-    extern __shared__ uint4 live_lds4[];
-    __shared__ unsigned wave_live_words[4][8];
-    if ((int)blockIdx.x < B) {
-        // ---- BFS role ----
-        BfsCtl *ctl = a.ctl;
-        int failed = 0;
-        if (!bfs_over(ctl, a.aux, a.first_level)) {
-            const int wave = ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x) >> 6, nwaves = (B * (int)blockDim.x) >> 6;
-            const int nchunks = (a.E + CHUNK - 1) >> CHUNK_SHIFT;
-            unsigned episode = 0;
-            for (int level = a.first_level;; ++level) {
-                const u64 *front = a.front[(level - 1) % 3];
-                u64 *acc = a.front[level % 3], *idle = a.front[(level + 1) % 3];
-                const unsigned *live = a.live[(level - 1) % 3];
-                unsigned *live_acc = a.live[level % 3], *live_idle = a.live[(level + 1) % 3];
-                int4 vr = make_int4(-1, -1, -1, -1), ur = make_int4(0, 0, 0, 0);
-                if (wave < nchunks && wave * CHUNK + lane * SLOTS < a.E) {
-                    vr = *reinterpret_cast<const int4 *>(a.erow + wave * CHUNK + lane * SLOTS);
-                    ur = *reinterpret_cast<const int4 *>(a.col + wave * CHUNK + lane * SLOTS);
-                }
-                if constexpr (LIVE == 1) {
-                    stage_live_table(live, a.live_words, live_lds4);
-                    __syncthreads();
-                }
-                level_housekeeping<WT, LIVE>(a.E, a.N, a.Wp, front, a.seen, idle, a.hop_planes, a.plane_elems, level, a.aux, live, live_idle,
-                                             a.live_words, (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x, B * (int)blockDim.x, 0, true);
-                const bool found = level_expand<WT, LIVE>(a.erow, a.col, a.E, a.Wp, front, a.seen, acc, live, live_acc,
-                                                          reinterpret_cast<const unsigned *>(live_lds4), a.variant, level, lane, wave, nwaves, nchunks,
-                                                          0, 1, vr, ur, wave_live_words[threadIdx.x >> 6]);
-                if (__any(found) && lane == 0) raise_level(ctl, level);
-                if (!tail_barrier(ctl, B, ++episode)) { failed = 1; break; }
-                // every block reads the same word here: all raises of this level came before the barrier
-                const int la = __hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (la < level || level + 1 >= a.level_stop) break;
-            }
-        }
-        if (failed && threadIdx.x == 0) __hip_atomic_store(&ctl->tail_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            // The other BFS blocks are past their last barrier too (or this block ran out of patience): publish.
-            const int la = __hip_atomic_load(&ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int bad = failed | __hip_atomic_load(&ctl->tail_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.report) {
-                a.report[0] = la;
-                a.report[1] = csr_flags(ctl, a.aux) | (bad ? BFS_FLAG_TAIL_FAILED : 0);
-                __hip_atomic_store(&a.report[2], a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            __hip_atomic_store(&ctl->tail_done, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-    // ---- copy + expansion role ----
-    const int nb = (int)gridDim.x - B, cb = (int)blockIdx.x - B;
-    const int w = threadIdx.x >> 6;
-    const unsigned F4 = (unsigned)a.F >> 2, opitch4 = (unsigned)(a.out_cols >> 2);
-    if (a.x && F4) {
-        const unsigned piece_begin = (unsigned)a.x_row_begin * F4, piece_end = (unsigned)a.N * F4;
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.x);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(a.out);
-        for (unsigned batch = (unsigned)cb;; batch += (unsigned)nb) {
-            const unsigned long long base64 = (unsigned long long)piece_begin + ((unsigned long long)batch * 4u + w) * (64u * LEVEL_COPY_PIECES) + lane;
-            if ((unsigned long long)piece_begin + (unsigned long long)batch * LEVEL_COPY_BLOCK_PIECES >= piece_end) break;
-            if (base64 >= piece_end) continue;
-            const unsigned base = (unsigned)base64;
-            f32x4 v[LEVEL_COPY_PIECES];
-#pragma unroll
-            for (int j = 0; j < LEVEL_COPY_PIECES; ++j) {
-                const unsigned long long p = (unsigned long long)base + 64u * j;
-                if (p < piece_end) v[j] = __builtin_nontemporal_load(src + p);
-            }
-            unsigned row = base / F4, q = base - row * F4;
-#pragma unroll
-            for (int j = 0; j < LEVEL_COPY_PIECES; ++j) {
-                const unsigned long long p = (unsigned long long)base + 64u * j;
-                if (p < piece_end) {
-                    if (a.variant & 8) __builtin_nontemporal_store(v[j], dst + (size_t)row * opitch4 + q);
-                    else dst[(size_t)row * opitch4 + q] = v[j];
-                }
-                q += 64u;
-                while (q >= F4) { q -= F4; ++row; }
-            }
-        }
-    }
-    // wait for the verdict of the BFS blocks
-    __shared__ int go_s;
-    __shared__ float inv[16];
-    if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
-    if (threadIdx.x == 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        int go = 1;
-        while (__hip_atomic_load(&a.ctl->tail_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.ticket) {
-            __builtin_amdgcn_s_sleep(32);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > TAIL_WAIT_TICKS) { go = 0; break; }
-        }
-        __threadfence();
-        if (!go) __hip_atomic_store(&a.ctl->tail_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        go_s = go;
-    }
-    __syncthreads();
-    if (!go_s) return;
-    const int m = __hip_atomic_load(&a.ctl->last_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
-    const int wave = cb * 4 + w, nwaves = nb * 4;
-    const int per = (a.N + nwaves - 1) / nwaves;
-    const int v_begin = wave * per, v_end = min(a.N, v_begin + per);
-    const int K4 = a.K >> 2;
-    const u64 *planes = a.seen;                                  // plane 0 = reachability, planes 1.. = hop bits (contiguous)
-    for (int v = v_begin; v < v_end; ++v) {
-        f32x4 *erow = reinterpret_cast<f32x4 *>(a.out + (size_t)v * a.out_cols + a.F);
-        const size_t wbase = (size_t)v * a.Wp;
-        for (int q = lane; q < K4; q += 64) {
-            const int j = q * 4;
-            const size_t widx = wbase + (j >> 6);
-            const int bit = j & 63;
-            const unsigned reach = (unsigned)(planes[widx] >> bit) & 15u;
-            unsigned t = 0;
-            for (int b = 0; b < n_hop_bits; ++b)
-                t |= ((unsigned)(planes[(size_t)(b + 1) * a.plane_elems + widx] >> bit) & 15u) << (4 * b);
-            const unsigned h0 = (((t) & 0x1111u) * 0x1248u >> 12) & 15u;
-            const unsigned h1 = (((t >> 1) & 0x1111u) * 0x1248u >> 12) & 15u;
-            const unsigned h2 = (((t >> 2) & 0x1111u) * 0x1248u >> 12) & 15u;
-            const unsigned h3 = (((t >> 3) & 0x1111u) * 0x1248u >> 12) & 15u;
-            f32x4 r;
-            r.x = (reach & 1u) ? inv[h0] : 0.0f;
-            r.y = (reach & 2u) ? inv[h1] : 0.0f;
-            r.z = (reach & 4u) ? inv[h2] : 0.0f;
-            r.w = (reach & 8u) ? inv[h3] : 0.0f;
-            erow[q] = r;
-        }
     }
 }
 
@@ -1665,15 +1425,18 @@ extern "C" size_t pope_plane_bytes(int64_t N, int32_t K) {
 }
 
 static size_t live_bytes(int64_t N) { return align_up((size_t)((N + 31) / 32) * sizeof(unsigned), 256); }
+// the live tables' summary (LIVE = 3): one bit per table word, written two words per 64 table words (k_live_summary), padded like the tables
+static size_t live_sum_bytes(int64_t N) { return align_up(live_bytes(N) / 32, 256); }
 
 extern "C" size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K) {
     if (N < 0 || E < 0 || K <= 0) return 0;
     (void)E;
-    // control block | anchors[K] | three rotating frontier planes | their three live-bit tables
-    return CTL_BYTES + align_up((size_t)K * sizeof(long long), 256) + 3 * align_up(pope_plane_bytes(N, K), 256) + 3 * live_bytes(N);
+    // control block | anchors[K] | three rotating frontier planes | their three live-bit tables | one summary of a live table
+    return CTL_BYTES + align_up((size_t)K * sizeof(long long), 256) + 3 * align_up(pope_plane_bytes(N, K), 256) + 3 * live_bytes(N) + live_sum_bytes(N);
 }
 
 constexpr int LIVE_MAX_NODES = 256 * 1024;   // live table of 32 KB per block in LDS (4 blocks per CU); beyond: read from global
+constexpr size_t LIVE_SUM_MAX_BYTES = 48 * 1024;   // ... behind a summary of at most this size in LDS (12.5 M nodes); beyond: the global table alone
 constexpr int EAGER_PLANES = 4;      // hop-bit planes cleared up front (levels < 16); deeper ones when first needed
 
 // Optional per-launch timing of the level kernels with HIP events on the launch stream (bench.py's roofline leg).
@@ -1695,20 +1458,12 @@ static void profile_mark(hipStream_t stream, int level, int which, bool span = f
 }
 
 // Diagnostic knobs behind pope_debug_set() (include/graphpope_hip.h): process-global, not thread-safe, A/B tooling only.
-static int g_live_mode = -1;            // -1: by graph size (LDS table up to LIVE_MAX_NODES, global table beyond)
-static int g_finalize_variant = 1;      // 0: generic kernel, 1: pipelined fast path (default), 2: round 1-3 fast path + non-temporal stores, 3 / 4: two launches, 5: pipelined with contiguous rows, 7: round 1-3 fast path
+static int g_live_mode = -1;            // -1: by graph size (LDS table up to LIVE_MAX_NODES, global table beyond); 2: the global table on a small graph too (tests)
+static int g_finalize_variant = 1;      // 1: pipelined / wide fast paths (default), 7: round 1-3 fast path, 0: generic kernel -- kept so the tests can compare their bits
 static int g_finalize_blocks = 256 * 8;
-static bool g_finalize_blocks_set = false;   // POPE_KNOB_FINALIZE_BLOCKS given: it also sizes the pipelined kernel (default 4 096 blocks)
-static int g_level_blocks = 0;           // cap on the expand blocks of a level launch (0: one wave per chunk up to 2048 blocks)
-static int g_tail_level = 0;             // POPE_KNOB_TAIL_LEVEL: first level that runs inside k_tail_finalize (0: no tail kernel)
-static int g_tail_blocks = 256;          // POPE_KNOB_TAIL_BLOCKS: BFS blocks of k_tail_finalize
+static bool g_finalize_blocks_set = false;   // POPE_KNOB_FINALIZE_BLOCKS given: it also sizes the pipelined kernels (default: one work item per wave)
 static int g_prepare_merge = 1;          // POPE_KNOB_PREPARE_MERGE: 1 (default) = pope_geodesic_run clears, seeds and builds the CSR in ONE launch (k_prepare); 0 = two launches
-static int g_level_variant = 0;          // POPE_KNOB_LEVEL_VARIANT bits: 1 nt index streams, 2 XCD-contiguous chunks, 4 nt reachability loads
-// POPE_KNOB_LEVEL_COPY: per mille of x's rows that level launch l of pope_geodesic_run copies in its copy role (LevelCopy).
-// Index 0 is unused.  Launches the speculative window does not reach leave their share to the finalise kernel.
-constexpr int LEVEL_COPY_SLOTS = 16;
-static int g_level_copy_permille[LEVEL_COPY_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0, g_host_result_mode = 0, g_gemm_split_bf16 = 0, g_gather_lds_pad_kb = 0, g_sage_forward_overlap = 1, g_gemm_small_tile16 = 1, g_gemm_tile16_buffers = 4; extern int g_sage_lanes; }
+namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0, g_sage_forward_overlap = 1, g_gemm_small_tile16 = 1, g_gemm_tile16_buffers = 4; }
 
 extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     clear_error();
@@ -1719,58 +1474,45 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_GEMM_TILE:        pope::g_gemm_force_tile = value; break;
     case POPE_KNOB_PAIRWISE_KERNEL:  pope::g_pairwise_kernel = value; break;
     case POPE_KNOB_COPY_BATCHES:     pope::g_copy_batches_per_wave = value; break;
-    case POPE_KNOB_LEVEL_BLOCKS:     g_level_blocks = value; break;
     case POPE_KNOB_FAIL_HOST_REGISTER: pope::g_fail_host_register = value; break;
-    case POPE_KNOB_HOST_RESULT_MODE: pope::g_host_result_mode = value; break;
-    case POPE_KNOB_GEMM_SPLIT_BF16:  pope::g_gemm_split_bf16 = value; break;
-    case POPE_KNOB_GATHER_LDS_PAD_KB: pope::g_gather_lds_pad_kb = value; break;
-    case POPE_KNOB_SAGE_FORWARD_OVERLAP: pope::g_sage_forward_overlap = value; break;
+    case POPE_KNOB_SAGE_FORWARD_OVERLAP: pope::g_sage_forward_overlap = value != 0; break;
     case POPE_KNOB_GEMM_TILE16_BUFFERS: pope::g_gemm_tile16_buffers = value == 4 ? 4 : 3; break;
     case POPE_KNOB_GEMM_SMALL_TILE16: pope::g_gemm_small_tile16 = value; break;
-    case POPE_KNOB_SAGE_LANES:       pope::g_sage_lanes = value; break;
-    case POPE_KNOB_LEVEL_VARIANT:    g_level_variant = value; break;
-    case POPE_KNOB_TAIL_LEVEL:       g_tail_level = value; break;
-    case POPE_KNOB_TAIL_BLOCKS:      g_tail_blocks = value > 0 ? value : 256; break;
     case POPE_KNOB_PREPARE_MERGE:    g_prepare_merge = value; break;
-    case POPE_KNOB_LEVEL_COPY: {                                     // value = level << 16 | per mille; level 0: every launch
-        const int lv = (value >> 16) & 0xff, pm = value & 0xffff;
-        if (lv >= LEVEL_COPY_SLOTS || pm > 1000) { set_error("pope_debug_set: level copy %d / %d", lv, pm); return POPE_ERR_INVALID; }
-        if (lv == 0) for (int i = 1; i < LEVEL_COPY_SLOTS; ++i) g_level_copy_permille[i] = pm;
-        else g_level_copy_permille[lv] = pm;
-        break;
-    }
     default: set_error("pope_debug_set: unknown knob %d", knob); return POPE_ERR_INVALID;
     }
     return POPE_OK;
 }
 
-template <int WT>
+template <int WT, int TILES>
 static void launch_level(int E, int N, int Wp, const int *col, const int *erow, const int *aux, const u64 *front, u64 *seen,
                          u64 *acc, u64 *idle, u64 *hop_planes, size_t plane_elems, int level, BfsCtl *ctl,
-                         const unsigned *live, unsigned *live_acc, unsigned *live_idle, int live_words, LevelCopy cp, hipStream_t stream) {
+                         const unsigned *live, unsigned *live_acc, unsigned *live_idle, int live_words, int mode, unsigned *live_sum, hipStream_t stream) {
     const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
+    const int tiles = Wp / WT;
     int expand_blocks = (nchunks + 3) / 4;                           // one wave per chunk ...
     if (expand_blocks > 256 * 8) expand_blocks = 256 * 8;            // ... up to 8 blocks per CU, then waves loop
-    if (g_level_blocks > 0 && expand_blocks > g_level_blocks) expand_blocks = g_level_blocks;   // A/B: POPE_KNOB_LEVEL_BLOCKS
+    if (TILES == 2) expand_blocks *= tiles;                          // ... and per tile (4 waves per block: the tiles of a chunk share a block for 1, 2 or 4 tiles)
     int house_blocks = (N + 255) / 256;                              // the commit of the previous level: one thread per node
     if (house_blocks > 1024) house_blocks = 1024;                    // (+ the clears: rows that span chunks, the live table)
-    cp.first_block = expand_blocks + house_blocks;                   // the copy role's blocks come last: dispatched behind the BFS roles
-    cp.blocks = (int)((cp.piece_end - cp.piece_begin + LEVEL_COPY_BLOCK_PIECES - 1) / LEVEL_COPY_BLOCK_PIECES);
-    const int gx = cp.first_block + cp.blocks;
+    const int gx = expand_blocks + house_blocks;                     // the housekeeping blocks come last
     profile_mark(stream, level, 0);
-    const int mode = g_live_mode >= 0 ? g_live_mode : (live_words <= LIVE_MAX_NODES / 32 ? 1 : 2);
-    if (mode == 1 && live_words <= LIVE_MAX_NODES / 32)
-        hipLaunchKernelGGL((k_bfs_level<WT, 1>), dim3(gx, Wp / WT), dim3(256),
-                           align_up((size_t)live_words * sizeof(unsigned), 16), stream, erow, col, E, N, Wp, front, seen, acc, idle, hop_planes,
-                           plane_elems, level, ctl, aux, expand_blocks, live, live_acc, live_idle, live_words, g_level_variant, cp);
-    else if (mode == 2)
-        hipLaunchKernelGGL((k_bfs_level<WT, 2>), dim3(gx, Wp / WT), dim3(256), 0, stream, erow,
-                           col, E, N, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
-                           live_acc, live_idle, live_words, g_level_variant, cp);
-    else
-        hipLaunchKernelGGL((k_bfs_level<WT, 0>), dim3(gx, Wp / WT), dim3(256), 0, stream, erow,
-                           col, E, N, Wp, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live,
-                           live_acc, live_idle, live_words, g_level_variant, cp);
+    const int padded_words = (int)(align_up((size_t)live_words * sizeof(unsigned), 256) / sizeof(unsigned));
+    const int sum_words = padded_words / 32;
+    if (mode == 1) {
+        hipLaunchKernelGGL((k_bfs_level<WT, 1, TILES>), dim3(gx), dim3(256), align_up((size_t)live_words * sizeof(unsigned), 16), stream, erow, col, E, N,
+                           Wp, tiles, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live, live_acc, live_idle, live_words,
+                           (const unsigned *)nullptr, 0);
+    } else if (mode == 3) {
+        // the summary of the table this launch reads (complete since the previous launch ended), then the level
+        hipLaunchKernelGGL(k_live_summary, dim3((padded_words + 255) / 256), dim3(256), 0, stream, live, padded_words, live_sum);
+        hipLaunchKernelGGL((k_bfs_level<WT, 3, TILES>), dim3(gx), dim3(256), align_up((size_t)sum_words * sizeof(unsigned), 16), stream, erow, col, E, N,
+                           Wp, tiles, front, seen, acc, idle, hop_planes, plane_elems, level, ctl, aux, expand_blocks, live, live_acc, live_idle, live_words,
+                           (const unsigned *)live_sum, sum_words);
+    } else {
+        hipLaunchKernelGGL((k_bfs_level<WT, 2, TILES>), dim3(gx), dim3(256), 0, stream, erow, col, E, N, Wp, tiles, front, seen, acc, idle, hop_planes,
+                           plane_elems, level, ctl, aux, expand_blocks, live, live_acc, live_idle, live_words, (const unsigned *)nullptr, 0);
+    }
     profile_mark(stream, level, 1);
 }
 
@@ -1869,6 +1611,8 @@ struct Bfs {
     u64 *seen, *hop_planes, *front[3];
     unsigned *live[3];           // one bit per node beside each frontier buffer: row not all zero
     int live_words;
+    unsigned *live_sum;          // LIVE = 3: summary of the table the next level launch reads (one bit per table word)
+    int live_mode;               // 1 / 2 / 3 (k_bfs_level's LIVE)
     char *base;
     BfsCtl *ctl;
     long long *anchors_dev;
@@ -1943,6 +1687,10 @@ static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const in
     b.live[1] = (unsigned *)((char *)b.live[0] + live_bytes(N));
     b.live[2] = (unsigned *)((char *)b.live[1] + live_bytes(N));
     b.live_words = (int)((N + 31) / 32);
+    b.live_sum = (unsigned *)((char *)b.live[2] + live_bytes(N));
+    b.live_mode = g_live_mode > 0 ? g_live_mode : (b.live_words <= LIVE_MAX_NODES / 32 ? 1 : 3);
+    if (b.live_mode == 1 && b.live_words > LIVE_MAX_NODES / 32) b.live_mode = 3;
+    if (b.live_mode == 3 && live_sum_bytes(N) > LIVE_SUM_MAX_BYTES) b.live_mode = 2;
     b.level_limit = 1ll << plane_capacity;
     return slot_acquire(&b.slot, (size_t)K);
 }
@@ -1951,10 +1699,11 @@ static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const in
 // (pope_geodesic_run) the CSR status header.
 static void bfs_enqueue_clear(const Bfs &b, int *aux_header, hipStream_t stream) {
     const int eager = b.capacity < EAGER_PLANES ? b.capacity : EAGER_PLANES;
+    const size_t words = (size_t)(1 + eager) * b.plane_elems;        // odd (N * W odd, an even number of eager planes): one word behind the last 16-byte unit
     hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, stream, (uint4 *)b.base,
                        (b.front_off + 3 * align_up(b.plane_bytes, 256) + 3 * live_bytes(b.N)) / 16, (uint4 *)b.seen,
-                       (size_t)(1 + eager) * b.plane_bytes / 16, (uint4 *)aux_header,
-                       aux_header ? (size_t)AUX_HEADER * sizeof(int) / 16 : (size_t)0);
+                       words / 2, (uint4 *)aux_header, aux_header ? (size_t)AUX_HEADER * sizeof(int) / 16 : (size_t)0,
+                       (words & 1) ? b.seen + words - 1 : (u64 *)nullptr);
 }
 
 // Anchors go through pinned, device-mapped host memory and the seed kernel reads them in place: no copy kernel.
@@ -1969,37 +1718,8 @@ static int bfs_enqueue_init(const Bfs &b, const int64_t *anchors_host, hipStream
     return bfs_enqueue_seed(b, anchors_host, stream);
 }
 
-// Which rows of x the level launches of one pope_geodesic_run copy (LevelCopy): launch l takes rows [cut[l - 1], cut[l]).
-struct CopyPlan {
-    const float *x = nullptr;
-    float *out = nullptr;
-    unsigned F4 = 0, opitch4 = 0;
-    int cut[LEVEL_COPY_SLOTS] = {};
-    int levels = 0;                     // launches 1 .. levels carry a slice
-    int rows() const { return cut[levels]; }
-};
-
-// out[:, :F] = x in 16-byte pieces with 32-bit piece indices, and a finalise kernel that can start at a row of its choice.
-static bool level_copy_eligible(const float *x, int32_t F, const float *out, int64_t out_cols, int64_t N, int32_t K) {
-    return x && out && F > 0 && (F & 3) == 0 && (K & 3) == 0 && (out_cols & 3) == 0 && aligned16(x) && aligned16(out) &&
-           (uint64_t)N * (uint64_t)(F / 4) < (1ull << 32);
-}
-
-static CopyPlan make_copy_plan(const float *x, int32_t F, float *out, int64_t out_cols, int64_t N, int launches) {
-    CopyPlan p;
-    p.x = x; p.out = out; p.F4 = (unsigned)F / 4; p.opitch4 = (unsigned)(out_cols / 4);
-    p.levels = launches < LEVEL_COPY_SLOTS - 1 ? launches : LEVEL_COPY_SLOTS - 1;
-    int64_t acc = 0;                                                 // per mille so far
-    for (int l = 1; l <= p.levels; ++l) {
-        acc += g_level_copy_permille[l];
-        if (acc > 1000) acc = 1000;
-        p.cut[l] = (int)(N * acc / 1000);
-    }
-    return p;
-}
-
 // Enqueue levels [level, stop) (clipped to what the hop-bit capacity can represent); returns the next level.
-static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t stream, const CopyPlan *plan = nullptr) {
+static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t stream) {
     const int first = level;
     profile_mark(stream, 0, 0, true);                                // span mode: one event pair around the whole run
     for (; level < stop; ++level) {
@@ -2007,64 +1727,29 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
         if ((level & (level - 1)) == 0 && level >= (1 << EAGER_PLANES)) {   // first level with this hop bit
             int bit = 0;
             while ((1 << bit) < level) ++bit;
-            hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, stream, (uint4 *)(b.hop_planes + (size_t)bit * b.plane_elems),
-                               b.plane_bytes / 16, (uint4 *)nullptr, (size_t)0, (uint4 *)nullptr, (size_t)0);
+            // (8-byte stores: with an odd N * W every second plane starts 8 bytes off a 16-byte boundary)
+            hipLaunchKernelGGL(k_zero_words, dim3(1024), dim3(256), 0, stream, b.hop_planes + (size_t)bit * b.plane_elems, b.plane_elems);
         }
         const u64 *prev = b.front[(level - 1) % 3];           // frontier of level - 1
         u64 *next = b.front[level % 3];                          // receives the frontier of this level
         u64 *idle = b.front[(level + 1) % 3];                    // next level's accumulator: rows spanning chunks cleared now
         const unsigned *lp = b.live[(level - 1) % 3];
         unsigned *ln = b.live[level % 3], *li = b.live[(level + 1) % 3];
-        LevelCopy cp;
-        if (plan && level <= plan->levels && plan->cut[level] > plan->cut[level - 1]) {
-            cp.x = plan->x; cp.out = plan->out; cp.F4 = plan->F4; cp.opitch4 = plan->opitch4;
-            cp.piece_begin = (unsigned)plan->cut[level - 1] * plan->F4;
-            cp.piece_end = (unsigned)plan->cut[level] * plan->F4;
-        }
-        if (b.Wp == 1)      launch_level<1>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, cp, stream);
-        else if (b.Wp == 2) launch_level<2>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, cp, stream);
-        else                launch_level<4>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, cp, stream);
+        // more than 256 anchors: tiles of 4 words -- a wave each where the graph lives in L2 (latency-bound levels), walked inside the
+        // wave where the frontier comes from HBM (one pass over the index stream)
+        const int multi = b.Wp <= 4 ? 0 : (b.live_mode == 1 ? 2 : 1);
+#define POPE_LEVEL(WT, MULTI) launch_level<WT, MULTI>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, b.live_mode, b.live_sum, stream)
+        if (b.Wp == 1)       POPE_LEVEL(1, 0);
+        else if (b.Wp == 2)  POPE_LEVEL(2, 0);
+        else if (multi == 0) POPE_LEVEL(4, 0);
+        else if (multi == 1) POPE_LEVEL(4, 1);
+        else                 POPE_LEVEL(4, 2);
+#undef POPE_LEVEL
     }
     profile_mark(stream, 0, 1, true);
     if (g_profile.enabled && g_profile.span_only && !g_profile.level.empty())
         g_profile.level.back() = -(level - first);                  // span entries carry minus the number of launches
     return level;
-}
-
-// The tail kernel (k_tail_finalize): levels [first_level, level_stop) until one finds nothing, the verdict, and -- with `out` --
-// the rest of the feature copy and the embedding columns.  The BFS blocks must all be resident at once (they wait for one
-// another): their number is capped at half of what the device holds of this kernel, the copy blocks fill the rest.
-template <int WT, int LIVE>
-static int launch_tail_t(const TailArgs &a0, size_t lds, hipStream_t stream) {
-    TailArgs a = a0;
-    static std::atomic<int> resident_cache{0};
-    int resident = resident_cache.load(std::memory_order_relaxed);
-    if (!resident) {
-        int per_cu = 0, dev = 0, cus = 0;
-        POPE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail_finalize<WT, LIVE>, 256, LIVE == 1 ? 32 * 1024 : 0));
-        POPE_HIP(hipGetDevice(&dev));
-        POPE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        resident = per_cu * cus;
-        POPE_REQUIRE(resident >= 2, "tail kernel: the device holds %d blocks", resident);
-        resident_cache.store(resident, std::memory_order_relaxed);
-    }
-    if (a.bfs_blocks > resident / 2) a.bfs_blocks = resident / 2;
-    const int copy_blocks = a.out ? resident - a.bfs_blocks : 0;
-    hipLaunchKernelGGL((k_tail_finalize<WT, LIVE>), dim3(a.bfs_blocks + copy_blocks), dim3(256), lds, stream, a);
-    POPE_HIP(hipGetLastError());
-    return POPE_OK;
-}
-
-static int launch_tail(const TailArgs &a, hipStream_t stream) {
-    const int mode = g_live_mode >= 0 ? g_live_mode : (a.live_words <= LIVE_MAX_NODES / 32 ? 1 : 2);
-    const int live = mode == 1 && a.live_words <= LIVE_MAX_NODES / 32 ? 1 : (mode == 2 ? 2 : 0);
-    const size_t lds = live == 1 ? align_up((size_t)a.live_words * sizeof(unsigned), 16) : 0;
-#define POPE_TAIL(WT)                                                      \
-    (live == 1 ? launch_tail_t<WT, 1>(a, lds, stream) : live == 2 ? launch_tail_t<WT, 2>(a, lds, stream) : launch_tail_t<WT, 0>(a, lds, stream))
-    if (a.Wp == 1) return POPE_TAIL(1);
-    if (a.Wp == 2) return POPE_TAIL(2);
-    return POPE_TAIL(4);
-#undef POPE_TAIL
 }
 
 // Wait for the stream and read the verdicts.  Returns POPE_OK with *done set, or an error code.
@@ -2108,10 +1793,6 @@ static int bfs_poll(const Bfs &b, int next_level, int *last_active, bool *done, 
     if (flags & CSR_FLAG_UNSORTED) {
         set_error("geodesic bfs: edge_index is not sorted by source; rebuild the CSR with defer_check = 0");
         return POPE_ERR_UNSORTED;
-    }
-    if (flags & BFS_FLAG_TAIL_FAILED) {
-        set_error("geodesic bfs: a bounded wait inside the tail kernel ran out (its BFS blocks did not meet)");
-        return POPE_ERR_HIP;
     }
     *done = *last_active < next_level - 1 || b.E == 0;          // some enqueued level found nothing
     if (!*done && next_level >= b.level_limit) {
@@ -2236,17 +1917,38 @@ extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, cons
     return POPE_OK;
 }
 
+// Which finalise kernel a shape gets (bench.py labels its roofline entry with the same choice: pope_finalize_kernel_name).
+enum FinKernel { FIN_GENERIC, FIN_FAST, FIN_PIPE, FIN_WIDE };
+struct FinChoice { FinKernel kernel; int xp, ep; };
+
+static FinChoice finalize_choice(int64_t N, int32_t K, bool has_x, int32_t F, int n_shards, bool vec, bool four_bits) {
+    FinChoice c{FIN_GENERIC, 0, 0};
+    if (!(vec && (g_finalize_variant > 0 || n_shards > 1) && four_bits)) return c;
+    c.kernel = FIN_FAST;
+    const int xp = !has_x ? 0 : (F <= 256 ? 1 : F <= 512 ? 2 : F <= 1024 ? 4 : -1);
+    const int64_t ne = (int64_t)(K / 4) * n_shards;
+    const int ep = ne <= 64 ? 1 : ne <= 128 ? 2 : 4;             // wider rows: segments of 256 pieces, one work item each
+    const int64_t items = N * ((ne + 64 * ep - 1) / (64 * ep));
+    const int64_t witems = N * ((ne / 16 + 15) / 16);
+    c.xp = xp; c.ep = ep;
+    if (g_finalize_variant != 1 || xp < 0) return c;
+    if (ne > 64 && (K & 63) == 0 && witems + 32768 * 4 < INT32_MAX) c.kernel = FIN_WIDE;      // wide rows: one load per plane half-word, shuffles to the lanes
+    else if (items + 32768 * 4 < INT32_MAX) c.kernel = FIN_PIPE;
+    return c;
+}
+
 static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_hop_dev, int64_t N, int32_t K,
                             const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, hipStream_t stream,
                             int n_shards = 1, size_t shard_elems = 0, const int *aux = nullptr, int *report = nullptr,
-                            int ticket = 0, int x_row_begin = 0) {
+                            int ticket = 0) {
     const int Wp = words_for(K);
     const size_t plane_elems = (size_t)N * Wp;
     const bool vec = F % 4 == 0 && K % 4 == 0 && c0 % 4 == 0 && out_cols % 4 == 0 && aligned16(out) && (!x || aligned16(x));
     dim3 grid(capped_grid((size_t)N * 64, 256)), block(256);
     // The device-side depth (max_hop_dev) is only used by pope_geodesic_run, whose speculative window stops at
-    // LEVEL_BATCH = 12 levels: at most 4 hop bits.  With a host-side count the fast path needs n_hop_bits <= 4.
-    if (n_shards > 1 && !(vec && n_hop_bits <= 4)) {          // generic kernel: one launch per shard
+    // LEVEL_BATCH = 12 levels: at most 4 hop bits.  With a host-side count the fast paths need n_hop_bits <= 4.
+    const bool four_bits = max_hop_dev || n_hop_bits <= 4;
+    if (n_shards > 1 && !(vec && four_bits)) {                // generic kernel: one launch per shard
         for (int g = 0; g < n_shards; ++g) {
             int rc = finalize_enqueue(planes + (size_t)g * shard_elems, n_hop_bits, max_hop_dev, N, K, g == 0 ? x : nullptr, F, out,
                                       out_cols, c0 + g * K, stream);
@@ -2254,68 +1956,54 @@ static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_ho
         }
         return POPE_OK;
     }
-    if (vec && (g_finalize_variant > 0 || n_shards > 1) && (max_hop_dev || n_hop_bits <= 4)) {
-        dim3 fgrid(g_finalize_blocks);                          // 8 blocks per CU, contiguous row blocks per wave
-        // POPE_KNOB_FINALIZE_VARIANT 3 / 4 (round-4 A/B): the embedding columns and the feature copy as TWO launches on the same
-        // stream -- 3: columns first (that kernel carries the verdict, so the host still hears it when the BFS ends), then
-        // side_copy.hip's copy kernel (5.9 TB/s alone); 4: the copy first.
-        if ((g_finalize_variant == 3 || g_finalize_variant == 4) && x && n_shards == 1 && x_row_begin < N &&
-            SideCopy::eligible(x, F, out, out_cols, N)) {
-            const float *xs = x + (size_t)x_row_begin * F;
-            float *os = out + (size_t)x_row_begin * out_cols;
-            if (g_finalize_variant == 4) { int rc = enqueue_copy_features(xs, F, os, out_cols, N - x_row_begin, stream); if (rc) return rc; }
-            hipLaunchKernelGGL(k_finalize_fast<0>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, (int)N);
-            if (g_finalize_variant == 3) { int rc = enqueue_copy_features(xs, F, os, out_cols, N - x_row_begin, stream); if (rc) return rc; }
-            POPE_HIP(hipGetLastError());
-            return POPE_OK;
-        }
-        // the pipelined kernel (default, variant 1; 5: with contiguous row blocks; 7: the round 1-3 kernel): shapes it has instances for
-        {
-            const int xp = !x ? 0 : (F <= 256 ? 1 : F <= 512 ? 2 : F <= 1024 ? 4 : -1);
-            const int64_t ne = (int64_t)(K / 4) * n_shards;
-            const int ep = ne <= 64 ? 1 : ne <= 128 ? 2 : 4;             // wider rows: segments of 256 pieces, one work item each
-            const int64_t items = N * ((ne + 64 * ep - 1) / (64 * ep));
-            const int64_t witems = N * ((ne / 16 + 15) / 16);
-            if (g_finalize_variant == 1 && xp >= 0 && ne > 64 && (K & 63) == 0 && witems + 32768 * 4 < INT32_MAX) {      // wide rows: one load per plane half-word, shuffles to the lanes
-                dim3 wgrid(g_finalize_blocks_set ? g_finalize_blocks : (unsigned)std::min<int64_t>(std::max<int64_t>((witems + 3) / 4, 256), 32768));
+    const FinChoice ch = finalize_choice(N, K, x != nullptr, F, n_shards, vec, four_bits);
+    const int64_t ne = (int64_t)(K / 4) * n_shards;
+    if (ch.kernel == FIN_WIDE) {
+        const int64_t witems = N * ((ne / 16 + 15) / 16);
+        dim3 wgrid(g_finalize_blocks_set ? g_finalize_blocks : (unsigned)std::min<int64_t>(std::max<int64_t>((witems + 3) / 4, 256), 32768));
 #define POPE_FIN_WIDE(XP)                                                                                                                 \
     hipLaunchKernelGGL((k_finalize_wide<XP>), wgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, \
-                       (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, x_row_begin)
-                if (xp == 0) POPE_FIN_WIDE(0); else if (xp == 1) POPE_FIN_WIDE(1); else if (xp == 2) POPE_FIN_WIDE(2); else POPE_FIN_WIDE(4);
+                       (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket)
+        if (ch.xp == 0) POPE_FIN_WIDE(0); else if (ch.xp == 1) POPE_FIN_WIDE(1); else if (ch.xp == 2) POPE_FIN_WIDE(2); else POPE_FIN_WIDE(4);
 #undef POPE_FIN_WIDE
-                POPE_HIP(hipGetLastError());
-                return POPE_OK;
-            }
-            if ((g_finalize_variant == 1 || g_finalize_variant == 5) && xp >= 0 && items + 32768 * 4 < INT32_MAX) {
-                const int contiguous = g_finalize_variant == 5;
-                // one row per wave by default (grid sweep, profiles/r04_finalize_pipe*.txt: 2 048 blocks 0.2479 ms, 4 096 0.2456, 8 192
-                // 0.2416, 16 384 0.2394, one row per wave 0.2395, 32 768 0.2400): short-lived waves in row order
-                const int64_t one_row_per_wave = std::min<int64_t>(std::max<int64_t>((items + 3) / 4, 256), 32768);
-                dim3 pgrid(g_finalize_blocks_set ? g_finalize_blocks : (unsigned)one_row_per_wave);
+    } else if (ch.kernel == FIN_PIPE) {
+        // one row per wave by default (grid sweep, profiles/r04_finalize_pipe*.txt: 2 048 blocks 0.2479 ms, 4 096 0.2456, 8 192
+        // 0.2416, 16 384 0.2394, one row per wave 0.2395, 32 768 0.2400): short-lived waves in row order
+        const int64_t items = N * ((ne + 64 * ch.ep - 1) / (64 * ch.ep));
+        dim3 pgrid(g_finalize_blocks_set ? g_finalize_blocks : (unsigned)std::min<int64_t>(std::max<int64_t>((items + 3) / 4, 256), 32768));
+        const int xp = ch.xp, ep = ch.ep;
 #define POPE_FIN_PIPE(XP, EP)                                                                                                             \
     hipLaunchKernelGGL((k_finalize_pipe<XP, EP>), pgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, \
-                       (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, x_row_begin, contiguous)
-                if (xp == 0)      { if (ep == 1) POPE_FIN_PIPE(0, 1); else if (ep == 2) POPE_FIN_PIPE(0, 2); else POPE_FIN_PIPE(0, 4); }
-                else if (xp == 1) { if (ep == 1) POPE_FIN_PIPE(1, 1); else if (ep == 2) POPE_FIN_PIPE(1, 2); else POPE_FIN_PIPE(1, 4); }
-                else if (xp == 2) { if (ep == 1) POPE_FIN_PIPE(2, 1); else if (ep == 2) POPE_FIN_PIPE(2, 2); else POPE_FIN_PIPE(2, 4); }
-                else              { if (ep == 1) POPE_FIN_PIPE(4, 1); else if (ep == 2) POPE_FIN_PIPE(4, 2); else POPE_FIN_PIPE(4, 4); }
+                       (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket)
+        if (xp == 0)      { if (ep == 1) POPE_FIN_PIPE(0, 1); else if (ep == 2) POPE_FIN_PIPE(0, 2); else POPE_FIN_PIPE(0, 4); }
+        else if (xp == 1) { if (ep == 1) POPE_FIN_PIPE(1, 1); else if (ep == 2) POPE_FIN_PIPE(1, 2); else POPE_FIN_PIPE(1, 4); }
+        else if (xp == 2) { if (ep == 1) POPE_FIN_PIPE(2, 1); else if (ep == 2) POPE_FIN_PIPE(2, 2); else POPE_FIN_PIPE(2, 4); }
+        else              { if (ep == 1) POPE_FIN_PIPE(4, 1); else if (ep == 2) POPE_FIN_PIPE(4, 2); else POPE_FIN_PIPE(4, 4); }
 #undef POPE_FIN_PIPE
-                POPE_HIP(hipGetLastError());
-                return POPE_OK;
-            }
-        }
-        if (g_finalize_variant == 2)
-            hipLaunchKernelGGL(k_finalize_fast<1>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, x_row_begin);
-        else
-            hipLaunchKernelGGL(k_finalize_fast<0>, fgrid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket, x_row_begin);
-        POPE_HIP(hipGetLastError());
-        return POPE_OK;
+    } else if (ch.kernel == FIN_FAST) {
+        hipLaunchKernelGGL(k_finalize_fast, dim3(g_finalize_blocks), block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out,
+                           (long long)out_cols, c0, n_shards, shard_elems, aux, report, ticket);
+    } else if (vec) {
+        hipLaunchKernelGGL(k_finalize<true>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, aux, report, ticket);
+    } else {
+        hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, aux, report, ticket);
     }
-    if (vec)
-        hipLaunchKernelGGL(k_finalize<true>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, aux, report, ticket, x_row_begin);
-    else
-        hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, aux, report, ticket, x_row_begin);
     POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+// The name of the finalise kernel pope_geodesic_run / pope_geodesic_finalize(_shards) launches for a shape (what a profile will show).
+extern "C" int pope_finalize_kernel_name(int64_t N, int32_t K, int32_t F, int32_t has_x, int32_t n_shards, char *name, size_t cap) {
+    clear_error();
+    POPE_REQUIRE(name && cap > 0 && N > 0 && K > 0 && F >= 0 && n_shards >= 1, "pope_finalize_kernel_name: bad argument");
+    const bool vec = F % 4 == 0 && K % 4 == 0;                   // aligned bases and row pitches assumed (torch allocations)
+    const FinChoice c = finalize_choice(N, K, has_x != 0, F, n_shards, vec, true);
+    switch (c.kernel) {
+    case FIN_WIDE: snprintf(name, cap, "k_finalize_wide<%d>", c.xp); break;
+    case FIN_PIPE: snprintf(name, cap, "k_finalize_pipe<%d, %d>", c.xp, c.ep); break;
+    case FIN_FAST: snprintf(name, cap, "k_finalize_fast"); break;
+    default:       snprintf(name, cap, vec ? "k_finalize<true>" : "k_finalize<false>"); break;
+    }
     return POPE_OK;
 }
 
@@ -2391,9 +2079,6 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     if ((rc = bfs_setup(b, rowptr, col, erow, aux, N, E, anchors_host, K, (uint64_t *)planes, plane_capacity,
                         ws + L.bfs_scratch, L.total - L.bfs_scratch))) return rc;
     const int window = speculative_window(N, E, K);
-    // The level launches copy part of out[:, :F] = x in their copy role (LevelCopy); the finalise kernel copies the rest.
-    CopyPlan plan;
-    if (out && level_copy_eligible(x, F, out, out_cols, N, K)) plan = make_copy_plan(x, F, out, out_cols, N, window);
     memcpy(b.slot->anchors, anchors_host, (size_t)K * sizeof(long long));     // this call's pinned, device-mapped slot: read in place
     if (g_prepare_merge && K <= PREP_MAX_ANCHORS && E > 0) {
         // one launch: clear + seed role beside the speculative CSR role (k_prepare)
@@ -2403,7 +2088,9 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
         PrepSeeds seeds;
         for (int j = 0; j < K; ++j) seeds.a[j] = (int)anchors_host[j];          // (validated by bfs_setup)
         const int eager = b.capacity < EAGER_PLANES ? b.capacity : EAGER_PLANES;
-        const size_t na = (b.front_off + 3 * align_up(b.plane_bytes, 256) + 3 * live_bytes(b.N)) / 16, nb = (size_t)(1 + eager) * b.plane_bytes / 16;
+        const size_t zwords = (size_t)(1 + eager) * b.plane_elems;          // odd: one 8-byte word behind the last 16-byte unit (zb_tail)
+        const size_t na = (b.front_off + 3 * align_up(b.plane_bytes, 256) + 3 * live_bytes(b.N)) / 16, nb = zwords / 2;
+        u64 *zb_tail = (zwords & 1) ? b.seen + zwords - 1 : nullptr;
         const long long *src = (const long long *)edge_index, *dst = src + E;
         // (knob values above 1, for A/B: low 16 bits = the clear role's block count, high 16 bits = a cap on the CSR role's)
         const int zero_blocks = (g_prepare_merge & 0xffff) > 1 ? (g_prepare_merge & 0xffff) : 1024;
@@ -2412,10 +2099,10 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
         if ((g_prepare_merge >> 16) > 0) csr_blocks = std::min<unsigned>(csr_blocks, (unsigned)(g_prepare_merge >> 16));
         if (pairs)
             hipLaunchKernelGGL(k_prepare<true>, dim3(zero_blocks + csr_blocks), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, aux,
-                               (uint4 *)b.base, na, (uint4 *)b.seen, nb, zero_blocks, epoch, seeds, K, b.Wp, b.seen, b.front[0], b.live[0]);
+                               (uint4 *)b.base, na, (uint4 *)b.seen, nb, zb_tail, zero_blocks, epoch, seeds, K, b.Wp, b.seen, b.front[0], b.live[0]);
         else
             hipLaunchKernelGGL(k_prepare<false>, dim3(zero_blocks + csr_blocks), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, aux,
-                               (uint4 *)b.base, na, (uint4 *)b.seen, nb, zero_blocks, epoch, seeds, K, b.Wp, b.seen, b.front[0], b.live[0]);
+                               (uint4 *)b.base, na, (uint4 *)b.seen, nb, zb_tail, zero_blocks, epoch, seeds, K, b.Wp, b.seen, b.front[0], b.live[0]);
         POPE_HIP(hipGetLastError());
     } else {
         bfs_enqueue_clear(b, aux, stream);                    // BFS state and the CSR status header in one launch
@@ -2424,32 +2111,14 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
         rc = csr_build(edge_index, E, N, rowptr, col, erow, aux, ws + L.csr_scratch, L.planes - L.csr_scratch, 2, seed, stream);
         if (rc) return rc;
     }
-    // Round 4: the sparse last levels run inside the finalise kernel's launch (k_tail_finalize) when POPE_KNOB_TAIL_LEVEL names
-    // the first of them: one word tile per node, levels below 16, and -- with an output -- the fast expansion's shapes.
-    const int level_stop = (int)std::min<long long>(b.level_limit, 1 << EAGER_PLANES);
-    const bool tail = g_tail_level >= 2 && g_tail_level <= window && g_tail_level < level_stop && b.Wp <= 4 && E > 0 &&
-                      (!out || ((F & 3) == 0 && (K & 3) == 0 && (out_cols & 3) == 0 && aligned16(out) && (!x || aligned16(x)) &&
-                                (uint64_t)N * (uint64_t)(F / 4 + 1) < (1ull << 32)));
-    int level = bfs_enqueue_levels(b, 1, tail ? g_tail_level : 1 + window, stream, plan.levels ? &plan : nullptr);
-    const int x_row_begin = plan.levels ? plan.cut[std::min(level - 1, plan.levels)] : 0;      // rows the launches really took
+    int level = bfs_enqueue_levels(b, 1, 1 + window, stream);
     // The finalise kernel writes the verdict into the pinned report when it starts: no report launch, and the host
     // returns as soon as the BFS is known to be complete -- `out` is finished in stream order.
     int ticket = 0;
-    if (tail && level == g_tail_level) {
-        ticket = b.slot->ticket = b.slot->ticket == INT32_MAX ? 1 : b.slot->ticket + 1;
-        TailArgs a;
-        a.erow = b.erow; a.col = b.col; a.E = b.E; a.N = b.N; a.Wp = b.Wp;
-        for (int i = 0; i < 3; ++i) { a.front[i] = b.front[i]; a.live[i] = b.live[i]; }
-        a.live_words = b.live_words; a.seen = b.seen; a.hop_planes = b.hop_planes; a.plane_elems = b.plane_elems;
-        a.ctl = b.ctl; a.aux = b.aux; a.first_level = level; a.level_stop = level_stop; a.bfs_blocks = g_tail_blocks; a.variant = g_level_variant;
-        a.K = K; a.F = out ? F : 0; a.x = out ? x : nullptr; a.out = out; a.out_cols = out_cols; a.x_row_begin = x_row_begin;
-        a.report = b.slot->report_dev; a.ticket = ticket;
-        if ((rc = launch_tail(a, stream))) return rc;
-        level = level_stop;                               // what the tail kernel may have run
-    } else if (out) {
+    if (out) {
         ticket = b.slot->ticket = b.slot->ticket == INT32_MAX ? 1 : b.slot->ticket + 1;
         if ((rc = finalize_enqueue(planes, 0, &b.ctl->last_active, N, K, x, F, out, out_cols, 0, stream, 1, 0, aux,
-                                   b.slot->report_dev, ticket, x_row_begin))) return rc;
+                                   b.slot->report_dev, ticket))) return rc;
     }
     int last_active = 0;
     bool done = false;
@@ -2474,8 +2143,7 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
         level = bfs_enqueue_levels(b, level, level + LEVEL_BATCH, stream);
         if ((rc = bfs_poll(b, level, &last_active, &done, stream))) return rc;
     }
-    if (out && (rc = finalize_enqueue(planes, hop_bits(last_active), nullptr, N, K, x, F, out, out_cols, 0, stream, 1, 0, nullptr, nullptr, 0,
-                                      x_row_begin))) return rc;
+    if (out && (rc = finalize_enqueue(planes, hop_bits(last_active), nullptr, N, K, x, F, out, out_cols, 0, stream))) return rc;
     guard.quiescent = true;                               // every poll of this path synchronised the stream; the late finalise kernel does not touch the slot
     remember_depth(N, E, K, last_active, window < LEVEL_BATCH);
     if (max_hop_host) *max_hop_host = last_active;

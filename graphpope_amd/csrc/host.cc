@@ -7,11 +7,12 @@
 //
 // pope_assemble_host_result (round 3) does that INTO AN ORDINARY PAGEABLE TENSOR, like the one the reference returns.
 // The reference calls Graphpope once per process (utils.py:195-208 memoises), so what counts is the first call: a
-// 270 MB hipHostMalloc'd result took 34 ms to allocate and stayed page-locked for the life of the process.  Here the
-// result is cut into row chunks; worker threads copy data.x into a chunk (first touch: with MADV_HUGEPAGE the faults
-// are 2 MB each), the calling thread registers the chunk's pages with the HIP runtime (hipHostRegister: ~3 us per MB
-// once the pages are present) and enqueues the chunk's pitched DMA of the K embedding columns, so PCIe, the page
-// faults and the host copy overlap; everything is unregistered before the call returns.
+// 270 MB hipHostMalloc'd result took 34 ms to allocate and stayed page-locked for the life of the process.  Here worker
+// threads copy data.x into the result (first touch: with MADV_HUGEPAGE the faults are 2 MB each) while the K embedding
+// columns arrive, chunk by chunk, in a small pinned ring of the library's own, and the same threads copy each landed chunk
+// out.  The HIP runtime is never handed a page of the result.  (Round 3's other transport -- registering the result's own pages
+// chunk by chunk for pitched DMA -- measured slower on first and repeated calls, was where every host-side fault of rounds 3-4
+// lived, and was removed in round 5 together with the pre-fault helper threads: DESIGN.md section 1 keeps the figures.)
 #include <emmintrin.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -34,7 +35,6 @@
 namespace pope {
 void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void clear_error();
-extern int g_host_result_mode;          // pope_debug_set(POPE_KNOB_HOST_RESULT_MODE): 0 pinned ring (default), 1 register the result's pages
 extern int g_fail_host_register;         // pope_debug_set(POPE_KNOB_FAIL_HOST_REGISTER): tests of the fallback path
 }  // namespace pope
 
@@ -233,66 +233,11 @@ extern "C" int pope_copy_to_device(const void *src_host, void *dst, size_t bytes
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fresh result pages, faulted in beside the GPU work (the first host -> host call of a process)
-// ------------------------------------------------------------------------------------------------
-// A new 270 MB result costs the kernel 3-10 ms of page clearing whoever touches it first (tools/populate_probe.py on the GPU box:
-// madvise(MADV_POPULATE_WRITE) with huge pages takes 9.8 / 5.9 / 3.2 / 4.2 ms on 1 / 2 / 4 / 8 threads).  Round 3 let the sixteen
-// copy threads take those faults AFTER the GPU work (taking them beside it with sixteen threads stalled the GPU queues); here a
-// FEW threads populate the mapping with one madvise call each while the upload and the BFS run, and the copy threads then
-// write pages that exist.  pope_host_prefault_begin returns at once; _wait joins (and frees the handle).
-namespace {
-struct Prefault {
-    std::vector<std::thread> threads;
-};
-}  // namespace
-
-#ifndef MADV_POPULATE_WRITE
-#define MADV_POPULATE_WRITE 23
-#endif
-
-extern "C" void *pope_host_prefault_begin(void *host, size_t bytes, int32_t threads) {
-    if (!host || bytes == 0) return nullptr;
-    int t = threads > 0 ? threads : 4;
-    if (t > 16) t = 16;
-    char *base = static_cast<char *>(host);
-    if (!getenv("GRAPHPOPE_NO_HUGEPAGE")) {
-        const uintptr_t huge = (uintptr_t)1 << 21, b = reinterpret_cast<uintptr_t>(base);
-        const uintptr_t lo = (b + huge - 1) & ~(huge - 1), hi = (b + bytes) & ~(huge - 1);
-        if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
-    }
-    Prefault *p = new Prefault;
-    const size_t page = 4096, huge = (size_t)1 << 21;
-    // ranges cut at 2 MB boundaries, so that no huge page is faulted by two threads
-    const uintptr_t b0 = reinterpret_cast<uintptr_t>(base) & ~(uintptr_t)(page - 1), b1 = (reinterpret_cast<uintptr_t>(base) + bytes + page - 1) & ~(uintptr_t)(page - 1);
-    const size_t span = b1 - b0, per = ((span / (size_t)t) + huge - 1) / huge * huge;
-    for (int i = 0; i < t; ++i) {
-        uintptr_t lo = b0 + (uintptr_t)i * per, hi = lo + per < b1 ? lo + per : b1;
-        if (i > 0) lo = lo & ~(uintptr_t)(huge - 1);
-        if (i + 1 < t) hi = hi & ~(uintptr_t)(huge - 1);
-        if (lo >= b1 || hi <= lo) continue;
-        p->threads.emplace_back([lo, hi, page] {
-            if (madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_POPULATE_WRITE) != 0) {
-                // a kernel without MADV_POPULATE_WRITE (< 5.14): touch the pages (a locked OR with 0 changes nothing that is there)
-                for (uintptr_t a = lo; a < hi; a += page) (void)__atomic_fetch_or(reinterpret_cast<char *>(a), 0, __ATOMIC_RELAXED);
-            }
-        });
-    }
-    return p;
-}
-
-extern "C" void pope_host_prefault_wait(void *handle) {
-    Prefault *p = static_cast<Prefault *>(handle);
-    if (!p) return;
-    for (auto &th : p->threads) th.join();
-    delete p;
-}
-
-// ------------------------------------------------------------------------------------------------
 // out[:, :F] = x (host cores) and out[:, F:] = emb (DMA), into a pageable result, chunk by chunk
 // ------------------------------------------------------------------------------------------------
 // Phase times of the last pope_assemble_host_result call of the process, in ms (diagnostic: tools/boundary_breakdown.py):
-// 0 madvise, 1 waiting for the chunks' host copies, 2 hipHostRegister, 3 enqueueing DMAs, 4 joining the workers,
-// 5 waiting for the stream, 6 hipHostUnregister, 7 total.
+// 0 madvise, 1 waiting for the chunks' host copies, 2 the ring's allocation (first call), 3 enqueueing DMAs, 4 joining the workers,
+// 5 waiting for the stream, 6 unused, 7 total.
 static double g_assemble_trace[8];
 static std::mutex g_assemble_trace_mu;       // two assemblies may finish at the same time (found by tools/host_race_harness under -fsanitize=thread)
 extern "C" void pope_debug_boundary_trace(double *host8) {
@@ -336,7 +281,6 @@ struct Assembly {
     size_t out_pitch = 0;
     int64_t rows = 0;
     int chunks = 0, slices = 0;                  // every chunk is cut into `slices` row slices, one work item each
-    bool touch_only_pages = false;               // registered mode without feature columns: fault the pages in
     std::vector<int64_t> chunk_lo;               // chunks + 1 row boundaries
     std::atomic<int> next{0};
     std::vector<std::atomic<int>> done;          // per chunk: slices finished
@@ -357,7 +301,6 @@ struct Assembly {
     // abort() wake them.  Once the embedding phase has begun the waits are short (a chunk is on the bus) and they yield-spin.
     std::mutex idle_m;
     std::condition_variable idle_cv;
-    bool no_register = false;                    // this assembly never hands the result's pages to hipHostRegister
 
     explicit Assembly(int nchunks) : done((size_t)nchunks), emb_done(0) {
         for (auto &d : done) d.store(0, std::memory_order_relaxed);
@@ -371,13 +314,6 @@ struct Assembly {
             if (x_row) {
                 for (int64_t r = r0; r < r1; ++r) copy_segment(x + (size_t)r * x_pitch, out + (size_t)r * out_pitch, x_row);
                 _mm_sfence();
-            } else if (touch_only_pages) {
-                // no feature columns: touch the pages so that registering them does not fault them in one by one.  An
-                // atomic OR with 0: a page at a chunk boundary may already be receiving the previous region's DMA (whole
-                // rows inside a region travel with it), and a locked read-modify-write cannot lose those bytes.
-                const size_t page = 4096;
-                char *b = out + (size_t)r0 * out_pitch, *e = out + (size_t)r1 * out_pitch;
-                for (char *p = b; p < e; p += page) (void)__atomic_fetch_or(p, 0, __ATOMIC_RELAXED);
             }
         }
         done[(size_t)c].fetch_add(1, std::memory_order_release);
@@ -535,7 +471,6 @@ struct HostAssembly {
     Workers pool;
     size_t total = 0;
     double t_begin = 0, t_madvise = 0;
-    bool ring = false;                           // the embedding columns come through the pinned ring (else: the result's pages are registered)
     explicit HostAssembly(int nch) : a(nch) {}
 };
 
@@ -545,19 +480,7 @@ struct HostAssembly {
 // and runs underneath whatever the caller does next (upload edge_index, enqueue and wait for the GPU).
 extern "C" void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, void *out_host,
                                      int64_t out_pitch_bytes, int64_t rows, int32_t threads, int32_t chunks) {
-    // the transport follows the process-global test knobs; callers with a choice of their own use pope_assemble_begin_mode
-    return pope_assemble_begin_mode(x_host, x_pitch_bytes, x_row_bytes, out_host, out_pitch_bytes, rows, threads, chunks,
-                                    pope::g_host_result_mode == 0 ? POPE_RESULT_RING : POPE_RESULT_REGISTERED, (pope::g_fail_host_register & 1) != 0);
-}
-
-extern "C" void *pope_assemble_begin_mode(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, void *out_host,
-                                          int64_t out_pitch_bytes, int64_t rows, int32_t threads, int32_t chunks, int32_t result_mode,
-                                          int32_t no_register) {
     pope::clear_error();
-    if (result_mode != POPE_RESULT_RING && result_mode != POPE_RESULT_REGISTERED) {
-        pope::set_error("pope_assemble_begin_mode: unknown result mode %d", result_mode);
-        return nullptr;
-    }
     if (!out_host || rows <= 0 || x_row_bytes < 0 || (x_row_bytes > 0 && (!x_host || x_pitch_bytes < x_row_bytes)) || out_pitch_bytes < x_row_bytes ||
         out_pitch_bytes <= 0) {
         pope::set_error("pope_assemble_begin: null pointer or bad size");
@@ -584,10 +507,6 @@ extern "C" void *pope_assemble_begin_mode(const void *x_host, int64_t x_pitch_by
     a.x = static_cast<const char *>(x_host); a.x_pitch = (size_t)x_pitch_bytes; a.x_row = (size_t)x_row_bytes;
     a.out = out; a.out_pitch = (size_t)out_pitch_bytes; a.rows = rows; a.chunks = nch;
     a.slices = t;
-    h->ring = result_mode == POPE_RESULT_RING;
-    a.no_register = no_register != 0;
-    a.touch_only_pages = !h->ring;
-    if (!h->ring) a.emb_total.store(0, std::memory_order_relaxed);     // no ring items: the threads leave after the feature copy (they have not started yet)
     a.chunk_lo.resize((size_t)nch + 1);
     // the first chunk is small so that the first DMA starts early; the rest are equal
     for (int c = 0; c <= nch; ++c) a.chunk_lo[(size_t)c] = rows * c / nch;
@@ -607,7 +526,7 @@ extern "C" void pope_assemble_abort(void *handle) {
 
 // The three pinned slots, the code table and their events; g_ring.mu held.  Allocated once per process (2 ms of hipHostMalloc)
 // and never released.  false: no pinned ring -- the runtime refused the 24 MB (not retried), or POPE_KNOB_FAIL_HOST_REGISTER bit
-// 1 says to behave as if it had -- and the caller sends float columns through the registered / staged path instead.
+// 1 says to behave as if it had -- and the caller sends float columns through the bounce buffer instead.
 // (A ring of ORDINARY memory as the fallback was built and withdrawn: asynchronous copies into heap memory that is freed and
 // reused afterwards left the runtime with stale mappings, and a later, unrelated transfer died with a GPU memory fault at a
 // host heap address.)
@@ -659,9 +578,10 @@ extern "C" int32_t pope_assemble_ring_ready(void) {
 
 // Rows [r0, r1) of a DEVICE matrix (row bytes `eb`, pitch `epitch`) into pageable host rows at dst0 + r * dpitch WITHOUT giving
 // the runtime the pageable pointer: 4 MB pinned bounce buffer (allocated once per process, guarded by its own mutex),
-// one blocking pitched copy per buffer-full, memcpy out.  Slow (nothing overlaps) and only used when neither the pinned ring
-// nor a registration of the result's pages is available.  If even the 4 MB are refused, a BLOCKING hipMemcpy2D writes the
-// rows directly (the runtime's own staging; nothing is in flight when it returns).
+// one blocking pitched copy per buffer-full, memcpy out.  Slow (nothing overlaps) and only used when the pinned ring is not
+// available (refused, or rows wider than a ring slot).  Rows wider than the buffer travel in column pieces (round 5: they used to
+// fall through to the runtime).  Only if even the 4 MB are refused does a BLOCKING hipMemcpy2D write the rows directly (the
+// runtime's own staging; nothing is in flight when it returns, and no page of the result is registered anywhere).
 constexpr size_t BOUNCE_BYTES = (size_t)4 << 20;
 static std::mutex g_bounce_mu;
 static char *g_bounce = nullptr;
@@ -677,7 +597,7 @@ static int bounce_rows(const char *embp, size_t epitch, size_t eb, char *dst0, s
             g_bounce_failed = true;
         }
     }
-    const bool use_bounce = g_bounce && eb <= BOUNCE_BYTES && !(pope::g_fail_host_register & 4);
+    const bool use_bounce = g_bounce && !(pope::g_fail_host_register & 4);
     if (!use_bounce) {
         hipError_t e = hipStreamSynchronize(stream);
         if (e == hipSuccess)
@@ -688,17 +608,21 @@ static int bounce_rows(const char *embp, size_t epitch, size_t eb, char *dst0, s
         }
         return POPE_OK;
     }
-    const int64_t per = (int64_t)(BOUNCE_BYTES / eb);
-    for (int64_t r = r0; r < r1; r += per) {
-        const int64_t n = r + per < r1 ? per : r1 - r;
-        hipError_t e = epitch == eb ? hipMemcpyAsync(g_bounce, embp + (size_t)r * epitch, (size_t)n * eb, hipMemcpyDeviceToHost, stream)
-                                    : hipMemcpy2DAsync(g_bounce, eb, embp + (size_t)r * epitch, epitch, eb, (size_t)n, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) {
-            pope::set_error("D2H through the bounce buffer (rows %lld..%lld) failed: %s", (long long)r, (long long)(r + n), hipGetErrorString(e));
-            return POPE_ERR_HIP;
+    const size_t piece = eb < BOUNCE_BYTES ? eb : BOUNCE_BYTES;                // bytes of a row per pass (a whole row where it fits)
+    const int64_t per = (int64_t)(BOUNCE_BYTES / piece);
+    for (size_t c0 = 0; c0 < eb; c0 += piece) {
+        const size_t cb = c0 + piece < eb ? piece : eb - c0;
+        for (int64_t r = r0; r < r1; r += per) {
+            const int64_t n = r + per < r1 ? per : r1 - r;
+            hipError_t e = (epitch == eb && cb == eb) ? hipMemcpyAsync(g_bounce, embp + (size_t)r * epitch, (size_t)n * eb, hipMemcpyDeviceToHost, stream)
+                                                      : hipMemcpy2DAsync(g_bounce, cb, embp + (size_t)r * epitch + c0, epitch, cb, (size_t)n, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) {
+                pope::set_error("D2H through the bounce buffer (rows %lld..%lld) failed: %s", (long long)r, (long long)(r + n), hipGetErrorString(e));
+                return POPE_ERR_HIP;
+            }
+            for (int64_t i = 0; i < n; ++i) memcpy(dst0 + (size_t)(r + i) * dpitch + c0, g_bounce + (size_t)i * cb, cb);
         }
-        for (int64_t i = 0; i < n; ++i) memcpy(dst0 + (size_t)(r + i) * dpitch, g_bounce + (size_t)i * eb, eb);
     }
     return POPE_OK;
 }
@@ -719,49 +643,27 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
     const bool coded = lut_dev != nullptr;
     const size_t out_row = (size_t)(emb_row_bytes < 0 ? 0 : emb_row_bytes) * (coded ? sizeof(float) : 1);
     if (emb_row_bytes < 0 || (emb_row_bytes > 0 && (!emb || emb_pitch_bytes < emb_row_bytes)) || a.out_pitch < a.x_row + out_row ||
-        (coded && (!h->ring || emb_row_bytes == 0))) {
+        (coded && emb_row_bytes == 0)) {
         pope_assemble_abort(h);
-        pope::set_error(coded && !h->ring ? "pope_assemble_finish_codes: the hop-code transport needs the ring mode (POPE_KNOB_HOST_RESULT_MODE 0)"
-                                          : "pope_assemble_finish: null pointer or bad size");
+        pope::set_error("pope_assemble_finish: null pointer or bad size");
         return POPE_ERR_INVALID;
     }
     double tr[8] = {h->t_madvise, 0, 0, 0, 0, 0, 0, 0};
     const double t_begin = h->t_begin;
-    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
     char *out = a.out;
-    const size_t total = h->total;
     const int64_t rows = a.rows, x_row_bytes = (int64_t)a.x_row;
     const int nch = a.chunks;
     int rc = POPE_OK;
-    std::vector<std::pair<void *, size_t>> pinned;
-    const uintptr_t base = reinterpret_cast<uintptr_t>(out), pmask = (uintptr_t)(page - 1);
+    const uintptr_t base = reinterpret_cast<uintptr_t>(out);
     const size_t xb = (size_t)x_row_bytes, eb = (size_t)emb_row_bytes, pitch = a.out_pitch, epitch = (size_t)emb_pitch_bytes;
     const char *embp = static_cast<const char *>(emb);
-    auto S = [&](int64_t r) { return base + (uintptr_t)r * pitch + xb; };          // where row r's embedding columns start ...
-    auto T = [&](int64_t r) { return S(r) + eb; };                                  // ... and end
-    auto copy1d = [&](uintptr_t lo, uintptr_t hi, int64_t r) {                      // bytes [lo, hi) of row r's embedding columns
-        if (hi <= lo || rc != POPE_OK) return;
-        const hipError_t e = hipMemcpyAsync(reinterpret_cast<void *>(lo), embp + (size_t)r * epitch + (lo - S(r)), hi - lo, hipMemcpyDeviceToHost, stream);
-        if (e != hipSuccess) {
-            pope::set_error("hipMemcpyAsync(D2H, row %lld) failed: %s", (long long)r, hipGetErrorString(e));
-            rc = POPE_ERR_HIP;
-        }
-    };
-    auto copy2d = [&](int64_t r0, int64_t r1) {                                     // whole rows [r0, r1)
-        if (r1 <= r0 || rc != POPE_OK) return;
-        const hipError_t e = hipMemcpy2DAsync(reinterpret_cast<void *>(S(r0)), pitch, embp + (size_t)r0 * epitch, epitch, eb, (size_t)(r1 - r0),
-                                              hipMemcpyDeviceToHost, stream);
-        if (e != hipSuccess) {
-            pope::set_error("hipMemcpy2DAsync(D2H, rows %lld..%lld) failed: %s", (long long)r0, (long long)r1, hipGetErrorString(e));
-            rc = POPE_ERR_HIP;
-        }
-    };
-    // Ring mode (default): the embedding columns land in three 8 MB pinned slots allocated once per process, and the threads
-    // that copied the features copy each landed chunk out into the pageable result while the next one is on the bus.  No
-    // page of the result is ever registered, so nothing about the call depends on how the kernel driver handles pinning
-    // and unpinning a fresh quarter-gigabyte range (which made repeated calls erratic, 4 .. 18 ms).
+    auto S = [&](int64_t r) { return base + (uintptr_t)r * pitch + xb; };          // where row r's embedding columns start
+    // The embedding columns land in three 8 MB pinned slots allocated once per process, and the threads that copied the features
+    // copy each landed chunk out into the pageable result while the next one is on the bus.  No page of the result is ever
+    // registered, so nothing about the call depends on how the kernel driver handles pinning and unpinning a fresh
+    // quarter-gigabyte range (which made repeated calls erratic, 4 .. 18 ms, when round 3 tried it).
     bool ring_done = false;
-    if (h->ring && eb > 0 && eb <= RING_SLOT_BYTES) {
+    if (eb > 0 && eb <= RING_SLOT_BYTES) {
         std::unique_lock<std::mutex> lock(g_ring.mu);
         double t0 = now_ms();
         const bool usable = ring_usable_locked();
@@ -830,9 +732,9 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
             tr[4] = now_ms() - t0;
             ring_done = true;
         } else {
-            a.begin_embedding(0);                                                  // no ring: register the result's pages instead
+            a.begin_embedding(0);                                                  // no ring: the bounce buffer below
         }
-    } else if (h->ring) {
+    } else {
         a.begin_embedding(0);
     }
     if (coded && !ring_done) {
@@ -846,62 +748,14 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
         delete h;
         return rc;
     }
-    // Registered regions are page-aligned byte ranges [lo, hi) that follow one another; a DMA must stay inside ONE of them
-    // (the runtime rejects a destination that spans two registrations).  Region c ends behind chunk c's last row; whole rows
-    // inside it go as one pitched copy, and the one row whose embedding columns cross into the next region (row pitches
-    // are not multiples of the page size) is sent as two plain copies once both regions exist.
-    uintptr_t reg_hi = 0;
-    int64_t next_row = 0;                          // rows below have been enqueued
-    // Only pages that belong to the result ALONE are ever registered (round 4): the result must start on a page boundary (the
-    // library's own results are anonymous mappings: engine.host_result_tensor) and be at least 1 MB, and the last region ends at the
-    // last page boundary INSIDE it.  Registering the partial pages at the ends of a heap allocation registers whatever else lives
-    // on those pages -- other tensors, the allocator's and the runtime's own data; tests did that with torch heap tensors as small
-    // as 140 bytes, and every unexplained abort / GPU memory fault of rounds 3 and 4 came after such a test.
-    const uintptr_t reg_end = (base + total) & ~pmask;
-    bool registering = eb > 0 && !a.no_register && (base & pmask) == 0 && total >= ((size_t)1 << 20);
-    for (int c = 0; c < nch && rc == POPE_OK; ++c) {
-        double t0 = now_ms();
+    // No pinned ring (refused, or rows wider than a slot): wait for the feature copy, then stage the columns through the library's
+    // 4 MB pinned bounce buffer and copy them out in this thread.  The runtime never sees the result's pages.
+    for (int c = 0; c < nch; ++c) {
+        const double t1 = now_ms();
         while (a.done[(size_t)c].load(std::memory_order_acquire) < a.slices) std::this_thread::yield();
-        tr[1] += now_ms() - t0;
-        if (eb == 0 || !registering) continue;
-        const int64_t r1 = a.chunk_lo[(size_t)c + 1];
-        const uintptr_t lo = c == 0 ? base : reg_hi;
-        uintptr_t hi = c + 1 == nch ? reg_end : ((base + (uintptr_t)r1 * pitch + pmask) & ~pmask);
-        if (hi > reg_end) hi = reg_end;
-        if (hi <= lo) continue;
-        t0 = now_ms();
-        const hipError_t e = hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterDefault);
-        tr[2] += now_ms() - t0;
-        if (e != hipSuccess) {
-            (void)hipGetLastError();               // the rest goes through the runtime's own staging buffers: slower, same bytes
-            registering = false;
-            continue;
-        }
-        pinned.emplace_back(reinterpret_cast<void *>(lo), hi - lo);
-        reg_hi = hi;
-        t0 = now_ms();
-        if (next_row < rows && S(next_row) < lo) {                                  // the row that crosses from the previous region
-            copy1d(S(next_row), lo, next_row);
-            copy1d(lo, T(next_row), next_row);
-            ++next_row;
-        }
-        int64_t last = hi >= base + xb + eb ? (int64_t)((hi - base - xb - eb) / pitch) : -1;      // last row that ends inside the region
-        if (last >= rows) last = rows - 1;
-        if (last >= next_row) {
-            copy2d(next_row, last + 1);
-            next_row = last + 1;
-        }
-        tr[3] += now_ms() - t0;
+        tr[1] += now_ms() - t1;
     }
-    if (eb > 0 && next_row < rows && rc == POPE_OK) {                               // not registered: refused, switched off, or the tail behind the last whole page
-        // The rest of the rows lie in pageable memory the runtime holds no registration for.  Round 3 handed them to
-        // hipMemcpy2DAsync as they were (the runtime then pins such pages on the fly and may keep that mapping cached after
-        // the caller has freed or unmapped them: the one explanation that fits round 3's GPU memory fault at a host heap
-        // address).  Now they are staged through a pinned buffer of the library's own and copied out by
-        // this thread: the runtime never sees the result's pages.
-        rc = bounce_rows(embp, epitch, eb, reinterpret_cast<char *>(S(0)), pitch, next_row, rows, stream);
-        next_row = rows;
-    }
+    if (eb > 0) rc = bounce_rows(embp, epitch, eb, reinterpret_cast<char *>(S(0)), pitch, 0, rows, stream);
     double t0 = now_ms();
     pool.join();
     tr[4] = now_ms() - t0;
@@ -912,18 +766,6 @@ static int assemble_finish_impl(void *handle, const void *emb, int64_t emb_pitch
         pope::set_error("hipStreamSynchronize failed: %s", hipGetErrorString(es));
         rc = POPE_ERR_HIP;
     }
-    t0 = now_ms();
-    for (auto &p : pinned) {
-        const hipError_t eu = hipHostUnregister(p.first);
-        if (eu != hipSuccess) {                        // the pages stay registered: say so instead of leaving a stale registration behind silently
-            (void)hipGetLastError();
-            if (rc == POPE_OK) {
-                pope::set_error("hipHostUnregister(%p, %zu bytes) failed: %s -- the result's pages are still registered", p.first, p.second, hipGetErrorString(eu));
-                rc = POPE_ERR_HIP;
-            }
-        }
-    }
-    tr[6] = now_ms() - t0;
     tr[7] = now_ms() - t_begin;
     publish_trace(tr);
     delete h;

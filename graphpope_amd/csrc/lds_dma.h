@@ -27,18 +27,4 @@ __device__ __forceinline__ void sk_glds16_saddr(const float *base_uniform, unsig
                  : "=&s"(keep) : "v"(lane_byte_off), "s"(base_uniform), "s"(lds_wave_base) : "memory");
 }
 
-// The same, read at agent scope (sc1): the bytes were written through by another CU -- possibly behind another L2 -- earlier in the
-// SAME launch (gemm_tile16.h, WAIT), so neither this CU's L1 nor this XCD's L2 may answer from a line it holds.
-__device__ __forceinline__ void sk_glds16_saddr_agent(const float *base_uniform, unsigned lane_byte_off, unsigned lds_wave_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane_byte_off), "s"(base_uniform), "s"(lds_wave_base) : "memory");
-}
-
-__device__ __forceinline__ void sk_glds16_agent(const float *src, unsigned lds_wave_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds_wave_base) : "memory");
-}
-
 }  // namespace pope

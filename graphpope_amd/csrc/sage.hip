@@ -459,9 +459,7 @@ static int launch_gemm(const Operand &A0, const Operand &B0, int K0, const Opera
 extern int g_gemm_force_tile;          // pope_debug_set(POPE_KNOB_GEMM_TILE, ...) in geodesic.hip: 0 = automatic choice
 extern int g_gemm_small_tile16;        // POPE_KNOB_GEMM_SMALL_TILE16: 1 (default) = forward products too small for stream-K take 16 / 32-row whole tiles (layer 1: 14.4 us against 21)
 extern int g_sage_forward_overlap;     // pope_debug_set(POPE_KNOB_SAGE_FORWARD_OVERLAP, ...): 1 (default) gather beside half of the projection, 0 one after the other
-extern int g_gather_lds_pad_kb;        // pope_debug_set(POPE_KNOB_GATHER_LDS_PAD_KB, ...): occupancy experiment
 extern int g_gemm_tile16_buffers;     // pope_debug_set(POPE_KNOB_GEMM_TILE16_BUFFERS, ...)
-extern int g_gemm_split_bf16;         // pope_debug_set(POPE_KNOB_GEMM_SPLIT_BF16, ...): 1 = opt-in split-bf16 arithmetic in the whole-tile forward GEMM
 
 static long long tiles(int M, int N, int tm, int tn) { return (long long)((M + tm - 1) / tm) * ((N + tn - 1) / tn); }
 
@@ -588,24 +586,22 @@ static int gemm_streamk(const float *A0, const float *B0, int K0, const float *A
 }
 
 // ---- forward projection as whole tiles fitted to the chip (gemm_tile16.h): no partial tiles, no fix-up ----
-template <int RB, bool SPLIT, int NBUF>
+template <int RB, int NBUF>
 static int launch_tile16_as(const T16Args &a, int grid, hipStream_t stream) {
     static LdsOptIn opt_in;
     constexpr int lds = T16Shape<RB, NBUF>::LDS_BYTES;
     if (!opt_in.done()) {
-        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_tile16<RB, SPLIT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gemm_tile16<RB, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         opt_in.mark();
     }
-    hipLaunchKernelGGL((k_gemm_tile16<RB, SPLIT, NBUF>), dim3((unsigned)grid), dim3(T16_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((k_gemm_tile16<RB, NBUF>), dim3((unsigned)grid), dim3(T16_THREADS), lds, stream, a);
     return POPE_OK;
 }
 
-// POPE_KNOB_GEMM_SPLIT_BF16 = 1 (opt-in, off by default): the split-bf16 arithmetic of gemm_tile16.h instead of exact f32 products.
 // POPE_KNOB_GEMM_TILE16_BUFFERS: 3 or 4 stage buffers (gemm_tile16.h: one or two stage times to hide a request).
 template <int RB>
 static int launch_tile16(const T16Args &a, int grid, hipStream_t stream) {
-    if (g_gemm_split_bf16) return launch_tile16_as<RB, true, 3>(a, grid, stream);
-    return g_gemm_tile16_buffers == 4 ? launch_tile16_as<RB, false, 4>(a, grid, stream) : launch_tile16_as<RB, false, 3>(a, grid, stream);
+    return g_gemm_tile16_buffers == 4 ? launch_tile16_as<RB, 4>(a, grid, stream) : launch_tile16_as<RB, 3>(a, grid, stream);
 }
 
 // A whole-tile product ready to launch: arguments, tile height and grid; ok = false if the shape does not fit the chip well
@@ -637,7 +633,7 @@ static int t16_plan(const float *A0, const float *B0, int K0, const float *A1, c
     a.p[0] = SkProduct{A0, B0, lda, ldb, K0};
     a.p[1] = SkProduct{K1 > 0 ? A1 : A0, K1 > 0 ? B1 : B0, lda, ldb, K1};
     a.M = M; a.N = N; a.bias = bias; a.C = C; a.ldc = ldc; a.zero = zero_page[dev]; a.m_dev = m_dev;
-    a.rows = nullptr; a.accumulate = 0; a.done = nullptr; a.fail = nullptr;
+    a.rows = nullptr; a.accumulate = 0;
     a.tiles_m = (M + 16 * rb - 1) / (16 * rb); a.tiles_n = (N + T16_TN - 1) / T16_TN;
     a.S0 = (K0 + T16_GK - 1) / T16_GK; a.S1 = (K1 + T16_GK - 1) / T16_GK;
     plan->grid = a.tiles_n == 2 ? (a.tiles_m + 7) / 8 * 16 : a.tiles_m * a.tiles_n;
@@ -698,17 +694,7 @@ struct GatherArgs {
     const long long *n_id;
     float *x_dst;
     const int *n_dst_dev;
-    int *done;                 // fused launch (forward_fused): done[i / tile_rows] += 1 once row i of agg is visible to every CU; else nullptr
-    int tile_rows;
 };
-
-// A 16-byte store that is written through to memory at once (the agent-scope form, as a relaxed atomic store at that scope
-// would be): blocks on other XCDs -- behind other L2s -- read the row in the same launch.
-typedef float sage_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16_agent(float4 *p, const float4 &v) {
-    const sage_f32x4 t = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(t) : "memory");
-}
 
 // Only one or two of these blocks fit a CU beside the GEMM role's LDS, so what k_gather_mean hides behind occupancy is
 // hidden here by a pipeline over the rows of a wave: while row j's data is in flight the wave loads rowptr of row j + 3, the
@@ -717,7 +703,6 @@ __device__ __forceinline__ void store16_agent(float4 *p, const float4 &v) {
 // formed in k_gather_mean's order (a short last group re-reads the last neighbour with weight 0: v * 1 and s + v * 0 are
 // exact), so agg is bit for bit the same.  Rows with more than 64 neighbours take the plain loop.  (s_setprio 3 for this role:
 // measured, no difference.)
-template <bool FUSED>
 __device__ __forceinline__ void gather_role(const GatherArgs &g, const int block, const int nblocks) {
     const int lane = threadIdx.x & 63;
     const int wave = block * (T16_THREADS / 64) + (threadIdx.x >> 6), nwaves = nblocks * (T16_THREADS / 64);
@@ -727,21 +712,11 @@ __device__ __forceinline__ void gather_role(const GatherArgs &g, const int block
     int b1 = 0, e1 = 0, b2 = 0, e2 = 0, c1 = 0;
     long long id0 = 0, own0 = 0;
     int b0 = 0, e0 = 0;
-    int published = -1;                                                // fused launch: the last row whose stores are out but not yet counted
-    // Counting a row needs its stores complete (s_waitcnt vmcnt(0)).  Right behind the stores that is a store round trip per row;
-    // one row later, between that row's last load and its first store, everything older has long completed and the wait is free.
-    auto publish = [&]() {
-        if (published < 0) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(g.done + (published / g.tile_rows) * T16_DONE_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        published = -1;
-    };
     auto rowptr_pair = [&](int i, int &b, int &e) {
         if (i < n_dst) { b = g.rowptr[i]; e = g.rowptr[i + 1]; } else { b = e = 0; }
     };
     auto neighbour = [&](int b, int e) { return b + lane < e && lane < 64 ? g.col[b + lane] : 0; };
     auto source = [&](int c) { return g.n_id ? g.n_id[c] : (long long)c; };
-    if (FUSED && (threadIdx.x >> 6) == 0) T16_STAMP(4);
     // prologue: fill the pipeline for the wave's first three rows
     rowptr_pair(wave, b0, e0);
     rowptr_pair(wave + nwaves, b1, e1);
@@ -800,13 +775,11 @@ __device__ __forceinline__ void gather_role(const GatherArgs &g, const int block
                         s[k].x += v[t][k].x * w[t]; s[k].y += v[t][k].y * w[t]; s[k].z += v[t][k].z * w[t]; s[k].w += v[t][k].w * w[t];
                     }
             }
-            if constexpr (FUSED) publish();
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (!ok[k]) continue;
                 s[k].x *= inv; s[k].y *= inv; s[k].z *= inv; s[k].w *= inv;
-                if constexpr (FUSED) store16_agent(reinterpret_cast<float4 *>(g.agg + (size_t)i * C) + q[k], s[k]);
-                else reinterpret_cast<float4 *>(g.agg + (size_t)i * C)[q[k]] = s[k];
+                reinterpret_cast<float4 *>(g.agg + (size_t)i * C)[q[k]] = s[k];
             }
             if (g.x_dst) {                                                 // the destination's own row: requested after the neighbour loop, so that
                 const float4 *own = reinterpret_cast<const float4 *>(g.x + (size_t)own0 * C);      // it does not hold twelve registers across it
@@ -817,103 +790,32 @@ __device__ __forceinline__ void gather_role(const GatherArgs &g, const int block
                 if (ok[2]) dst[q[2]] = o2;
             }
         }
-        if constexpr (FUSED) published = i;
         // advance the pipeline
         b0 = b1; e0 = e1; id0 = id1; own0 = own1;
         b1 = b2; e1 = e2; c1 = c2;
         b2 = b3; e2 = e3;
     }
-    if constexpr (FUSED) publish();
-    if (FUSED && (threadIdx.x >> 6) == 0) T16_STAMP(5);
 }
 
 // (registers are allotted per kernel, not per role: at the GEMM role's 138 a gather block's two extra waves per SIMD would not fit
 //  beside a GEMM block -- 4 x 144 > 512 -- and the roles ran one after the other: 62 + 45 us.  Hence four waves per SIMD.)
-template <int RB, bool FUSED>
+template <int RB>
 __global__ __launch_bounds__(T16_THREADS, 4) void k_gather_beside_gemm(T16Args a, GatherArgs g, int gemm_blocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < gemm_blocks) t16_block_loop<RB, false, FUSED>(a, smem, (int)blockIdx.x, gemm_blocks);
-    else gather_role<FUSED>(g, (int)blockIdx.x - gemm_blocks, (int)gridDim.x - gemm_blocks);
+    if ((int)blockIdx.x < gemm_blocks) t16_block_loop<RB>(a, smem, (int)blockIdx.x, gemm_blocks);
+    else gather_role(g, (int)blockIdx.x - gemm_blocks, (int)gridDim.x - gemm_blocks);
 }
 
-// ---- the fused form (round 4): ONE launch does the whole layer ----
-// The GEMM role runs both products in one pass of a tile (x_dst W_r^T first: it needs nothing from this launch) and its loader
-// waves wait, tile by tile, until the gather role has counted that tile's rows of agg as written (T16Args::done).  The gather role
-// walks the rows in order, so early tiles never wait and the launch ends about one half-tile of MFMA work after the last row
-// lands -- instead of a second launch that does all of agg W_l^T behind the gather.  Both roles are resident together (two
-// blocks per CU, checked on the host) and the gather role waits for nothing, so the waits end; they are bounded all the same,
-// and k_fwd_guard behind the launch redoes the layer in one ordinary pass if one ever timed out, and leaves the counters zero
-// for the next call.  Counters live in library memory, one slot per (device, stream): calls on one stream are ordered, calls on
-// different streams use different slots (no free slot: the two-launch form).
-constexpr int FWD_SLOTS = 8, FWD_MAX_TILES = 2048, FWD_AUX = 64;
-static __device__ int g_fwd_sync[FWD_SLOTS][FWD_MAX_TILES * T16_DONE_STRIDE + FWD_AUX];      // [tiles: rows done, a line each][fail, ticket]
-
-struct FwdSlot { int *done, *fail, *ticket; };
-
-static int fwd_slot(hipStream_t stream, FwdSlot *out, bool *ok) {
-    static std::mutex mu;
-    static struct { int dev; hipStream_t stream; bool used; } table[64][FWD_SLOTS];
-    static int *base[64];
-    *ok = false;
-    int dev = 0;
-    POPE_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return POPE_OK;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!base[dev]) POPE_HIP(hipGetSymbolAddress((void **)&base[dev], HIP_SYMBOL(g_fwd_sync)));
-    int slot = -1;
-    for (int i = 0; i < FWD_SLOTS && slot < 0; ++i)
-        if (table[dev][i].used && table[dev][i].stream == stream) slot = i;
-    for (int i = 0; i < FWD_SLOTS && slot < 0; ++i)
-        if (!table[dev][i].used) {
-            table[dev][i].used = true;
-            table[dev][i].stream = stream;
-            slot = i;
-        }
-    if (slot < 0) return POPE_OK;
-    out->done = base[dev] + (size_t)slot * (FWD_MAX_TILES * T16_DONE_STRIDE + FWD_AUX);
-    out->fail = out->done + FWD_MAX_TILES * T16_DONE_STRIDE;
-    out->ticket = out->fail + 1;
-    *ok = true;
-    return POPE_OK;
-}
-
-// Behind the fused launch: zero the row counters; if a wait timed out (never seen), do the whole layer again as an ordinary
-// one-pass product (everything it reads is complete by now).  The last block out clears the flag.
+// (Round 4 built the layer as ONE launch -- the projection's tiles waiting, inside the launch, for their rows of the aggregate: 124-127 us
+//  against 114-119 for these two launches; removed in round 5.)
 template <int RB>
-__global__ __launch_bounds__(T16_THREADS) void k_fwd_guard(T16Args a, int *done, int n_done, int *fail, int *ticket) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int failed;
-    if (threadIdx.x == 0) failed = *fail;
-    for (int t = (int)(blockIdx.x * T16_THREADS + threadIdx.x); t < n_done; t += (int)(gridDim.x * T16_THREADS)) done[t * T16_DONE_STRIDE] = 0;
-    __syncthreads();
-    if (failed) t16_block_loop<RB, false>(a, smem, (int)blockIdx.x, (int)gridDim.x);
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
-        *fail = 0;
-        *ticket = 0;
-    }
-}
-
-template <int RB>
-static int launch_fwd_guard(const T16Args &a, int grid, const FwdSlot &slot, hipStream_t stream) {
-    static LdsOptIn opt_in;
-    if (!opt_in.done()) {
-        POPE_HIP(hipFuncSetAttribute((const void *)k_fwd_guard<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, T16Shape<RB>::LDS_BYTES));
-        opt_in.mark();
-    }
-    hipLaunchKernelGGL(k_fwd_guard<RB>, dim3((unsigned)grid), dim3(T16_THREADS), T16Shape<RB>::LDS_BYTES, stream, a, slot.done, a.tiles_m, slot.fail,
-                       slot.ticket);
-    return POPE_OK;
-}
-
-template <int RB, bool FUSED = false>
 static int launch_gather_beside_gemm(const T16Args &a, const GatherArgs &g, int gemm_blocks, int gather_blocks, hipStream_t stream) {
     static LdsOptIn opt_in;
     if (!opt_in.done()) {
-        POPE_HIP(hipFuncSetAttribute((const void *)k_gather_beside_gemm<RB, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, T16Shape<RB>::LDS_BYTES));
+        POPE_HIP(hipFuncSetAttribute((const void *)k_gather_beside_gemm<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, T16Shape<RB>::LDS_BYTES));
         opt_in.mark();
     }
-    hipLaunchKernelGGL((k_gather_beside_gemm<RB, FUSED>), dim3((unsigned)(gemm_blocks + gather_blocks)), dim3(T16_THREADS), T16Shape<RB>::LDS_BYTES, stream, a, g,
+    hipLaunchKernelGGL((k_gather_beside_gemm<RB>), dim3((unsigned)(gemm_blocks + gather_blocks)), dim3(T16_THREADS), T16Shape<RB>::LDS_BYTES, stream, a, g,
                        gemm_blocks);
     return POPE_OK;
 }
@@ -924,7 +826,7 @@ static int forward_overlapped(const int32_t *rowptr, const int32_t *col, int64_t
                               const long long *n_id, float *x_dst, float *agg, const float *w_l, const float *b_l, const float *w_r,
                               int32_t c_out, float *out, const int32_t *dims, hipStream_t stream, bool *used) {
     *used = false;
-    if (g_sage_forward_overlap == 0 || g_gemm_split_bf16) return POPE_OK;
+    if (g_sage_forward_overlap == 0) return POPE_OK;
     if (!streamk_shape_ok(n_dst, c_in, c_in, c_out) || !aligned16(x) || !aligned16(agg) || (x_dst && !aligned16(x_dst))) return POPE_OK;
     T16Plan first, second;
     int rc = t16_plan(x, w_r, c_in, nullptr, nullptr, 0, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, dims, &first, x_rows);
@@ -938,37 +840,7 @@ static int forward_overlapped(const int32_t *rowptr, const int32_t *col, int64_t
     if ((rc = device_cu_count(&cus))) return rc;
     const int gemm_blocks = first.a.tiles_n == 2 ? std::min(first.grid, (cus + 15) / 16 * 16) : std::min(first.grid, cus);
     const int gather_blocks = cus;                                  // one per CU, beside its GEMM block (2-6 per CU measured: 2-10 us slower -- the row pipeline wants rows)
-    if (g_sage_forward_overlap == 2 && first.a.S0 >= 2 && first.a.tiles_m <= FWD_MAX_TILES && gemm_blocks + gather_blocks <= 2 * cus) {
-        FwdSlot slot;
-        bool have = false;
-        if ((rc = fwd_slot(stream, &slot, &have))) return rc;
-        if (have) {
-            T16Args whole = first.a;                                // x_dst W_r^T (through n_id) + agg W_l^T + b in one pass
-            whole.p[1] = second.a.p[0];
-            whole.S1 = second.a.S0;
-            T16Args fused = whole;
-            fused.done = slot.done;
-            fused.fail = slot.fail;
-            const GatherArgs gf{rowptr, col, (int)n_dst, x, c_in, agg, n_id, x_dst, dims, slot.done, 16 * first.rb};
-            switch (first.rb) {
-            case 3: rc = launch_gather_beside_gemm<3, true>(fused, gf, gemm_blocks, gather_blocks, stream); break;
-            case 4: rc = launch_gather_beside_gemm<4, true>(fused, gf, gemm_blocks, gather_blocks, stream); break;
-            default: rc = launch_gather_beside_gemm<5, true>(fused, gf, gemm_blocks, gather_blocks, stream); break;
-            }
-            if (rc) return rc;
-            const int guard_blocks = std::min(gemm_blocks, 64);
-            switch (first.rb) {
-            case 3: rc = launch_fwd_guard<3>(whole, guard_blocks, slot, stream); break;
-            case 4: rc = launch_fwd_guard<4>(whole, guard_blocks, slot, stream); break;
-            default: rc = launch_fwd_guard<5>(whole, guard_blocks, slot, stream); break;
-            }
-            if (rc) return rc;
-            POPE_HIP(hipGetLastError());
-            *used = true;
-            return POPE_OK;
-        }
-    }
-    const GatherArgs g{rowptr, col, (int)n_dst, x, c_in, agg, n_id, x_dst, dims, nullptr, 0};
+    const GatherArgs g{rowptr, col, (int)n_dst, x, c_in, agg, n_id, x_dst, dims};
     switch (first.rb) {
     case 3: rc = launch_gather_beside_gemm<3>(first.a, g, gemm_blocks, gather_blocks, stream); break;
     case 4: rc = launch_gather_beside_gemm<4>(first.a, g, gemm_blocks, gather_blocks, stream); break;
@@ -1113,12 +985,11 @@ static void enqueue_gather_mean(const int32_t *rowptr, const int32_t *col, int64
                                 float *agg, hipStream_t stream, const int64_t *n_id = nullptr, float *x_dst = nullptr,
                                 const int32_t *n_dst_dev = nullptr) {
     dim3 grid(capped_grid((size_t)n_dst * 64, 256));
-    const size_t lds_pad = (size_t)g_gather_lds_pad_kb << 10;       // diagnostic: reserve LDS to cap the kernel's occupancy
     if ((c_in & 3) == 0 && aligned16(x_src) && aligned16(agg) && (!x_dst || aligned16(x_dst)))
-        hipLaunchKernelGGL(k_gather_mean<true>, grid, dim3(256), lds_pad, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
+        hipLaunchKernelGGL(k_gather_mean<true>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
                            (const long long *)n_id, x_dst, n_dst_dev);
     else
-        hipLaunchKernelGGL(k_gather_mean<false>, grid, dim3(256), lds_pad, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
+        hipLaunchKernelGGL(k_gather_mean<false>, grid, dim3(256), 0, stream, rowptr, col, (int)n_dst, x_src, c_in, agg,
                            (const long long *)n_id, x_dst, n_dst_dev);
 }
 
@@ -1194,13 +1065,9 @@ extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *c
     return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream, Twin{Operand{nullptr, 0, 0}, nullptr, 0}, dyn);
 }
 
-namespace pope { int g_sage_lanes = 0; }     // pope_debug_set(POPE_KNOB_SAGE_LANES): 1 = bias gradient and grad_x chain on side streams (measured: slower)
-
-// The three results of the backward pass only share grad_out.  POPE_KNOB_SAGE_LANES = 1 runs the bias gradient (two short
-// launches) and the grad_x chain (zero the scatter-only rows, grad_out * [W_r | W_l], scatter) on side streams beside the
-// weight gradients, forked and joined inside the call.  Measured on the Flickr-shaped step (tools/sage_step_ab.py): 0.449 ms
-// against 0.378 ms on one stream -- the persistent stream-K kernel deals its units out statically, so CUs that start late
-// because a side kernel sits on them delay the whole launch, and every fork / join is two cross-stream dependencies.  Off.
+// (Round 3 measured the bias gradient and the grad_x chain on side streams beside the weight gradients: 0.449 ms against 0.378 ms on
+//  one stream -- every fork / join is two cross-stream dependencies and a side kernel on a CU delays the statically dealt stream-K
+//  launch; removed in round 5.)
 // x_rows == nullptr: x_src holds the block's source rows (the destinations first).  Otherwise the destination rows are
 // x_src[x_rows[i]] (the resident feature matrix read through n_id) and x_tmp is room for them as a matrix, used only by the
 // kernel paths that cannot follow the index.
@@ -1219,15 +1086,12 @@ static int conv_backward_impl(const int32_t *rowptr, const int32_t *col, int64_t
     const Operand none{nullptr, 0, 0};
     int rc;
 
-    SideLanes lanes;
-    const bool side = g_sage_lanes != 0 && (grad_b_l || grad_x);
-    if (side && (rc = lanes.fork(stream, SIDE_LANES))) return rc;
-    hipStream_t s_bias = side ? lanes.lane(0) : stream, s_x = side ? lanes.lane(1) : stream;
+    hipStream_t s_bias = stream, s_x = stream;
 
     // grad_w_l[o, c] = sum_i grad_out[i, o] * agg[i, c];  grad_w_r likewise with x_dst   (depth = rows i)
     bool used = false;
     const bool colsum_vec = (c_out & 3) == 0 && aligned16(grad_out);
-    const bool bias_with_gemm = grad_b_l && !side;               // the bias gradient's two stages travel with the stream-K launches
+    const bool bias_with_gemm = grad_b_l != nullptr;             // the bias gradient's two stages travel with the stream-K launches
     if ((rc = gemm_streamk_tn(grad_out, agg, x_src, n_dst, c_out, c_in, grad_w_l, grad_w_r, slab, slab_bytes, stream, &used, n_dst_dev,
                               bias_with_gemm ? colsum : nullptr, grad_b_l, colsum_vec, x_rows))) return rc;
     const bool bias_done = used && bias_with_gemm;
@@ -1244,7 +1108,7 @@ static int conv_backward_impl(const int32_t *rowptr, const int32_t *col, int64_t
     // Small layer (the weight gradients did not qualify for the stream-K kernel) with an input gradient: the two twin GEMMs,
     // the zeroing of grad_x's scatter-only rows and the bias gradient's partial sums all read grad_out and nothing of one
     // another -- one launch (k_gemm_dual), then one launch for both reductions, then the scatter.
-    const bool dual = !used && grad_x && !side && g_gemm_force_tile == 0 && splits > 1 && grad_b_l && colsum_vec &&
+    const bool dual = !used && grad_x && g_gemm_force_tile == 0 && splits > 1 && grad_b_l && colsum_vec &&
                       pick_layout(G, (int)n_dst, c_out) == LAYOUT_KC_VEC && pick_layout(WrT, c_in, c_out) == LAYOUT_OC_VEC &&
                       pick_layout(WlT, c_in, c_out) == LAYOUT_OC_VEC && pick_layout(Gt, c_out, (int)n_dst) == LAYOUT_OC_VEC &&
                       pick_layout(AggT, c_in, (int)n_dst) == LAYOUT_OC_VEC && pick_layout(XdT, c_in, (int)n_dst) == LAYOUT_OC_VEC &&
@@ -1306,7 +1170,6 @@ static int conv_backward_impl(const int32_t *rowptr, const int32_t *col, int64_t
             hipLaunchKernelGGL(k_scatter_mean, dim3(capped_grid((size_t)n_dst * ((c_in + 255) / 256) * 64, 256)), dim3(256), 0, s_x, rowptr, col,
                                (int)n_dst, gagg, c_in, grad_x, n_dst_dev);
     }
-    if (side && (rc = lanes.join(stream))) return rc;
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }

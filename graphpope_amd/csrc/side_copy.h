@@ -27,27 +27,6 @@ class SideCopy {
     std::unique_lock<std::mutex> hold_;        // held from fork() until this object dies: the event pair is shared by the device's callers
 };
 
-// Fork / join of up to SIDE_LANES side streams per device for INDEPENDENT kernels of one call (sage_conv_backward: the
-// bias-gradient column sums and the grad_x chain beside the weight-gradient GEMM -- each a few launches of 5-15 us that
-// would otherwise queue up behind one another).  fork(): every lane waits for what `main` has enqueued so far; join():
-// `main` waits for every lane.  The same event pattern as SideCopy: it survives stream capture into a HIP graph, where
-// the lanes become parallel branches.
-constexpr int SIDE_LANES = 2;
-struct LaneSet;
-
-class SideLanes {
-  public:
-    int fork(hipStream_t main, int lanes);
-    hipStream_t lane(int i) const;
-    int join(hipStream_t main);
-    bool forked() const { return set_ != nullptr; }
-
-  private:
-    LaneSet *set_ = nullptr;
-    int lanes_ = 0;
-    std::unique_lock<std::mutex> hold_;
-};
-
 int enqueue_copy_features(const float *x, int32_t F, float *out, int64_t out_cols, int64_t N, hipStream_t stream);   // SideCopy's kernel on any stream
 
 extern int g_copy_batches_per_wave;            // pope_debug_set(POPE_KNOB_COPY_BATCHES)

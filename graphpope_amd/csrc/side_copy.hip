@@ -111,56 +111,4 @@ int SideCopy::join(hipStream_t main) {
     return POPE_OK;
 }
 
-// The events of a fork / join pair are taken from a ring: one call forks once, but a captured training step makes several
-// such calls, and every fork of a capture gets events of its own (re-recording an event that an earlier part of the same
-// capture still refers to is asking for trouble).
-constexpr int LANE_EVENT_SETS = 32;
-struct LaneSet {
-    std::mutex mu;
-    hipStream_t stream[SIDE_LANES] = {};
-    hipEvent_t fork[LANE_EVENT_SETS] = {}, join[LANE_EVENT_SETS][SIDE_LANES] = {};
-    int next = 0, cur = 0;
-    bool ready = false;
-};
-static LaneSet g_lanes[SIDE_MAX_DEVICES];
-
-int SideLanes::fork(hipStream_t main, int lanes) {
-    int dev = 0;
-    POPE_HIP(hipGetDevice(&dev));
-    POPE_REQUIRE(dev >= 0 && dev < SIDE_MAX_DEVICES && lanes >= 1 && lanes <= SIDE_LANES, "side lanes: device %d, %d lanes", dev, lanes);
-    LaneSet &s = g_lanes[dev];
-    {
-        std::lock_guard<std::mutex> once(g_side_create);
-        if (!s.ready) {
-            for (int i = 0; i < SIDE_LANES; ++i) POPE_HIP(hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking));
-            for (int e = 0; e < LANE_EVENT_SETS; ++e) {
-                POPE_HIP(hipEventCreateWithFlags(&s.fork[e], hipEventDisableTiming));
-                for (int i = 0; i < SIDE_LANES; ++i) POPE_HIP(hipEventCreateWithFlags(&s.join[e][i], hipEventDisableTiming));
-            }
-            s.ready = true;
-        }
-    }
-    hold_ = std::unique_lock<std::mutex>(s.mu);
-    set_ = &s;
-    lanes_ = lanes;
-    s.cur = s.next;
-    s.next = (s.next + 1) % LANE_EVENT_SETS;
-    POPE_HIP(hipEventRecord(s.fork[s.cur], main));
-    for (int i = 0; i < lanes; ++i) POPE_HIP(hipStreamWaitEvent(s.stream[i], s.fork[s.cur], 0));
-    return POPE_OK;
-}
-
-hipStream_t SideLanes::lane(int i) const { return set_->stream[i]; }
-
-int SideLanes::join(hipStream_t main) {
-    POPE_REQUIRE(set_, "side lanes: join before fork");
-    for (int i = 0; i < lanes_; ++i) {
-        POPE_HIP(hipEventRecord(set_->join[set_->cur][i], set_->stream[i]));
-        POPE_HIP(hipStreamWaitEvent(main, set_->join[set_->cur][i], 0));
-    }
-    set_ = nullptr;                      // the lanes are free for the next fork (of this or another caller)
-    hold_.unlock();
-    return POPE_OK;
-}
-
 }  // namespace pope

@@ -91,8 +91,10 @@ def stage_to_device(t: torch.Tensor, device, register: bool = True) -> torch.Ten
                 out = torch.empty(t.shape, dtype=t.dtype, device=device)
                 check(lib.pope_copy_to_device(ptr(t), ptr(out), nbytes, _stream()))
                 torch.cuda.current_stream().synchronize()          # the pages stay registered exactly as long as the DMA reads them
-        finally:
-            check(lib.pope_host_unpin(ptr(t)))                      # a refused release is an error: the pages would stay registered
+        except BaseException:
+            lib.pope_host_unpin(ptr(t))                             # the copy's own error is the one to report
+            raise
+        check(lib.pope_host_unpin(ptr(t)))                          # a refused release is an error: the pages would stay registered
         return out
     staged = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host_copy_2d(t.view(1, -1), staged.view(1, -1))
@@ -188,22 +190,15 @@ class HostAssembly:
     feature copy run underneath whatever happens between the two calls -- the upload of edge_index and the GPU work.
     Use as a context manager: an exception in between aborts the assembly (waits for the host threads)."""
 
-    def __init__(self, x: torch.Tensor | None, out: torch.Tensor, f: int, threads: int = 0, chunks: int = 0, mode: str | None = None,
-                 register: bool = True):
-        """mode: "ring" (the embedding columns through the process's pinned ring) or "registered" (the result's pages are
-        registered chunk by chunk); None: what the library's test knobs say.  register=False: never hand the result's pages to
-        hipHostRegister (columns staged through the library's bounce buffer)."""
+    def __init__(self, x: torch.Tensor | None, out: torch.Tensor, f: int, threads: int = 0, chunks: int = 0):
         lib = _lib.load()
         assert not out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.dim() == 2 and out.shape[1] >= f
         assert f == 0 or (x is not None and not x.is_cuda and x.dtype == torch.float32 and x.shape == (out.shape[0], f) and x.stride(1) == 1)
         self.out, self.x, self.f, self.handle = out, x, f, None        # x is kept alive until finish
         if out.shape[0] == 0:
             return
-        args = (ptr(x) if f else None, (x.stride(0) * 4) if f else 0, f * 4, ptr(out), out.shape[1] * 4, out.shape[0], threads or host_threads(), chunks)
-        if mode is None:
-            self.handle = lib.pope_assemble_begin(*args)
-        else:
-            self.handle = lib.pope_assemble_begin_mode(*args, {"ring": _lib.RESULT_RING, "registered": _lib.RESULT_REGISTERED}[mode], 0 if register else 1)
+        self.handle = lib.pope_assemble_begin(ptr(x) if f else None, (x.stride(0) * 4) if f else 0, f * 4, ptr(out), out.shape[1] * 4, out.shape[0],
+                                              threads or host_threads(), chunks)
         if not self.handle:
             raise _lib.PopeError(_lib.ERR_INVALID, lib.pope_last_error().decode())
 
@@ -220,7 +215,7 @@ class HostAssembly:
     def finish_codes(self, codes: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
         """:meth:`finish` for the embedding in its transport form (:func:`hop_codes`): uint8 [N, K] codes and the 256 floats
         they stand for, both on the device; a quarter of the bytes cross PCIe and the host threads look the floats up
-        (pope_assemble_finish_codes, ring mode only)."""
+        (pope_assemble_finish_codes; needs the process's pinned ring: pope_assemble_ring_ready)."""
         lib = _lib.load()
         n, k = codes.shape
         assert codes.is_cuda and codes.dtype == torch.uint8 and codes.stride(1) == 1 and self.out.shape == (n, self.f + k)

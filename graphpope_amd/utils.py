@@ -125,11 +125,12 @@ def _assemble_on_host(data, k, embedding_fn):
 
     out[:, :F] = data.x is copied host to host by a few threads (data.x never crosses PCIe); out[:, F:] = the device
     embedding (utils.py:129-135 torch.cat((data.x, embedding), 1)) comes over in 8 MB chunks through a ring of three pinned
-    slots allocated once per process, and the same threads copy each landed chunk out while the next is on the bus.
-    ``GRAPHPOPE_HOST_RESULT`` selects the other paths that were built and measured: ``registered`` (the result's own pages
-    are registered chunk by chunk and the DMA writes them directly -- 11.4 ms first call, but 4-18 ms on repeated calls,
-    the driver's pin/unpin of a fresh quarter gigabyte being erratic), ``staged`` (the runtime's own staging) and ``pinned``
-    (rounds 1-2: page-locked result).  On a FIRST call (fresh result pages) the assembly starts AFTER ``embedding_fn()`` has
+    slots allocated once per process, and the same threads copy each landed chunk out while the next is on the bus; without
+    the ring (allocation refused) the columns are staged through the library's 4 MB bounce buffer.  No page of the result is
+    ever handed to the HIP runtime.  ``GRAPHPOPE_HOST_RESULT=staged`` additionally keeps the caller's edge_index pages away from
+    hipHostRegister (the upload goes through pinned staging memory).  (Rounds 3-4 also had a ``registered`` mode -- the result's
+    own pages registered chunk by chunk, 11.4 ms first call and 4-18 ms on repeated calls -- and a ``pinned`` one; both were
+    slower and were removed in round 5.)  On a FIRST call (fresh result pages) the assembly starts AFTER ``embedding_fn()`` has
     uploaded edge_index and run the GPU work: sixteen threads faulting in a quarter gigabyte of huge pages beside it stalled the
     GPU queues for milliseconds (3.4-3.9 ms in a fresh process, 13-20 ms inside bench.py).  On a repeated call the pages come
     from the pool, nothing faults, and the feature copy runs underneath the upload and the GPU work."""
@@ -139,57 +140,29 @@ def _assemble_on_host(data, k, embedding_fn):
     x = _host_features(data)
     n, f = int(x.shape[0]), int(x.shape[1])
     mode = os.environ.get("GRAPHPOPE_HOST_RESULT", "ring")
-    if mode not in ("ring", "registered", "staged", "pinned"):
-        raise ValueError(f"GRAPHPOPE_HOST_RESULT={mode!r}: expected ring, registered, staged or pinned")
-    if mode == "ring":                                 # first call of a process: the pinned ring is allocated beside the GPU work
-        _lib_mod.load().pope_assemble_prepare(torch.cuda.current_device())
-    if mode == "pinned":                               # rounds 1-2: a page-locked result (fast when torch's host cache holds one, 34 ms when not)
-        emb_dev = embedding_fn().contiguous()
+    if mode not in ("ring", "staged"):
+        raise ValueError(f"GRAPHPOPE_HOST_RESULT={mode!r}: expected ring or staged")
+    _lib_mod.load().pope_assemble_prepare(torch.cuda.current_device())     # first call of a process: the pinned ring is allocated beside the GPU work
+    out, reused = engine.host_result_tensor(n, f + k, with_origin=True)
+    asm = None
+    try:
+        # pages from the pool (a repeated call): no page faults to take, so the feature copy may start now and run underneath
+        # the upload and the GPU work; fresh pages (the first call): the copy starts after the GPU work
+        if reused:
+            asm = engine.HostAssembly(x if f else None, out, f)
+        emb_dev = embedding_fn()                   # float32 [N, K], or (uint8 codes [N, K], float32 lut [256]): engine.hop_codes
+        coded = isinstance(emb_dev, tuple)
+        if not coded:
+            emb_dev = emb_dev.contiguous()
         t1 = _t.perf_counter()
-        out = torch.empty((n, f + k), dtype=torch.float32, pin_memory=True)
-        engine.copy_columns_to_host(emb_dev, out[:, f:])
-        if f:
-            engine.host_copy_2d(x, out[:, :f])
-        torch.cuda.current_stream().synchronize()
-        res = out
-    else:
-        out, reused = engine.host_result_tensor(n, f + k, with_origin=True)
-        # the transport is an ARGUMENT of this assembly (pope_assemble_begin_mode), not a process-global knob: concurrent callers
-        # with different choices do not meet.  "staged": nothing of the caller's is ever registered with the runtime.
-        asm_mode, register = ("ring" if mode == "ring" else "registered"), mode != "staged"
-        asm = None
-        prefault = None
-        try:
-            # pages from the pool (a repeated call): no page faults to take, so the feature copy may start now and run underneath
-            # the upload and the GPU work; fresh pages (the first call): the copy starts after the GPU work.  Opt-in (round 4,
-            # GRAPHPOPE_PREFAULT_THREADS = n > 0): n helper threads populate the fresh pages beside the GPU work -- measured
-            # SLOWER inside bench.py (6.4 ms -> 8.9 / 14.7 / 17.0 ms with 2 / 4 / 8 threads: page population beside the launches
-            # stalls the GPU queues of a large process, as the sixteen copy threads did in round 3), hence off by default
-            if reused and mode == "ring":
-                asm = engine.HostAssembly(x if f else None, out, f, mode=asm_mode, register=register)
-            elif not reused and out.numel() * 4 >= (8 << 20):
-                nthreads = int(os.environ.get("GRAPHPOPE_PREFAULT_THREADS", "0"))
-                if nthreads > 0:
-                    prefault = _lib_mod.load().pope_host_prefault_begin(out.data_ptr(), out.numel() * 4, nthreads)
-            emb_dev = embedding_fn()                   # float32 [N, K], or (uint8 codes [N, K], float32 lut [256]): engine.hop_codes
-            if prefault:
-                _lib_mod.load().pope_host_prefault_wait(prefault)
-                prefault = None
-            coded = isinstance(emb_dev, tuple)
-            if not coded:
-                emb_dev = emb_dev.contiguous()
-            assert not coded or mode == "ring"
-            t1 = _t.perf_counter()
-            if asm is None:
-                asm = engine.HostAssembly(x if f else None, out, f, mode=asm_mode, register=register)
-            with asm:
-                res = asm.finish_codes(*emb_dev) if coded else asm.finish(emb_dev)
-        except BaseException:
-            if prefault:
-                _lib_mod.load().pope_host_prefault_wait(prefault)
-            if asm is not None:
-                asm.__exit__(None, None, None)         # waits for the host threads of an assembly that will not be finished
-            raise
+        if asm is None:
+            asm = engine.HostAssembly(x if f else None, out, f)
+        with asm:
+            res = asm.finish_codes(*emb_dev) if coded else asm.finish(emb_dev)
+    except BaseException:
+        if asm is not None:
+            asm.__exit__(None, None, None)         # waits for the host threads of an assembly that will not be finished
+        raise
     if trace:
         import sys as _s
         print(f"[trace] upload + GPU {1e3 * (t1 - t0):.2f} ms, result assembly {1e3 * (_t.perf_counter() - t1):.2f} ms", file=_s.stderr)

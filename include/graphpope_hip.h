@@ -77,26 +77,20 @@ int pope_require_device(int32_t *cu_count_host);
  * Diagnostic knobs for A/B runs (tools/ab_*.py and the kernel-variant tests): process-global, not thread-safe, never
  * needed by a caller.  value < 0 restores the automatic choice where one exists.
  */
-#define POPE_KNOB_LIVE_MODE         0   /* level kernel: -1 auto, 0 no live-bit table, 1 table in LDS, 2 table in global memory */
-#define POPE_KNOB_FINALIZE_VARIANT  1   /* 1 (default) the pipelined finalise kernel (every load of a row in flight, next row requested before this one is stored, rows dealt round-robin); 5 the same with contiguous row blocks per wave; 7 the round 1-3 kernel (serial loops); 2 that kernel with non-temporal stores; 3 / 4 embedding columns and feature copy as two launches; 0 the generic kernel */
-#define POPE_KNOB_FINALIZE_BLOCKS   2   /* grid of the finalise kernel (default: 4096 blocks for the pipelined kernel, 2048 for the round 1-3 one)                   */
+#define POPE_KNOB_LIVE_MODE         0   /* level kernel: -1 auto (by graph size), 1 live-bit table staged in LDS, 2 table read from global memory, 3 global table behind a summary in LDS */
+#define POPE_KNOB_FINALIZE_VARIANT  1   /* 1 (default) the pipelined finalise kernels (every load of a row in flight, next row requested before this one is stored, rows dealt round-robin); 7 the round 1-3 kernel (serial loops); 0 the generic kernel -- kept so that tests can compare their bits */
+#define POPE_KNOB_FINALIZE_BLOCKS   2   /* grid of the finalise kernel (default: one work item per wave for the pipelined kernels, 2048 blocks for the round 1-3 one) */
 #define POPE_KNOB_GEMM_TILE         3   /* SAGE GEMM: 0 auto, 1 64x64, 2 64x128, 3 128x256 tiles, 4 / 5 stream-K without loader waves, 6 stream-K with stages of 64 in two 80 KB buffers, 7 stream-K instead of the chip-fitted whole tiles (gemm_tile16.h) */
-#define POPE_KNOB_COPY_BATCHES      5   /* node2vec embedding: 16-piece batches per wave of the feature-copy kernel beside the tile kernel (default 1) */
-#define POPE_KNOB_LEVEL_BLOCKS       6   /* level kernel: cap on the expand blocks of a launch (0 = one wave per 256-slot chunk, up to 2048 blocks)      */
-#define POPE_KNOB_FAIL_HOST_REGISTER 7  /* host -> host boundary, tests of the fallbacks, bit mask: 1 = every hipHostRegister is refused, 2 = behave as if the pinned ring's hipHostMalloc had been refused (float columns through registration / the bounce buffer), 4 = behave as if the 4 MB bounce buffer had been refused too (blocking copies by the runtime) */
-#define POPE_KNOB_SAGE_LANES        8   /* sage_conv_backward: 0 (default) one stream; 1 bias gradient and grad_x chain on side streams beside the weight gradients (measured slower) */
-#define POPE_KNOB_LEVEL_VARIANT     9   /* level kernel experiments, bit mask: 1 non-temporal index streams, 2 XCD-contiguous chunk ranges, 4 non-temporal reachability loads */
-#define POPE_KNOB_LEVEL_COPY        10  /* pope_geodesic_run: per mille of the feature rows that level launch l copies in its copy role beside the BFS blocks; value = l << 16 | per mille, l = 0 sets every launch */
-#define POPE_KNOB_HOST_RESULT_MODE  11  /* host -> host boundary: 0 (default) embedding columns through a reused pinned ring, 1 register the result's own pages for the DMA */
-#define POPE_KNOB_GEMM_SPLIT_BF16   12  /* SAGE forward projection, OPT-IN (default 0 = exact f32 products): 1 = every f32 operand as three bf16 terms, six bf16 MFMAs per product, f32 accumulate -- same accuracy class (~2^-24), not the same bits */
-#define POPE_KNOB_GATHER_LDS_PAD_KB 13  /* k_gather_mean: KB of LDS reserved per block (0): an occupancy experiment, 40 -> 16 waves per CU, 80 -> 8 */
-#define POPE_KNOB_SAGE_FORWARD_OVERLAP 14 /* sage_conv_forward(_indexed): 1 (default) the gather runs beside the x_dst half of the projection in one launch, the agg half follows; 0 gather, then the whole projection; 2 ONE launch: the projection's tiles wait, inside the launch, for their rows of the aggregate (measured slower) */
-#define POPE_KNOB_GEMM_SMALL_TILE16 15  /* SAGE forward products too small for stream-K: 1 (default) = whole tiles of 16 or 32 rows (gemm_tile16.h), 0 = the 64 x 64 tile kernel */
-#define POPE_KNOB_TAIL_LEVEL        16  /* pope_geodesic_run: first BFS level that runs inside the finalise kernel's launch (k_tail_finalize: a few blocks run the sparse last levels with a barrier among themselves while the others copy the features); 0 = every level is a launch of its own */
-#define POPE_KNOB_TAIL_BLOCKS       17  /* k_tail_finalize: number of its BFS blocks (default 256) */
-#define POPE_KNOB_PREPARE_MERGE     19  /* pope_geodesic_run: 1 (default) = the clear + seed of the BFS state and the speculative CSR build as two roles of ONE launch (k_prepare; at most 256 anchors per call); 0 = two launches */
-#define POPE_KNOB_GEMM_TILE16_BUFFERS 18 /* whole-tile forward GEMM: 4 (default) or 3 LDS stage buffers (two or one stage times to hide a request; same bits) */
 #define POPE_KNOB_PAIRWISE_KERNEL   4   /* node2vec embedding: 0 auto (anchor-resident persistent kernel for depths <= 128), 1 one tile per block, 2 / 3 persistent kernel with one / two consumer sets */
+#define POPE_KNOB_COPY_BATCHES      5   /* node2vec embedding: 16-piece batches per wave of the feature-copy kernel beside the tile kernel (default 1) */
+#define POPE_KNOB_FAIL_HOST_REGISTER 7  /* host -> host boundary, tests of the fallbacks, bit mask: 1 = every hipHostRegister is refused (edge_index then goes up through pinned staging), 2 = behave as if the pinned ring's hipHostMalloc had been refused (float columns through the bounce buffer), 4 = behave as if the 4 MB bounce buffer had been refused too (blocking copies by the runtime) */
+#define POPE_KNOB_SAGE_FORWARD_OVERLAP 14 /* sage_conv_forward(_indexed): 1 (default) the gather runs beside the x_dst half of the projection in one launch, the agg half follows; 0 gather, then the whole projection */
+#define POPE_KNOB_GEMM_SMALL_TILE16 15  /* SAGE forward products too small for stream-K: 1 (default) = whole tiles of 16 or 32 rows (gemm_tile16.h), 0 = the 64 x 64 tile kernel */
+#define POPE_KNOB_GEMM_TILE16_BUFFERS 18 /* whole-tile forward GEMM: 4 (default) or 3 LDS stage buffers (two or one stage times to hide a request; same bits) */
+#define POPE_KNOB_PREPARE_MERGE     19  /* pope_geodesic_run: 1 (default) = the clear + seed of the BFS state and the speculative CSR build as two roles of ONE launch (k_prepare; at most 256 anchors per call); 0 = two launches */
+/* (Knob numbers 6, 8-13, 16 and 17 belonged to experiments that were measured slower and removed in round 5 -- a copy role and block caps
+ * in the level launches, the last levels inside the finalise launch, side streams in the SAGE backward pass, split-bf16 products, the
+ * one-launch SAGE layer, the registered result mode: DESIGN.md keeps their figures.) */
 int pope_debug_set(int32_t knob, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------
@@ -187,8 +181,8 @@ int pope_kmeans_lloyd_step(const float *X, int64_t N, int32_t D, const float *ce
 /* Words per node for K anchors: ceil(K / 64) rounded up to 1, 2 or a multiple of 4. */
 int32_t pope_words(int32_t K);
 
-/* Bytes of one plane, and of the scratch pope_geodesic_bfs needs (two frontier planes, one word set per 64 CSR
- * slots, a small control block). */
+/* Bytes of one plane, and of the scratch pope_geodesic_bfs needs (a control block, the anchors, three rotating frontier planes,
+ * their three one-bit-per-node live tables and one summary of a live table). */
 size_t pope_plane_bytes(int64_t N, int32_t K);
 size_t pope_bfs_scratch_bytes(int64_t N, int64_t E, int32_t K);
 
@@ -240,6 +234,11 @@ int pope_geodesic_finalize(const uint64_t *planes, int32_t n_hop_bits, int64_t N
 int pope_geodesic_finalize_shards(const uint64_t *planes, int32_t n_shards, int64_t shard_stride_words, int32_t n_hop_bits,
                                   int64_t N, int32_t K_shard, const float *x, int32_t F, float *out, int64_t out_cols,
                                   void *stream);
+
+/* The name of the finalise kernel the three calls above and pope_geodesic_run launch for a shape, as a kernel trace shows it
+ * ("k_finalize_pipe<2, 1>", "k_finalize_wide<0>", ...), written into name[0 .. cap): lets a measurement label itself with the
+ * kernel that really ran (utils.py:129-135 is one torch.cat whatever the shape).  Aligned bases and row pitches assumed. */
+int pope_finalize_kernel_name(int64_t N, int32_t K_shard, int32_t F, int32_t has_x, int32_t n_shards, char *name, size_t cap);
 
 /*
  * The whole geodesic hot path in ONE call (what utils.py:137-147 does after sampling the anchors):
@@ -345,17 +344,13 @@ int pope_copy_2d_to_host(const void *src, int64_t src_pitch_bytes, void *dst_hos
  * The whole torch.cat((data.x, embedding), 1) of the host -> host call (utils.py:129-135) into an ORDINARY PAGEABLE
  * result, as the reference returns one: out[:, :x_row_bytes] = x_host rows (host threads, streaming stores) and
  * out[:, x_row_bytes : x_row_bytes + emb_row_bytes] = emb rows (DEVICE memory, DMA on `stream`, behind whatever produced
- * emb there).  Default (POPE_KNOB_HOST_RESULT_MODE 0): the embedding rows come over in 8 MB chunks through three pinned
- * slots that are allocated once per process, and the worker threads copy each landed chunk out while the next one is on
- * the bus -- no page of the result is ever registered.  Mode 1: the result is cut into `chunks` row chunks (<= 0: 8),
- * worker threads fill a chunk's feature columns (its first touch: MADV_HUGEPAGE is applied first), the calling thread
- * registers that chunk's pages with the HIP runtime and the pitched DMA writes them directly -- only for a result that starts on
- * a page boundary and is at least 1 MB (the library's own results are anonymous mappings), and only up to the last page boundary
- * inside it: pages the result shares with other objects are never registered, their rows take the bounce buffer; every registration is
- * released before the call returns (a release the runtime refuses is reported as POPE_ERR_HIP: the pages would stay
- * registered), and if a registration is refused the remaining rows are staged through a 4 MB pinned bounce buffer of the
- * library's own and copied out by the host (slower, same bytes; only if that buffer is refused as well does a blocking
- * copy by the runtime write the pageable rows).  `stream` is synchronised before the call returns.  x_row_bytes or emb_row_bytes may be 0.
+ * emb there).  The feature columns are filled by `threads` host threads over `chunks` row chunks (<= 0: 8; first touch:
+ * MADV_HUGEPAGE is applied first); the embedding rows come over in 8 MB chunks through three pinned slots that are allocated
+ * once per process, and the worker threads copy each landed chunk out while the next one is on the bus -- no page of the
+ * result is ever registered with the runtime.  If the pinned ring is refused (or a row is wider than a slot) the rows are staged
+ * through a 4 MB pinned bounce buffer of the library's own and copied out by the calling thread (slower, same bytes; only if
+ * that buffer is refused as well does a blocking copy by the runtime write the pageable rows).  `stream` is synchronised
+ * before the call returns.  x_row_bytes or emb_row_bytes may be 0.
  */
 int pope_assemble_host_result(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, const void *emb,
                               int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *out_host, int64_t out_pitch_bytes,
@@ -364,36 +359,19 @@ int pope_assemble_host_result(const void *x_host, int64_t x_pitch_bytes, int64_t
 /*
  * The same in two halves, so that the page faults and the feature copy run UNDERNEATH the upload of edge_index and the GPU
  * work: pope_assemble_begin starts the host threads on out[:, :x_row_bytes] = x_host and returns a handle (NULL + an error
- * message on bad arguments); pope_assemble_finish registers / DMAs the embedding columns as pope_assemble_host_result does,
+ * message on bad arguments); pope_assemble_finish brings the embedding columns down as pope_assemble_host_result does,
  * waits for everything and frees the handle (also when it fails).  pope_assemble_abort frees a handle that will not be finished.
  */
 void *pope_assemble_begin(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, void *out_host, int64_t out_pitch_bytes,
                           int64_t rows, int32_t threads, int32_t chunks);
-/* Fresh result pages faulted in beside the GPU work (the first host -> host call of a process; utils.py:134 allocates the result
- * with torch.cat): `threads` (<= 0: 4) helper threads populate [host, host + bytes) -- MADV_HUGEPAGE, then one
- * madvise(MADV_POPULATE_WRITE) per thread over disjoint 2 MB-aligned ranges (page touches on kernels without it) -- while the
- * caller uploads edge_index and runs the BFS.  _begin returns at once (NULL: nothing to do); _wait joins and frees the handle. */
-void *pope_host_prefault_begin(void *host, size_t bytes, int32_t threads);
-void pope_host_prefault_wait(void *handle);
-/* pope_assemble_begin takes the transport from the process-global test knobs (POPE_KNOB_HOST_RESULT_MODE, bit 0 of
- * POPE_KNOB_FAIL_HOST_REGISTER); pope_assemble_begin_mode takes it as ARGUMENTS, so that concurrent callers with different
- * choices do not meet in global state (utils.py:129-135; what graphpope_amd.utils calls): result_mode = POPE_RESULT_RING (the
- * embedding columns through the process's pinned ring) or POPE_RESULT_REGISTERED (the result's own pages are registered chunk
- * by chunk); no_register != 0: this assembly never hands the result's pages to hipHostRegister -- the columns are staged
- * through a small pinned bounce buffer of the library's own and copied out by the host, so the runtime never holds a
- * mapping of pageable memory that the caller will free or unmap later. */
-#define POPE_RESULT_RING       0
-#define POPE_RESULT_REGISTERED 1
-void *pope_assemble_begin_mode(const void *x_host, int64_t x_pitch_bytes, int64_t x_row_bytes, void *out_host, int64_t out_pitch_bytes,
-                               int64_t rows, int32_t threads, int32_t chunks, int32_t result_mode, int32_t no_register);
 int pope_assemble_finish(void *handle, const void *emb, int64_t emb_pitch_bytes, int64_t emb_row_bytes, void *stream);
 void pope_assemble_abort(void *handle);
 /* Optional, returns at once: the process's pinned ring (24 MB, 2 ms of hipHostMalloc) is allocated by a helper thread on
  * `device` (< 0: the thread's default), beside the caller's GPU work, instead of inside the first pope_assemble_finish. */
 void pope_assemble_prepare(int32_t device);
 /* 1 if pope_assemble_finish_codes can be used now (the pinned ring exists or could be allocated by this call), else 0 -- the
- * caller then brings float columns down with pope_assemble_finish, which registers the result's pages or uses the runtime's
- * staging.  Waits for an allocation that pope_assemble_prepare started. */
+ * caller then brings float columns down with pope_assemble_finish, which stages them through the bounce buffer.  Waits for an
+ * allocation that pope_assemble_prepare started. */
 int32_t pope_assemble_ring_ready(void);
 
 /*
@@ -401,7 +379,7 @@ int32_t pope_assemble_ring_ready(void);
  * pope_geodesic_hop_codes writes codes[v * pitch + j] = 0 if node v has no path to anchor j, hops + 1 otherwise, and the
  * 256 floats the bytes stand for (lut[0] = 0, lut[c] = 1 / c, the finalise kernel's own arithmetic) -- hop counts above 254
  * are refused (POPE_ERR_INVALID; use pope_geodesic_finalize).  pope_assemble_finish_codes is pope_assemble_finish for that
- * form (ring mode only): K code bytes per row cross PCIe -- a quarter of the float columns -- and the worker threads write
+ * form (it needs the pinned ring): K code bytes per row cross PCIe -- a quarter of the float columns -- and the worker threads write
  * out[:, x_row_bytes + 4 j] = lut[code] while they copy out of the ring; the host looks floats up, it computes none.
  */
 int pope_geodesic_hop_codes(const uint64_t *planes, int32_t n_hop_bits, int32_t max_hop, int64_t N, int32_t K, uint8_t *codes,

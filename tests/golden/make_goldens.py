@@ -198,6 +198,14 @@ def geodesic_fixtures():
     x, out = run_geodesic_with_anchors(ei, 6, anc)
     save_geodesic("noedges6", ei, 6, anc, x, out)
 
+    # 13 odd N with one 64-anchor word per node and depth >= 8: N * W is odd, so the planes' byte length is 8 mod 16 (a clear in
+    #    16-byte units must not skip the last word: the hop-bit-3 word of node N - 1); the last node is an anchor (hop 0 to itself)
+    n = 201
+    ei = both_ways([(i, i + 1) for i in range(n - 1)])
+    anc = [0, 200, 100, 7, 193, 200]
+    x, out = run_geodesic_with_anchors(ei, n, anc)
+    save_geodesic("path201_odd", ei, n, anc, x, out)
+
 
 def anchor_fixtures():
     """utils.py:22-24 under main.py:260's seed_everything(seed) -> np.random.seed(seed)."""

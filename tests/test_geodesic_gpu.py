@@ -124,14 +124,16 @@ def test_large_rmat_waves_loop_over_chunks(k, dev, oracle):
     assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), oracle.geodesic_hops(ei, n, anchors))
 
 
-@pytest.mark.parametrize("mode,k", [(-1, 70), (0, 70), (1, 70), (-1, 300)])
+@pytest.mark.parametrize("mode,k", [(-1, 70), (2, 70), (1, 70), (-1, 300), (2, 300), (-1, 600)])
 def test_graph_too_large_for_the_lds_live_table(mode, k, dev, oracle):
-    """More than 256 Ki nodes: the level kernel reads the live-bit table from global memory (k_bfs_level<WT, 2>);
-    mode 0 forces the table-less variant kept for A/B (tools/ab_live_mode.py), mode 1 must fall back the same way."""
+    """More than 256 Ki nodes: the level kernel reads the live-bit table from global memory behind a summary staged in LDS
+    (k_bfs_level<WT, 3>, built by k_live_summary between the launches; the default there); mode 2 forces the plain global table
+    (k_bfs_level<WT, 2>), mode 1 must fall back to the summary form.  k = 300 and 600: two and three 4-word tiles per node,
+    walked inside the wave."""
     from graphpope_amd import engine, synth, _lib
     ei, n = synth.rmat(19, edge_factor=3, seed=23)
     assert n > 256 * 1024
-    anchors = np.random.RandomState(5).choice(np.arange(n), k)        # k = 300: two 4-word tiles share the live bits
+    anchors = np.random.RandomState(5).choice(np.arange(n), k)        # k >= 300: several 4-word tiles share the live bits
     lib = _lib.load()
     _lib.check(lib.pope_debug_set(_lib.KNOB_LIVE_MODE, mode))
     try:
@@ -443,17 +445,15 @@ def test_general_csr_build_is_deterministic(dev):
 
 
 @pytest.mark.parametrize("mode,refuse,transport", [("ring", 0, "codes"), ("ring", 0, "float"), ("ring", 3, "codes"), ("ring", 2, "float"),
-                                                   ("registered", 0, "codes"), ("registered", 1, "codes"), ("staged", 0, "codes"), ("pinned", 0, "codes")],
-                         ids=["ring_codes", "ring_float", "nothing_can_be_pinned", "ring_refused_float", "registered", "registration_refused", "staged",
-                              "pinned"])
+                                                   ("ring", 6, "float"), ("staged", 0, "codes")],
+                         ids=["ring_codes", "ring_float", "nothing_can_be_pinned", "ring_refused_bounce", "ring_and_bounce_refused", "staged"])
 def test_host_to_host_call_returns_a_pageable_tensor_in_every_result_mode(mode, refuse, transport, dev, oracle, monkeypatch):
     """utils.py:129-147 from CPU tensors to a CPU tensor, at a size that takes the chunked paths (38 MB result: 4 chunks
-    through the 3-slot pinned ring, 8 registered chunks): ordinary pageable memory like the reference's torch.cat,
-    bit-exact, in the default ring mode, with the result's pages registered, and when the runtime refuses to register the
-    caller's pages (POPE_KNOB_FAIL_HOST_REGISTER bit 0: edge_index then goes through pinned staging, the embedding columns
-    through the runtime's own staging) or to allocate the pinned ring (bit 1: no byte transport, float columns through the
-    registered / staged path).
-    ``pinned`` is the rounds 1-2 behaviour (a page-locked result)."""
+    through the 3-slot pinned ring): ordinary pageable memory like the reference's torch.cat, bit-exact, in the default ring
+    mode, and when the runtime refuses to register the caller's pages (POPE_KNOB_FAIL_HOST_REGISTER bit 0: edge_index then goes
+    through pinned staging), to allocate the pinned ring (bit 1: no byte transport, float columns through the 4 MB bounce
+    buffer) or the bounce buffer as well (bit 2: a blocking copy by the runtime).  ``staged``: the caller's edge_index pages are
+    never registered either."""
     from graphpope_amd import _lib, synth, utils as gp
     lib = _lib.load()
     ei, n = synth.rmat(15, edge_factor=8, seed=5)
@@ -465,14 +465,14 @@ def test_host_to_host_call_returns_a_pageable_tensor_in_every_result_mode(mode, 
     d = Data()
     d.x, d.edge_index, d.num_nodes = x, torch.as_tensor(ei), n
     monkeypatch.setenv("GRAPHPOPE_HOST_RESULT", mode)
-    monkeypatch.setenv("GRAPHPOPE_HOST_TRANSPORT", transport)       # byte codes only travel in ring mode; the others send floats
+    monkeypatch.setenv("GRAPHPOPE_HOST_TRANSPORT", transport)       # byte codes only travel through the ring; without it: floats
     lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, refuse)
     try:
         for _ in range(2):                                    # the ring is reused by the second call
             gp.clear_cache()
             np.random.seed(7)
             out = gp.Graphpope(d, "flickr", "geodesic", "stochastic", k, None, 2)
-            assert out.device.type == "cpu" and out.is_contiguous() and out.is_pinned() == (mode == "pinned")
+            assert out.device.type == "cpu" and out.is_contiguous() and not out.is_pinned()
             want = oracle.geodesic_features(x.numpy(), ei, n, d.anchor_nodes)
             assert np.array_equal(out.numpy().view(np.uint32), want.view(np.uint32))
     finally:
@@ -496,21 +496,21 @@ def test_host_to_host_call_rejects_an_unknown_result_mode(dev, monkeypatch):
     gp.clear_cache()
 
 
-@pytest.mark.parametrize("register", [0, 1], ids=["ring", "registered"])
-def test_host_result_assembly_shapes(register, dev):
+@pytest.mark.parametrize("refuse", [0, 2, 6], ids=["ring", "bounce", "runtime_copy"])
+def test_host_result_assembly_shapes(refuse, dev):
     """pope_assemble_host_result on its own: no feature columns, one chunk, more chunks than rows, a strided x, and a result
-    of seven ring chunks with rows of 132 bytes (the ring wraps twice, chunks end inside rows' cache lines)."""
+    of seven ring chunks with rows of 132 bytes (the ring wraps twice, chunks end inside rows' cache lines) -- through the pinned
+    ring, through the 4 MB bounce buffer (the ring refused) and by the runtime's blocking copy (both refused); into heap tensors
+    and into page-aligned anonymous mappings like the ones Graphpope() returns.  No page of a result is ever registered."""
     from graphpope_amd import _lib, engine
     lib = _lib.load()
     g = torch.Generator().manual_seed(0)
-    lib.pope_debug_set(_lib.KNOB_HOST_RESULT_MODE, register)
+    lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, refuse)
     try:
         for n, f, k, chunks in ((5, 3, 4, 8), (40000, 0, 64, 8), (70001, 40, 36, 3), (3000, 700, 8, 0), (400003, 7, 33, 8)):
             emb = torch.rand(n, k, generator=g).to(dev)
             xw = torch.rand(n, f + 5, generator=g)
             x = xw[:, :f]                                     # row pitch larger than the row
-            # heap tensors (never registered: their end pages hold other objects -> the bounce buffer in registered mode) and
-            # page-aligned anonymous mappings like the ones Graphpope() returns (registered chunk by chunk in registered mode)
             for out in (torch.full((n, f + k), -1.0), engine.host_result_tensor(n, f + k)):
                 out.fill_(-1.0)
                 engine.assemble_host_result(x if f else None, emb, out, f, threads=4, chunks=chunks)
@@ -521,7 +521,20 @@ def test_host_result_assembly_shapes(register, dev):
         engine.assemble_host_result(None, emb, out, 0, threads=3, chunks=2)
         assert torch.equal(out, emb.cpu())
     finally:
-        lib.pope_debug_set(_lib.KNOB_HOST_RESULT_MODE, 0)
+        lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, 0)
+
+
+def test_host_result_rows_wider_than_the_ring_and_the_bounce_buffer(dev):
+    """Rows of 9 MB: wider than a slot of the pinned ring (8 MB) and than the bounce buffer (4 MB) -- the columns travel through
+    the bounce buffer in column pieces (round 5; they used to fall through to a copy by the runtime), next to 12 feature bytes."""
+    from graphpope_amd import engine
+    g = torch.Generator().manual_seed(1)
+    n, f, k = 3, 3, (9 << 20) // 4 + 5
+    emb = torch.rand(n, k, generator=g).to(dev)
+    x = torch.rand(n, f, generator=g)
+    out = torch.full((n, f + k), -1.0)
+    engine.assemble_host_result(x, emb, out, f, threads=2, chunks=0)
+    assert torch.equal(out[:, :f], x) and torch.equal(out[:, f:], emb.cpu())
 
 
 @pytest.mark.parametrize("k", [1, 37, 64, 200, 1024])
@@ -634,65 +647,40 @@ def test_concurrent_host_assemblies_take_turns_on_the_ring(dev):
     assert len(results) == 8
 
 
-@pytest.mark.parametrize("k", [40, 100, 256])
-def test_copy_role_of_the_level_launches_leaves_the_result_unchanged(dev, oracle, k):
-    """POPE_KNOB_LEVEL_COPY (round-4 experiment, off by default): level launch l copies a share of x's rows beside its BFS
-    blocks and the finalise kernel starts at the first row nobody took.  Shares that end before, at and beyond the number of
-    launches, on a poisoned output buffer: bit-exact against the oracle (utils.py:129-135)."""
-    from graphpope_amd import _lib, engine, synth
+def test_odd_plane_length_is_cleared_to_the_last_word(dev):
+    """N * W odd (N = 201, one 64-anchor word per node): the (1 + 4) eagerly cleared planes are 8 mod 16 bytes long, so a clear in
+    16-byte units stops one word short -- the hop-bit-3 word of node N - 1 (ADVICE r04).  The reference's golden (utils.py:64-81;
+    depth 200, node N - 1 is an anchor: hop 0) through every clearing path, each on memory filled with 0xFF: pope_geodesic_run with
+    the merged prepare launch and with the separate launches (reused workspace), and pope_geodesic_bfs on poisoned planes and
+    scratch (k_zero; the deep planes' clears start 8 bytes off a 16-byte boundary)."""
+    import ctypes
+    from graphpope_amd import _lib, engine
     lib = _lib.load()
-    ei, n = synth.rmat(12, edge_factor=8, seed=31)
-    eid = torch.as_tensor(ei, device=dev)
-    x = torch.rand(n, 20, device=dev)
-    anchors = np.random.RandomState(k).choice(np.arange(n), k)
-    want = oracle.geodesic_features(x.cpu().numpy(), ei, n, anchors)
+    g = load_golden(os.path.join(GOLDEN, "geodesic_path201_odd.npz"))
+    n, anchors = int(g["num_nodes"]), np.ascontiguousarray(g["anchors"], dtype=np.int64)
+    assert n % 2 == 1 and len(anchors) <= 64 and int(g["hops"].max()) >= 8
+    ei = torch.as_tensor(g["edge_index"].astype(np.int64), device=dev)
     try:
-        for shares in ({1: 100, 2: 250}, {0: 60}, {1: 700, 2: 700}, {3: 333, 14: 500}):
-            lib.pope_debug_set(_lib.KNOB_LEVEL_COPY, 0)
-            for level, pm in shares.items():
-                assert lib.pope_debug_set(_lib.KNOB_LEVEL_COPY, (level << 16) | pm) == 0
-            for _ in range(2):                                   # the second call runs the window the first one found
-                out = engine.geodesic_run(x, eid, n, anchors, reuse_workspace=True)[0]
-                assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), shares
-                out.fill_(float("nan"))
-                del out
+        for merge in (1, 0):
+            lib.pope_debug_set(_lib.KNOB_PREPARE_MERGE, merge)
+            engine.geodesic_run(None, ei, n, anchors, want_out=False, reuse_workspace=True)     # creates the workspace of this size
+            for _ in range(2):
+                for ws in engine._WORKSPACE.values():
+                    ws.fill_(0xFF)
+                _, hp = engine.geodesic_run(None, ei, n, anchors, want_out=False, reuse_workspace=True)
+                assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), g["hops"]), merge
     finally:
-        lib.pope_debug_set(_lib.KNOB_LEVEL_COPY, 0)
-
-
-@pytest.mark.parametrize("k", [40, 100, 256])
-@pytest.mark.parametrize("blocks", [8, 64])
-def test_tail_kernel_runs_the_last_levels_inside_the_finalise_launch(dev, oracle, k, blocks):
-    """POPE_KNOB_TAIL_LEVEL (round-4 experiment, off by default): levels T, T + 1, ... run in a few blocks of the finalise
-    kernel's launch with a barrier among themselves, the others copy x and wait for the verdict.  T inside, at the end of and
-    beyond the depth of the graph, with and without an output matrix, on a graph deeper than the 15 levels the kernel may run
-    (the host continues with level launches): bit-exact against the oracle (utils.py:64-81, 129-135)."""
-    from graphpope_amd import _lib, engine, synth
-    lib = _lib.load()
-    ei, n = synth.rmat(12, edge_factor=8, seed=37)
-    path = np.arange(40)                                          # a tail of 40 extra hops hanging off node 0
-    deep = np.concatenate([ei, np.stack([np.r_[0, n + path[:-1]], n + path]), np.stack([n + path, np.r_[0, n + path[:-1]]])], axis=1)
-    deep = np.ascontiguousarray(deep[:, np.lexsort((deep[1], deep[0]))])
-    try:
-        for graph, nn in ((ei, n), (deep, n + 40)):
-            eid = torch.as_tensor(graph, device=dev)
-            x = torch.rand(nn, 20, device=dev)
-            anchors = np.random.RandomState(k).choice(np.arange(nn), k)
-            want = oracle.geodesic_features(x.cpu().numpy(), graph, nn, anchors)
-            want_hops = oracle.geodesic_hops(graph, nn, anchors)
-            for t in (0, 2, 3, 5, 9, 14):
-                lib.pope_debug_set(_lib.KNOB_TAIL_LEVEL, t)
-                lib.pope_debug_set(_lib.KNOB_TAIL_BLOCKS, blocks)
-                for _ in range(2):
-                    out, hp = engine.geodesic_run(x, eid, nn, anchors, reuse_workspace=True)
-                    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (t, nn)
-                    out.fill_(float("nan"))
-                    del out
-                hp = engine.geodesic_run(None, eid, nn, anchors, want_out=False)[1]
-                assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), want_hops), (t, nn)
-    finally:
-        lib.pope_debug_set(_lib.KNOB_TAIL_LEVEL, 0)
-        lib.pope_debug_set(_lib.KNOB_TAIL_BLOCKS, 0)
+        lib.pope_debug_set(_lib.KNOB_PREPARE_MERGE, 1)
+    csr = engine.build_csr(ei, n)
+    k, cap = len(anchors), 8
+    planes = torch.full((cap + 1, n, lib.pope_words(k)), -1, dtype=torch.int64, device=dev)
+    scratch = torch.full((lib.pope_bfs_scratch_bytes(n, csr.num_edges, k),), 0xFF, dtype=torch.uint8, device=dev)
+    max_hop, bits = ctypes.c_int32(0), ctypes.c_int32(0)
+    _lib.check(lib.pope_geodesic_bfs(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(csr.erow), _lib.ptr(csr.aux), n, csr.num_edges,
+                                     ctypes.c_void_p(anchors.ctypes.data), k, _lib.ptr(planes), cap, _lib.ptr(scratch), scratch.numel(),
+                                     ctypes.byref(max_hop), ctypes.byref(bits), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    hp = engine.HopPlanes(planes, int(bits.value), int(max_hop.value), n, k)
+    assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), g["hops"])
 
 
 def test_one_prepare_launch_gives_the_same_bits(dev, oracle):
@@ -747,7 +735,8 @@ def test_pipelined_finalise_kernel_writes_the_same_bits(dev, f, k, shards):
     """The finalise kernel of round 4 (every load of a row in flight at once, the next row requested before this one is stored, rows
     dealt round-robin to the waves; utils.py:73, 129-135) against the round 1-3 kernel (POPE_KNOB_FINALIZE_VARIANT 7) on random
     planes: one and several shards, feature widths and anchor counts on both sides of every instance's limits (and beyond them,
-    where the old kernel takes over), both row orders -- the same bits, NaN-poisoned outputs."""
+    where the old kernel takes over) -- the same bits, NaN-poisoned outputs; and the library's own name for the kernel it picks
+    (pope_finalize_kernel_name, what bench.py labels its roofline entry with) follows the shape."""
     from graphpope_amd import _lib, engine
     lib = _lib.load()
     n, bits = 3001, 4
@@ -757,7 +746,7 @@ def test_pipelined_finalise_kernel_writes_the_same_bits(dev, f, k, shards):
     x = torch.rand((n, f), generator=g).to(dev) if f else None
     outs = []
     try:
-        for variant in (7, 1, 5):
+        for variant in (7, 1, 0):
             lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, variant)
             out = torch.full((n, f + shards * k), float("nan"), device=dev)
             if shards == 1:
@@ -769,3 +758,9 @@ def test_pipelined_finalise_kernel_writes_the_same_bits(dev, f, k, shards):
         lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 1)
     assert not torch.isnan(outs[0]).any()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    import ctypes
+    name = ctypes.create_string_buffer(64)
+    _lib.check(lib.pope_finalize_kernel_name(n, k, f, 1 if f else 0, shards, name, 64))
+    ne = k // 4 * shards
+    want = "k_finalize_fast" if f > 1024 else ("k_finalize_wide" if ne > 64 and k % 64 == 0 else "k_finalize_pipe")
+    assert name.value.decode().startswith(want), (name.value, want)

@@ -8,8 +8,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from graphpope_amd import _lib, engine, synth
 dev = engine.require_gpu()
-if os.environ.get("POPE_LEVEL_VARIANT"):          # POPE_KNOB_LEVEL_VARIANT experiments (lesson 12)
-    _lib.load().pope_debug_set(_lib.KNOB_LEVEL_VARIANT, int(os.environ["POPE_LEVEL_VARIANT"]))
 ei_np, n = synth.flickr_like()
 anchors = synth.seeded_anchors(n, 256, 42)
 csr = engine.build_csr(torch.as_tensor(ei_np, device=dev), n)

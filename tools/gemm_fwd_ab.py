@@ -19,10 +19,8 @@ for n_dst, c_in, c_out in shapes:
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     want = xd.double() @ wr.double().t() + b.double()          # agg = 0 for the empty block
     res = {}
-    for name, tile, split, small in (("auto", 0, 0, 0), ("split-bf16", 0, 1, 0), ("stream-K", 7, 0, 0), ("64x64", 1, 0, 0), ("small-tile16", 0, 0, 1),
-                                     ("auto", 0, 0, 0), ("split-bf16", 0, 1, 0), ("small-tile16", 0, 0, 1)):
+    for name, tile, small in (("auto", 0, 0), ("stream-K", 7, 0), ("64x64", 1, 0), ("small-tile16", 0, 1), ("auto", 0, 0), ("small-tile16", 0, 1)):
         lib.pope_debug_set(_lib.KNOB_GEMM_TILE, tile)
-        lib.pope_debug_set(_lib.KNOB_GEMM_SPLIT_BF16, split)
         lib.pope_debug_set(_lib.KNOB_GEMM_SMALL_TILE16, small)
         lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, 0)
         def run():
@@ -36,7 +34,6 @@ for n_dst, c_in, c_out in shapes:
         err = float((out.double() - want).abs().max())
         res.setdefault(name, []).append((ev[0].elapsed_time(ev[1]) / 20 * 1e3, err))
     lib.pope_debug_set(_lib.KNOB_GEMM_TILE, 0)
-    lib.pope_debug_set(_lib.KNOB_GEMM_SPLIT_BF16, 0)
     lib.pope_debug_set(_lib.KNOB_GEMM_SMALL_TILE16, 1)
     lib.pope_debug_set(_lib.KNOB_SAGE_FORWARD_OVERLAP, 1)
     xcat = torch.cat([aggb, xd], 1); wcat = torch.cat([wl, wr], 1)

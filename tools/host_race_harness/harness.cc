@@ -1,6 +1,7 @@
 // Drives graphpope_amd/csrc/host.cc (the host half of the host -> host boundary, utils.py:129-147) against fake_hip.cc:
-// the parked worker pool, the pinned-ring hand-off, the registered and the bounce transport, aborts, and two assemblies at
-// once -- every result compared with a plain reference.  Built by run.sh under -fsanitize=thread and -fsanitize=address.
+// the parked worker pool, the pinned-ring hand-off, the bounce transport (whole rows and column pieces of rows wider than the
+// buffer), the runtime's blocking copy behind it, aborts, and two assemblies at once -- every result compared with a plain reference;
+// no page of a result may ever be registered, and no asynchronous copy may target unpinned memory.  Built by run.sh under -fsanitize=thread and -fsanitize=address.
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -12,7 +13,7 @@
 #include "graphpope_hip.h"
 
 namespace pope {            // what abi.cpp / geodesic.hip provide in the real library
-int g_host_result_mode = 0, g_fail_host_register = 0;
+int g_fail_host_register = 0;
 static thread_local char g_error[512];
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -66,10 +67,9 @@ struct Case {
 
 enum How { FLOATS, CODES, ABORT };
 
-static void run_case(Case &c, int mode, int no_register, How how, int threads, void *stream, int delay_us = 0) {
-    if (getenv("HARNESS_VERBOSE")) fprintf(stderr, "case rows %lld f %d k %d mode %d no_register %d how %d threads %d stream %p\n", (long long)c.rows, c.f, c.k, mode, no_register, (int)how, threads, stream);
-    void *h = pope_assemble_begin_mode(c.f ? c.x.data() : nullptr, (int64_t)c.f * 4, (int64_t)c.f * 4, c.out.data(), (int64_t)(c.f + c.k) * 4, c.rows, threads, 0, mode,
-                                       no_register);
+static void run_case(Case &c, How how, int threads, void *stream, int delay_us = 0) {
+    if (getenv("HARNESS_VERBOSE")) fprintf(stderr, "case rows %lld f %d k %d refuse %d how %d threads %d stream %p\n", (long long)c.rows, c.f, c.k, pope::g_fail_host_register, (int)how, threads, stream);
+    void *h = pope_assemble_begin(c.f ? c.x.data() : nullptr, (int64_t)c.f * 4, (int64_t)c.f * 4, c.out.data(), (int64_t)(c.f + c.k) * 4, c.rows, threads, 0);
     CHECK(h != nullptr, "begin");
     if (!h) return;
     if (delay_us) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));    // the "GPU phase": the workers must sleep, not spin
@@ -80,7 +80,7 @@ static void run_case(Case &c, int mode, int no_register, How how, int threads, v
     int rc = how == CODES ? pope_assemble_finish_codes(h, c.codes.data(), c.k, c.k, c.lut, stream)
                           : pope_assemble_finish(h, c.emb.data(), (int64_t)c.k * 4, (int64_t)c.k * 4, stream);
     CHECK(rc == POPE_OK, "finish rc %d", rc);
-    CHECK(c.ok(), "result differs (rows %lld f %d k %d mode %d no_register %d how %d)", (long long)c.rows, c.f, c.k, mode, no_register, (int)how);
+    CHECK(c.ok(), "result differs (rows %lld f %d k %d refuse %d how %d)", (long long)c.rows, c.f, c.k, pope::g_fail_host_register, (int)how);
 }
 
 int main() {
@@ -88,48 +88,51 @@ int main() {
     for (int rep = 0; rep < 4; ++rep)
         for (int f : {500, 0, 3}) {
             Case a(30000 + 17 * rep, f, 256, 1 + rep), b(30000 + 17 * rep, f, 256, 7 + rep);
-            run_case(a, POPE_RESULT_RING, 0, FLOATS, 16, nullptr, rep ? 300 : 0);
-            run_case(b, POPE_RESULT_RING, 0, CODES, 16, nullptr, rep ? 300 : 0);
+            run_case(a, FLOATS, 16, nullptr, rep ? 300 : 0);
+            run_case(b, CODES, 16, nullptr, rep ? 300 : 0);
         }
-    // 2. registered transport: the result's pages registered chunk by chunk, everything released afterwards
-    {
-        Case a(40000, 500, 64, 11);
-        run_case(a, POPE_RESULT_REGISTERED, 0, FLOATS, 8, nullptr);
-        CHECK(fake_live_registrations() == 0, "%ld registrations left behind", fake_live_registrations());
-    }
-    // 3. no registration allowed: the bounce buffer; the runtime must never be given a pageable destination
+    CHECK(fake_live_registrations() == 0, "%ld pages of a result registered", fake_live_registrations());
+    // 2. the ring refused (knob bit 2): the bounce buffer -- whole rows, and rows wider than the 4 MB buffer in column pieces (also
+    //    wider than an 8 MB ring slot, so they take this path with the ring available too); the runtime must never be given a
+    //    pageable destination for an asynchronous copy, and nothing is registered
     {
         const long before = fake_unpinned_async_targets();
-        Case a(40000, 500, 64, 12), b(1000, 8, 1100, 13);
-        run_case(a, POPE_RESULT_REGISTERED, 1, FLOATS, 8, nullptr);
-        run_case(b, POPE_RESULT_REGISTERED, 1, FLOATS, 3, nullptr);
+        pope::g_fail_host_register = 2;
+        Case a(40000, 500, 64, 12), b(1000, 8, 1100, 13), wide(3, 2, (9 << 20) / 4 + 3, 17);
+        run_case(a, FLOATS, 8, nullptr);
+        run_case(b, FLOATS, 3, nullptr);
+        run_case(wide, FLOATS, 2, nullptr);
+        pope::g_fail_host_register = 0;
+        Case wide2(2, 0, (9 << 20) / 4 + 1, 18);
+        run_case(wide2, FLOATS, 2, nullptr);
         CHECK(fake_unpinned_async_targets() == before, "%ld asynchronous copies into unpinned, unregistered host memory", fake_unpinned_async_targets() - before);
-        pope::g_fail_host_register = 4;                        // even the bounce buffer refused: blocking copies
+        CHECK(fake_live_registrations() == 0, "%ld registrations left behind", fake_live_registrations());
+    }
+    // 3. ring and bounce buffer refused (bits 2 | 4): blocking copies by the runtime
+    {
+        pope::g_fail_host_register = 6;
         Case c(5000, 20, 40, 14);
-        run_case(c, POPE_RESULT_REGISTERED, 1, FLOATS, 4, nullptr);
+        run_case(c, FLOATS, 4, nullptr);
         pope::g_fail_host_register = 0;
     }
-    // 4. ring refused (knob bit 2): floats fall back to registration; codes are refused with an error, not a hang
+    // 4. codes without a ring are refused with an error, not a hang
     {
         pope::g_fail_host_register = 2;
-        Case a(20000, 100, 128, 15);
-        run_case(a, POPE_RESULT_RING, 0, FLOATS, 8, nullptr);
         Case b(20000, 100, 128, 16);
-        void *h = pope_assemble_begin_mode(b.x.data(), 400, 400, b.out.data(), (100 + 128) * 4, b.rows, 8, 0, POPE_RESULT_RING, 0);
+        void *h = pope_assemble_begin(b.x.data(), 400, 400, b.out.data(), (100 + 128) * 4, b.rows, 8, 0);
         CHECK(h && pope_assemble_finish_codes(h, b.codes.data(), 128, 128, b.lut, nullptr) == POPE_ERR_HIP, "codes without a ring must fail cleanly");
         pope::g_fail_host_register = 0;
-        CHECK(fake_live_registrations() == 0, "%ld registrations left behind", fake_live_registrations());
     }
     // 5. aborts: before any work, and with the workers asleep in the "GPU phase"
     for (int rep = 0; rep < 3; ++rep) {
         Case a(25000, 500, 256, 20 + rep);
-        run_case(a, POPE_RESULT_RING, 0, ABORT, 16, nullptr, rep * 200);
+        run_case(a, ABORT, 16, nullptr, rep * 200);
     }
     // 6. two assemblies at once on two streams (one borrows the parked pool, the other starts threads of its own), repeatedly
     for (int rep = 0; rep < 6; ++rep) {
         Case a(30000, 200, 256, 30 + rep), b(28000, 64, 128, 40 + rep);
-        std::thread t1([&] { run_case(a, POPE_RESULT_RING, 0, rep & 1 ? CODES : FLOATS, 8, (void *)0x10, 100); });
-        std::thread t2([&] { run_case(b, rep & 2 ? POPE_RESULT_REGISTERED : POPE_RESULT_RING, 0, FLOATS, 6, (void *)0x20, 50); });
+        std::thread t1([&] { run_case(a, rep & 1 ? CODES : FLOATS, 8, (void *)0x10, 100); });
+        std::thread t2([&] { run_case(b, FLOATS, 6, (void *)0x20, 50); });
         t1.join();
         t2.join();
     }

@@ -26,6 +26,20 @@
 #include "common.h"
 #include "side_copy.h"
 
+// Level-kernel look-ahead, as macros so that tools/ab_variants.sh can build the alternatives side by side (level_expand):
+#ifndef POPE_AHEAD
+#define POPE_AHEAD 2                  // 0 no look-ahead, 1 indices and live bits of the next chunk, 2 its indices only   (graphs with LIVE >= 2)
+#endif
+#ifndef POPE_TILE_PREFETCH
+#define POPE_TILE_PREFETCH 1          // 0 = the next tile's gathers go out when the tile is reached
+#endif
+#ifndef POPE_NT_INDEX
+#define POPE_NT_INDEX 1               // 1 = graphs with LIVE >= 2 read the erow / col index streams with the non-temporal hint
+#endif
+#ifndef POPE_NT_PLANES
+#define POPE_NT_PLANES 0              // 1 = ... and the reachability / hop-bit planes (row masks, the housekeeping's commit) likewise
+#endif
+
 namespace pope {
 
 // ------------------------------------------------------------------------------------------------
@@ -272,10 +286,16 @@ __device__ __forceinline__ void raise_level(BfsCtl *ctl, int level) {
 
 // Zero `n16` 16-byte units at each of up to 3 regions + the control block, then nothing else: one launch
 // instead of a string of hipMemsetAsync calls (each is its own ~4 us fill kernel).
-__global__ __launch_bounds__(256) void k_zero(uint4 *a, size_t na, uint4 *b, size_t nb, uint4 *c, size_t nc, u64 *b_tail) {
+// rows != nullptr: also the Wp words of row rows[j] of `row_base`, j < n_rows (the anchors' rows of the level-0 frontier, when the
+// frontier buffers themselves are not cleared: bfs_enqueue_clear).
+__global__ __launch_bounds__(256) void k_zero(uint4 *a, size_t na, uint4 *b, size_t nb, uint4 *c, size_t nc, u64 *b_tail, uint4 *d, size_t nd,
+                                              const long long *__restrict__ rows, int n_rows, u64 *row_base, int Wp) {
     const uint4 z = make_uint4(0, 0, 0, 0);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     if (b_tail && blockIdx.x == 0 && threadIdx.x == 0) *b_tail = 0;       // the 8-byte word behind region b's last 16-byte unit (odd word count)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += stride) d[i] = z;
+    if (rows)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n_rows * Wp; i += stride) row_base[(size_t)rows[i / Wp] * Wp + i % Wp] = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = z;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = z;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += stride) c[i] = z;
@@ -284,6 +304,17 @@ __global__ __launch_bounds__(256) void k_zero(uint4 *a, size_t na, uint4 *b, siz
 // A run of 8-byte words that need not start on a 16-byte boundary (hop-bit planes of an odd N * W: deep levels only).
 __global__ __launch_bounds__(256) void k_zero_words(u64 *p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0;
+}
+
+// The words of the rows that span chunks, in one frontier buffer (the accumulator of level 1 when the buffers are not cleared wholesale:
+// their pieces are OR-ed in with atomics; later levels' accumulators are cleared by the housekeeping blocks two levels ahead).
+__global__ __launch_bounds__(256) void k_clear_spanning_rows(const int *__restrict__ aux, int nchunks, u64 *__restrict__ buf, int Wp) {
+    const int *mrows = aux + AUX_HEADER;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += gridDim.x * blockDim.x) {
+        const int mv = mrows[i];
+        if (mv >= 0)
+            for (int w = 0; w < Wp; ++w) buf[(size_t)mv * Wp + w] = 0;
+    }
 }
 
 __global__ void k_bfs_seed(const long long *__restrict__ anchors, int K, int Wp, u64 *seen, u64 *front, unsigned *live) {
@@ -340,6 +371,27 @@ __device__ __forceinline__ Words<WT> load_words(const u64 *__restrict__ p) {
 
 // Frontier gathers go through L1 like any load: reading them with the non-temporal hint was measured 57 % slower
 // (BFS 349 us against 223 us, tools/ab_lib.py) -- the rows of hubs are gathered again and again and L1 serves them.
+// The same accesses with the non-temporal hint: streams that are read or written once per level and should not displace the frontier
+// rows (the gathers' table) from L2 and the Infinity Cache on graphs whose frontier does not fit beside them.
+typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+template <int WT, bool NT>
+__device__ __forceinline__ Words<WT> load_words_hint(const u64 *__restrict__ p) {
+    if constexpr (!NT) return load_words<WT>(p);
+    Words<WT> r;
+    if constexpr (WT == 1) {
+        r.w[0] = __builtin_nontemporal_load(p);
+    } else {
+#pragma unroll
+        for (int i = 0; i < WT; i += 2) {
+            const u64x2v v = __builtin_nontemporal_load(reinterpret_cast<const u64x2v *>(p + i));
+            r.w[i] = v.x;
+            r.w[i + 1] = v.y;
+        }
+    }
+    return r;
+}
+
 template <int WT>
 __device__ __forceinline__ Words<WT> gather_words(const u64 *__restrict__ p) { return load_words<WT>(p); }
 
@@ -350,6 +402,21 @@ __device__ __forceinline__ void store_words(u64 *__restrict__ p, const Words<WT>
     } else {
 #pragma unroll
         for (int i = 0; i < WT; i += 2) *reinterpret_cast<ulonglong2 *>(p + i) = make_ulonglong2(r.w[i], r.w[i + 1]);
+    }
+}
+
+template <int WT, bool NT>
+__device__ __forceinline__ void store_words_hint(u64 *__restrict__ p, const Words<WT> &r) {
+    if constexpr (!NT) {
+        store_words<WT>(p, r);
+    } else if constexpr (WT == 1) {
+        __builtin_nontemporal_store(r.w[0], p);
+    } else {
+#pragma unroll
+        for (int i = 0; i < WT; i += 2) {
+            const u64x2v v = {r.w[i], r.w[i + 1]};
+            __builtin_nontemporal_store(v, reinterpret_cast<u64x2v *>(p + i));
+        }
     }
 }
 
@@ -364,34 +431,34 @@ __device__ __forceinline__ u64 any_bits(const Words<WT> &r) {
 // Newly reached anchors of node slot idx at `level`: reachability plane and hop-bit planes (bit-sliced count).
 // All plane loads are issued before the first store, so the read-modify-writes cost ONE memory round trip
 // instead of one per set bit of the level.
-template <int WT>
+template <int WT, bool NT = false>
 __device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words<WT> &seen_old, size_t idx,
                                              u64 *__restrict__ seen, u64 *__restrict__ hop_planes,
                                              size_t plane_elems, int level) {
     Words<WT> s;
 #pragma unroll
     for (int i = 0; i < WT; ++i) s.w[i] = seen_old.w[i] | fresh.w[i];
-    store_words<WT>(seen + idx, s);
+    store_words_hint<WT, NT>(seen + idx, s);
     Words<WT> h[5];
 #pragma unroll
     for (int b = 0; b < 5; ++b) {
         h[b] = fresh;
-        if ((level >> b) & 1) h[b] = load_words<WT>(hop_planes + (size_t)b * plane_elems + idx);
+        if ((level >> b) & 1) h[b] = load_words_hint<WT, NT>(hop_planes + (size_t)b * plane_elems + idx);
     }
 #pragma unroll
     for (int b = 0; b < 5; ++b)
         if ((level >> b) & 1) {
 #pragma unroll
             for (int i = 0; i < WT; ++i) h[b].w[i] |= fresh.w[i];
-            store_words<WT>(hop_planes + (size_t)b * plane_elems + idx, h[b]);
+            store_words_hint<WT, NT>(hop_planes + (size_t)b * plane_elems + idx, h[b]);
         }
     for (int b = 5, l = level >> 5; l; ++b, l >>= 1)              // levels >= 32: rare, one at a time
         if (l & 1) {
             u64 *p = hop_planes + (size_t)b * plane_elems + idx;
-            Words<WT> g = load_words<WT>(p);
+            Words<WT> g = load_words_hint<WT, NT>(p);
 #pragma unroll
             for (int i = 0; i < WT; ++i) g.w[i] |= fresh.w[i];
-            store_words<WT>(p, g);
+            store_words_hint<WT, NT>(p, g);
         }
 }
 
@@ -482,11 +549,12 @@ __device__ __forceinline__ void level_housekeeping(int E, int N, int Wp, int til
     if (level > 1) {
         for (int v = t0; v < N; v += tstride) {
             if (!((live[v >> 5] >> (v & 31)) & 1u)) continue;                      // frontier row all zero: nothing gained
+            constexpr bool NT = LIVE >= 2 && POPE_NT_PLANES != 0;
             for (int t = 0; t < tiles; ++t) {
                 const size_t idx = (size_t)v * Wp + t * WT;
                 const Words<WT> fresh = load_words<WT>(front + idx);
                 if (any_bits<WT>(fresh))
-                    commit_words<WT>(fresh, load_words<WT>(seen + idx), idx, seen, hop_planes, plane_elems, level - 1);
+                    commit_words<WT, NT>(fresh, load_words_hint<WT, NT>(seen + idx), idx, seen, hop_planes, plane_elems, level - 1);
             }
         }
     }
@@ -516,44 +584,101 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
                                              const unsigned *__restrict__ live, unsigned *__restrict__ live_acc,
                                              const unsigned *live_lds, int level, int lane, int wave, int nwaves, int nchunks,
                                              int4 vr, int4 ur, unsigned *wave_words) {
-    auto load_idx = [&](const int *p) { return *reinterpret_cast<const int4 *>(p); };
-    constexpr bool LOOP = TILES == 1;                          // only then a wave sees more than one tile (and carries the prefetch registers)
+    auto load_idx = [&](const int *p) {
+        if constexpr (LIVE >= 2 && POPE_NT_INDEX != 0) {
+            const i32x4v t = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(p));
+            return make_int4(t.x, t.y, t.z, t.w);
+        } else {
+            return *reinterpret_cast<const int4 *>(p);
+        }
+    };
+    constexpr bool LOOP = TILES == 1;                          // only then a wave sees more than one tile
+    constexpr bool TILE_AHEAD = LOOP && POPE_TILE_PREFETCH != 0;   // ... and carries the prefetch registers
     if (!TILES) { tile_begin = 0; tile_end = 1; }
     bool found = false;
     STAMP(0);
-    for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
-        const int base = chunk * CHUNK + lane * SLOTS;
-        int v0 = -1, v1 = -1, v2 = -1, v3 = -1, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
-        if (base < E) {                       // arrays are padded to a multiple of 4 entries: the 16-byte load is in bounds
-            if (chunk != wave) {
-                vr = load_idx(erow + base);
-                ur = load_idx(col + base);
-            }
-            v0 = vr.x; u0 = ur.x;
-            if (base + 1 < E) { v1 = vr.y; u1 = ur.y; }
-            if (base + 2 < E) { v2 = vr.z; u2 = ur.z; }
-            if (base + 3 < E) { v3 = vr.w; u3 = ur.w; }
+    // One bit per node: is the frontier row of node u non-zero?  LIVE = 3: a two-level table -- the summary in LDS says whether the
+    // node's table word holds any bit at all, and only then the word itself matters (from L2); lanes whose summary bit is clear read
+    // word 0 instead (one address, served by a broadcast), so the four look-ups of a lane are four loads in flight at once and a
+    // sparse level's waves stream the indices and touch little else.  (As `if (!summary) return false; return word` every look-up was
+    // a branch with a load inside: four serial L2 round trips per chunk, 4.2 us of a chunk's 21.8 on R-MAT scale 22.)
+    auto live4 = [&](int u0, int u1, int u2, int u3, bool &q0, bool &q1, bool &q2, bool &q3) {
+        if constexpr (LIVE == 3) {
+            const bool s0 = (live_lds[u0 >> 10] >> ((u0 >> 5) & 31)) & 1u, s1 = (live_lds[u1 >> 10] >> ((u1 >> 5) & 31)) & 1u,
+                       s2 = (live_lds[u2 >> 10] >> ((u2 >> 5) & 31)) & 1u, s3 = (live_lds[u3 >> 10] >> ((u3 >> 5) & 31)) & 1u;
+            const unsigned w0 = live[s0 ? u0 >> 5 : 0], w1 = live[s1 ? u1 >> 5 : 0], w2 = live[s2 ? u2 >> 5 : 0], w3 = live[s3 ? u3 >> 5 : 0];
+            q0 = s0 & ((w0 >> (u0 & 31)) & 1u); q1 = s1 & ((w1 >> (u1 & 31)) & 1u);
+            q2 = s2 & ((w2 >> (u2 & 31)) & 1u); q3 = s3 & ((w3 >> (u3 & 31)) & 1u);
+        } else {
+            const unsigned *t = LIVE == 1 ? live_lds : live;
+            const unsigned w0 = t[u0 >> 5], w1 = t[u1 >> 5], w2 = t[u2 >> 5], w3 = t[u3 >> 5];
+            q0 = (w0 >> (u0 & 31)) & 1u; q1 = (w1 >> (u1 & 31)) & 1u; q2 = (w2 >> (u2 & 31)) & 1u; q3 = (w3 >> (u3 & 31)) & 1u;
         }
-        auto is_live = [&](int u) {
-            if constexpr (LIVE == 3) {
-                // two-level table: the summary in LDS says whether the node's table word holds any bit at all; only then the word
-                // itself is fetched (from L2).  A sparse level's waves then stream the indices and touch little else.
-                if (!((live_lds[u >> 10] >> ((u >> 5) & 31)) & 1u)) return false;
-                return ((live[u >> 5] >> (u & 31)) & 1u) != 0;
-            } else {
-                const unsigned w = LIVE == 1 ? live_lds[u >> 5] : live[u >> 5];
-                return ((w >> (u & 31)) & 1u) != 0;
+    };
+    // Graphs whose waves walk many chunks (LIVE >= 2): the NEXT chunk's indices are requested before this chunk is worked on and its
+    // live look-ups go out behind this chunk's gathers -- memory instructions retire in order, so neither waits for the gathers -- and
+    // the chain index load -> live look-up -> gather of a chunk no longer starts from nothing (round 5: 4 of a chunk's ~22 us).
+    constexpr bool AHEAD = LIVE >= 2 && POPE_AHEAD != 0;
+    constexpr bool AHEAD_LIVE = AHEAD && POPE_AHEAD == 1;
+    auto slots_of = [&](int chunk, const int4 &vr_, const int4 &ur_, int &v0, int &v1, int &v2, int &v3, int &u0, int &u1, int &u2, int &u3) {
+        const int base = chunk * CHUNK + lane * SLOTS;
+        v0 = v1 = v2 = v3 = -1;
+        u0 = u1 = u2 = u3 = 0;
+        if (base < E) {                       // arrays are padded to a multiple of 4 entries: the 16-byte load is in bounds
+            v0 = vr_.x; u0 = ur_.x;
+            if (base + 1 < E) { v1 = vr_.y; u1 = ur_.y; }
+            if (base + 2 < E) { v2 = vr_.z; u2 = ur_.z; }
+            if (base + 3 < E) { v3 = vr_.w; u3 = ur_.w; }
+        }
+    };
+    bool q0 = false, q1 = false, q2 = false, q3 = false;       // AHEAD_LIVE: the live bits of the chunk about to be worked on
+    if (AHEAD_LIVE && wave < nchunks) {
+        int a0, a1, a2, a3, b0, b1, b2, b3;
+        slots_of(wave, vr, ur, a0, a1, a2, a3, b0, b1, b2, b3);
+        live4(b0, b1, b2, b3, q0, q1, q2, q3);
+    }
+    for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
+        STAMP(7);                                              // (slots 1-5 and 7 hold the wave's LAST chunk; 2-4 its first tile)
+        if (!AHEAD && chunk != wave && chunk * CHUNK + lane * SLOTS < E) {
+            vr = load_idx(erow + chunk * CHUNK + lane * SLOTS);
+            ur = load_idx(col + chunk * CHUNK + lane * SLOTS);
+        }
+        int v0, v1, v2, v3, u0, u1, u2, u3;
+        slots_of(chunk, vr, ur, v0, v1, v2, v3, u0, u1, u2, u3);
+        // the next chunk's indices: requested now, looked at behind this chunk's gathers (next_live)
+        int4 vr_n = make_int4(-1, -1, -1, -1), ur_n = make_int4(0, 0, 0, 0);
+        bool qn0 = false, qn1 = false, qn2 = false, qn3 = false;
+        const int chunk_n = chunk + nwaves;
+        if (AHEAD && chunk_n < nchunks && chunk_n * CHUNK + lane * SLOTS < E) {
+            vr_n = load_idx(erow + chunk_n * CHUNK + lane * SLOTS);
+            ur_n = load_idx(col + chunk_n * CHUNK + lane * SLOTS);
+        }
+        auto next_live = [&]() {
+            if constexpr (AHEAD_LIVE) {
+                if (chunk_n < nchunks) {
+                    int a0, a1, a2, a3, b0, b1, b2, b3;
+                    slots_of(chunk_n, vr_n, ur_n, a0, a1, a2, a3, b0, b1, b2, b3);
+                    live4(b0, b1, b2, b3, qn0, qn1, qn2, qn3);
+                }
             }
+        };
+        auto advance = [&]() {
+            if constexpr (AHEAD) { vr = vr_n; ur = ur_n; }
+            if constexpr (AHEAD_LIVE) { q0 = qn0; q1 = qn1; q2 = qn2; q3 = qn3; }
         };
         // the four look-ups first, unconditionally (u = 0 for an empty slot), then the tests: as `v >= 0 && is_live(u)` each look-up sat
         // behind a branch and was waited for on its own
-        const bool q0 = is_live(u0), q1 = is_live(u1), q2 = is_live(u2), q3 = is_live(u3);
+        if constexpr (!AHEAD_LIVE) live4(u0, u1, u2, u3, q0, q1, q2, q3);
         const bool g0 = (v0 >= 0) & q0, g1 = (v1 >= 0) & q1, g2 = (v2 >= 0) & q2, g3 = (v3 >= 0) & q3;
         const int vc = __builtin_amdgcn_readlane(v0, 0);                               // row of the chunk's first slot
         const int vl = __builtin_amdgcn_readlane(v3, 63);                              // row of its last slot (-1: short chunk)
         STAMP(1);
         const bool work = __any(g0 || g1 || g2 || g3);                 // else: no live neighbour behind these 256 slots
-        if (!work) continue;                                           // nothing to gather, nothing to store (nobody gathers a row whose live bit is clear), nothing to mark
+        if (!work) {                                                   // nothing to gather, nothing to store (nobody gathers a row whose live bit is clear), nothing to mark
+            next_live();
+            advance();
+            continue;
+        }
         // the rows of the slots just outside the chunk: does its first row begin earlier, does its last row run on?
         const int2 er = chunk_edge_rows(erow, __builtin_amdgcn_readfirstlane(chunk), E);     // wave-uniform: scalar loads
         const bool head_multi = chunk > 0 && er.x == vc;                               // first row began in an earlier chunk
@@ -573,7 +698,8 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
         const bool connects = lane > 0 && pv3 == v0 && v0 >= 0;
         const bool head0 = !(connects && v0 == v3);
         // the live bits of the rows themselves: row v's mask includes front[v] only when v is live
-        const bool lv0 = is_live(max(v0, 0)), lv1 = is_live(max(v1, 0)), lv2 = is_live(max(v2, 0)), lv3 = is_live(max(v3, 0));     // (only used for v >= 0)
+        bool lv0, lv1, lv2, lv3;                                       // (only used for v >= 0)
+        live4(max(v0, 0), max(v1, 0), max(v2, 0), max(v3, 0), lv0, lv1, lv2, lv3);
         bool m0 = false, m1 = false, m2 = false, m3 = false;           // run ends here with something new, in any tile
         // With the live table an all-zero row need not be written: nobody gathers a row whose live bit is clear.
         // (Several tiles share one live bit per node: then zeros are written too, so a live row is exact in every tile.)
@@ -589,6 +715,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
         };
         Words<WT> c0, c1, c2, c3;
         gather4(tile_begin * WT, c0, c1, c2, c3);
+        next_live();                                                   // behind the gathers: its loads wait for the NEXT chunk's indices only
         for (int tile = tile_begin; tile < tile_end; ++tile) {
             const int woff = tile * WT;
             // mask of row v: what reached it before this level = seen[v] | front[v].  front[v] (level - 1's gain) is committed to
@@ -601,7 +728,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
             //  the chunk with the index loads made no measurable difference either.  profiles/r04_level_ab_libs.txt)
             {
                 auto row_mask = [&](int v, bool lv) {
-                    Words<WT> m = load_words<WT>(seen + (size_t)v * Wp + woff);
+                    Words<WT> m = load_words_hint<WT, LIVE >= 2 && POPE_NT_PLANES != 0>(seen + (size_t)v * Wp + woff);
                     if (lv) {
                         const Words<WT> f = load_words<WT>(front + (size_t)v * Wp + woff);
 #pragma unroll
@@ -628,9 +755,9 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
             // the next tile's gathers go out behind this tile's mask loads (memory instructions retire in order: requested in front of
             // them they would be waited for first), and fly while this tile is scanned and stored
             Words<WT> d0, d1, d2, d3;
-            if (LOOP && tile + 1 < tile_end) gather4(woff + WT, d0, d1, d2, d3);
+            if (TILE_AHEAD && tile + 1 < tile_end) gather4(woff + WT, d0, d1, d2, d3);
             const u64 any = any_bits<WT>(c0) | any_bits<WT>(c1) | any_bits<WT>(c2) | any_bits<WT>(c3);
-            STAMP(2);
+            if (tile == tile_begin) STAMP(2);
             if (__any(any != 0)) {                                         // else: nothing new through these 256 edges
                 // inclusive OR along the lane's own slots, restarting where the row changes
 #pragma unroll
@@ -676,7 +803,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
                     if (v3 == v0) c3.w[i] |= ci;
                 }
             }
-            STAMP(3);
+            if (tile == tile_begin) STAMP(3);
             // Emit every run that ends in this lane.
             const size_t i0 = (size_t)v0 * Wp + woff, i1 = (size_t)v1 * Wp + woff, i2 = (size_t)v2 * Wp + woff,
                          i3 = (size_t)v3 * Wp + woff;
@@ -699,9 +826,10 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
                 if (n2 && x2) piece(i2, c2);
                 if (n3 && x3) piece(i3, c3);
             }
-            STAMP(4);
+            if (tile == tile_begin) STAMP(4);
             m0 |= n0; m1 |= n1; m2 |= n2; m3 |= n3;
-            if (LOOP && tile + 1 < tile_end) { c0 = d0; c1 = d1; c2 = d2; c3 = d3; }
+            if (TILE_AHEAD && tile + 1 < tile_end) { c0 = d0; c1 = d1; c2 = d2; c3 = d3; }
+            else if (LOOP && tile + 1 < tile_end) gather4(woff + WT, c0, c1, c2, c3);
         }
         found |= m0 || m1 || m2 || m3;
         // Mark the rows that received something.  The chunk's rows are a short ascending run of node ids: build each
@@ -735,6 +863,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
             }
         }
         STAMP(5);
+        advance();
     }
     STAMP(6);
     return found;
@@ -779,8 +908,15 @@ __global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow,
     // The first chunk's slot loads are issued before the live table is staged: they fly while LDS fills.
     int4 vr = make_int4(-1, -1, -1, -1), ur = make_int4(0, 0, 0, 0);
     if (wave < nchunks && wave * CHUNK + lane * SLOTS < E) {
-        vr = *reinterpret_cast<const int4 *>(erow + wave * CHUNK + lane * SLOTS);
-        ur = *reinterpret_cast<const int4 *>(col + wave * CHUNK + lane * SLOTS);
+        if constexpr (LIVE >= 2 && POPE_NT_INDEX != 0) {
+            const i32x4v a = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(erow + wave * CHUNK + lane * SLOTS));
+            const i32x4v b = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(col + wave * CHUNK + lane * SLOTS));
+            vr = make_int4(a.x, a.y, a.z, a.w);
+            ur = make_int4(b.x, b.y, b.z, b.w);
+        } else {
+            vr = *reinterpret_cast<const int4 *>(erow + wave * CHUNK + lane * SLOTS);
+            ur = *reinterpret_cast<const int4 *>(col + wave * CHUNK + lane * SLOTS);
+        }
     }
     extern __shared__ uint4 live_lds4[];
     const unsigned *live_lds = reinterpret_cast<const unsigned *>(live_lds4);
@@ -1155,6 +1291,103 @@ __global__ __launch_bounds__(256) void k_finalize_wide(const u64 *__restrict__ p
     }
 }
 
+// Wide rows without shuffles and with a tenth of the bit arithmetic (round 5).  k_finalize_wide spends ~50 vector instructions and
+// five ds_bpermute per 16-byte store pulling nibbles out of bit-sliced planes (8.6 GB of [N, 512] columns for R-MAT scale 22 at
+// 4.0 TB/s; 3.8 TB/s at 8 x 256 anchors).  Here a lane owns one 32-bit HALF of a plane word -- 32 anchors, 128 bytes of output -- and
+// turns it into floats byte by byte through two tables in LDS:
+//   spread[b][byte]   the byte's 8 bits moved to bit b of 8 nibbles (u32), so the OR over the four hop-bit planes is the 8 anchors'
+//                     4-bit hop counts side by side;
+//   pair[code]        code = two neighbouring hop nibbles + their two reachability bits (10 bits) -> float2{1 / (h + 1) or 0}, built
+//                     per block with the same IEEE division as every other finalise kernel (bit-identical to f32(1.0 / (h + 1))).
+// Per 8 anchors: four spread look-ups, three ORs, and per pair one field extract for the code, one for the reachability bits, one
+// OR and one 8-byte look-up.  A wave takes 64 consecutive half-words of the flat (row, half-word) sequence (rows with few words do
+// not leave lanes idle), prefetches the next batch's five plane dwords before it stores, and transposes its 8 KB through LDS so that
+// every store instruction writes 1 KB of whole lines (a lane's own 128 bytes are 64 partial lines per instruction).  Shapes: K a
+// multiple of 64, words per shard and number of shards powers of two (the half-words per row then are one: shifts, no divisions).
+constexpr int FIN_LUT_LDS = 4 * 256 * 4 + 1024 * 8 + 4 * 8192;      // spread tables, pair table, one 8 KB transpose image per wave
+
+__global__ __launch_bounds__(256) void k_finalize_lut(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
+                                                      const int *__restrict__ max_hop_dev, int N, int Wp, float *__restrict__ out,
+                                                      long long out_cols, int col0, int hpr_shift, int wps_shift, size_t shard_elems,
+                                                      const int *__restrict__ aux, int *report, int ticket) {
+    if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
+    extern __shared__ __attribute__((aligned(16))) char fin_lds[];
+    unsigned *spread = reinterpret_cast<unsigned *>(fin_lds);                       // [4][256]
+    float2 *pair = reinterpret_cast<float2 *>(fin_lds + 4 * 256 * 4);               // [1024]
+    char *image = fin_lds + 4 * 256 * 4 + 1024 * 8 + (threadIdx.x >> 6) * 8192;     // this wave's transpose image
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int b = i >> 8, x = i & 255;
+        unsigned y = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y |= ((unsigned)(x >> k) & 1u) << (4 * k + b);
+        spread[i] = y;
+        const int h0 = i & 15, h1 = (i >> 4) & 15;
+        pair[i] = make_float2((i & 256) ? 1.0f / (float)(h0 + 1) : 0.0f, (i & 512) ? 1.0f / (float)(h1 + 1) : 0.0f);
+    }
+    __syncthreads();
+    if (max_hop_dev) {
+        const int m = *max_hop_dev;
+        n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned hpr_mask = (1u << hpr_shift) - 1u;
+    const long long total = (long long)N << hpr_shift;                              // half-words in all (< 2^31: checked on the host)
+    const int batches = (int)((total + 63) >> 6);
+    const unsigned *planes32 = reinterpret_cast<const unsigned *>(planes);
+    struct Halves { unsigned w[5]; };
+    auto load = [&](int batch) {
+        Halves r;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) r.w[b] = 0;
+        const long long g = (long long)batch * 64 + lane;
+        if (g < total) {
+            const unsigned v = (unsigned)(g >> hpr_shift), hw = (unsigned)g & hpr_mask, word = hw >> 1;
+            const unsigned shard = word >> wps_shift, wl = word & ((1u << wps_shift) - 1u);
+            const unsigned *p = planes32 + (((size_t)shard * shard_elems + (size_t)v * Wp + wl) << 1) + (hw & 1u);
+            r.w[0] = p[0];
+            if (n_hop_bits > 0) r.w[1] = p[2 * plane_elems];
+            if (n_hop_bits > 1) r.w[2] = p[4 * plane_elems];
+            if (n_hop_bits > 2) r.w[3] = p[6 * plane_elems];
+            if (n_hop_bits > 3) r.w[4] = p[8 * plane_elems];
+        }
+        return r;
+    };
+    if (wave >= batches) return;
+    Halves cur = load(wave);
+    for (int batch = wave; batch < batches; batch += nwaves) {
+        Halves nxt = cur;
+        if (batch + nwaves < batches) nxt = load(batch + nwaves);
+        // this lane's 32 floats, as 8 pieces of 16 bytes, into the wave's image: piece j of lane l at l * 128 + ((j ^ (l & 7)) * 16)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned code = spread[(cur.w[1] >> (8 * k)) & 255u] | spread[256 + ((cur.w[2] >> (8 * k)) & 255u)] |
+                                  spread[512 + ((cur.w[3] >> (8 * k)) & 255u)] | spread[768 + ((cur.w[4] >> (8 * k)) & 255u)];
+            const unsigned reach = (cur.w[0] >> (8 * k)) & 255u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                                            // two pairs = one 16-byte piece
+                const float2 a = pair[((code >> (16 * q)) & 255u) | (((reach >> (4 * q)) & 3u) << 8)];
+                const float2 b = pair[((code >> (16 * q + 8)) & 255u) | (((reach >> (4 * q + 2)) & 3u) << 8)];
+                const int j = 2 * k + q;
+                *reinterpret_cast<float4 *>(image + lane * 128 + ((j ^ (lane & 7)) << 4)) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        // store instruction e writes bytes [1024 e, 1024 e + 1024) of the batch's 8 KB: lane l takes piece l & 7 of owner 8 e + (l >> 3)
+        // (a wave's LDS instructions execute in order: no barrier between the writes above and these reads)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int o = 8 * e + (lane >> 3), pc = lane & 7;
+            const float4 val = *reinterpret_cast<const float4 *>(image + o * 128 + ((pc ^ (o & 7)) << 4));
+            const long long g = (long long)batch * 64 + o;
+            if (g < total) {
+                const unsigned v = (unsigned)(g >> hpr_shift), hw = (unsigned)g & hpr_mask;
+                *reinterpret_cast<float4 *>(out + (size_t)v * out_cols + col0 + hw * 32 + pc * 4) = val;
+            }
+        }
+        cur = nxt;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_hops(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
                                               int N, int K, int Wp, int *__restrict__ hops) {
     const size_t total = (size_t)N * K;
@@ -1462,6 +1695,7 @@ static int g_live_mode = -1;            // -1: by graph size (LDS table up to LI
 static int g_finalize_variant = 1;      // 1: pipelined / wide fast paths (default), 7: round 1-3 fast path, 0: generic kernel -- kept so the tests can compare their bits
 static int g_finalize_blocks = 256 * 8;
 static bool g_finalize_blocks_set = false;   // POPE_KNOB_FINALIZE_BLOCKS given: it also sizes the pipelined kernels (default: one work item per wave)
+static int g_finalize_lut = 1;           // wide rows: 1 (default) k_finalize_lut for rows without features, k_finalize_wide with them (copy kernel + table kernel measured slower: Flickr / 1 024 anchors 0.619 against 0.562 ms); 2 always; 0 never -- POPE_KNOB_FINALIZE_VARIANT 8 / 9 / 10
 static int g_prepare_merge = 1;          // POPE_KNOB_PREPARE_MERGE: 1 (default) = pope_geodesic_run clears, seeds and builds the CSR in ONE launch (k_prepare); 0 = two launches
 namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0, g_sage_forward_overlap = 1, g_gemm_small_tile16 = 1, g_gemm_tile16_buffers = 4; }
 
@@ -1469,7 +1703,10 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     clear_error();
     switch (knob) {
     case POPE_KNOB_LIVE_MODE:        g_live_mode = value; break;
-    case POPE_KNOB_FINALIZE_VARIANT: g_finalize_variant = value; break;
+    case POPE_KNOB_FINALIZE_VARIANT:                                 // 8 / 9: the default kernels, but shapes with features keep k_finalize_wide (8) or not (9)
+        if (value >= 8 && value <= 10) { g_finalize_variant = 1; g_finalize_lut = value == 9 ? 2 : value == 8 ? 1 : 0; }
+        else g_finalize_variant = value;
+        break;
     case POPE_KNOB_FINALIZE_BLOCKS:  g_finalize_blocks = value > 0 ? value : 256 * 8; g_finalize_blocks_set = value > 0; break;
     case POPE_KNOB_GEMM_TILE:        pope::g_gemm_force_tile = value; break;
     case POPE_KNOB_PAIRWISE_KERNEL:  pope::g_pairwise_kernel = value; break;
@@ -1611,6 +1848,7 @@ struct Bfs {
     u64 *seen, *hop_planes, *front[3];
     unsigned *live[3];           // one bit per node beside each frontier buffer: row not all zero
     int live_words;
+    bool frontiers_cleared = false;  // the merged prepare launch zeroed the three frontier buffers (else: k_clear_spanning_rows in front of level 1)
     unsigned *live_sum;          // LIVE = 3: summary of the table the next level launch reads (one bit per table word)
     int live_mode;               // 1 / 2 / 3 (k_bfs_level's LIVE)
     char *base;
@@ -1695,25 +1933,29 @@ static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const in
     return slot_acquire(&b.slot, (size_t)K);
 }
 
-// One launch clears the control block, the three frontier buffers, the reachability plane, the first hop planes and
-// (pope_geodesic_run) the CSR status header.
+// One launch clears the control block, the live tables, the reachability plane, the first hop planes and (pope_geodesic_run) the CSR
+// status header.  The three frontier buffers (a third of the bytes: 0.8 of 2.15 GB for R-MAT scale 22 with 512 anchors) are NOT cleared
+// (round 5): nobody reads a frontier row whose live bit is clear, so what has to be zero is only what is OR-ed into -- the anchors' rows
+// of the level-0 buffer (cleared here, through the call's pinned anchor list, which the caller has filled) and the rows that span
+// chunks in level 1's accumulator (k_clear_spanning_rows in front of level 1; later accumulators are cleared two levels ahead by the
+// housekeeping blocks).  Tests run every entry point on workspaces filled with 0xFF.
 static void bfs_enqueue_clear(const Bfs &b, int *aux_header, hipStream_t stream) {
     const int eager = b.capacity < EAGER_PLANES ? b.capacity : EAGER_PLANES;
     const size_t words = (size_t)(1 + eager) * b.plane_elems;        // odd (N * W odd, an even number of eager planes): one word behind the last 16-byte unit
-    hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, stream, (uint4 *)b.base,
-                       (b.front_off + 3 * align_up(b.plane_bytes, 256) + 3 * live_bytes(b.N)) / 16, (uint4 *)b.seen,
+    hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, stream, (uint4 *)b.base, b.front_off / 16, (uint4 *)b.seen,
                        words / 2, (uint4 *)aux_header, aux_header ? (size_t)AUX_HEADER * sizeof(int) / 16 : (size_t)0,
-                       (words & 1) ? b.seen + words - 1 : (u64 *)nullptr);
+                       (words & 1) ? b.seen + words - 1 : (u64 *)nullptr, (uint4 *)b.live[0], 3 * live_bytes(b.N) / 16,
+                       (const long long *)b.slot->anchors_dev, b.K, b.front[0], b.Wp);
 }
 
 // Anchors go through pinned, device-mapped host memory and the seed kernel reads them in place: no copy kernel.
 static int bfs_enqueue_seed(const Bfs &b, const int64_t *anchors_host, hipStream_t stream) {
-    memcpy(b.slot->anchors, anchors_host, (size_t)b.K * sizeof(long long));
     hipLaunchKernelGGL(k_bfs_seed, dim3((b.K + 255) / 256), dim3(256), 0, stream, b.slot->anchors_dev, b.K, b.Wp, b.seen, b.front[0], b.live[0]);
     return POPE_OK;
 }
 
 static int bfs_enqueue_init(const Bfs &b, const int64_t *anchors_host, hipStream_t stream) {
+    memcpy(b.slot->anchors, anchors_host, (size_t)b.K * sizeof(long long));     // this call's pinned, device-mapped slot: the clear and the seed read it in place
     bfs_enqueue_clear(b, nullptr, stream);
     return bfs_enqueue_seed(b, anchors_host, stream);
 }
@@ -1730,6 +1972,9 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
             // (8-byte stores: with an odd N * W every second plane starts 8 bytes off a 16-byte boundary)
             hipLaunchKernelGGL(k_zero_words, dim3(1024), dim3(256), 0, stream, b.hop_planes + (size_t)bit * b.plane_elems, b.plane_elems);
         }
+        if (level == 1 && !b.frontiers_cleared)                  // (the frontier buffers are not cleared wholesale: bfs_enqueue_clear)
+            hipLaunchKernelGGL(k_clear_spanning_rows, dim3(capped_grid((size_t)((b.E + CHUNK - 1) >> CHUNK_SHIFT), 256, 1024)), dim3(256), 0, stream, b.aux,
+                               (b.E + CHUNK - 1) >> CHUNK_SHIFT, b.front[1], b.Wp);
         const u64 *prev = b.front[(level - 1) % 3];           // frontier of level - 1
         u64 *next = b.front[level % 3];                          // receives the frontier of this level
         u64 *idle = b.front[(level + 1) % 3];                    // next level's accumulator: rows spanning chunks cleared now
@@ -1918,7 +2163,7 @@ extern "C" int pope_geodesic_bfs(const int32_t *rowptr, const int32_t *col, cons
 }
 
 // Which finalise kernel a shape gets (bench.py labels its roofline entry with the same choice: pope_finalize_kernel_name).
-enum FinKernel { FIN_GENERIC, FIN_FAST, FIN_PIPE, FIN_WIDE };
+enum FinKernel { FIN_GENERIC, FIN_FAST, FIN_PIPE, FIN_WIDE, FIN_LUT };
 struct FinChoice { FinKernel kernel; int xp, ep; };
 
 static FinChoice finalize_choice(int64_t N, int32_t K, bool has_x, int32_t F, int n_shards, bool vec, bool four_bits) {
@@ -1932,10 +2177,17 @@ static FinChoice finalize_choice(int64_t N, int32_t K, bool has_x, int32_t F, in
     const int64_t witems = N * ((ne / 16 + 15) / 16);
     c.xp = xp; c.ep = ep;
     if (g_finalize_variant != 1 || xp < 0) return c;
-    if (ne > 64 && (K & 63) == 0 && witems + 32768 * 4 < INT32_MAX) c.kernel = FIN_WIDE;      // wide rows: one load per plane half-word, shuffles to the lanes
+    const auto pow2 = [](int64_t x) { return x > 0 && (x & (x - 1)) == 0; };
+    if (ne > 64 && (K & 63) == 0 && pow2(K / 64) && pow2(n_shards) && N * (ne / 8) < INT32_MAX && g_finalize_lut > (has_x ? 1 : 0))
+        c.kernel = FIN_LUT;                                                                      // wide rows: a half-word per lane through the LDS tables
+    else if (ne > 64 && (K & 63) == 0 && witems + 32768 * 4 < INT32_MAX) c.kernel = FIN_WIDE;      // wide rows: one load per plane half-word, shuffles to the lanes
     else if (items + 32768 * 4 < INT32_MAX) c.kernel = FIN_PIPE;
     return c;
 }
+
+static int finalize_launch(const FinChoice &ch, const u64 *planes, size_t plane_elems, int n_hop_bits, const int *max_hop_dev, int64_t N, int32_t K, int Wp,
+                           const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, hipStream_t stream, int n_shards, size_t shard_elems,
+                           const int *aux, int *report, int ticket);
 
 static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_hop_dev, int64_t N, int32_t K,
                             const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, hipStream_t stream,
@@ -1944,7 +2196,6 @@ static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_ho
     const int Wp = words_for(K);
     const size_t plane_elems = (size_t)N * Wp;
     const bool vec = F % 4 == 0 && K % 4 == 0 && c0 % 4 == 0 && out_cols % 4 == 0 && aligned16(out) && (!x || aligned16(x));
-    dim3 grid(capped_grid((size_t)N * 64, 256)), block(256);
     // The device-side depth (max_hop_dev) is only used by pope_geodesic_run, whose speculative window stops at
     // LEVEL_BATCH = 12 levels: at most 4 hop bits.  With a host-side count the fast paths need n_hop_bits <= 4.
     const bool four_bits = max_hop_dev || n_hop_bits <= 4;
@@ -1957,8 +2208,37 @@ static int finalize_enqueue(const u64 *planes, int n_hop_bits, const int *max_ho
         return POPE_OK;
     }
     const FinChoice ch = finalize_choice(N, K, x != nullptr, F, n_shards, vec, four_bits);
+    if (ch.kernel == FIN_LUT && x && !SideCopy::eligible(x, F, out, out_cols, N)) {     // no separate feature copy for this shape: the shuffle kernel copies and expands
+        FinChoice alt = ch;
+        alt.kernel = FIN_WIDE;
+        return finalize_launch(alt, planes, plane_elems, n_hop_bits, max_hop_dev, N, K, Wp, x, F, out, out_cols, c0, stream, n_shards, shard_elems, aux, report, ticket);
+    }
+    return finalize_launch(ch, planes, plane_elems, n_hop_bits, max_hop_dev, N, K, Wp, x, F, out, out_cols, c0, stream, n_shards, shard_elems, aux, report, ticket);
+}
+
+static int finalize_launch(const FinChoice &ch, const u64 *planes, size_t plane_elems, int n_hop_bits, const int *max_hop_dev, int64_t N, int32_t K, int Wp,
+                           const float *x, int32_t F, float *out, int64_t out_cols, int32_t c0, hipStream_t stream, int n_shards, size_t shard_elems,
+                           const int *aux, int *report, int ticket) {
+    const bool vec = ch.kernel != FIN_GENERIC || (F % 4 == 0 && K % 4 == 0 && c0 % 4 == 0 && out_cols % 4 == 0 && aligned16(out) && (!x || aligned16(x)));
+    dim3 grid(capped_grid((size_t)N * 64, 256)), block(256);
     const int64_t ne = (int64_t)(K / 4) * n_shards;
-    if (ch.kernel == FIN_WIDE) {
+    if (ch.kernel == FIN_LUT) {
+        // the feature columns first, by the copy kernel (5.9 TB/s alone); the verdict travels with the column kernel behind it
+        if (x) { int rc = enqueue_copy_features(x, F, out, out_cols, N, stream); if (rc) return rc; }
+        int hpr_shift = 0, wps_shift = 0;
+        while ((1 << wps_shift) < K / 64) ++wps_shift;
+        while ((1ll << hpr_shift) < (int64_t)(K / 64) * n_shards * 2) ++hpr_shift;
+        const int64_t batches = ((N << hpr_shift) + 63) >> 6;
+        static LdsOptIn opt_in;
+        if (!opt_in.done()) {
+            POPE_HIP(hipFuncSetAttribute((const void *)k_finalize_lut, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LUT_LDS));
+            opt_in.mark();
+        }
+        // blocks live for a few batches each: the tables cost a block ~1 us to build
+        const unsigned blocks = g_finalize_blocks_set ? (unsigned)g_finalize_blocks : (unsigned)std::min<int64_t>(std::max<int64_t>((batches + 15) / 16, 1), 4096);
+        hipLaunchKernelGGL(k_finalize_lut, dim3(blocks), block, FIN_LUT_LDS, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, Wp, out,
+                           (long long)out_cols, F + c0, hpr_shift, wps_shift, shard_elems, aux, report, ticket);
+    } else if (ch.kernel == FIN_WIDE) {
         const int64_t witems = N * ((ne / 16 + 15) / 16);
         dim3 wgrid(g_finalize_blocks_set ? g_finalize_blocks : (unsigned)std::min<int64_t>(std::max<int64_t>((witems + 3) / 4, 256), 32768));
 #define POPE_FIN_WIDE(XP)                                                                                                                 \
@@ -1999,6 +2279,7 @@ extern "C" int pope_finalize_kernel_name(int64_t N, int32_t K, int32_t F, int32_
     const bool vec = F % 4 == 0 && K % 4 == 0;                   // aligned bases and row pitches assumed (torch allocations)
     const FinChoice c = finalize_choice(N, K, has_x != 0, F, n_shards, vec, true);
     switch (c.kernel) {
+    case FIN_LUT:  snprintf(name, cap, "k_finalize_lut"); break;
     case FIN_WIDE: snprintf(name, cap, "k_finalize_wide<%d>", c.xp); break;
     case FIN_PIPE: snprintf(name, cap, "k_finalize_pipe<%d, %d>", c.xp, c.ep); break;
     case FIN_FAST: snprintf(name, cap, "k_finalize_fast"); break;
@@ -2104,6 +2385,7 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
             hipLaunchKernelGGL(k_prepare<false>, dim3(zero_blocks + csr_blocks), dim3(256), 0, stream, src, dst, (int)E, (int)N, rowptr, col, erow, aux,
                                (uint4 *)b.base, na, (uint4 *)b.seen, nb, zb_tail, zero_blocks, epoch, seeds, K, b.Wp, b.seen, b.front[0], b.live[0]);
         POPE_HIP(hipGetLastError());
+        b.frontiers_cleared = true;
     } else {
         bfs_enqueue_clear(b, aux, stream);                    // BFS state and the CSR status header in one launch
         SeedArgs seed;
@@ -2127,6 +2409,7 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
         clear_error();
         if ((rc = csr_fallback((const long long *)edge_index, (const long long *)edge_index + E, (int)E, (int)N, rowptr, col,
                                erow, aux, ws + L.csr_scratch, stream))) return rc;
+        b.frontiers_cleared = false;
         if ((rc = bfs_enqueue_init(b, anchors_host, stream))) return rc;
         level = 1;
         done = false;

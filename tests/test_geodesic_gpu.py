@@ -746,7 +746,7 @@ def test_pipelined_finalise_kernel_writes_the_same_bits(dev, f, k, shards):
     x = torch.rand((n, f), generator=g).to(dev) if f else None
     outs = []
     try:
-        for variant in (7, 1, 0):
+        for variant in (7, 9, 0, 10):                              # 9: the default (wide rows on the table kernel); 10: wide rows on the shuffle kernel
             lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, variant)
             out = torch.full((n, f + shards * k), float("nan"), device=dev)
             if shards == 1:
@@ -755,12 +755,14 @@ def test_pipelined_finalise_kernel_writes_the_same_bits(dev, f, k, shards):
                 engine.finalize_shards(planes, bits, n, k, x, f, out)
             outs.append(out)
     finally:
-        lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 1)
+        lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 9)          # (9: variant 1 with the table kernel for shapes with features too = the default)
     assert not torch.isnan(outs[0]).any()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
     import ctypes
     name = ctypes.create_string_buffer(64)
     _lib.check(lib.pope_finalize_kernel_name(n, k, f, 1 if f else 0, shards, name, 64))
     ne = k // 4 * shards
-    want = "k_finalize_fast" if f > 1024 else ("k_finalize_wide" if ne > 64 and k % 64 == 0 else "k_finalize_pipe")
+    pow2 = lambda v: v > 0 and v & (v - 1) == 0
+    wide = ne > 64 and k % 64 == 0
+    want = "k_finalize_fast" if f > 1024 else ("k_finalize_lut" if wide and pow2(k // 64) and pow2(shards) else "k_finalize_wide" if wide else "k_finalize_pipe")
     assert name.value.decode().startswith(want), (name.value, want)

@@ -27,10 +27,10 @@ for world, k in ((8, 256), (8, 128), (4, 256), (2, 256), (8, 64), (1, 1024)):
     planes = torch.randint(-2**62, 2**62, (world, 1 + bits, n, w), dtype=torch.int64, device=dev)
     out = torch.empty((n, f + world * k), device=dev)
     res = {}
-    for variant in (7, 5, 1):
+    for variant in (7, 10, 9):
         lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, variant)
         res[variant] = timed(lambda: engine.finalize_shards(planes, bits, n, k, None, f, out))
-    lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 1)
+    lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 9)
     sweep = {}
     for blocks in (1024, 2048, 4096, 8192, 16384):
         lib.pope_debug_set(_lib.KNOB_FINALIZE_BLOCKS, blocks)
@@ -39,7 +39,7 @@ for world, k in ((8, 256), (8, 128), (4, 256), (2, 256), (8, 64), (1, 1024)):
     print("   round-4 default kernel by grid size:", sweep)
     cp = timed(lambda: engine.copy_features(x, f, out))
     mb = n * world * k * 4 / 1e6
-    print("   pipelined k_finalize_pipe (contiguous rows) %.1f us" % res[5])
-    print(f"world {world} x {k} anchors: K columns {mb:.0f} MB: rounds 1-3 kernel {res[7]:.1f} us ({mb / res[7]:.2f} TB/s), round-4 default {res[1]:.1f} us ({mb / res[1]:.2f} TB/s); "
+    print("   shuffle kernel k_finalize_wide %.1f us" % res[10])
+    print(f"world {world} x {k} anchors: K columns {mb:.0f} MB: rounds 1-3 kernel {res[7]:.1f} us ({mb / res[7]:.2f} TB/s), round-4 default {res[9]:.1f} us ({mb / res[9]:.2f} TB/s); "
           f"feature copy into the [N, {f + world * k}] matrix {cp:.1f} us", flush=True)
     del planes, out

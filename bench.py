@@ -384,12 +384,25 @@ def config3_leg(x, ei, n, steps):
             "note": "the 8-GPU form shards 128 anchors per rank (tests/test_configs_gpu.py runs it sharded over 2 ranks)"}
 
 
+def config4_pmc():
+    """HBM-side bytes per launch of configs[4]'s kernels from the committed rocprofv3 --pmc passes (profiles/r05_config4_pmc.json, a
+    separate run of tools/r05_config4_profile.sh: not measured live)."""
+    path = os.path.join(ROOT, "profiles", "r05_config4_pmc.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh), "profiles/r05_config4_pmc.json"
+    except (OSError, ValueError):
+        return None, None
+
+
 def config4_leg(dev, steps=3):
     from oracle import oracle
+    lib = _lib.load()
     t0 = time.perf_counter()
     ei_np, n = synth.rmat(22, edge_factor=8, seed=1)
     gen = time.perf_counter() - t0
-    anchors = synth.seeded_anchors(n, 512, 42)
+    k = 512
+    anchors = synth.seeded_anchors(n, k, 42)
     ei = torch.as_tensor(ei_np, device=dev)
     for _ in range(2):
         out, hp = engine.geodesic_run(None, ei, n, anchors, reuse_workspace=True)
@@ -399,20 +412,77 @@ def config4_leg(dev, steps=3):
         out, hp = engine.geodesic_run(None, ei, n, anchors, reuse_workspace=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    cols = np.random.RandomState(0).choice(512, 8, replace=False)
+    cols = np.random.RandomState(0).choice(k, 8, replace=False)
     t0 = time.perf_counter()
     want = oracle.geodesic_hops(ei_np, n, anchors[cols])
     cpu = time.perf_counter() - t0
     got = engine.hop_matrix(hp)[:, torch.as_tensor(cols, device=dev)].cpu().numpy()
     e = ei_np.shape[1]
+    wp = hp.planes.shape[2]
+    bits = hp.n_hop_bits
+    # the level kernel on this graph: HIP events around every level launch of the hot path (pope_profile_levels(1)); the average over
+    # EVERY launch is what rocprofv3 --stats averages, the densest level is the one the HBM roof applies to
+    lib.pope_profile_levels(1)
+    for _ in range(steps):
+        engine.geodesic_run(None, ei, n, anchors, want_out=False, reuse_workspace=True)
+    torch.cuda.synchronize()
+    cap = 4096
+    lv = (ctypes.c_int32 * cap)()
+    ex = (ctypes.c_float * cap)()
+    cnt = lib.pope_profile_read(lv, ex, cap)
+    lib.pope_profile_levels(0)
+    per = {}
+    for i in range(cnt):
+        per.setdefault(lv[i], []).append(ex[i])
+    level_ms = {int(l): float(np.median(v)) for l, v in sorted(per.items())}
+    launches = len(level_ms)
+    avg_ms = sum(level_ms.values()) / launches
+    dense_bytes = e * (8.0 + 8.0 * wp) + n * 16.0 * wp                # DESIGN.md section 5 model: per slot index + neighbour row, per node seen read + frontier write
+    active = hp.max_hop + 1
+    alg_bytes = dense_bytes * active / launches
+    dense_level = max(level_ms, key=level_ms.get)
+    pmc, pmc_src = config4_pmc()
+    pmc = pmc or {}
+    # the finalise kernel of this shape: launches queued back to back between two HIP events
+    fin_out = torch.empty((n, k), dtype=torch.float32, device=dev)
+    planes = hp.valid().contiguous()
+    for _ in range(2):
+        engine.finalize(planes, bits, n, k, None, 0, fin_out, 0)
+    ev = [_event(), _event()]
+    ev[0].record()
+    for _ in range(5):
+        engine.finalize(planes, bits, n, k, None, 0, fin_out, 0)
+    ev[1].record()
+    torch.cuda.synchronize()
+    fin_ms = ev[0].elapsed_time(ev[1]) / 5
+    fin_bytes = 4.0 * n * k + 8.0 * n * wp * (1 + bits)
+    del fin_out
     res = {"workload": f"configs[4] on ONE GPU: R-MAT scale 22 (a,b,c,d)=(.57,.19,.19,.05), N={n}, E={e} CSR slots, 512 anchors "
                        "(np seed 42), F=0: edge_index resident -> [N, 512] f32 (graph generation outside the timed region)",
-           "ms_per_step": dt * 1e3, "embeddings_per_s": n * 512 / dt, "max_hop": hp.max_hop, "graph_generation_s": gen,
+           "ms_per_step": dt * 1e3, "embeddings_per_s": n * k / dt, "max_hop": hp.max_hop, "graph_generation_s": gen,
            "sampled_columns_bit_exact": bool(np.array_equal(got, want)),
+           "roofline": {"kernel": "k_bfs_level<4, 3, 1>", "bound": "hbm", "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch"),
+                        "traffic_source": pmc_src, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_per_step": launches,
+                        "algorithmic_bytes_per_active_level": dense_bytes, "level_ms": {str(l): round(v, 4) for l, v in level_ms.items()},
+                        "densest_level": {"level": dense_level, "ms": level_ms[dense_level], "achieved": dense_bytes / (level_ms[dense_level] * 1e-3) / 1e9,
+                                          "frac": dense_bytes / (level_ms[dense_level] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "traffic": pmc.get("k_bfs_level_hbm_bytes_densest_launch"),
+                                          "gather_roof_ms": e / 56.0e9 * 1e3},
+                        "note": "W = 8 words per node as two 4-word tiles walked inside the wave; every neighbour row is a random 64-byte gather that "
+                                "costs a 128-byte line from the fabric (tools/micro/gather_rows.hip: 56 G lines/s chip-wide whatever the row size, "
+                                "profiles/r05_micro_gather_rows.txt), so the densest level cannot take less than E / 56 G/s (gather_roof_ms); HIP events "
+                                "between the launches, one level per launch"},
+           "roofline_finalize": {"kernel": finalize_kernel_name(n, k, 0, False, 1), "bound": "hbm", "achieved": fin_bytes / (fin_ms * 1e-3) / 1e9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fin_bytes / (fin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": pmc.get("k_finalize_hbm_bytes_per_launch"), "algorithmic_bytes_per_launch": fin_bytes, "avg_launch_ms": fin_ms,
+                                 "store_roof_ms": 1.49,
+                                 "note": "8.59 GB of columns written + 1.34 GB of planes read; a kernel that only stores the columns (no loads, no "
+                                         "arithmetic: tools/micro/column_fill.hip) takes 1.49 ms = 5.8 TB/s on this part (store_roof_ms)"},
            "per_source_model_gbs": 512 * (4.0 * e + 8.0 * n) / dt / 1e9,
            "cpu_baseline": {"value": n * 8 / cpu, "unit": "embeddings/s", "cores": 1, "kind": "port",
                             "sample": f"8 of the 512 anchor columns (RandomState(0)), full N, oracle/pope_oracle.c one BFS per anchor, {cpu:.1f} s"}}
-    del out, hp, ei
+    del out, hp, ei, planes
     engine._WORKSPACE.clear()
     torch.cuda.empty_cache()
     return res
@@ -590,7 +660,7 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
         x = IndexedFeatures(feats, n_id)                         # main.py:118-123 convert_batch without the copy: layer 0 reads feats[n_id[j]]
         for p in params:                                         # opt.zero_grad(set_to_none=True) without its bookkeeping
             p.grad = None
-        loss = cross_entropy(model(x, adjs), y, unit_upstream=True)   # main.py:216 F.cross_entropy: two launches, gradient pre-scaled
+        loss = cross_entropy(model(x, adjs), y, unit_upstream=True, loss_in=opt)   # main.py:216 F.cross_entropy: one launch, gradient pre-scaled; the scalar is finished in Adam's launch
         loss.backward(gradient=one)                          # seeded with 1 (the promise unit_upstream makes): no backward launch for the loss
         opt.step()
         return loss
@@ -966,7 +1036,7 @@ def main():
         pmc, pmc_src = pmc_traffic()
         pmc = pmc or {}
         result["roofline"] = {
-            "kernel": "k_bfs_level<%d, %d, %s>" % (min(wp, 4), 1 if n <= 256 * 1024 else 3, "true" if wp > 4 else "false"), "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "k_bfs_level<%d, %d, %d>" % (min(wp, 4), 1 if n <= 256 * 1024 else 3, 0 if wp <= 4 else (2 if n <= 256 * 1024 else 1)), "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": exp_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch") if cfg == 1 else None,
             "traffic_source": (pmc_src + " (rocprofv3 --pmc passes of this command, collected in a separate run: not measured live)") if pmc_src else None,
             "algorithmic_bytes_per_launch": exp_bytes, "avg_launch_ms": exp_ms, "launches_per_step": launches,

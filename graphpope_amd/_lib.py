@@ -93,6 +93,12 @@ SIGNATURES = {
     "sage_conv_forward_indexed": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32,
                                           c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                           c_void_p, c_void_p]),
+    "sage_conv_forward_stats": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p,
+                                        c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int32,
+                                        c_void_p, c_void_p]),
+    "sage_conv_forward_indexed_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32,
+                                                c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "sage_conv_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int32,
                                    c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -104,6 +110,9 @@ SIGNATURES = {
     "sage_bn_relu_dropout_forward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                              c_int32, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                              c_void_p, c_void_p, c_void_p]),
+    "sage_bn_relu_dropout_forward_stats": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                                   c_int32, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "sage_bn_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_int32, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                               c_void_p, c_void_p, c_void_p]),
@@ -112,6 +121,8 @@ SIGNATURES = {
     "sage_cross_entropy_backward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sage_adam_step": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
                                c_double, c_int64, c_void_p, c_void_p]),
+    "sage_adam_step_loss": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
+                                    c_double, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "sage_advance_counters": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
     "sage_copy_segments": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sage_sample_batch_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_uint64, c_void_p,

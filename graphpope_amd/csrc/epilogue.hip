@@ -168,11 +168,14 @@ __device__ __forceinline__ void fold_parts(const double *__restrict__ pa, const 
 }
 
 // training: batch statistics + running-stat update; else: the running statistics.  Launch: 256 threads, C/16 blocks.
+// rows_per_part > 0: the partials come from the projection's epilogue, one per row tile of that height (sage_conv_forward_stats):
+// with a device extent only the tiles in front of the true row count were written.
 __global__ __launch_bounds__(256) void k_bn_final(const double *__restrict__ pa, const double *__restrict__ pb, int parts, int M, int C, int training,
                            float momentum, float eps, float *__restrict__ running_mean, float *__restrict__ running_var,
                            float *__restrict__ mean, float *__restrict__ rstd, long long *num_batches_tracked,
-                           const int *__restrict__ m_dev) {
+                           const int *__restrict__ m_dev, int rows_per_part) {
     M = dyn_extent(m_dev, M);
+    if (rows_per_part > 0) parts = min(parts, (M + rows_per_part - 1) / rows_per_part);
     // nn.BatchNorm1d's step counter (`num_batches_tracked += 1` in training mode): as a torch op it is a launch of its own
     if (training && num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     const int c = blockIdx.x * 16 + (threadIdx.x & 15);
@@ -289,13 +292,12 @@ using namespace pope;
 
 extern "C" size_t sage_bn_scratch_bytes(int32_t C) { return C <= 0 ? 0 : bn_scratch(C); }
 
-extern "C" int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C, const float *gamma, const float *beta,
-                                            float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
-                                            int32_t training, float p, uint64_t seed, float *y, float *save_mean,
-                                            float *save_rstd, void *scratch, size_t scratch_bytes, const int32_t *rows_dev,
-                                            const uint64_t *seed_dev_, void *stream_) {
-    clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
+static int bn_forward_impl(const float *x, int64_t M, int32_t C, const float *gamma, const float *beta,
+                           float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
+                           int32_t training, float p, uint64_t seed, float *y, float *save_mean,
+                           float *save_rstd, void *scratch, size_t scratch_bytes, const int32_t *rows_dev,
+                           const uint64_t *seed_dev_, const double *ext_pa, const double *ext_pb, int ext_parts, int ext_rows_per_part,
+                           hipStream_t stream) {
     POPE_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && scratch, "sage_bn_relu_dropout_forward: null pointer");
     POPE_REQUIRE(M > 0 && M < INT32_MAX && C > 0 && (size_t)M * C < ((size_t)1 << 40), "sage_bn_relu_dropout_forward: bad size");
     POPE_REQUIRE(training || (running_mean && running_var), "sage_bn_relu_dropout_forward: eval mode needs running statistics");
@@ -307,7 +309,8 @@ extern "C" int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C
     }
     const BnPlan pl = bn_plan(M, C, scratch, x, y, nullptr, gamma, beta, save_mean, save_rstd);
     const unsigned long long *seed_dev = (const unsigned long long *)seed_dev_;
-    if (training) {
+    const bool external = training && ext_pa && ext_pb && ext_parts > 0 && ext_rows_per_part > 0;     // the first stage was done by the projection's epilogue
+    if (training && !external) {
         const dim3 grid(pl.parts, (C + 64 * pl.vec - 1) / (64 * pl.vec));
         if (pl.vec == 4)
             hipLaunchKernelGGL((k_bn_partial<4, false>), grid, dim3(256), 0, stream, x, nullptr, (int)M, C, pl.rows_per_part,
@@ -316,8 +319,9 @@ extern "C" int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C
             hipLaunchKernelGGL((k_bn_partial<1, false>), grid, dim3(256), 0, stream, x, nullptr, (int)M, C, pl.rows_per_part,
                                nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb, rows_dev, nullptr);
     }
-    hipLaunchKernelGGL(k_bn_final, dim3((C + 15) / 16), dim3(256), 0, stream, pl.pa, pl.pb, pl.parts, (int)M, C, training,
-                       momentum, eps, running_mean, running_var, save_mean, save_rstd, (long long *)num_batches_tracked, rows_dev);
+    hipLaunchKernelGGL(k_bn_final, dim3((C + 15) / 16), dim3(256), 0, stream, external ? ext_pa : pl.pa, external ? ext_pb : pl.pb,
+                       external ? ext_parts : pl.parts, (int)M, C, training, momentum, eps, running_mean, running_var, save_mean, save_rstd,
+                       (long long *)num_batches_tracked, rows_dev, external ? ext_rows_per_part : 0);
     const unsigned thr = training ? drop_threshold(p) : 0u;
     const float inv_keep = (training && p > 0.f && p < 1.f) ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
     const size_t total = (size_t)M * C;
@@ -330,6 +334,29 @@ extern "C" int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C
                            gamma, beta, nullptr, nullptr, (unsigned long long)seed, thr, inv_keep, y, rows_dev, seed_dev);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
+}
+
+extern "C" int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C, const float *gamma, const float *beta,
+                                            float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
+                                            int32_t training, float p, uint64_t seed, float *y, float *save_mean,
+                                            float *save_rstd, void *scratch, size_t scratch_bytes, const int32_t *rows_dev,
+                                            const uint64_t *seed_dev_, void *stream_) {
+    clear_error();
+    return bn_forward_impl(x, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training, p, seed, y, save_mean,
+                           save_rstd, scratch, scratch_bytes, rows_dev, seed_dev_, nullptr, nullptr, 0, 0, (hipStream_t)stream_);
+}
+
+// The same with the first stage of the statistics -- per-row-tile column sums of x and of x^2 in float64 -- already done by the
+// kernel that wrote x (sage_conv_forward_stats: pa / pb [parts, C], one part per `rows_per_part` rows): two launches instead of three.
+extern "C" int sage_bn_relu_dropout_forward_stats(const float *x, int64_t M, int32_t C, const float *gamma, const float *beta,
+                                                  float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
+                                                  int32_t training, float p, uint64_t seed, float *y, float *save_mean, float *save_rstd,
+                                                  void *scratch, size_t scratch_bytes, const int32_t *rows_dev, const uint64_t *seed_dev_,
+                                                  const double *pa, const double *pb, int32_t parts, int32_t rows_per_part, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(pa && pb && parts > 0 && rows_per_part > 0 && (int64_t)parts * rows_per_part >= M, "sage_bn_relu_dropout_forward_stats: the partials do not cover the rows");
+    return bn_forward_impl(x, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training, p, seed, y, save_mean,
+                           save_rstd, scratch, scratch_bytes, rows_dev, seed_dev_, pa, pb, parts, rows_per_part, (hipStream_t)stream_);
 }
 
 extern "C" int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,
@@ -372,6 +399,10 @@ extern "C" int sage_bn_relu_dropout_backward(const float *x, const float *grad_y
     return POPE_OK;
 }
 
+namespace pope {
+__global__ void k_xent_final(const float *__restrict__ row_loss, int N, float *__restrict__ loss, float *__restrict__ inv_count);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Adam step over every parameter tensor in ONE launch (main.py:244 torch.optim.Adam(self.parameters(), lr=args.lr)).
 // torch's default implementation is eight foreach launches plus ~80 us of Python per step; the training step is
@@ -395,12 +426,50 @@ struct AdamTable {
     int count;
 };
 
+// The last stage of the cross-entropy (csrc below: k_xent_rows leaves one loss per row): loss = mean over the counted rows, and
+// 1 / count.  One block.  A launch of its own (k_xent_final), or -- round 5 -- the extra block of the optimiser's launch: the scalar
+// is only read by the host after the step, so it need not hold up the backward pass (sage_adam_step_loss).
+__device__ __forceinline__ void xent_final_block(const float *__restrict__ row_loss, int N, float *__restrict__ loss,
+                                                 float *__restrict__ inv_count) {
+    __shared__ double ssum[256];
+    __shared__ int scnt[256];
+    double s = 0.0;
+    int n = 0;
+    for (int base = 0; base < N; base += 8 * 256) {             // eight row losses per thread in flight (same order of additions)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float t = row_loss[min(base + (int)threadIdx.x + 256 * u, N - 1)];
+            v[u] = base + (int)threadIdx.x + 256 * u < N ? t : -1.f;         // a select, not a branch: -1 marks "not counted"
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u] >= 0.f) { s += (double)v[u]; ++n; }
+    }
+    ssum[threadIdx.x] = s;
+    scnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { ssum[threadIdx.x] += ssum[threadIdx.x + off]; scnt[threadIdx.x] += scnt[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *loss = scnt[0] > 0 ? (float)(ssum[0] / scnt[0]) : __builtin_nanf("");      // torch: nan when every label is ignored
+        *inv_count = scnt[0] > 0 ? 1.f / (float)scnt[0] : 0.f;
+    }
+}
+
 // one_minus_b1 / one_minus_b2 are formed in double on the host, as Python does for torch (1 - 0.999f != float(1 - 0.999)).
 // step_dev != nullptr: the 1-based step count lives on the device (a replayed HIP graph cannot take it as an argument);
 // lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t) are then formed here, in double like on the host.
 __global__ __launch_bounds__(256) void k_adam(AdamTable t, float step_size, float one_minus_b1, float beta2, float one_minus_b2,
                                               float eps, float weight_decay, float inv_bc2_sqrt, const long long *__restrict__ step_dev,
-                                              double lr, double beta1_d, double beta2_d) {
+                                              double lr, double beta1_d, double beta2_d, const float *__restrict__ xent_rows, int xent_n,
+                                              float *__restrict__ xent_out) {
+    if ((int)blockIdx.x == t.first_block[t.count]) {                 // the one block behind the parameter chunks: the loss scalar of this step
+        xent_final_block(xent_rows, xent_n, xent_out, xent_out + 1);
+        return;
+    }
     if (step_dev) {
         const double step = (double)*step_dev;
         step_size = (float)(lr / (1.0 - pow(beta1_d, step)));
@@ -449,11 +518,10 @@ __global__ __launch_bounds__(256) void k_adam(AdamTable t, float step_size, floa
 
 }  // namespace pope
 
-extern "C" int sage_adam_step(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
-                              float *const *exp_avg_sq, const int64_t *numel, double lr, double beta1, double beta2, double eps,
-                              double weight_decay, int64_t step, const int64_t *step_dev, void *stream_) {
-    clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
+static int adam_step_impl(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                          float *const *exp_avg_sq, const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                          double weight_decay, int64_t step, const int64_t *step_dev, const float *xent_rows, int64_t xent_n, float *xent_out,
+                          hipStream_t stream) {
     POPE_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (params && grads && exp_avg && exp_avg_sq && numel)), "sage_adam_step: null pointer");
     if (step_dev) step = 1;                                         // the device word is the step count; `step` is ignored
     POPE_REQUIRE(step >= 1 && lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0,
@@ -476,11 +544,36 @@ extern "C" int sage_adam_step(int32_t n_tensors, float *const *params, const flo
         }
         if (tab.count == 0) continue;
         tab.first_block[tab.count] = blocks;
-        hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, stream, tab, step_size, (float)(1.0 - beta1), (float)beta2,
-                           (float)(1.0 - beta2), (float)eps, (float)weight_decay, inv_bc2_sqrt, (const long long *)step_dev, lr, beta1, beta2);
+        const bool with_loss = xent_rows != nullptr;              // the first launch carries the loss block
+        hipLaunchKernelGGL(k_adam, dim3(blocks + (with_loss ? 1 : 0)), dim3(256), 0, stream, tab, step_size, (float)(1.0 - beta1), (float)beta2,
+                           (float)(1.0 - beta2), (float)eps, (float)weight_decay, inv_bc2_sqrt, (const long long *)step_dev, lr, beta1, beta2,
+                           xent_rows, (int)xent_n, xent_out);
+        xent_rows = nullptr;
     }
+    if (xent_rows)                                                   // no parameter had anything to update: the loss still has to be finished
+        hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, stream, xent_rows, (int)xent_n, xent_out, xent_out + 1);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
+}
+
+extern "C" int sage_adam_step(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                              float *const *exp_avg_sq, const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, int64_t step, const int64_t *step_dev, void *stream_) {
+    clear_error();
+    return adam_step_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, step, step_dev, nullptr, 0,
+                          nullptr, (hipStream_t)stream_);
+}
+
+// The same step, and in the same launch the last stage of this step's cross-entropy (sage_cross_entropy_forward with fused = 2 left
+// it out): loss_out[0] = mean row loss, loss_out[1] = 1 / count.  main.py:216 + 244: the loss is a number the host logs after the step.
+extern "C" int sage_adam_step_loss(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                                   float *const *exp_avg_sq, const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                                   double weight_decay, int64_t step, const int64_t *step_dev, const float *xent_rows, int64_t xent_n,
+                                   float *loss_out, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(xent_rows && loss_out && xent_n > 0 && xent_n < INT32_MAX, "sage_adam_step_loss: null pointer or bad row count");
+    return adam_step_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, step, step_dev, xent_rows,
+                          xent_n, loss_out, (hipStream_t)stream_);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -590,32 +683,7 @@ __global__ __launch_bounds__(256) void k_xent_rows(const float *__restrict__ log
 
 __global__ __launch_bounds__(256) void k_xent_final(const float *__restrict__ row_loss, int N, float *__restrict__ loss,
                                                     float *__restrict__ inv_count) {
-    __shared__ double ssum[256];
-    __shared__ int scnt[256];
-    double s = 0.0;
-    int n = 0;
-    for (int base = 0; base < N; base += 8 * 256) {             // eight row losses per thread in flight (same order of additions)
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float t = row_loss[min(base + (int)threadIdx.x + 256 * u, N - 1)];
-            v[u] = base + (int)threadIdx.x + 256 * u < N ? t : -1.f;         // a select, not a branch: -1 marks "not counted"
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (v[u] >= 0.f) { s += (double)v[u]; ++n; }
-    }
-    ssum[threadIdx.x] = s;
-    scnt[threadIdx.x] = n;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) { ssum[threadIdx.x] += ssum[threadIdx.x + off]; scnt[threadIdx.x] += scnt[threadIdx.x + off]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        *loss = scnt[0] > 0 ? (float)(ssum[0] / scnt[0]) : __builtin_nanf("");      // torch: nan when every label is ignored
-        *inv_count = scnt[0] > 0 ? 1.f / (float)scnt[0] : 0.f;
-    }
+    xent_final_block(row_loss, N, loss, inv_count);
 }
 
 __global__ __launch_bounds__(256) void k_xent_scale(const float *__restrict__ g, size_t n, const float *__restrict__ upstream,
@@ -639,7 +707,8 @@ extern "C" int sage_cross_entropy_forward(const float *logits, const int64_t *ta
     else
         hipLaunchKernelGGL(k_xent_rows<false>, dim3(capped_grid((size_t)N * 64, 256)), dim3(256), 0, stream, logits, (const long long *)target,
                            (int)N, C, (long long)ignore_index, grad_unscaled, row_scratch, bad_label);
-    hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, stream, row_scratch, (int)N, loss, inv_count);
+    if (fused != 2)                                                  // 2: the caller folds the last stage into the optimiser's launch (sage_adam_step_loss)
+        hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, stream, row_scratch, (int)N, loss, inv_count);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
 }

@@ -36,6 +36,10 @@ struct T16Args {
     const long long *rows;     // nullptr, or: row m of the FIRST product's A operand is p[0].A + rows[m] * p[0].lda (the resident
                                // feature matrix read through n_id; byte offsets must fit 32 bits)
     int accumulate;            // 1: C += product (no bias): the second half of a layer whose first half another launch wrote
+    // Round 5: the column sums of what this launch leaves in C and of its squares, per row tile, in float64 -- the first stage of the
+    // BatchNorm statistics of the layer's output (main.py:207: bns[i](x)), which was a launch of its own reading C back
+    // (k_bn_partial).  stat_a / stat_b: [tiles_m, N] doubles each, or nullptr.  Only the launch that writes C's FINAL value gets them.
+    double *stat_a, *stat_b;
 };
 
 #ifdef POPE_STAMP
@@ -232,13 +236,27 @@ __device__ __forceinline__ void t16_tile(const T16Args &a, const int M, const in
                 const int m = m0 + i * 16 + 4 * g + r;
                 add[i][r] = a.accumulate ? a.C[(size_t)min(m, M - 1) * a.ldc + n] : b;      // all loads issued before the first store
             }
+        double cs = 0.0, cq = 0.0;
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + i * 16 + 4 * g + r;
-                if (m < M) a.C[(size_t)m * a.ldc + n] = acc[i][t][r] + add[i][r];
+                const float val = acc[i][t][r] + add[i][r];
+                if (m < M) a.C[(size_t)m * a.ldc + n] = val;
+                if (a.stat_a && m < M) {                               // (wave-uniform pointer test: no cost without statistics)
+                    cs += (double)val;
+                    cq += (double)val * (double)val;
+                }
             }
+        if (a.stat_a) {                                                // the four lanes that share column n (g = 0 .. 3), in a fixed order
+            cs += __shfl_xor(cs, 16); cq += __shfl_xor(cq, 16);
+            cs += __shfl_xor(cs, 32); cq += __shfl_xor(cq, 32);
+            if (g == 0) {
+                a.stat_a[(size_t)tm * a.N + n] = cs;
+                a.stat_b[(size_t)tm * a.N + n] = cq;
+            }
+        }
     }
 }
 

@@ -633,7 +633,7 @@ static int t16_plan(const float *A0, const float *B0, int K0, const float *A1, c
     a.p[0] = SkProduct{A0, B0, lda, ldb, K0};
     a.p[1] = SkProduct{K1 > 0 ? A1 : A0, K1 > 0 ? B1 : B0, lda, ldb, K1};
     a.M = M; a.N = N; a.bias = bias; a.C = C; a.ldc = ldc; a.zero = zero_page[dev]; a.m_dev = m_dev;
-    a.rows = nullptr; a.accumulate = 0;
+    a.rows = nullptr; a.accumulate = 0; a.stat_a = a.stat_b = nullptr;
     a.tiles_m = (M + 16 * rb - 1) / (16 * rb); a.tiles_n = (N + T16_TN - 1) / T16_TN;
     a.S0 = (K0 + T16_GK - 1) / T16_GK; a.S1 = (K1 + T16_GK - 1) / T16_GK;
     plan->grid = a.tiles_n == 2 ? (a.tiles_m + 7) / 8 * 16 : a.tiles_m * a.tiles_n;
@@ -660,15 +660,31 @@ static int t16_launch(const T16Plan &plan, hipStream_t stream) {
     return POPE_OK;
 }
 
+// A caller's wish for the first stage of the BatchNorm statistics of the layer's output (main.py:207) out of the projection's epilogue:
+// pa / pb [parts_cap, c_out] doubles.  Filled in by the whole-tile kernels only; parts = 0 says "not produced" (the caller then runs
+// the statistics pass of sage_bn_relu_dropout_forward as before).
+struct BnStatsOut {
+    double *pa = nullptr, *pb = nullptr;
+    int parts_cap = 0;
+    int parts = 0, rows_per_part = 0;      // out
+};
+
+static bool stats_fit(const BnStatsOut *st, const T16Plan &plan) { return st && st->pa && st->pb && plan.a.tiles_m <= st->parts_cap; }
+
 // *used = false if nothing was launched (see T16Plan).
 static int gemm_tile16(const float *A0, const float *B0, int K0, const float *A1, const float *B1, int K1, long long lda, long long ldb,
-                       int M, int N, const float *bias, float *C, long long ldc, hipStream_t stream, bool *used, const int *m_dev = nullptr) {
+                       int M, int N, const float *bias, float *C, long long ldc, hipStream_t stream, bool *used, const int *m_dev = nullptr,
+                       BnStatsOut *stats = nullptr) {
     *used = false;
     const bool small = !streamk_shape_ok(M, K0, K1, N);
     if (small && (g_gemm_small_tile16 == 0 || (long long)M * N < 64 * 1024)) return POPE_OK;   // (tiny products stay on the plain tile kernel)
     T16Plan plan;
     int rc = t16_plan(A0, B0, K0, A1, B1, K1, lda, ldb, M, N, bias, C, ldc, m_dev, &plan, 0, small);
     if (rc || !plan.ok) return rc;
+    if (stats_fit(stats, plan)) {
+        plan.a.stat_a = stats->pa; plan.a.stat_b = stats->pb;
+        stats->parts = plan.a.tiles_m; stats->rows_per_part = 16 * plan.rb;
+    }
     if ((rc = t16_launch(plan, stream))) return rc;
     *used = true;
     return POPE_OK;
@@ -824,7 +840,7 @@ static int launch_gather_beside_gemm(const T16Args &a, const GatherArgs &g, int 
 // row count.  *used = false: nothing launched, the caller runs gather + one-pass projection as before.
 static int forward_overlapped(const int32_t *rowptr, const int32_t *col, int64_t n_dst, const float *x, int64_t x_rows, int32_t c_in,
                               const long long *n_id, float *x_dst, float *agg, const float *w_l, const float *b_l, const float *w_r,
-                              int32_t c_out, float *out, const int32_t *dims, hipStream_t stream, bool *used) {
+                              int32_t c_out, float *out, const int32_t *dims, hipStream_t stream, bool *used, BnStatsOut *stats = nullptr) {
     *used = false;
     if (g_sage_forward_overlap == 0) return POPE_OK;
     if (!streamk_shape_ok(n_dst, c_in, c_in, c_out) || !aligned16(x) || !aligned16(agg) || (x_dst && !aligned16(x_dst))) return POPE_OK;
@@ -836,6 +852,10 @@ static int forward_overlapped(const int32_t *rowptr, const int32_t *col, int64_t
     if (first.rb > 5) return POPE_OK;                               // taller tiles do not fit the fused kernel's 128 registers (they spill 140-430 bytes per lane)
     first.a.rows = n_id;                                            // nullptr: destination i is row i of x
     second.a.accumulate = 1;
+    if (stats_fit(stats, second)) {                                 // the launch that leaves the layer's final values in `out`
+        second.a.stat_a = stats->pa; second.a.stat_b = stats->pb;
+        stats->parts = second.a.tiles_m; stats->rows_per_part = 16 * second.rb;
+    }
     int cus = 0;
     if ((rc = device_cu_count(&cus))) return rc;
     const int gemm_blocks = first.a.tiles_n == 2 ? std::min(first.grid, (cus + 15) / 16 * 16) : std::min(first.grid, cus);
@@ -1004,21 +1024,19 @@ extern "C" int sage_gather_mean(const int32_t *rowptr, const int32_t *col, int64
 }
 
 // `dims` (device int32 [4] = {n_dst, n_src, nnz, 0}, or NULL): see include/graphpope_hip.h, "Device extents".
-extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
-                                 const float *x_src, int32_t c_in, const float *w_l, const float *b_l, const float *w_r,
-                                 int32_t c_out, float *agg, float *out, void *scratch, size_t scratch_bytes, const int32_t *dims,
-                                 void *stream_) {
-    clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
+static int conv_forward_impl(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
+                             const float *x_src, int32_t c_in, const float *w_l, const float *b_l, const float *w_r,
+                             int32_t c_out, float *agg, float *out, void *scratch, size_t scratch_bytes, const int32_t *dims,
+                             BnStatsOut *stats, hipStream_t stream) {
     POPE_REQUIRE(rowptr && (col || nnz == 0) && x_src && w_l && w_r && agg && out, "sage_conv_forward: null pointer");
     POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && nnz >= 0 && nnz < INT32_MAX && c_in > 0 && c_out > 0,
                  "sage_conv_forward: bad size (destinations must be the first n_dst sources)");
     bool used = false;
-    int rc = forward_overlapped(rowptr, col, n_dst, x_src, n_src, c_in, nullptr, nullptr, agg, w_l, b_l, w_r, c_out, out, dims, stream, &used);
+    int rc = forward_overlapped(rowptr, col, n_dst, x_src, n_src, c_in, nullptr, nullptr, agg, w_l, b_l, w_r, c_out, out, dims, stream, &used, stats);
     if (rc || used) return rc;
     enqueue_gather_mean(rowptr, col, n_dst, x_src, c_in, agg, stream, nullptr, nullptr, dims);
     // out = agg * w_l^T + b_l + x_dst * w_r^T in one pass
-    if ((rc = gemm_tile16(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used, dims))) return rc;
+    if ((rc = gemm_tile16(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used, dims, stats))) return rc;
     if (used) return POPE_OK;
     rc = gemm_streamk(agg, w_l, c_in, x_src, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);
     if (rc || used) return rc;
@@ -1031,18 +1049,16 @@ extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int6
 // The same layer on rows of the resident feature matrix: source j of the block is feats[n_id[j]].  Replaces
 // Batch.x = data.x[n_id] (main.py:118-123) + the layer: x[n_id] is never materialised, only the n_dst destination rows
 // (x_dst, needed again by the backward pass) are.
-extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
-                                         int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l,
-                                         const float *b_l, const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out,
-                                         void *scratch, size_t scratch_bytes, const int32_t *dims, void *stream_) {
-    clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
+static int conv_forward_indexed_impl(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
+                                     int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l,
+                                     const float *b_l, const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out,
+                                     void *scratch, size_t scratch_bytes, const int32_t *dims, BnStatsOut *stats, hipStream_t stream) {
     POPE_REQUIRE(rowptr && (col || nnz == 0) && n_id && feats && w_l && w_r && agg && out, "sage_conv_forward_indexed: null pointer");
     POPE_REQUIRE(n_dst > 0 && n_dst <= n_src && n_src < INT32_MAX && n_rows > 0 && nnz >= 0 && nnz < INT32_MAX && c_in > 0 && c_out > 0,
                  "sage_conv_forward_indexed: bad size (destinations must be the first n_dst entries of n_id)");
     bool used = false;
     int rc = forward_overlapped(rowptr, col, n_dst, feats, n_rows, c_in, (const long long *)n_id, x_dst, agg, w_l, b_l, w_r, c_out, out, dims, stream,
-                                &used);
+                                &used, stats);
     if (rc || used) return rc;
     if (!x_dst) {                                                    // no matrix of the destination rows from the caller: the kernels below want one
         const size_t at = align_up(sage_conv_forward_scratch_bytes(n_dst, c_in, c_out), 256);
@@ -1055,7 +1071,7 @@ extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *c
         scratch_bytes = at;
     }
     enqueue_gather_mean(rowptr, col, n_dst, feats, c_in, agg, stream, n_id, x_dst, dims);
-    if ((rc = gemm_tile16(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used, dims))) return rc;
+    if ((rc = gemm_tile16(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, stream, &used, dims, stats))) return rc;
     if (used) return POPE_OK;
     rc = gemm_streamk(agg, w_l, c_in, x_dst, w_r, c_in, c_in, c_in, (int)n_dst, c_out, b_l, out, c_out, scratch, scratch_bytes, stream, &used, dims);
     if (rc || used) return rc;
@@ -1063,6 +1079,58 @@ extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *c
     GemmDyn dyn;
     dyn.m = dims;
     return gemm(A0, B0, c_in, A1, B1, c_in, (int)n_dst, c_out, b_l, out, c_out, 1, nullptr, stream, Twin{Operand{nullptr, 0, 0}, nullptr, 0}, dyn);
+}
+
+extern "C" int sage_conv_forward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
+                                 const float *x_src, int32_t c_in, const float *w_l, const float *b_l, const float *w_r,
+                                 int32_t c_out, float *agg, float *out, void *scratch, size_t scratch_bytes, const int32_t *dims,
+                                 void *stream_) {
+    clear_error();
+    return conv_forward_impl(rowptr, col, n_src, n_dst, nnz, x_src, c_in, w_l, b_l, w_r, c_out, agg, out, scratch, scratch_bytes, dims, nullptr,
+                             (hipStream_t)stream_);
+}
+
+extern "C" int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
+                                         int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l,
+                                         const float *b_l, const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out,
+                                         void *scratch, size_t scratch_bytes, const int32_t *dims, void *stream_) {
+    clear_error();
+    return conv_forward_indexed_impl(rowptr, col, n_id, n_src, n_dst, nnz, feats, n_rows, c_in, w_l, b_l, w_r, c_out, agg, x_dst, out, scratch,
+                                     scratch_bytes, dims, nullptr, (hipStream_t)stream_);
+}
+
+// The same two calls for a layer whose output goes into BatchNorm (main.py:206-207: x = convs[i](...); x = bns[i](x)): the projection's
+// epilogue also leaves the column sums of `out` and of its squares per row tile in bn_pa / bn_pb ([bn_parts_cap, c_out] doubles each;
+// bn_parts_cap >= ceil(n_dst / 16) always suffices) -- the first stage of the BatchNorm statistics, which was a launch of its own
+// re-reading `out`.  bn_info[0] = row tiles written, bn_info[1] = rows per tile (host ints); bn_info[0] = 0: this shape's kernel
+// path produces no statistics, run sage_bn_relu_dropout_forward; else sage_bn_relu_dropout_forward_stats.
+extern "C" int sage_conv_forward_stats(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
+                                       const float *x_src, int32_t c_in, const float *w_l, const float *b_l, const float *w_r,
+                                       int32_t c_out, float *agg, float *out, void *scratch, size_t scratch_bytes, const int32_t *dims,
+                                       double *bn_pa, double *bn_pb, int32_t bn_parts_cap, int32_t *bn_info, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(bn_pa && bn_pb && bn_info && bn_parts_cap > 0, "sage_conv_forward_stats: null pointer");
+    BnStatsOut st;
+    st.pa = bn_pa; st.pb = bn_pb; st.parts_cap = bn_parts_cap;
+    const int rc = conv_forward_impl(rowptr, col, n_src, n_dst, nnz, x_src, c_in, w_l, b_l, w_r, c_out, agg, out, scratch, scratch_bytes, dims, &st,
+                                     (hipStream_t)stream_);
+    bn_info[0] = st.parts; bn_info[1] = st.rows_per_part;
+    return rc;
+}
+
+extern "C" int sage_conv_forward_indexed_stats(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
+                                               int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l,
+                                               const float *b_l, const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out,
+                                               void *scratch, size_t scratch_bytes, const int32_t *dims, double *bn_pa, double *bn_pb,
+                                               int32_t bn_parts_cap, int32_t *bn_info, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(bn_pa && bn_pb && bn_info && bn_parts_cap > 0, "sage_conv_forward_indexed_stats: null pointer");
+    BnStatsOut st;
+    st.pa = bn_pa; st.pb = bn_pb; st.parts_cap = bn_parts_cap;
+    const int rc = conv_forward_indexed_impl(rowptr, col, n_id, n_src, n_dst, nnz, feats, n_rows, c_in, w_l, b_l, w_r, c_out, agg, x_dst, out,
+                                             scratch, scratch_bytes, dims, &st, (hipStream_t)stream_);
+    bn_info[0] = st.parts; bn_info[1] = st.rows_per_part;
+    return rc;
 }
 
 // (Round 3 measured the bias gradient and the grad_x chain on side streams beside the weight gradients: 0.449 ms against 0.378 ms on

@@ -23,6 +23,7 @@ class Adam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self._tables = {}            # per group: cached ctypes pointer arrays, rebuilt when the set of tensors changes
         self.step_dev = None         # device int64 scalar holding the 1-based step count (use_device_step)
+        self._pending_loss = None    # (row losses, [loss, 1 / count]) of a cross-entropy whose last stage rides in the next step's launch
 
     def use_device_step(self, word: torch.Tensor | None) -> None:
         """Read the step count of the bias corrections from a device word instead of the host counter: a training step that
@@ -30,6 +31,14 @@ class Adam(torch.optim.Optimizer):
         taken (the caller advances it, sage_advance_counters); the host-side counters keep counting the calls made here."""
         assert word is None or (word.is_cuda and word.dtype == torch.int64 and word.numel() == 1)
         self.step_dev = word
+
+    def fold_loss(self, row_losses: torch.Tensor, out: torch.Tensor) -> None:
+        """The next :meth:`step` finishes a cross-entropy in its own launch (sage_adam_step_loss): ``row_losses`` (float32 [N], one
+        loss per row, written by sage_cross_entropy_forward with fused = 2) -> ``out`` (float32 [2]: mean loss, 1 / count).  The
+        scalar is only valid once that step has run -- graphpope_amd.sage.cross_entropy(loss_in=optimizer) arranges this for a
+        training step that owns its backward() and step() calls."""
+        assert row_losses.is_cuda and row_losses.dtype == torch.float32 and row_losses.is_contiguous() and out.numel() >= 2
+        self._pending_loss = (row_losses, out)
 
     def _build(self, group, live):
         """Slow path, taken when the set of parameters with gradients changes: checks, state creation, pointer tables."""
@@ -81,13 +90,27 @@ class Adam(torch.optim.Optimizer):
                     gg[i] = a
             step = tab["step"] = tab["step"] + 1
             b1, b2 = group["betas"]
+            pending, self._pending_loss = self._pending_loss, None
             with on_device(tab["dev"]):
-                check(lib.sage_adam_step(tab["n"], tab["pp"], gg, tab["mm"], tab["vv"], tab["nn"], float(group["lr"]), float(b1),
-                                         float(b2), float(group["eps"]), float(group["weight_decay"]), step,
-                                         ctypes.c_void_p(0 if self.step_dev is None else self.step_dev.data_ptr()),
-                                         ctypes.c_void_p(torch.cuda.current_stream(tab["dev"]).cuda_stream)))
+                if pending is None:
+                    check(lib.sage_adam_step(tab["n"], tab["pp"], gg, tab["mm"], tab["vv"], tab["nn"], float(group["lr"]), float(b1),
+                                             float(b2), float(group["eps"]), float(group["weight_decay"]), step,
+                                             ctypes.c_void_p(0 if self.step_dev is None else self.step_dev.data_ptr()),
+                                             ctypes.c_void_p(torch.cuda.current_stream(tab["dev"]).cuda_stream)))
+                else:                                         # this launch also finishes the step's cross-entropy (one block more)
+                    check(lib.sage_adam_step_loss(tab["n"], tab["pp"], gg, tab["mm"], tab["vv"], tab["nn"], float(group["lr"]), float(b1),
+                                                  float(b2), float(group["eps"]), float(group["weight_decay"]), step,
+                                                  ctypes.c_void_p(0 if self.step_dev is None else self.step_dev.data_ptr()),
+                                                  ctypes.c_void_p(pending[0].data_ptr()), pending[0].numel(), ctypes.c_void_p(pending[1].data_ptr()),
+                                                  ctypes.c_void_p(torch.cuda.current_stream(tab["dev"]).cuda_stream)))
             for st in tab["states"]:
                 st["step"] = step
+        if self._pending_loss is not None:                   # no parameter had a gradient: finish the loss on its own
+            pending, self._pending_loss = self._pending_loss, None
+            with on_device(pending[0].device):
+                check(lib.sage_adam_step_loss(0, None, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 1, None,
+                                              ctypes.c_void_p(pending[0].data_ptr()), pending[0].numel(), ctypes.c_void_p(pending[1].data_ptr()),
+                                              ctypes.c_void_p(torch.cuda.current_stream(pending[0].device).cuda_stream)))
         return loss
 
     def state_dict(self):

@@ -68,9 +68,15 @@ def _forward_scratch(lib, n_dst, c_in, c_out, dev):
     return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
 
 
+def _stats_buffers(n_dst, c_out, dev):
+    """Room for the per-row-tile column sums the projection's epilogue leaves for BatchNorm (sage_conv_forward_stats): float64
+    [2, ceil(n_dst / 16), c_out] on the device and the two host ints the call reports (tiles written, rows per tile)."""
+    return torch.empty((2, (n_dst + 15) // 16, c_out), dtype=torch.float64, device=dev), (ctypes.c_int32 * 2)(0, 0)
+
+
 class _SageConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_src, w_l, b_l, w_r, rowptr, col, n_dst, dims=None):
+    def forward(ctx, x_src, w_l, b_l, w_r, rowptr, col, n_dst, dims=None, bn_stats=None):
         lib = _lib.load()
         if not x_src.is_cuda:
             raise RuntimeError("SAGEConv runs on the GPU only (no CPU fallback)")
@@ -82,8 +88,16 @@ class _SageConvFn(torch.autograd.Function):
         out = torch.empty((n_dst, c_out), dtype=torch.float32, device=x_src.device)
         with on_device(x_src.device):
             scratch, nbytes = _forward_scratch(lib, n_dst, c_in, c_out, x_src.device)
-            check(lib.sage_conv_forward(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), c_in, ptr(w_l),
-                                        ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(out), ptr(scratch), nbytes, ptr(dims), _stream()))
+            if bn_stats is not None:                  # the projection's epilogue leaves the first stage of the BatchNorm statistics of `out`
+                stats, info = _stats_buffers(n_dst, c_out, x_src.device)
+                check(lib.sage_conv_forward_stats(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), c_in, ptr(w_l),
+                                                  ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(out), ptr(scratch), nbytes, ptr(dims),
+                                                  ptr(stats[0]), ptr(stats[1]), stats.shape[1], info, _stream()))
+                if info[0] > 0:
+                    bn_stats.append((stats, int(info[0]), int(info[1])))
+            else:
+                check(lib.sage_conv_forward(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), c_in, ptr(w_l),
+                                            ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(out), ptr(scratch), nbytes, ptr(dims), _stream()))
         ctx.save_for_backward(x_src, agg, w_l, w_r, rowptr, col)
         ctx.has_bias = b_l is not None
         ctx.n_dst = n_dst
@@ -109,7 +123,7 @@ class _SageConvFn(torch.autograd.Function):
             check(lib.sage_conv_backward(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), ptr(agg), c_in,
                                          ptr(w_l), ptr(w_r), c_out, ptr(grad_out), ptr(grad_x), ptr(grad_w_l), ptr(grad_b),
                                          ptr(grad_w_r), ptr(scratch), scratch.numel(), ptr(ctx.dims), _stream()))
-        return grad_x, grad_w_l, grad_b, grad_w_r, None, None, None, None
+        return grad_x, grad_w_l, grad_b, grad_w_r, None, None, None, None, None
 
 
 class IndexedFeatures:
@@ -128,7 +142,7 @@ class IndexedFeatures:
 
 class _SageConvIndexedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, w_l, b_l, w_r, feats, n_id, rowptr, col, n_dst, dims=None):
+    def forward(ctx, w_l, b_l, w_r, feats, n_id, rowptr, col, n_dst, dims=None, bn_stats=None):
         lib = _lib.load()
         if not feats.is_cuda:
             raise RuntimeError("SAGEConv runs on the GPU only (no CPU fallback)")
@@ -140,9 +154,18 @@ class _SageConvIndexedFn(torch.autograd.Function):
         out = torch.empty((n_dst, c_out), dtype=torch.float32, device=dev)
         with on_device(dev):
             scratch, nbytes = _forward_scratch(lib, n_dst, c_in, c_out, dev)
-            check(lib.sage_conv_forward_indexed(ptr(rowptr), ptr(col), ptr(n_id), n_id.numel(), n_dst, col.numel(), ptr(feats),
-                                                feats.shape[0], c_in, ptr(w_l), ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(x_dst),
-                                                ptr(out), ptr(scratch), nbytes, ptr(dims), _stream()))
+            if bn_stats is not None:
+                stats, info = _stats_buffers(n_dst, c_out, dev)
+                check(lib.sage_conv_forward_indexed_stats(ptr(rowptr), ptr(col), ptr(n_id), n_id.numel(), n_dst, col.numel(), ptr(feats),
+                                                          feats.shape[0], c_in, ptr(w_l), ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(x_dst),
+                                                          ptr(out), ptr(scratch), nbytes, ptr(dims), ptr(stats[0]), ptr(stats[1]),
+                                                          stats.shape[1], info, _stream()))
+                if info[0] > 0:
+                    bn_stats.append((stats, int(info[0]), int(info[1])))
+            else:
+                check(lib.sage_conv_forward_indexed(ptr(rowptr), ptr(col), ptr(n_id), n_id.numel(), n_dst, col.numel(), ptr(feats),
+                                                    feats.shape[0], c_in, ptr(w_l), ptr(b_l), ptr(w_r), c_out, ptr(agg), ptr(x_dst),
+                                                    ptr(out), ptr(scratch), nbytes, ptr(dims), _stream()))
         # x_dst is kept as a matrix for the backward pass: reading the destination rows through n_id in the weight-gradient kernel
         # (sage_conv_backward_indexed) was measured 29 us slower per step than the 60 MB this copy costs
         ctx.save_for_backward(x_dst, agg, w_l, w_r, rowptr, col)
@@ -164,7 +187,7 @@ class _SageConvIndexedFn(torch.autograd.Function):
             check(lib.sage_conv_backward(ptr(rowptr), ptr(col), n_dst, n_dst, col.numel(), ptr(x_dst), ptr(agg), c_in, ptr(w_l),
                                          ptr(w_r), c_out, ptr(grad_out), None, ptr(grad_w_l), ptr(grad_b), ptr(grad_w_r),
                                          ptr(scratch), scratch.numel(), ptr(ctx.dims), _stream()))
-        return grad_w_l, grad_b, grad_w_r, None, None, None, None, None, None
+        return grad_w_l, grad_b, grad_w_r, None, None, None, None, None, None, None
 
 
 class _Linear(nn.Module):
@@ -192,13 +215,20 @@ class SAGEConv(nn.Module):
         self.lin_l = _Linear(in_channels, out_channels, bias=True)
         self.lin_r = _Linear(in_channels, out_channels, bias=False)
 
-    def forward(self, x, adj_t: SampledAdj):
+    def forward(self, x, adj_t: SampledAdj, bn_stats: bool = False):
+        """``bn_stats``: the output goes straight into :func:`bn_relu_dropout` in training mode -- the projection's epilogue then also
+        produces the first stage of its BatchNorm statistics (carried on the returned tensor as ``_bn_stats``), one launch less."""
+        holder = [] if bn_stats else None                         # the autograd function appends (stats, tiles, rows per tile) when its kernels produced them
         if isinstance(x, IndexedFeatures):                        # neighbours read straight from the resident feature matrix
-            return _SageConvIndexedFn.apply(self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, x.feats, x.n_id, adj_t.rowptr,
-                                            adj_t.col, adj_t.size(0), adj_t.dims)
-        x_src = x[0] if isinstance(x, (tuple, list)) else x       # x_dst = x_src[:n_dst] by construction (main.py:206)
-        return _SageConvFn.apply(x_src, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, adj_t.rowptr, adj_t.col,
-                                 adj_t.size(0), adj_t.dims)
+            out = _SageConvIndexedFn.apply(self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, x.feats, x.n_id, adj_t.rowptr,
+                                           adj_t.col, adj_t.size(0), adj_t.dims, holder)
+        else:
+            x_src = x[0] if isinstance(x, (tuple, list)) else x   # x_dst = x_src[:n_dst] by construction (main.py:206)
+            out = _SageConvFn.apply(x_src, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, adj_t.rowptr, adj_t.col,
+                                    adj_t.size(0), adj_t.dims, holder)
+        if holder:
+            out._bn_stats = holder[0]
+        return out
 
 
 class _BnReluDropoutFn(torch.autograd.Function):
@@ -206,7 +236,7 @@ class _BnReluDropoutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, p, seed, num_batches_tracked=None,
-                rows=None, seed_dev=None):
+                rows=None, seed_dev=None, stats=None):
         lib = _lib.load()
         if not x.is_cuda:
             raise RuntimeError("the fused BatchNorm/ReLU/dropout epilogue runs on the GPU only (no CPU fallback)")
@@ -218,9 +248,16 @@ class _BnReluDropoutFn(torch.autograd.Function):
         rstd = torch.empty(c, dtype=torch.float32, device=dev)
         with on_device(dev):
             scratch = torch.empty(lib.sage_bn_scratch_bytes(c), dtype=torch.uint8, device=dev)
-            check(lib.sage_bn_relu_dropout_forward(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                                                   ptr(num_batches_tracked), momentum, eps, int(training), p, seed, ptr(y), ptr(mean), ptr(rstd),
-                                                   ptr(scratch), scratch.numel(), ptr(rows), ptr(seed_dev), _stream()))
+            if stats is not None and training:        # the first stage of the statistics came with x (sage_conv_forward_stats)
+                st, parts, rows_per_part = stats
+                check(lib.sage_bn_relu_dropout_forward_stats(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                                             ptr(num_batches_tracked), momentum, eps, int(training), p, seed, ptr(y), ptr(mean),
+                                                             ptr(rstd), ptr(scratch), scratch.numel(), ptr(rows), ptr(seed_dev), ptr(st[0]),
+                                                             ptr(st[1]), parts, rows_per_part, _stream()))
+            else:
+                check(lib.sage_bn_relu_dropout_forward(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                                       ptr(num_batches_tracked), momentum, eps, int(training), p, seed, ptr(y), ptr(mean), ptr(rstd),
+                                                       ptr(scratch), scratch.numel(), ptr(rows), ptr(seed_dev), _stream()))
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.cfg = (bool(training), float(p), int(seed))
         ctx.dev_words = (rows, seed_dev)
@@ -242,7 +279,7 @@ class _BnReluDropoutFn(torch.autograd.Function):
             check(lib.sage_bn_relu_dropout_backward(ptr(x), ptr(grad_y), m, c, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                                     int(training), p, seed, ptr(grad_x), ptr(grad_gamma), ptr(grad_beta),
                                                     ptr(scratch), scratch.numel(), ptr(ctx.dev_words[0]), ptr(ctx.dev_words[1]), _stream()))
-        return grad_x, grad_gamma, grad_beta, None, None, None, None, None, None, None, None, None, None
+        return grad_x, grad_gamma, grad_beta, None, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_relu_dropout(x: torch.Tensor, bn: nn.BatchNorm1d, p: float, training: bool, seed: int | None = None,
@@ -269,8 +306,9 @@ def bn_relu_dropout(x: torch.Tensor, bn: nn.BatchNorm1d, p: float, training: boo
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p > 0 and seed_dev is None) else 0
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
+    stats = getattr(x, "_bn_stats", None) if (use_batch_stats and x.is_contiguous()) else None      # left by SAGEConv(..., bn_stats=True) for exactly this tensor
     out = _BnReluDropoutFn.apply(x, bn.weight, bn.bias, rm, rv, float(bn.momentum), float(bn.eps), use_batch_stats,
-                                 float(p) if training else 0.0, seed, nbt, rows, seed_dev)       # the step counter goes up inside the statistics kernel
+                                 float(p) if training else 0.0, seed, nbt, rows, seed_dev, stats)       # the step counter goes up inside the statistics kernel
     return out
 
 
@@ -289,7 +327,7 @@ def bad_label_flag(device) -> torch.Tensor:
 
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, ignore_index, unit_upstream=False):
+    def forward(ctx, logits, target, ignore_index, unit_upstream=False, loss_in=None):
         lib = _lib.load()
         if not logits.is_cuda:
             raise RuntimeError("cross_entropy runs on the GPU only (no CPU fallback)")
@@ -302,7 +340,9 @@ class _CrossEntropyFn(torch.autograd.Function):
         with on_device(dev):
             check(lib.sage_cross_entropy_forward(ptr(logits), ptr(target), n, c, ignore_index, ptr(out), ptr(grad),
                                                  ctypes.c_void_p(out.data_ptr() + 4), ptr(rows), ptr(bad_label_flag(dev)),
-                                                 1 if unit_upstream else 0, _stream()))
+                                                 (2 if loss_in is not None else 1) if unit_upstream else 0, _stream()))
+        if unit_upstream and loss_in is not None:
+            loss_in.fold_loss(rows, out)              # the optimiser's launch finishes the scalar (sage_adam_step_loss)
         ctx.save_for_backward(grad, out)
         ctx.unit_upstream = bool(unit_upstream)
         return out[0]
@@ -312,27 +352,33 @@ class _CrossEntropyFn(torch.autograd.Function):
         lib = _lib.load()
         grad, out = ctx.saved_tensors
         if ctx.unit_upstream:                 # the forward launch already produced d(mean loss) / d(logits): nothing to launch
-            return grad, None, None, None
+            return grad, None, None, None, None
         n, c = grad.shape
         grad_loss = grad_loss.contiguous()
         res = torch.empty_like(grad)
         with on_device(grad.device):
             check(lib.sage_cross_entropy_backward(ptr(grad), n, c, ptr(grad_loss), ctypes.c_void_p(out.data_ptr() + 4), ptr(res),
                                                   _stream()))
-        return res, None, None, None
+        return res, None, None, None, None
 
 
-def cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = -100, unit_upstream: bool = False) -> torch.Tensor:
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = -100, unit_upstream: bool = False, loss_in=None) -> torch.Tensor:
     """``F.cross_entropy(logits, target)`` (main.py:216: mean over the rows, integer labels) in two launches forward and
     one backward: the softmax - onehot gradient is produced with the loss and only scaled in the backward pass.
 
     ``unit_upstream=True`` is a promise that the loss is the root of the backward pass and is seeded with a gradient of 1
     (``loss.backward()``): the whole forward pass is then ONE launch that also scales the gradient by 1 / count, and the
     backward pass launches nothing.  Any other upstream gradient would be ignored -- only a training step that owns its
-    ``backward()`` call (graphpope_amd.train.SageTrainStep) sets it."""
+    ``backward()`` call (graphpope_amd.train.SageTrainStep) sets it.
+
+    ``loss_in`` (a graphpope_amd.optim.Adam, with ``unit_upstream``): the last stage of the forward pass -- the mean of the row
+    losses -- becomes one more block of that optimiser's next ``step()`` launch instead of a launch of its own in front of the
+    backward pass; the returned scalar is valid once that step has run (round 5: one launch and one kernel boundary less per step)."""
     if target.dtype != torch.int64 or target.dim() != 1 or logits.dim() != 2 or target.shape[0] != logits.shape[0]:
         raise ValueError("cross_entropy: logits [N, C] float32 and int64 labels [N] expected")
-    return _CrossEntropyFn.apply(logits, target.contiguous(), int(ignore_index), bool(unit_upstream))
+    if loss_in is not None and not unit_upstream:
+        raise ValueError("cross_entropy: loss_in needs unit_upstream=True (a step that owns its backward() and step() calls)")
+    return _CrossEntropyFn.apply(logits, target.contiguous(), int(ignore_index), bool(unit_upstream), loss_in)
 
 
 class SAGE(nn.Module):
@@ -355,8 +401,9 @@ class SAGE(nn.Module):
 
     def forward(self, x, adjs):
         for i, adj_t in enumerate(adjs):
-            x = self.convs[i](x if isinstance(x, IndexedFeatures) else (x, x[:adj_t.size(0)]), adj_t)
-            if i < len(adjs) - 1:
+            to_bn = i < len(adjs) - 1
+            x = self.convs[i](x if isinstance(x, IndexedFeatures) else (x, x[:adj_t.size(0)]), adj_t, bn_stats=to_bn and self.training)
+            if to_bn:
                 rows = None if adj_t.dims is None else adj_t.dims[0:1]
                 if self.dropout_seed_dev is not None:
                     x = bn_relu_dropout(x, self.bns[i], self.dropout, self.training, seed=0x9E3779B97F4A7C15 * (i + 1) % (1 << 63),

@@ -133,7 +133,7 @@ class SageTrainStep:
         for p in self.params:
             p.grad = None
         logits = self.model(x, self.batch.adjs)
-        loss = cross_entropy(logits, self.y, unit_upstream=True)      # main.py:216; the backward pass below is seeded with 1
+        loss = cross_entropy(logits, self.y, unit_upstream=True, loss_in=self.opt)   # main.py:216; the backward pass below is seeded with 1, the scalar is finished by opt.step()'s launch
         loss.backward(gradient=self._one)
         # detached views of the results: nothing outside this call keeps the autograd graph (and its AccumulateGrad nodes,
         # which remember the stream they were created on) alive into the next call or into the capture

@@ -446,6 +446,22 @@ int sage_conv_forward_indexed(const int32_t *rowptr, const int32_t *col, const i
                               int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l, const float *b_l,
                               const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out, void *scratch,
                               size_t scratch_bytes, const int32_t *dims, void *stream);
+/*
+ * The same two forward calls for a layer whose output goes into BatchNorm (main.py:206-207: x = convs[i](...); x = bns[i](x)): the
+ * projection's epilogue also leaves the column sums of `out` and of its squares, per row tile, in bn_pa / bn_pb ([bn_parts_cap, c_out]
+ * float64 each; bn_parts_cap >= ceil(n_dst / 16) always suffices) -- the first stage of the BatchNorm statistics, which otherwise is a
+ * launch of its own that reads `out` back.  bn_info (HOST, 2 ints, out): [0] = row tiles written (0: this shape's kernels produce no
+ * statistics -- call sage_bn_relu_dropout_forward as usual), [1] = rows per tile; pass both to sage_bn_relu_dropout_forward_stats.
+ */
+int sage_conv_forward_stats(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz, const float *x_src,
+                            int32_t c_in, const float *w_l, const float *b_l, const float *w_r, int32_t c_out, float *agg, float *out,
+                            void *scratch, size_t scratch_bytes, const int32_t *dims, double *bn_pa, double *bn_pb, int32_t bn_parts_cap,
+                            int32_t *bn_info, void *stream);
+int sage_conv_forward_indexed_stats(const int32_t *rowptr, const int32_t *col, const int64_t *n_id, int64_t n_src, int64_t n_dst,
+                                    int64_t nnz, const float *feats, int64_t n_rows, int32_t c_in, const float *w_l, const float *b_l,
+                                    const float *w_r, int32_t c_out, float *agg, float *x_dst, float *out, void *scratch,
+                                    size_t scratch_bytes, const int32_t *dims, double *bn_pa, double *bn_pb, int32_t bn_parts_cap,
+                                    int32_t *bn_info, void *stream);
 int sage_conv_backward(const int32_t *rowptr, const int32_t *col, int64_t n_src, int64_t n_dst, int64_t nnz,
                        const float *x_src, const float *agg, int32_t c_in, const float *w_l, const float *w_r,
                        int32_t c_out, const float *grad_out, float *grad_x, float *grad_w_l, float *grad_b_l,
@@ -534,6 +550,14 @@ int sage_bn_relu_dropout_forward(const float *x, int64_t M, int32_t C, const flo
                                  float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps, int32_t training,
                                  float p, uint64_t seed, float *y, float *save_mean, float *save_rstd, void *scratch,
                                  size_t scratch_bytes, const int32_t *rows_dev, const uint64_t *seed_dev, void *stream);
+/* The forward pass with the first stage of the statistics taken from the kernel that wrote x (sage_conv_forward_stats: pa / pb
+ * [parts, C] float64, one part per rows_per_part rows; with rows_dev only the parts in front of the true row count are read): two
+ * launches instead of three.  Same arithmetic otherwise (float64 sums; the order of the additions differs from the three-launch form). */
+int sage_bn_relu_dropout_forward_stats(const float *x, int64_t M, int32_t C, const float *gamma, const float *beta,
+                                       float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
+                                       int32_t training, float p, uint64_t seed, float *y, float *save_mean, float *save_rstd, void *scratch,
+                                       size_t scratch_bytes, const int32_t *rows_dev, const uint64_t *seed_dev, const double *pa,
+                                       const double *pb, int32_t parts, int32_t rows_per_part, void *stream);
 int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,
                                   const float *beta, const float *save_mean, const float *save_rstd, int32_t training,
                                   float p, uint64_t seed, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
@@ -550,6 +574,13 @@ int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M
 int sage_adam_step(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                    float *const *exp_avg_sq, const int64_t *numel, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int64_t step, const int64_t *step_dev, void *stream);
+/* The same step with the LAST STAGE OF THIS STEP'S CROSS-ENTROPY as one more block of the same launch (main.py:216 + 244: the loss is a
+ * number the host logs after the step, it need not hold up the backward pass): xent_rows = the row_scratch that
+ * sage_cross_entropy_forward(fused = 2) filled, xent_n its row count; loss_out[0] = the mean loss, loss_out[1] = 1 / count. */
+int sage_adam_step_loss(int32_t n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                        float *const *exp_avg_sq, const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, int64_t step, const int64_t *step_dev, const float *xent_rows, int64_t xent_n,
+                        float *loss_out, void *stream);
 
 /*
  * Plumbing of a training step replayed as a HIP graph (main.py:213-222 training_step + Lightning's backward / optimizer
@@ -569,6 +600,8 @@ int sage_copy_segments(int32_t n, void *const *dst, const void *const *src, cons
  * fused != 0: ONE launch for the whole forward pass, and grad_unscaled then holds the gradient ALREADY SCALED by 1 / count,
  * i.e. the gradient of the mean loss for an upstream gradient of 1 -- a training step that seeds its backward pass with 1
  * (loss.backward()) needs no backward launch at all; sage_cross_entropy_backward must not be applied to it.
+ * fused == 2: as fused == 1, but the scalar loss and 1 / count are NOT written: the caller hands row_scratch to sage_adam_step_loss,
+ * whose launch finishes them (one launch less per training step).
  */
 int sage_cross_entropy_forward(const float *logits, const int64_t *target, int64_t N, int32_t C, int64_t ignore_index,
                                float *loss, float *grad_unscaled, float *inv_count, float *row_scratch, int32_t *bad_label,

@@ -131,6 +131,55 @@ def test_model_uses_the_fused_epilogue(dev, monkeypatch):
     assert calls == [1] and out.shape == (4, 32)
 
 
+@pytest.mark.parametrize("n_dst,c_in,c_out,extent", [(9988, 756, 256, False), (9988, 756, 256, True), (8100, 200, 256, False), (700, 40, 24, False)])
+@pytest.mark.parametrize("indexed", [False, True], ids=["materialised", "indexed"])
+def test_batchnorm_statistics_out_of_the_projections_epilogue(n_dst, c_in, c_out, extent, indexed, dev):
+    """main.py:206-209: x = convs[i](...); x = bns[i](x); relu; dropout.  SAGEConv(..., bn_stats=True) lets the projection's epilogue
+    produce the first stage of the BatchNorm statistics (float64 column sums per row tile) and bn_relu_dropout picks them up: one
+    launch less.  Against the same two modules without it: the conv output bit for bit, the BatchNorm output, its running
+    statistics and every gradient to 1e-6 of their scale (the float64 sums are added in another order); with a device extent
+    (capacity rows behind the true count are neither produced nor counted); at a shape whose kernels produce no statistics the
+    three-launch form runs (no _bn_stats on the tensor)."""
+    import copy
+    from graphpope_amd.sage import IndexedFeatures, SAGEConv, SampledAdj, bn_relu_dropout
+    g = torch.Generator().manual_seed(n_dst + c_in)
+    n_src = n_dst + 300
+    deg = torch.randint(1, 9, (n_dst,), generator=g)
+    rowptr = torch.cat([torch.zeros(1, dtype=torch.int64), deg.cumsum(0)]).to(torch.int32)
+    col = torch.randint(0, n_src, (int(rowptr[-1]),), generator=g, dtype=torch.int32)
+    torch.manual_seed(1)
+    conv = SAGEConv(c_in, c_out).to(dev)
+    bn_a = torch.nn.BatchNorm1d(c_out).to(dev)
+    bn_b = copy.deepcopy(bn_a)
+    n_true = n_dst - 77 if extent else n_dst
+    dims = torch.tensor([n_true, n_src, int(rowptr[n_true]), 0], dtype=torch.int32, device=dev) if extent else None
+    adj = SampledAdj(rowptr.to(dev), col.to(dev), n_src, dims)
+    if indexed:
+        feats = torch.rand(n_src + 1000, c_in, generator=g).to(dev)
+        n_id = torch.randperm(n_src + 1000, generator=g)[:n_src].to(dev)
+        x = IndexedFeatures(feats, n_id)
+    else:
+        xs = torch.rand(n_src, c_in, generator=g).to(dev)
+        x = (xs, xs[:n_dst])
+    rows = None if dims is None else dims[0:1]
+    res = []
+    for stats, bn in ((False, bn_a), (True, bn_b)):
+        conv.zero_grad(set_to_none=True)
+        h = conv(x, adj, bn_stats=stats)
+        produced = hasattr(h, "_bn_stats")
+        y = bn_relu_dropout(h, bn, 0.5, True, seed=1234, rows=rows)
+        (y[:n_true] * torch.linspace(0.5, 1.5, c_out, device=dev)).sum().backward()
+        res.append((h.detach(), y.detach(), bn.running_mean.clone(), bn.running_var.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                    conv.lin_l.weight.grad.clone(), conv.lin_l.bias.grad.clone(), produced))
+    a, b = res
+    assert not a[8] and b[8] == (n_dst * c_out >= 64 * 1024)                 # tiny products stay on kernels without the epilogue
+    assert torch.equal(a[0][:n_true], b[0][:n_true])
+    for u, v in zip(a[1:8], b[1:8]):
+        u, v = (u[:n_true], v[:n_true]) if u.dim() == 2 and u.shape[0] == n_dst else (u, v)
+        assert float((u - v).abs().max()) <= 1e-6 * max(float(u.abs().max()), 1e-3)
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
+
+
 @pytest.mark.parametrize("n,c", [(1550, 256), (1550, 7), (33, 3), (5, 1000)])
 def test_cross_entropy_matches_torch(n, c, dev):
     """graphpope_amd.sage.cross_entropy against F.cross_entropy (main.py:216): loss and gradient, 1e-6 relative, including
@@ -165,6 +214,44 @@ def test_fused_cross_entropy_with_unit_upstream_matches_torch(n, c, dev):
         _close(b.grad, a.grad, 1e-5)
         assert float(b.grad[::5].abs().max()) == 0.0
     assert torch.isnan(cross_entropy(torch.randn(8, 5, device=dev), torch.full((8,), -100, device=dev), unit_upstream=True))
+
+
+@pytest.mark.parametrize("n,c,with_params", [(1550, 256, True), (33, 3, True), (4097, 64, False)])
+def test_cross_entropy_finished_by_the_optimisers_launch(n, c, with_params, dev):
+    """cross_entropy(..., unit_upstream=True, loss_in=opt): the mean of the row losses is one more block of opt.step()'s launch
+    (sage_adam_step_loss) instead of a launch in front of the backward pass.  After the step: the loss F.cross_entropy gives
+    (main.py:216), the gradient of the mean loss, and bit for bit the parameters the plain one-launch step (sage_adam_step, itself
+    checked against torch.optim.Adam in test_optim_gpu.py; main.py:244) makes of the same gradients -- also when no parameter has a
+    gradient (the loss is then finished on its own)."""
+    from graphpope_amd.optim import Adam
+    from graphpope_amd.sage import cross_entropy
+    torch.manual_seed(n + 5 * c)
+    w = (torch.randn(c, c, device=dev) * 0.1)
+    mine, plain, ref = torch.nn.Parameter(w.clone()), torch.nn.Parameter(w.clone()), torch.nn.Parameter(w.clone())
+    opt, popt = Adam([mine], lr=1e-2), Adam([plain], lr=1e-2)
+    for rep in range(3):
+        x = torch.randn(n, c, device=dev) * 2
+        y = torch.randint(0, c, (n,), device=dev)
+        y[::6] = -100
+        opt.zero_grad(set_to_none=True)
+        if with_params:
+            ref.data.copy_(mine.data)
+            ref.grad = None
+            lm = cross_entropy(x @ mine, y, unit_upstream=True, loss_in=opt)
+            lm.backward()
+            lr_ = F.cross_entropy(x @ ref, y)
+            lr_.backward()
+            _close(mine.grad, ref.grad, 1e-4)
+            plain.grad = mine.grad.clone()
+            opt.step(); popt.step()
+            assert torch.equal(mine.detach(), plain.detach())
+        else:
+            lm = cross_entropy(x, y, unit_upstream=True, loss_in=opt)
+            lr_ = F.cross_entropy(x, y)
+            opt.step()                                                        # nothing to update: the loss is finished all the same
+        assert abs(float(lm) - float(lr_)) <= 1e-6 * max(1.0, abs(float(lr_))), rep
+    with pytest.raises(ValueError):
+        cross_entropy(torch.randn(4, 3, device=dev), torch.zeros(4, dtype=torch.int64, device=dev), loss_in=opt)
 
 
 def test_cross_entropy_all_ignored_and_bad_labels(dev):

@@ -60,8 +60,10 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
                                                     const float *__restrict__ beta, unsigned long long seed,
                                                     unsigned threshold, float inv_keep, double *__restrict__ pa,
                                                     double *__restrict__ pb, const int *__restrict__ m_dev,
-                                                    const unsigned long long *__restrict__ seed_dev) {
-    __shared__ double sh[2][4][64 * VEC];
+                                                    const unsigned long long *__restrict__ seed_dev, double *__restrict__ pc) {
+    // pc (BWD only, or nullptr): a third column sum, of xhat itself -- with it k_bn_bwd_final can give the column sums of dx, i.e. the
+    // bias gradient of the layer that produced x (sage_bn_relu_dropout_backward_bias), without anybody reading dx back
+    __shared__ double sh[3][4][64 * VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = (blockIdx.y * 64 + lane) * VEC;
     const bool valid = c0 < C;
@@ -71,11 +73,11 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
     }
     if (seed_dev) seed += *seed_dev;
     const int r0 = blockIdx.x * rows_per_part, r1 = min(M, r0 + rows_per_part);
-    double a[VEC], b[VEC];
+    double a[VEC], b[VEC], cc[VEC];
     float mu[VEC], rs[VEC], ga[VEC], be[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-        a[i] = b[i] = 0.0;
+        a[i] = b[i] = cc[i] = 0.0;
         mu[i] = rs[i] = ga[i] = be[i] = 0.f;
     }
     if (BWD && valid) {
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
                     const float g = on ? gv.v[i] * inv_keep : 0.f;
                     a[i] += (double)g;
                     b[i] += (double)g * (double)xhat;
+                    if (pc) cc[i] += (double)xhat;
                 }
             }
         };
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
     for (int i = 0; i < VEC; ++i) {
         sh[0][wave][lane * VEC + i] = a[i];
         sh[1][wave][lane * VEC + i] = b[i];
+        sh[2][wave][lane * VEC + i] = cc[i];
     }
     __syncthreads();
     if (wave == 0 && valid) {
@@ -138,33 +142,40 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
             const int j = lane * VEC + i;
             pa[(size_t)blockIdx.x * C + c0 + i] = sh[0][0][j] + sh[0][1][j] + sh[0][2][j] + sh[0][3][j];
             pb[(size_t)blockIdx.x * C + c0 + i] = sh[1][0][j] + sh[1][1][j] + sh[1][2][j] + sh[1][3][j];
+            if (BWD && pc) pc[(size_t)blockIdx.x * C + c0 + i] = sh[2][0][j] + sh[2][1][j] + sh[2][2][j] + sh[2][3][j];
         }
     }
 }
 
 // Column totals of the per-slab partials.  A block is 16 columns x 16 slab-groups: a thread adds every 16th slab, LDS
 // folds the groups in a fixed order (one thread per column walking all slabs was 2 x 256 dependent-latency loads: 69 us).
+template <bool THIRD = false>
 __device__ __forceinline__ void fold_parts(const double *__restrict__ pa, const double *__restrict__ pb, int parts, int C, int c,
-                                           double &s, double &q) {
-    __shared__ double red[2][16][17];
+                                           double &s, double &q, const double *__restrict__ pc = nullptr, double *t = nullptr) {
+    __shared__ double red[3][16][17];
     const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0, d = 0.0;
     if (c < C)
 #pragma unroll 4
-        for (int p = grp; p < parts; p += 16) {
+        for (int p = grp; p < parts; p += 16) {                  // (THIRD as a template argument: a run-time test of pc in here cost the loop its unrolling, +3.5 us)
             a += pa[(size_t)p * C + c];
             b += pb[(size_t)p * C + c];
+            if constexpr (THIRD) d += pc[(size_t)p * C + c];
         }
     red[0][grp][cl] = a;
     red[1][grp][cl] = b;
+    red[2][grp][cl] = d;
     __syncthreads();
     s = q = 0.0;
+    double tt = 0.0;
     if (grp == 0)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             s += red[0][g][cl];
             q += red[1][g][cl];
+            tt += red[2][g][cl];
         }
+    if (t) *t = tt;
 }
 
 // training: batch statistics + running-stat update; else: the running statistics.  Launch: 256 threads, C/16 blocks.
@@ -202,18 +213,25 @@ __global__ __launch_bounds__(256) void k_bn_final(const double *__restrict__ pa,
     }
 }
 
+// dx_colsum (or nullptr; needs pc): the column sums of dx = gamma * rstd * (g - c1 - xhat * c2), i.e. gamma * rstd * (sum g - M c1 - c2 sum xhat),
+// from the float64 sums -- the bias gradient of the layer whose output x is (in training mode it is zero up to rounding: BatchNorm
+// removes whatever a bias in front of it adds; summing the float32 dx matrix, as a launch of its own did, gives rounding noise too).
 __global__ __launch_bounds__(256) void k_bn_bwd_final(const double *__restrict__ pa, const double *__restrict__ pb, int parts, int M, int C,
                                int training, float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ c1,
-                               float *__restrict__ c2, const int *__restrict__ m_dev) {
+                               float *__restrict__ c2, const int *__restrict__ m_dev, const double *__restrict__ pc,
+                               const float *__restrict__ gamma, const float *__restrict__ rstd, float *__restrict__ dx_colsum) {
     M = dyn_extent(m_dev, M);
     const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-    double s, q;
-    fold_parts(pa, pb, parts, C, c, s, q);
+    double s, q, t = 0.0;
+    if (pc) fold_parts<true>(pa, pb, parts, C, c, s, q, pc, &t);          // (block-uniform)
+    else fold_parts<false>(pa, pb, parts, C, c, s, q);
     if ((threadIdx.x >> 4) != 0 || c >= C) return;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)q;
-    c1[c] = training ? (float)(s / M) : 0.f;                       // eval: the statistics are constants
-    c2[c] = training ? (float)(q / M) : 0.f;
+    const double k1 = training ? s / M : 0.0, k2 = training ? q / M : 0.0;
+    c1[c] = (float)k1;                                             // eval: the statistics are constants
+    c2[c] = (float)k2;
+    if (dx_colsum) dx_colsum[c] = (float)((double)gamma[c] * (double)rstd[c] * (s - (double)M * (double)(float)k1 - (double)(float)k2 * t));
 }
 
 // y = dropout(relu((x - mean) * rstd * gamma + beta));  BWD: dx = gamma * rstd * (g - c1 - xhat * c2)
@@ -257,11 +275,11 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, c
 
 struct BnPlan {
     int parts, rows_per_part, vec;
-    double *pa, *pb;
+    double *pa, *pb, *pc;
     float *c1, *c2;
 };
 
-static size_t bn_scratch(int C) { return 2 * (size_t)BN_MAX_PARTS * C * sizeof(double) + 2 * align_up((size_t)C * sizeof(float), 256); }
+static size_t bn_scratch(int C) { return 3 * (size_t)BN_MAX_PARTS * C * sizeof(double) + 2 * align_up((size_t)C * sizeof(float), 256); }
 
 static BnPlan bn_plan(int64_t M, int C, void *scratch, const void *p0, const void *p1, const void *p2, const void *p3,
                       const void *p4, const void *p5, const void *p6) {
@@ -275,7 +293,8 @@ static BnPlan bn_plan(int64_t M, int C, void *scratch, const void *p0, const voi
     p.vec = (C % 4 == 0 && aligned) ? 4 : 1;
     p.pa = (double *)scratch;
     p.pb = p.pa + (size_t)BN_MAX_PARTS * C;
-    p.c1 = (float *)(p.pb + (size_t)BN_MAX_PARTS * C);
+    p.pc = p.pb + (size_t)BN_MAX_PARTS * C;
+    p.c1 = (float *)(p.pc + (size_t)BN_MAX_PARTS * C);
     p.c2 = (float *)((char *)p.c1 + align_up((size_t)C * sizeof(float), 256));
     return p;
 }
@@ -314,10 +333,10 @@ static int bn_forward_impl(const float *x, int64_t M, int32_t C, const float *ga
         const dim3 grid(pl.parts, (C + 64 * pl.vec - 1) / (64 * pl.vec));
         if (pl.vec == 4)
             hipLaunchKernelGGL((k_bn_partial<4, false>), grid, dim3(256), 0, stream, x, nullptr, (int)M, C, pl.rows_per_part,
-                               nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb, rows_dev, nullptr);
+                               nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb, rows_dev, nullptr, nullptr);
         else
             hipLaunchKernelGGL((k_bn_partial<1, false>), grid, dim3(256), 0, stream, x, nullptr, (int)M, C, pl.rows_per_part,
-                               nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb, rows_dev, nullptr);
+                               nullptr, nullptr, nullptr, nullptr, 0ull, 0u, 1.f, pl.pa, pl.pb, rows_dev, nullptr, nullptr);
     }
     hipLaunchKernelGGL(k_bn_final, dim3((C + 15) / 16), dim3(256), 0, stream, external ? ext_pa : pl.pa, external ? ext_pb : pl.pb,
                        external ? ext_parts : pl.parts, (int)M, C, training, momentum, eps, running_mean, running_var, save_mean, save_rstd,
@@ -359,13 +378,11 @@ extern "C" int sage_bn_relu_dropout_forward_stats(const float *x, int64_t M, int
                            save_rstd, scratch, scratch_bytes, rows_dev, seed_dev_, pa, pb, parts, rows_per_part, (hipStream_t)stream_);
 }
 
-extern "C" int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,
-                                             const float *beta, const float *save_mean, const float *save_rstd,
-                                             int32_t training, float p, uint64_t seed, float *grad_x, float *grad_gamma,
-                                             float *grad_beta, void *scratch, size_t scratch_bytes, const int32_t *rows_dev,
-                                             const uint64_t *seed_dev_, void *stream_) {
-    clear_error();
-    hipStream_t stream = (hipStream_t)stream_;
+static int bn_backward_impl(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,
+                            const float *beta, const float *save_mean, const float *save_rstd,
+                            int32_t training, float p, uint64_t seed, float *grad_x, float *grad_gamma,
+                            float *grad_beta, void *scratch, size_t scratch_bytes, const int32_t *rows_dev,
+                            const uint64_t *seed_dev_, float *grad_x_colsum, hipStream_t stream) {
     POPE_REQUIRE(x && grad_y && gamma && beta && save_mean && save_rstd && grad_x && scratch,
                  "sage_bn_relu_dropout_backward: null pointer");
     POPE_REQUIRE(M > 0 && M < INT32_MAX && C > 0 && (size_t)M * C < ((size_t)1 << 40), "sage_bn_relu_dropout_backward: bad size");
@@ -381,12 +398,12 @@ extern "C" int sage_bn_relu_dropout_backward(const float *x, const float *grad_y
     const dim3 grid(pl.parts, (C + 64 * pl.vec - 1) / (64 * pl.vec));
     if (pl.vec == 4)
         hipLaunchKernelGGL((k_bn_partial<4, true>), grid, dim3(256), 0, stream, x, grad_y, (int)M, C, pl.rows_per_part, save_mean,
-                           save_rstd, gamma, beta, (unsigned long long)seed, thr, inv_keep, pl.pa, pl.pb, rows_dev, seed_dev);
+                           save_rstd, gamma, beta, (unsigned long long)seed, thr, inv_keep, pl.pa, pl.pb, rows_dev, seed_dev, grad_x_colsum ? pl.pc : nullptr);
     else
         hipLaunchKernelGGL((k_bn_partial<1, true>), grid, dim3(256), 0, stream, x, grad_y, (int)M, C, pl.rows_per_part, save_mean,
-                           save_rstd, gamma, beta, (unsigned long long)seed, thr, inv_keep, pl.pa, pl.pb, rows_dev, seed_dev);
+                           save_rstd, gamma, beta, (unsigned long long)seed, thr, inv_keep, pl.pa, pl.pb, rows_dev, seed_dev, grad_x_colsum ? pl.pc : nullptr);
     hipLaunchKernelGGL(k_bn_bwd_final, dim3((C + 15) / 16), dim3(256), 0, stream, pl.pa, pl.pb, pl.parts, (int)M, C, training,
-                       grad_gamma, grad_beta, pl.c1, pl.c2, rows_dev);
+                       grad_gamma, grad_beta, pl.c1, pl.c2, rows_dev, grad_x_colsum ? pl.pc : nullptr, gamma, save_rstd, grad_x_colsum);
     const size_t total = (size_t)M * C;
     const unsigned blocks = capped_grid(total / pl.vec, 256);
     if (pl.vec == 4)
@@ -397,6 +414,30 @@ extern "C" int sage_bn_relu_dropout_backward(const float *x, const float *grad_y
                            gamma, beta, pl.c1, pl.c2, (unsigned long long)seed, thr, inv_keep, grad_x, rows_dev, seed_dev);
     POPE_HIP(hipGetLastError());
     return POPE_OK;
+}
+
+extern "C" int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,
+                                             const float *beta, const float *save_mean, const float *save_rstd,
+                                             int32_t training, float p, uint64_t seed, float *grad_x, float *grad_gamma,
+                                             float *grad_beta, void *scratch, size_t scratch_bytes, const int32_t *rows_dev,
+                                             const uint64_t *seed_dev_, void *stream_) {
+    clear_error();
+    return bn_backward_impl(x, grad_y, M, C, gamma, beta, save_mean, save_rstd, training, p, seed, grad_x, grad_gamma, grad_beta, scratch,
+                            scratch_bytes, rows_dev, seed_dev_, nullptr, (hipStream_t)stream_);
+}
+
+// The same, and grad_x_colsum[c] = sum over the rows of grad_x[:, c] (float32 [C]) from the float64 sums of the statistics pass -- the
+// bias gradient of the layer that produced x (main.py:206-207: x = convs[i](...) feeds bns[i]), which sage_conv_backward otherwise
+// computes by reading grad_x back in a launch of its own (pass it grad_b_l = NULL then).
+extern "C" int sage_bn_relu_dropout_backward_bias(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,
+                                                  const float *beta, const float *save_mean, const float *save_rstd,
+                                                  int32_t training, float p, uint64_t seed, float *grad_x, float *grad_gamma,
+                                                  float *grad_beta, void *scratch, size_t scratch_bytes, const int32_t *rows_dev,
+                                                  const uint64_t *seed_dev_, float *grad_x_colsum, void *stream_) {
+    clear_error();
+    POPE_REQUIRE(grad_x_colsum, "sage_bn_relu_dropout_backward_bias: null pointer");
+    return bn_backward_impl(x, grad_y, M, C, gamma, beta, save_mean, save_rstd, training, p, seed, grad_x, grad_gamma, grad_beta, scratch,
+                            scratch_bytes, rows_dev, seed_dev_, grad_x_colsum, (hipStream_t)stream_);
 }
 
 namespace pope {

@@ -68,6 +68,16 @@ def _forward_scratch(lib, n_dst, c_in, c_out, dev):
     return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
 
 
+def _colsum_of(grad_out):
+    """The column sums of an incoming gradient if the op that produced it left them on the tensor (the fused BatchNorm backward,
+    sage_bn_relu_dropout_backward_bias: ``_colsum``, float32 [C] for exactly this tensor), else None -- the layer's bias gradient
+    without a pass over the gradient matrix."""
+    cs = getattr(grad_out, "_colsum", None)
+    if cs is not None and cs.is_cuda and cs.dtype == torch.float32 and cs.dim() == 1 and grad_out.dim() == 2 and cs.numel() == grad_out.shape[1]:
+        return cs
+    return None
+
+
 def _stats_buffers(n_dst, c_out, dev):
     """Room for the per-row-tile column sums the projection's epilogue leaves for BatchNorm (sage_conv_forward_stats): float64
     [2, ceil(n_dst / 16), c_out] on the device and the two host ints the call reports (tiles written, rows per tile)."""
@@ -110,20 +120,21 @@ class _SageConvFn(torch.autograd.Function):
         x_src, agg, w_l, w_r, rowptr, col = ctx.saved_tensors
         n_src, c_in = x_src.shape
         c_out, n_dst = w_l.shape[0], ctx.n_dst
+        given_b = _colsum_of(grad_out) if ctx.has_bias else None
         grad_out = grad_out.contiguous()
         dev = x_src.device
         need_x = ctx.needs_input_grad[0]
         grad_x = torch.empty_like(x_src) if need_x else None
         grad_w_l = torch.empty_like(w_l)
         grad_w_r = torch.empty_like(w_r)
-        grad_b = torch.empty(c_out, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        grad_b = torch.empty(c_out, dtype=torch.float32, device=dev) if (ctx.has_bias and given_b is None) else None
         with on_device(dev):
             scratch = torch.empty(max(lib.sage_conv_scratch_bytes(n_src, n_dst, col.numel(), c_in, c_out), 16),
                                   dtype=torch.uint8, device=dev)
             check(lib.sage_conv_backward(ptr(rowptr), ptr(col), n_src, n_dst, col.numel(), ptr(x_src), ptr(agg), c_in,
                                          ptr(w_l), ptr(w_r), c_out, ptr(grad_out), ptr(grad_x), ptr(grad_w_l), ptr(grad_b),
                                          ptr(grad_w_r), ptr(scratch), scratch.numel(), ptr(ctx.dims), _stream()))
-        return grad_x, grad_w_l, grad_b, grad_w_r, None, None, None, None, None
+        return grad_x, grad_w_l, (given_b if given_b is not None else grad_b), grad_w_r, None, None, None, None, None
 
 
 class IndexedFeatures:
@@ -179,15 +190,16 @@ class _SageConvIndexedFn(torch.autograd.Function):
         x_dst, agg, w_l, w_r, rowptr, col = ctx.saved_tensors
         n_dst, c_in = x_dst.shape
         c_out, dev = w_l.shape[0], x_dst.device
+        given_b = _colsum_of(grad_out) if ctx.has_bias else None
         grad_out = grad_out.contiguous()
         grad_w_l, grad_w_r = torch.empty_like(w_l), torch.empty_like(w_r)
-        grad_b = torch.empty(c_out, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        grad_b = torch.empty(c_out, dtype=torch.float32, device=dev) if (ctx.has_bias and given_b is None) else None
         with on_device(dev):
             scratch = torch.empty(max(lib.sage_conv_scratch_bytes(n_dst, n_dst, col.numel(), c_in, c_out), 16), dtype=torch.uint8, device=dev)
             check(lib.sage_conv_backward(ptr(rowptr), ptr(col), n_dst, n_dst, col.numel(), ptr(x_dst), ptr(agg), c_in, ptr(w_l),
                                          ptr(w_r), c_out, ptr(grad_out), None, ptr(grad_w_l), ptr(grad_b), ptr(grad_w_r),
                                          ptr(scratch), scratch.numel(), ptr(ctx.dims), _stream()))
-        return grad_w_l, grad_b, grad_w_r, None, None, None, None, None, None, None
+        return grad_w_l, (given_b if given_b is not None else grad_b), grad_w_r, None, None, None, None, None, None, None
 
 
 class _Linear(nn.Module):
@@ -261,6 +273,7 @@ class _BnReluDropoutFn(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.cfg = (bool(training), float(p), int(seed))
         ctx.dev_words = (rows, seed_dev)
+        ctx.producer_bias = stats is not None         # x came from a SAGEConv that cooperates: hand it its bias gradient too (backward)
         return y
 
     @staticmethod
@@ -276,9 +289,19 @@ class _BnReluDropoutFn(torch.autograd.Function):
         grad_beta = torch.empty_like(beta)
         with on_device(dev):
             scratch = torch.empty(lib.sage_bn_scratch_bytes(c), dtype=torch.uint8, device=dev)
-            check(lib.sage_bn_relu_dropout_backward(ptr(x), ptr(grad_y), m, c, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
-                                                    int(training), p, seed, ptr(grad_x), ptr(grad_gamma), ptr(grad_beta),
-                                                    ptr(scratch), scratch.numel(), ptr(ctx.dev_words[0]), ptr(ctx.dev_words[1]), _stream()))
+            if ctx.producer_bias:
+                # the column sums of grad_x out of the statistics pass's float64 sums: the producing layer's bias gradient, which
+                # its own backward pass would otherwise get by reading grad_x back (one launch); it finds them on the tensor
+                colsum = torch.empty(c, dtype=torch.float32, device=dev)
+                check(lib.sage_bn_relu_dropout_backward_bias(ptr(x), ptr(grad_y), m, c, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+                                                             int(training), p, seed, ptr(grad_x), ptr(grad_gamma), ptr(grad_beta),
+                                                             ptr(scratch), scratch.numel(), ptr(ctx.dev_words[0]), ptr(ctx.dev_words[1]),
+                                                             ptr(colsum), _stream()))
+                grad_x._colsum = colsum
+            else:
+                check(lib.sage_bn_relu_dropout_backward(ptr(x), ptr(grad_y), m, c, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+                                                        int(training), p, seed, ptr(grad_x), ptr(grad_gamma), ptr(grad_beta),
+                                                        ptr(scratch), scratch.numel(), ptr(ctx.dev_words[0]), ptr(ctx.dev_words[1]), _stream()))
         return grad_x, grad_gamma, grad_beta, None, None, None, None, None, None, None, None, None, None, None
 
 

@@ -562,6 +562,13 @@ int sage_bn_relu_dropout_backward(const float *x, const float *grad_y, int64_t M
                                   const float *beta, const float *save_mean, const float *save_rstd, int32_t training,
                                   float p, uint64_t seed, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
                                   size_t scratch_bytes, const int32_t *rows_dev, const uint64_t *seed_dev, void *stream);
+/* The backward pass, and out of its float64 sums the column sums of grad_x (grad_x_colsum, float32 [C]): the bias gradient of the layer
+ * that produced x (main.py:206-207), which sage_conv_backward otherwise computes by reading grad_x back (pass it grad_b_l = NULL). */
+int sage_bn_relu_dropout_backward_bias(const float *x, const float *grad_y, int64_t M, int32_t C, const float *gamma,
+                                       const float *beta, const float *save_mean, const float *save_rstd, int32_t training,
+                                       float p, uint64_t seed, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
+                                       size_t scratch_bytes, const int32_t *rows_dev, const uint64_t *seed_dev, float *grad_x_colsum,
+                                       void *stream);
 
 /*
  * One Adam step over every parameter tensor in a single launch  (main.py:244: torch.optim.Adam(self.parameters(), lr)).

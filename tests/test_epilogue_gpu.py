@@ -174,10 +174,45 @@ def test_batchnorm_statistics_out_of_the_projections_epilogue(n_dst, c_in, c_out
     a, b = res
     assert not a[8] and b[8] == (n_dst * c_out >= 64 * 1024)                 # tiny products stay on kernels without the epilogue
     assert torch.equal(a[0][:n_true], b[0][:n_true])
-    for u, v in zip(a[1:8], b[1:8]):
+    for u, v in zip(a[1:7], b[1:7]):
         u, v = (u[:n_true], v[:n_true]) if u.dim() == 2 and u.shape[0] == n_dst else (u, v)
         assert float((u - v).abs().max()) <= 1e-6 * max(float(u.abs().max()), 1e-3)
+    # the conv's bias gradient = column sums of BatchNorm's input gradient: zero in exact arithmetic (BatchNorm removes what a bias
+    # adds), rounding noise in both forms -- summed from the float32 matrix (a) or taken from the float64 sums (b, round 5)
+    scale = float(a[6].abs().max())
+    assert float(a[7].abs().max()) <= 1e-4 * scale and float(b[7].abs().max()) <= 1e-4 * scale
     assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("m,c,training", [(9988, 256, 1), (9988, 256, 0), (777, 36, 1), (777, 37, 0)])
+def test_column_sums_of_the_input_gradient_from_the_statistics_pass(m, c, training, dev):
+    """sage_bn_relu_dropout_backward_bias: grad_x_colsum[c] = sum over the rows of grad_x[:, c] (the bias gradient of the layer in front,
+    main.py:206-207) out of the backward statistics' float64 sums instead of a pass over grad_x.  Against the float64 column sums of
+    the grad_x matrix the same call writes: equal to 1e-6 of the sum of |grad_x| per column (in training mode the true value is zero
+    and both are rounding noise; in eval mode it is gamma * rstd * sum g); grad_x, grad_gamma, grad_beta are those of the plain call."""
+    import ctypes
+    from graphpope_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m + c)
+    x = (torch.randn(m, c, generator=g) * 2 + 0.5).to(dev)
+    dy = torch.randn(m, c, generator=g).to(dev)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(dev), torch.randn(c, generator=g).to(dev)
+    mean, rstd = x.mean(0), 1.0 / torch.sqrt(x.var(0, unbiased=False) + 1e-5)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scratch = torch.empty(lib.sage_bn_scratch_bytes(c), dtype=torch.uint8, device=dev)
+    outs = []
+    for with_bias in (False, True):
+        gx, gg, gb = torch.empty_like(x), torch.empty(c, device=dev), torch.empty(c, device=dev)
+        cs = torch.full((c,), float("nan"), device=dev)
+        args = (_lib.ptr(x), _lib.ptr(dy), m, c, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(rstd), training, 0.5, 99, _lib.ptr(gx),
+                _lib.ptr(gg), _lib.ptr(gb), _lib.ptr(scratch), scratch.numel(), None, None)
+        _lib.check(lib.sage_bn_relu_dropout_backward_bias(*args, _lib.ptr(cs), stream) if with_bias else lib.sage_bn_relu_dropout_backward(*args, stream))
+        outs.append((gx, gg, gb, cs))
+    assert all(torch.equal(u, v) for u, v in zip(outs[0][:3], outs[1][:3]))
+    gx, cs = outs[1][0].double(), outs[1][3].double()
+    assert float((cs - gx.sum(0)).abs().max()) <= 1e-6 * float(gx.abs().sum(0).max())
+    if not training:
+        assert float(cs.abs().max()) > 1e-3 * float(gx.abs().sum(0).max())        # a real quantity there, not noise
 
 
 @pytest.mark.parametrize("n,c", [(1550, 256), (1550, 7), (33, 3), (5, 1000)])

@@ -44,7 +44,7 @@ if mode == "eager":
         n_id, adjs, y = batches[i % 8]
         for p in params:
             p.grad = None
-        loss = cross_entropy(model(IndexedFeatures(feats, n_id), adjs), y, unit_upstream=True)
+        loss = cross_entropy(model(IndexedFeatures(feats, n_id), adjs), y, unit_upstream=True, loss_in=opt)
         loss.backward(gradient=one)
         opt.step()
 elif mode == "pool":

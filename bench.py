@@ -865,7 +865,7 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernels from the committed rocprofv3 --pmc summary of the same command
     (separate profiling run, newest round first); None if no summary is committed."""
-    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as fh:

@@ -4,7 +4,8 @@
     python3 tools/big_graph_run.py <graph> <K> [steps] [mode]
         graph: rmat22 | rmat20 | flickr        K: anchors of this call
         mode:  run (default: engine.geodesic_run, F = 0 for R-MAT, F = 500 for flickr) | levels (per-level HIP event times + live nodes)
-             | bfs (BFS only, no output matrix)
+             | bfs (BFS only, no output matrix) | shards (what a rank of an 8-GPU run does behind its all-gather: pope_geodesic_finalize_shards
+               of 8 shards of K anchors each on made-up planes, beside it the feature copy; HIP events)
 
 The R-MAT edge list takes 13 s to generate: it is cached as /tmp/<graph>.npy for the other processes of the same GPU call.
 Prints one JSON line.
@@ -56,6 +57,36 @@ def main():
     if name == "flickr":
         x = torch.rand((n, 500), device=dev, generator=torch.Generator(device=dev).manual_seed(0))
     res = {"graph": name, "N": n, "E": e, "K": k, "mode": mode, "steps": steps}
+    if mode == "shards":
+        world, bits = 8, 4
+        w = lib.pope_words(k)
+        planes = torch.randint(-2**62, 2**62, (world, 1 + bits, n, w), dtype=torch.int64, device=dev)
+        f = 0 if x is None else x.shape[1]
+        out = torch.empty((n, f + world * k), dtype=torch.float32, device=dev)
+
+        def timed(fn):
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / steps
+        res["finalize_shards_ms"] = timed(lambda: engine.finalize_shards(planes, bits, n, k, None, f, out))
+        res["kernel"] = ""
+        import ctypes as _c
+        buf = _c.create_string_buffer(64)
+        lib.pope_finalize_kernel_name(n, k, f, 0, world, buf, 64)
+        res["kernel"] = buf.value.decode()
+        res["columns_GB"] = n * world * k * 4 / 1e9
+        res["planes_all_gathered_GB"] = planes.numel() * 8 / 1e9
+        res["planes_sent_per_rank_GB"] = (1 + bits) * n * w * 8 / 1e9
+        if x is not None:
+            res["feature_copy_ms"] = timed(lambda: engine.copy_features(x, f, out))
+        print(json.dumps(res))
+        return
     if mode == "levels":
         csr = engine.build_csr(ei, n)
         for _ in range(2):

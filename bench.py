@@ -151,6 +151,13 @@ def finalize_kernel_name(n, k, f, has_x, shards):
     return buf.value.decode()
 
 
+def level_kernel_name(n, k):
+    """The level kernel the library launches for a BFS over n nodes from k anchors (pope_level_kernel_name)."""
+    buf = ctypes.create_string_buffer(64)
+    _lib.check(_lib.load().pope_level_kernel_name(n, k, buf, 64))
+    return buf.value.decode()
+
+
 def level_kernel_times(ei, n, anchors, reps):
     """Average duration of a k_bfs_level launch ON THE HOT PATH (pope_geodesic_run, the call the timed steps make): HIP
     events recorded by the library on the launch stream around each enqueued run of level launches (no events between
@@ -461,7 +468,7 @@ def config4_leg(dev, steps=3):
                        "(np seed 42), F=0: edge_index resident -> [N, 512] f32 (graph generation outside the timed region)",
            "ms_per_step": dt * 1e3, "embeddings_per_s": n * k / dt, "max_hop": hp.max_hop, "graph_generation_s": gen,
            "sampled_columns_bit_exact": bool(np.array_equal(got, want)),
-           "roofline": {"kernel": "k_bfs_level<4, 3, 1>", "bound": "hbm", "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+           "roofline": {"kernel": level_kernel_name(n, k), "bound": "hbm", "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch"),
                         "traffic_source": pmc_src, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_per_step": launches,
                         "algorithmic_bytes_per_active_level": dense_bytes, "level_ms": {str(l): round(v, 4) for l, v in level_ms.items()},
@@ -469,7 +476,7 @@ def config4_leg(dev, steps=3):
                                           "frac": dense_bytes / (level_ms[dense_level] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                           "traffic": pmc.get("k_bfs_level_hbm_bytes_densest_launch"),
                                           "gather_roof_ms": e / 56.0e9 * 1e3},
-                        "note": "W = 8 words per node as two 4-word tiles walked inside the wave; every neighbour row is a random 64-byte gather that "
+                        "note": "W = 8 words per node, the whole row in one gather; every neighbour row is a random 64-byte gather that "
                                 "costs a 128-byte line from the fabric (tools/micro/gather_rows.hip: 56 G lines/s chip-wide whatever the row size, "
                                 "profiles/r05_micro_gather_rows.txt), so the densest level cannot take less than E / 56 G/s (gather_roof_ms); HIP events "
                                 "between the launches, one level per launch"},
@@ -1036,7 +1043,7 @@ def main():
         pmc, pmc_src = pmc_traffic()
         pmc = pmc or {}
         result["roofline"] = {
-            "kernel": "k_bfs_level<%d, %d, %d>" % (min(wp, 4), 1 if n <= 256 * 1024 else 3, 0 if wp <= 4 else (2 if n <= 256 * 1024 else 1)), "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": level_kernel_name(n, k_rank), "bound": "hbm", "achieved": exp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": exp_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch") if cfg == 1 else None,
             "traffic_source": (pmc_src + " (rocprofv3 --pmc passes of this command, collected in a separate run: not measured live)") if pmc_src else None,
             "algorithmic_bytes_per_launch": exp_bytes, "avg_launch_ms": exp_ms, "launches_per_step": launches,

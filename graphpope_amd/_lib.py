@@ -73,6 +73,7 @@ SIGNATURES = {
     "pope_geodesic_finalize_shards": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int64, c_int32, c_void_p, c_int32,
                                               c_void_p, c_int64, c_void_p]),
     "pope_finalize_kernel_name": (c_int, [c_int64, c_int32, c_int32, c_int32, c_int32, c_char_p, c_size_t]),
+    "pope_level_kernel_name": (c_int, [c_int64, c_int32, c_char_p, c_size_t]),
     "pope_column_stats_scratch_bytes": (c_size_t, [c_int32]),
     "pope_geodesic_column_stats": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pope_geodesic_hops": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),

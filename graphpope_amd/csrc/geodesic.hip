@@ -31,7 +31,20 @@
 #define POPE_AHEAD 2                  // 0 no look-ahead, 1 indices and live bits of the next chunk, 2 its indices only   (graphs with LIVE >= 2)
 #endif
 #ifndef POPE_TILE_PREFETCH
-#define POPE_TILE_PREFETCH 1          // 0 = the next tile's gathers go out when the tile is reached
+#define POPE_TILE_PREFETCH 2          // 0 = the next tile's gathers go out when the tile is reached, 1 = behind this tile's mask loads,
+                                      // 2 = tiles in pairs, both gathers of a pair back to back (one fetch of the 128-byte line they share)
+#endif
+#ifndef POPE_WT8
+#define POPE_WT8 1                    // 1 = tiles of 8 words (a node's whole 64-byte row in one gather) where the frontier comes from HBM
+#endif
+#ifndef POPE_WT8_WAVES
+#define POPE_WT8_WAVES 3              // waves per SIMD the compiler must fit the 8-word kernel into (1: its own choice)
+#endif
+#ifndef POPE_WT8_LOOP_WAVES
+#define POPE_WT8_LOOP_WAVES 1         // the same for the 8-word kernel that walks several tiles
+#endif
+#ifndef POPE_WT8_PREFETCH
+#define POPE_WT8_PREFETCH 0           // POPE_TILE_PREFETCH of the 8-word tiles
 #endif
 #ifndef POPE_NT_INDEX
 #define POPE_NT_INDEX 1               // 1 = graphs with LIVE >= 2 read the erow / col index streams with the non-temporal hint
@@ -593,7 +606,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
         }
     };
     constexpr bool LOOP = TILES == 1;                          // only then a wave sees more than one tile
-    constexpr bool TILE_AHEAD = LOOP && POPE_TILE_PREFETCH != 0;   // ... and carries the prefetch registers
+    constexpr int TILE_AHEAD = LOOP ? (WT == 8 ? POPE_WT8_PREFETCH : POPE_TILE_PREFETCH) : 0;   // ... and carries the prefetch registers
     if (!TILES) { tile_begin = 0; tile_end = 1; }
     bool found = false;
     STAMP(0);
@@ -713,8 +726,13 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
             if (g2) c2 = gather_words<WT>(front + (size_t)u2 * Wp + woff);
             if (g3) c3 = gather_words<WT>(front + (size_t)u3 * Wp + woff);
         };
-        Words<WT> c0, c1, c2, c3;
+        Words<WT> c0, c1, c2, c3, d0, d1, d2, d3;
         gather4(tile_begin * WT, c0, c1, c2, c3);
+        // Tiles in pairs (TILE_AHEAD = 2): the two tiles' pieces of a node's row lie in one 128-byte line.  Requested a tile apart, the
+        // second request came 1-3 us after the first, behind a tile's mask loads and their waits -- by then the ~8 MB of lines the waves
+        // of one XCD have in flight had pushed the line out of its 4 MB L2 again: 103 raw bytes fetched per edge on the dense levels of
+        // R-MAT scale 22 / 512 anchors where one line per edge and the streams make 75 (profiles/r05_config4_pmc.json).
+        if (TILE_AHEAD == 2 && tile_begin + 1 < tile_end) gather4((tile_begin + 1) * WT, d0, d1, d2, d3);
         next_live();                                                   // behind the gathers: its loads wait for the NEXT chunk's indices only
         for (int tile = tile_begin; tile < tile_end; ++tile) {
             const int woff = tile * WT;
@@ -754,8 +772,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
             }
             // the next tile's gathers go out behind this tile's mask loads (memory instructions retire in order: requested in front of
             // them they would be waited for first), and fly while this tile is scanned and stored
-            Words<WT> d0, d1, d2, d3;
-            if (TILE_AHEAD && tile + 1 < tile_end) gather4(woff + WT, d0, d1, d2, d3);
+            if (TILE_AHEAD == 1 && tile + 1 < tile_end) gather4(woff + WT, d0, d1, d2, d3);
             const u64 any = any_bits<WT>(c0) | any_bits<WT>(c1) | any_bits<WT>(c2) | any_bits<WT>(c3);
             if (tile == tile_begin) STAMP(2);
             if (__any(any != 0)) {                                         // else: nothing new through these 256 edges
@@ -828,8 +845,14 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
             }
             if (tile == tile_begin) STAMP(4);
             m0 |= n0; m1 |= n1; m2 |= n2; m3 |= n3;
-            if (TILE_AHEAD && tile + 1 < tile_end) { c0 = d0; c1 = d1; c2 = d2; c3 = d3; }
-            else if (LOOP && tile + 1 < tile_end) gather4(woff + WT, c0, c1, c2, c3);
+            if (TILE_AHEAD == 1 && tile + 1 < tile_end) { c0 = d0; c1 = d1; c2 = d2; c3 = d3; }
+            else if (TILE_AHEAD == 2 && tile + 1 < tile_end) {
+                if (!((tile - tile_begin) & 1)) { c0 = d0; c1 = d1; c2 = d2; c3 = d3; }          // second tile of the pair: already here
+                else {                                                                         // the next pair
+                    gather4(woff + WT, c0, c1, c2, c3);
+                    if (tile + 2 < tile_end) gather4(woff + 2 * WT, d0, d1, d2, d3);
+                }
+            } else if (LOOP && tile + 1 < tile_end) gather4(woff + WT, c0, c1, c2, c3);
         }
         found |= m0 || m1 || m2 || m3;
         // Mark the rows that received something.  The chunk's rows are a short ascending run of node ids: build each
@@ -873,7 +896,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
 // in LDS (one bit per table word, built by k_live_summary between the launches).  TILES: 0 one WT-word tile per node; several tiles
 // walked inside the wave (1) or dealt to adjacent waves (2), see level_expand.
 template <int WT, int LIVE, int TILES>
-__global__ __launch_bounds__(256) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
+__global__ __launch_bounds__(256, WT == 8 ? (TILES ? POPE_WT8_LOOP_WAVES : POPE_WT8_WAVES) : 1) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
                                                    int E, int N, int Wp, int tiles, const u64 *__restrict__ front,
                                                    u64 *__restrict__ seen, u64 *__restrict__ acc,
                                                    u64 *__restrict__ idle, u64 *__restrict__ hop_planes,
@@ -1692,6 +1715,27 @@ static void profile_mark(hipStream_t stream, int level, int which, bool span = f
 
 // Diagnostic knobs behind pope_debug_set() (include/graphpope_hip.h): process-global, not thread-safe, A/B tooling only.
 static int g_live_mode = -1;            // -1: by graph size (LDS table up to LIVE_MAX_NODES, global table beyond); 2: the global table on a small graph too (tests)
+
+// Which instantiation of k_bfs_level a graph of N nodes and Wp words per node gets (bfs_enqueue_levels launches it; bench.py and the
+// profiles label it through pope_level_kernel_name).  LIVE: the live-bit table staged in LDS (1) up to LIVE_MAX_NODES, beyond that read
+// from global memory behind a summary in LDS (3), or plainly (2) where even the summary does not fit.  Tiles: up to 4 words in one
+// tile; more on a graph that lives in L2 (LIVE = 1): 4-word tiles, a wave each (TILES = 2); where the frontier rows come from HBM
+// (LIVE >= 2): 8-word tiles if the row is made of them -- ONE gather takes everything the row has in its 128-byte line -- else 4-word
+// tiles gathered in pairs, walked inside the wave (TILES = 1; a single 8-word tile: TILES = 0).
+struct LevelChoice { int wt, live, tiles; };
+static int live_mode_for(int64_t N) {
+    const int64_t live_words = (N + 31) / 32;
+    int mode = g_live_mode > 0 ? g_live_mode : (live_words <= LIVE_MAX_NODES / 32 ? 1 : 3);
+    if (mode == 1 && live_words > LIVE_MAX_NODES / 32) mode = 3;
+    if (mode == 3 && live_sum_bytes(N) > LIVE_SUM_MAX_BYTES) mode = 2;
+    return mode;
+}
+static LevelChoice level_choice(int Wp, int live_mode) {
+    if (Wp <= 4) return {Wp, live_mode, 0};
+    if (live_mode == 1) return {4, 1, 2};
+    if (POPE_WT8 && Wp % 8 == 0) return {8, live_mode, Wp == 8 ? 0 : 1};
+    return {4, live_mode, 1};
+}
 static int g_finalize_variant = 1;      // 1: pipelined / wide fast paths (default), 7: round 1-3 fast path, 0: generic kernel -- kept so the tests can compare their bits
 static int g_finalize_blocks = 256 * 8;
 static bool g_finalize_blocks_set = false;   // POPE_KNOB_FINALIZE_BLOCKS given: it also sizes the pipelined kernels (default: one work item per wave)
@@ -1926,9 +1970,7 @@ static int bfs_setup(Bfs &b, const int32_t *rowptr, const int32_t *col, const in
     b.live[2] = (unsigned *)((char *)b.live[1] + live_bytes(N));
     b.live_words = (int)((N + 31) / 32);
     b.live_sum = (unsigned *)((char *)b.live[2] + live_bytes(N));
-    b.live_mode = g_live_mode > 0 ? g_live_mode : (b.live_words <= LIVE_MAX_NODES / 32 ? 1 : 3);
-    if (b.live_mode == 1 && b.live_words > LIVE_MAX_NODES / 32) b.live_mode = 3;
-    if (b.live_mode == 3 && live_sum_bytes(N) > LIVE_SUM_MAX_BYTES) b.live_mode = 2;
+    b.live_mode = live_mode_for(N);
     b.level_limit = 1ll << plane_capacity;
     return slot_acquire(&b.slot, (size_t)K);
 }
@@ -1980,15 +2022,17 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
         u64 *idle = b.front[(level + 1) % 3];                    // next level's accumulator: rows spanning chunks cleared now
         const unsigned *lp = b.live[(level - 1) % 3];
         unsigned *ln = b.live[level % 3], *li = b.live[(level + 1) % 3];
-        // more than 256 anchors: tiles of 4 words -- a wave each where the graph lives in L2 (latency-bound levels), walked inside the
-        // wave where the frontier comes from HBM (one pass over the index stream)
-        const int multi = b.Wp <= 4 ? 0 : (b.live_mode == 1 ? 2 : 1);
+        const LevelChoice lc = level_choice(b.Wp, b.live_mode);
 #define POPE_LEVEL(WT, MULTI) launch_level<WT, MULTI>(b.E, b.N, b.Wp, b.col, b.erow, b.aux, prev, b.seen, next, idle, b.hop_planes, b.plane_elems, level, b.ctl, lp, ln, li, b.live_words, b.live_mode, b.live_sum, stream)
-        if (b.Wp == 1)       POPE_LEVEL(1, 0);
-        else if (b.Wp == 2)  POPE_LEVEL(2, 0);
-        else if (multi == 0) POPE_LEVEL(4, 0);
-        else if (multi == 1) POPE_LEVEL(4, 1);
-        else                 POPE_LEVEL(4, 2);
+        if (lc.wt == 1)                        POPE_LEVEL(1, 0);
+        else if (lc.wt == 2)                   POPE_LEVEL(2, 0);
+        else if (lc.wt == 4 && lc.tiles == 0)  POPE_LEVEL(4, 0);
+        else if (lc.wt == 4 && lc.tiles == 1)  POPE_LEVEL(4, 1);
+        else if (lc.wt == 4)                   POPE_LEVEL(4, 2);
+#if POPE_WT8
+        else if (lc.tiles == 0)                POPE_LEVEL(8, 0);
+        else                                   POPE_LEVEL(8, 1);
+#endif
 #undef POPE_LEVEL
     }
     profile_mark(stream, 0, 1, true);
@@ -2269,6 +2313,15 @@ static int finalize_launch(const FinChoice &ch, const u64 *planes, size_t plane_
         hipLaunchKernelGGL(k_finalize<false>, grid, block, 0, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, K, Wp, x, F, out, (long long)out_cols, c0, aux, report, ticket);
     }
     POPE_HIP(hipGetLastError());
+    return POPE_OK;
+}
+
+// The name of the level kernel a BFS over N nodes from K anchors launches (what a profile will show).
+extern "C" int pope_level_kernel_name(int64_t N, int32_t K, char *name, size_t cap) {
+    clear_error();
+    POPE_REQUIRE(name && cap > 0 && N > 0 && K > 0, "pope_level_kernel_name: bad argument");
+    const LevelChoice lc = level_choice(words_for(K), live_mode_for(N));
+    snprintf(name, cap, "k_bfs_level<%d, %d, %d>", lc.wt, lc.live, lc.tiles);
     return POPE_OK;
 }
 

@@ -240,6 +240,10 @@ int pope_geodesic_finalize_shards(const uint64_t *planes, int32_t n_shards, int6
  * kernel that really ran (utils.py:129-135 is one torch.cat whatever the shape).  Aligned bases and row pitches assumed. */
 int pope_finalize_kernel_name(int64_t N, int32_t K_shard, int32_t F, int32_t has_x, int32_t n_shards, char *name, size_t cap);
 
+/* The same for the level kernel of a BFS over N nodes from K anchors ("k_bfs_level<4, 1, 0>": words per tile, how the live-bit table is
+ * read, how a node's tiles are walked -- csrc/geodesic.hip: level_choice). */
+int pope_level_kernel_name(int64_t N, int32_t K, char *name, size_t cap);
+
 /*
  * The whole geodesic hot path in ONE call (what utils.py:137-147 does after sampling the anchors):
  * edge_index -> CSR -> multi-source BFS -> out[v, 0:F] = x[v, :], out[v, F + j] = 1 / (hops(v, anchor j) + 1).

@@ -124,16 +124,17 @@ def test_large_rmat_waves_loop_over_chunks(k, dev, oracle):
     assert np.array_equal(engine.hop_matrix(hp).cpu().numpy(), oracle.geodesic_hops(ei, n, anchors))
 
 
-@pytest.mark.parametrize("mode,k", [(-1, 70), (2, 70), (1, 70), (-1, 300), (2, 300), (-1, 600)])
+@pytest.mark.parametrize("mode,k", [(-1, 70), (2, 70), (1, 70), (-1, 300), (2, 300), (-1, 600), (2, 600), (-1, 1000), (2, 1000)])
 def test_graph_too_large_for_the_lds_live_table(mode, k, dev, oracle):
     """More than 256 Ki nodes: the level kernel reads the live-bit table from global memory behind a summary staged in LDS
     (k_bfs_level<WT, 3>, built by k_live_summary between the launches; the default there); mode 2 forces the plain global table
-    (k_bfs_level<WT, 2>), mode 1 must fall back to the summary form.  k = 300 and 600: two and three 4-word tiles per node,
-    walked inside the wave."""
+    (k_bfs_level<WT, 2>), mode 1 must fall back to the summary form.  k = 300: the node's whole 8-word row in one gather
+    (k_bfs_level<8, ., 0>); k = 600: 12 words = three 4-word tiles walked inside the wave, the first two gathered as a pair; k = 1000: two
+    8-word tiles walked inside the wave."""
     from graphpope_amd import engine, synth, _lib
     ei, n = synth.rmat(19, edge_factor=3, seed=23)
     assert n > 256 * 1024
-    anchors = np.random.RandomState(5).choice(np.arange(n), k)        # k >= 300: several 4-word tiles share the live bits
+    anchors = np.random.RandomState(5).choice(np.arange(n), k)        # k >= 600: several tiles share the live bits
     lib = _lib.load()
     _lib.check(lib.pope_debug_set(_lib.KNOB_LIVE_MODE, mode))
     try:

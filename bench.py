@@ -445,11 +445,10 @@ def config4_leg(dev, steps=3):
     launches = len(level_ms)
     avg_ms = sum(level_ms.values()) / launches
     dense_bytes = e * (8.0 + 8.0 * wp) + n * 16.0 * wp                # DESIGN.md section 5 model: per slot index + neighbour row, per node seen read + frontier write
-    active = hp.max_hop + 1
-    alg_bytes = dense_bytes * active / launches
     dense_level = max(level_ms, key=level_ms.get)
     pmc, pmc_src = config4_pmc()
     pmc = pmc or {}
+    traffic_avg = pmc.get("k_bfs_level_hbm_bytes_per_launch")
     # the finalise kernel of this shape: launches queued back to back between two HIP events
     fin_out = torch.empty((n, k), dtype=torch.float32, device=dev)
     planes = hp.valid().contiguous()
@@ -468,14 +467,16 @@ def config4_leg(dev, steps=3):
                        "(np seed 42), F=0: edge_index resident -> [N, 512] f32 (graph generation outside the timed region)",
            "ms_per_step": dt * 1e3, "embeddings_per_s": n * k / dt, "max_hop": hp.max_hop, "graph_generation_s": gen,
            "sampled_columns_bit_exact": bool(np.array_equal(got, want)),
-           "roofline": {"kernel": level_kernel_name(n, k), "bound": "hbm", "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch"),
-                        "traffic_source": pmc_src, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_per_step": launches,
-                        "algorithmic_bytes_per_active_level": dense_bytes, "level_ms": {str(l): round(v, 4) for l, v in level_ms.items()},
-                        "densest_level": {"level": dense_level, "ms": level_ms[dense_level], "achieved": dense_bytes / (level_ms[dense_level] * 1e-3) / 1e9,
-                                          "frac": dense_bytes / (level_ms[dense_level] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                          "traffic": pmc.get("k_bfs_level_hbm_bytes_densest_launch"),
-                                          "gather_roof_ms": e / 56.0e9 * 1e3},
+           # the dominant kernel's roofline entry is its DENSEST launch (every slot gathers: the byte model holds); the model overstates the
+           # sparse launches (the live table skips their gathers), so the average over all launches is given as measured traffic only
+           "roofline": {"kernel": level_kernel_name(n, k), "bound": "hbm", "achieved": dense_bytes / (level_ms[dense_level] * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dense_bytes / (level_ms[dense_level] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": pmc.get("k_bfs_level_hbm_bytes_densest_launch"), "traffic_source": pmc_src,
+                        "level": dense_level, "launch_ms": level_ms[dense_level],
+                        "algorithmic_bytes_per_launch": dense_bytes, "gather_roof_ms": e / 56.0e9 * 1e3,
+                        "level_ms": {str(l): round(v, 4) for l, v in level_ms.items()},
+                        "every_launch": {"avg_launch_ms": avg_ms, "launches_per_step": launches, "traffic": traffic_avg,
+                                         "traffic_rate": None if not traffic_avg else traffic_avg / (avg_ms * 1e-3) / 1e9},
                         "note": "W = 8 words per node, the whole row in one gather; every neighbour row is a random 64-byte gather that "
                                 "costs a 128-byte line from the fabric (tools/micro/gather_rows.hip: 56 G lines/s chip-wide whatever the row size, "
                                 "profiles/r05_micro_gather_rows.txt), so the densest level cannot take less than E / 56 G/s (gather_roof_ms); HIP events "

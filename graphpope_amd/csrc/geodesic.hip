@@ -37,6 +37,9 @@
 #ifndef POPE_WT8
 #define POPE_WT8 1                    // 1 = tiles of 8 words (a node's whole 64-byte row in one gather) where the frontier comes from HBM
 #endif
+#ifndef POPE_WT8_L2
+#define POPE_WT8_L2 1                 // 1 = 8-word tiles (a wave each) on graphs that live in L2 too
+#endif
 #ifndef POPE_WT8_WAVES
 #define POPE_WT8_WAVES 3              // waves per SIMD the compiler must fit the 8-word kernel into (1: its own choice)
 #endif
@@ -896,7 +899,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
 // in LDS (one bit per table word, built by k_live_summary between the launches).  TILES: 0 one WT-word tile per node; several tiles
 // walked inside the wave (1) or dealt to adjacent waves (2), see level_expand.
 template <int WT, int LIVE, int TILES>
-__global__ __launch_bounds__(256, WT == 8 ? (TILES ? POPE_WT8_LOOP_WAVES : POPE_WT8_WAVES) : 1) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
+__global__ __launch_bounds__(256, WT == 8 ? (TILES == 1 ? POPE_WT8_LOOP_WAVES : POPE_WT8_WAVES) : 1) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
                                                    int E, int N, int Wp, int tiles, const u64 *__restrict__ front,
                                                    u64 *__restrict__ seen, u64 *__restrict__ acc,
                                                    u64 *__restrict__ idle, u64 *__restrict__ hop_planes,
@@ -1331,7 +1334,7 @@ constexpr int FIN_LUT_LDS = 4 * 256 * 4 + 1024 * 8 + 4 * 8192;      // spread ta
 
 __global__ __launch_bounds__(256) void k_finalize_lut(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
                                                       const int *__restrict__ max_hop_dev, int N, int Wp, float *__restrict__ out,
-                                                      long long out_cols, int col0, int hpr_shift, int wps_shift, size_t shard_elems,
+                                                      long long out_cols, int col0, int hpr_shift, int wps_shift, int rows_shift, size_t shard_elems,
                                                       const int *__restrict__ aux, int *report, int ticket) {
     if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
     extern __shared__ __attribute__((aligned(16))) char fin_lds[];
@@ -1356,18 +1359,40 @@ __global__ __launch_bounds__(256) void k_finalize_lut(const u64 *__restrict__ pl
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const unsigned hpr_mask = (1u << hpr_shift) - 1u;
     const long long total = (long long)N << hpr_shift;                              // half-words in all (< 2^31: checked on the host)
-    const int batches = (int)((total + 63) >> 6);
+    // Which half-word slot o (0 .. 63) of batch `batch` is: node v, half-word hw of the output row, and where its plane dwords lie.
+    //  rows_shift < 0: the flat (row, half-word) sequence, 64 consecutive half-words a batch.
+    //  rows_shift >= 0 (several shards whose rows are shorter than a batch): a batch is ONE shard's half-words of 2^rows_shift consecutive
+    //    nodes -- 256 contiguous bytes of each plane, where the flat order reads eight 32-byte pieces from eight shards (R-MAT scale 22,
+    //    8 shards x 64 anchors: 2.79 -> ... ms); the batches of a row block in the other shards are the neighbouring waves'.
+    const int hps_shift = wps_shift + 1, shards_shift = hpr_shift - hps_shift;
+    const int batches = rows_shift < 0 ? (int)((total + 63) >> 6) : (((N + (1 << rows_shift) - 1) >> rows_shift) << shards_shift);
     const unsigned *planes32 = reinterpret_cast<const unsigned *>(planes);
+    struct Slot { unsigned v, hw; size_t off; bool ok; };
+    auto slot_of = [&](int batch, int o) {
+        Slot t;
+        if (rows_shift < 0) {
+            const long long g = (long long)batch * 64 + o;
+            t.ok = g < total;
+            t.v = (unsigned)(g >> hpr_shift);
+            t.hw = (unsigned)g & hpr_mask;
+        } else {
+            const unsigned shard = (unsigned)batch & ((1u << shards_shift) - 1u), rb = (unsigned)batch >> shards_shift;
+            t.v = (rb << rows_shift) + ((unsigned)o >> hps_shift);
+            t.hw = (shard << hps_shift) | ((unsigned)o & ((1u << hps_shift) - 1u));
+            t.ok = t.v < (unsigned)N;
+        }
+        const unsigned word = t.hw >> 1, shard = word >> wps_shift, wl = word & ((1u << wps_shift) - 1u);
+        t.off = (((size_t)shard * shard_elems + (size_t)t.v * Wp + wl) << 1) + (t.hw & 1u);
+        return t;
+    };
     struct Halves { unsigned w[5]; };
     auto load = [&](int batch) {
         Halves r;
 #pragma unroll
         for (int b = 0; b < 5; ++b) r.w[b] = 0;
-        const long long g = (long long)batch * 64 + lane;
-        if (g < total) {
-            const unsigned v = (unsigned)(g >> hpr_shift), hw = (unsigned)g & hpr_mask, word = hw >> 1;
-            const unsigned shard = word >> wps_shift, wl = word & ((1u << wps_shift) - 1u);
-            const unsigned *p = planes32 + (((size_t)shard * shard_elems + (size_t)v * Wp + wl) << 1) + (hw & 1u);
+        const Slot t = slot_of(batch, lane);
+        if (t.ok) {
+            const unsigned *p = planes32 + t.off;
             r.w[0] = p[0];
             if (n_hop_bits > 0) r.w[1] = p[2 * plane_elems];
             if (n_hop_bits > 1) r.w[2] = p[4 * plane_elems];
@@ -1401,11 +1426,8 @@ __global__ __launch_bounds__(256) void k_finalize_lut(const u64 *__restrict__ pl
         for (int e = 0; e < 8; ++e) {
             const int o = 8 * e + (lane >> 3), pc = lane & 7;
             const float4 val = *reinterpret_cast<const float4 *>(image + o * 128 + ((pc ^ (o & 7)) << 4));
-            const long long g = (long long)batch * 64 + o;
-            if (g < total) {
-                const unsigned v = (unsigned)(g >> hpr_shift), hw = (unsigned)g & hpr_mask;
-                *reinterpret_cast<float4 *>(out + (size_t)v * out_cols + col0 + hw * 32 + pc * 4) = val;
-            }
+            const Slot t = slot_of(batch, o);
+            if (t.ok) *reinterpret_cast<float4 *>(out + (size_t)t.v * out_cols + col0 + t.hw * 32 + pc * 4) = val;
         }
         cur = nxt;
     }
@@ -1732,13 +1754,14 @@ static int live_mode_for(int64_t N) {
 }
 static LevelChoice level_choice(int Wp, int live_mode) {
     if (Wp <= 4) return {Wp, live_mode, 0};
-    if (live_mode == 1) return {4, 1, 2};
+    if (live_mode == 1) return (POPE_WT8_L2 && Wp % 8 == 0) ? LevelChoice{8, 1, POPE_WT8_L2 == 2 && Wp > 8 ? 1 : 2} : LevelChoice{4, 1, 2};
     if (POPE_WT8 && Wp % 8 == 0) return {8, live_mode, Wp == 8 ? 0 : 1};
     return {4, live_mode, 1};
 }
 static int g_finalize_variant = 1;      // 1: pipelined / wide fast paths (default), 7: round 1-3 fast path, 0: generic kernel -- kept so the tests can compare their bits
 static int g_finalize_blocks = 256 * 8;
 static bool g_finalize_blocks_set = false;   // POPE_KNOB_FINALIZE_BLOCKS given: it also sizes the pipelined kernels (default: one work item per wave)
+static int g_finalize_shard_batches = 1;   // k_finalize_lut over several short-rowed shards: 1 = a batch per (shard, block of rows), 0 = the flat order (POPE_KNOB_FINALIZE_VARIANT 11 / 12)
 static int g_finalize_lut = 1;           // wide rows: 1 (default) k_finalize_lut for rows without features, k_finalize_wide with them (copy kernel + table kernel measured slower: Flickr / 1 024 anchors 0.619 against 0.562 ms); 2 always; 0 never -- POPE_KNOB_FINALIZE_VARIANT 8 / 9 / 10
 static int g_prepare_merge = 1;          // POPE_KNOB_PREPARE_MERGE: 1 (default) = pope_geodesic_run clears, seeds and builds the CSR in ONE launch (k_prepare); 0 = two launches
 namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0, g_sage_forward_overlap = 1, g_gemm_small_tile16 = 1, g_gemm_tile16_buffers = 4; }
@@ -1749,6 +1772,7 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_LIVE_MODE:        g_live_mode = value; break;
     case POPE_KNOB_FINALIZE_VARIANT:                                 // 8 / 9: the default kernels, but shapes with features keep k_finalize_wide (8) or not (9)
         if (value >= 8 && value <= 10) { g_finalize_variant = 1; g_finalize_lut = value == 9 ? 2 : value == 8 ? 1 : 0; }
+        else if (value == 11 || value == 12) g_finalize_shard_batches = value == 11;     // k_finalize_lut's batch order over several shards
         else g_finalize_variant = value;
         break;
     case POPE_KNOB_FINALIZE_BLOCKS:  g_finalize_blocks = value > 0 ? value : 256 * 8; g_finalize_blocks_set = value > 0; break;
@@ -2031,7 +2055,10 @@ static int bfs_enqueue_levels(const Bfs &b, int level, int stop, hipStream_t str
         else if (lc.wt == 4)                   POPE_LEVEL(4, 2);
 #if POPE_WT8
         else if (lc.tiles == 0)                POPE_LEVEL(8, 0);
-        else                                   POPE_LEVEL(8, 1);
+        else if (lc.tiles == 1)                POPE_LEVEL(8, 1);
+#endif
+#if POPE_WT8_L2
+        else                                   POPE_LEVEL(8, 2);
 #endif
 #undef POPE_LEVEL
     }
@@ -2272,7 +2299,9 @@ static int finalize_launch(const FinChoice &ch, const u64 *planes, size_t plane_
         int hpr_shift = 0, wps_shift = 0;
         while ((1 << wps_shift) < K / 64) ++wps_shift;
         while ((1ll << hpr_shift) < (int64_t)(K / 64) * n_shards * 2) ++hpr_shift;
-        const int64_t batches = ((N << hpr_shift) + 63) >> 6;
+        // several shards with rows shorter than a batch: a batch per (shard, block of rows) -- see the kernel
+        const int rows_shift = (n_shards > 1 && wps_shift + 1 < 6 && g_finalize_shard_batches) ? 6 - (wps_shift + 1) : -1;
+        const int64_t batches = rows_shift < 0 ? ((N << hpr_shift) + 63) >> 6 : ((N + (1 << rows_shift) - 1) >> rows_shift) * n_shards;
         static LdsOptIn opt_in;
         if (!opt_in.done()) {
             POPE_HIP(hipFuncSetAttribute((const void *)k_finalize_lut, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LUT_LDS));
@@ -2281,7 +2310,7 @@ static int finalize_launch(const FinChoice &ch, const u64 *planes, size_t plane_
         // blocks live for a few batches each: the tables cost a block ~1 us to build
         const unsigned blocks = g_finalize_blocks_set ? (unsigned)g_finalize_blocks : (unsigned)std::min<int64_t>(std::max<int64_t>((batches + 15) / 16, 1), 4096);
         hipLaunchKernelGGL(k_finalize_lut, dim3(blocks), block, FIN_LUT_LDS, stream, planes, plane_elems, n_hop_bits, max_hop_dev, (int)N, Wp, out,
-                           (long long)out_cols, F + c0, hpr_shift, wps_shift, shard_elems, aux, report, ticket);
+                           (long long)out_cols, F + c0, hpr_shift, wps_shift, rows_shift, shard_elems, aux, report, ticket);
     } else if (ch.kernel == FIN_WIDE) {
         const int64_t witems = N * ((ne / 16 + 15) / 16);
         dim3 wgrid(g_finalize_blocks_set ? g_finalize_blocks : (unsigned)std::min<int64_t>(std::max<int64_t>((witems + 3) / 4, 256), 32768));

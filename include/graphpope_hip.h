@@ -78,7 +78,7 @@ int pope_require_device(int32_t *cu_count_host);
  * needed by a caller.  value < 0 restores the automatic choice where one exists.
  */
 #define POPE_KNOB_LIVE_MODE         0   /* level kernel: -1 auto (by graph size), 1 live-bit table staged in LDS, 2 table read from global memory, 3 global table behind a summary in LDS */
-#define POPE_KNOB_FINALIZE_VARIANT  1   /* 1 (default) the pipelined finalise kernels (every load of a row in flight, next row requested before this one is stored, rows dealt round-robin; wide rows through LDS tables); 7 the round 1-3 kernel (serial loops); 0 the generic kernel -- kept so that tests can compare their bits; 8 / 9 / 10: as 1, with wide rows on the table kernel k_finalize_lut only without features (8), always (9, the default: features by the copy kernel in front of it) or never (10: the shuffle kernel k_finalize_wide) */
+#define POPE_KNOB_FINALIZE_VARIANT  1   /* 1 (default) the pipelined finalise kernels (every load of a row in flight, next row requested before this one is stored, rows dealt round-robin; wide rows through LDS tables); 7 the round 1-3 kernel (serial loops); 0 the generic kernel -- kept so that tests can compare their bits; 8 / 9 / 10: as 1, with wide rows on the table kernel k_finalize_lut only without features (8, the default), always (9: features by the copy kernel in front of it) or never (10: the shuffle kernel k_finalize_wide); 11 / 12: k_finalize_lut over several short-rowed shards takes a batch per (shard, block of rows) (11, the default) or the flat (row, half-word) order (12) */
 #define POPE_KNOB_FINALIZE_BLOCKS   2   /* grid of the finalise kernel (default: one work item per wave for the pipelined kernels, 2048 blocks for the round 1-3 one) */
 #define POPE_KNOB_GEMM_TILE         3   /* SAGE GEMM: 0 auto, 1 64x64, 2 64x128, 3 128x256 tiles, 4 / 5 stream-K without loader waves, 6 stream-K with stages of 64 in two 80 KB buffers, 7 stream-K instead of the chip-fitted whole tiles (gemm_tile16.h) */
 #define POPE_KNOB_PAIRWISE_KERNEL   4   /* node2vec embedding: 0 auto (anchor-resident persistent kernel for depths <= 128), 1 one tile per block, 2 / 3 persistent kernel with one / two consumer sets */

@@ -731,13 +731,15 @@ def test_one_prepare_launch_gives_the_same_bits(dev, oracle):
 
 
 @pytest.mark.parametrize("f,k,shards", [(0, 64, 1), (20, 100, 1), (300, 256, 1), (500, 256, 1), (700, 512, 1), (36, 1024, 1), (1100, 64, 1),
-                                         (0, 128, 3), (40, 256, 4), (8, 128, 8), (0, 256, 5), (0, 256, 8), (500, 1024, 3), (12, 1020, 1)])
+                                         (0, 128, 3), (40, 256, 4), (8, 128, 8), (0, 256, 5), (0, 256, 8), (500, 1024, 3), (12, 1020, 1),
+                                         (0, 64, 8), (0, 64, 4), (0, 128, 8), (0, 512, 2), (0, 1024, 2), (0, 2048, 2), (16, 64, 8)])
 def test_pipelined_finalise_kernel_writes_the_same_bits(dev, f, k, shards):
     """The finalise kernel of round 4 (every load of a row in flight at once, the next row requested before this one is stored, rows
     dealt round-robin to the waves; utils.py:73, 129-135) against the round 1-3 kernel (POPE_KNOB_FINALIZE_VARIANT 7) on random
     planes: one and several shards, feature widths and anchor counts on both sides of every instance's limits (and beyond them,
     where the old kernel takes over) -- the same bits, NaN-poisoned outputs; and the library's own name for the kernel it picks
-    (pope_finalize_kernel_name, what bench.py labels its roofline entry with) follows the shape."""
+    (pope_finalize_kernel_name, what bench.py labels its roofline entry with) follows the shape.  Several shards of 64 to 1 024 anchors:
+    the table kernel takes a batch per (shard, block of rows), 12 = the flat order it had before."""
     from graphpope_amd import _lib, engine
     lib = _lib.load()
     n, bits = 3001, 4
@@ -747,8 +749,9 @@ def test_pipelined_finalise_kernel_writes_the_same_bits(dev, f, k, shards):
     x = torch.rand((n, f), generator=g).to(dev) if f else None
     outs = []
     try:
-        for variant in (7, 9, 0, 10):                              # 9: the default (wide rows on the table kernel); 10: wide rows on the shuffle kernel
-            lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, variant)
+        for variant in (7, 8, 9, 0, 10, 12):                       # 8: the default; 9: the table kernel with features too; 10: wide rows on the shuffle kernel
+            lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 9 if variant == 12 else variant)
+            lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 12 if variant == 12 else 11)
             out = torch.full((n, f + shards * k), float("nan"), device=dev)
             if shards == 1:
                 engine.finalize(planes[0], bits, n, k, x, f, out, 0)
@@ -756,14 +759,15 @@ def test_pipelined_finalise_kernel_writes_the_same_bits(dev, f, k, shards):
                 engine.finalize_shards(planes, bits, n, k, x, f, out)
             outs.append(out)
     finally:
-        lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 9)          # (9: variant 1 with the table kernel for shapes with features too = the default)
+        lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 8)          # the defaults again
+        lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 11)
     assert not torch.isnan(outs[0]).any()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
     import ctypes
     name = ctypes.create_string_buffer(64)
     _lib.check(lib.pope_finalize_kernel_name(n, k, f, 1 if f else 0, shards, name, 64))
     ne = k // 4 * shards
     pow2 = lambda v: v > 0 and v & (v - 1) == 0
     wide = ne > 64 and k % 64 == 0
-    want = "k_finalize_fast" if f > 1024 else ("k_finalize_lut" if wide and pow2(k // 64) and pow2(shards) else "k_finalize_wide" if wide else "k_finalize_pipe")
+    want = "k_finalize_fast" if f > 1024 else ("k_finalize_lut" if wide and not f and pow2(k // 64) and pow2(shards) else "k_finalize_wide" if wide else "k_finalize_pipe")
     assert name.value.decode().startswith(want), (name.value, want)

@@ -2445,9 +2445,15 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
     memcpy(b.slot->anchors, anchors_host, (size_t)K * sizeof(long long));     // this call's pinned, device-mapped slot: read in place
     if (g_prepare_merge && K <= PREP_MAX_ANCHORS && E > 0) {
         // one launch: clear + seed role beside the speculative CSR role (k_prepare)
+        // The tag of this call's CSR status word: 29 bits whose TOP bit is always set and whose lower 28 are a scrambled call count.
+        // The word then reads as a NEGATIVE int32, and what a workspace holds from earlier use at that address -- node ids, row
+        // offsets, chunk rows of another graph's CSR, or -1 (tag 0x1fffffff, never handed out) -- cannot carry it.  (Round 4 counted
+        // 1, 2, 3, ...: the word (7 << 3) | 1 = 57 is also a node id, and a workspace reused across graphs of different sizes, or
+        // fresh from an allocator that had held index arrays, reported "node id outside [0, N)" for a clean edge list --
+        // tests/test_level_kernels_soak_gpu.py hit it on its fourth call; random and 0xFF fills, which round 4 soaked, could not.)
         static std::atomic<unsigned> epochs{0};
-        unsigned epoch = ++epochs & 0x1fffffffu;
-        if (epoch == 0) epoch = ++epochs & 0x1fffffffu;
+        unsigned epoch;
+        do epoch = 0x10000000u | ((++epochs * 0x9E3779B1u) & 0x0fffffffu); while (epoch == 0x1fffffffu);
         PrepSeeds seeds;
         for (int j = 0; j < K; ++j) seeds.a[j] = (int)anchors_host[j];          // (validated by bfs_setup)
         const int eager = b.capacity < EAGER_PLANES ? b.capacity : EAGER_PLANES;

@@ -730,6 +730,39 @@ def test_one_prepare_launch_gives_the_same_bits(dev, oracle):
         lib.pope_debug_set(_lib.KNOB_PREPARE_MERGE, 1)
 
 
+def test_status_word_of_the_prepare_launch_is_not_a_value_old_index_data_can_hold(dev):
+    """The merged prepare launch does not zero the CSR status word, it tags it; the tag must be a value nothing else stores there.
+    Round 4 counted its tags 1, 2, 3, ...: (tag << 3) | flags is then a small integer, and a workspace that had held index arrays (node
+    ids, row offsets: another graph's CSR at the same address) made a clean edge list fail with "node id outside [0, N)".  In a FRESH
+    process (the tag sequence starts over) every call i finds its workspace filled with the int32 the old scheme would have read as
+    call i's raised flag, and with other small integers: all must succeed, planes equal to the first call's."""
+    import subprocess
+    import sys
+    code = """
+import numpy as np, torch
+from graphpope_amd import engine, synth
+dev = engine.require_gpu()
+ei_np, n = synth.rmat(10, edge_factor=8, seed=3)
+ei = torch.as_tensor(ei_np, device=dev)
+anchors = np.random.RandomState(0).choice(n, 100)
+_, hp = engine.geodesic_run(None, ei, n, anchors, want_out=False, reuse_workspace=True)
+want = hp.valid().clone()
+for i in range(1, 41):
+    for ws in engine._WORKSPACE.values():
+        w32 = ws[: ws.numel() // 4 * 4].view(torch.int32)
+        if i % 2:
+            w32.fill_(((i + 1) << 3) | 1)        # call i + 1 of the process, flag 1 (node id out of range) under the counting tags
+        else:
+            w32.copy_(torch.randint(0, 512, w32.shape, dtype=torch.int32, device=w32.device))
+    _, hp = engine.geodesic_run(None, ei, n, anchors, want_out=False, reuse_workspace=True)
+    assert torch.equal(hp.valid(), want), i
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("f,k,shards", [(0, 64, 1), (20, 100, 1), (300, 256, 1), (500, 256, 1), (700, 512, 1), (36, 1024, 1), (1100, 64, 1),
                                          (0, 128, 3), (40, 256, 4), (8, 128, 8), (0, 256, 5), (0, 256, 8), (500, 1024, 3), (12, 1020, 1),
                                          (0, 64, 8), (0, 64, 4), (0, 128, 8), (0, 512, 2), (0, 1024, 2), (0, 2048, 2), (16, 64, 8)])

@@ -61,3 +61,51 @@ def test_forced_live_modes_and_tilings_on_random_graphs(seed, oracle):
                 assert np.array_equal(got, want), (seed, case, n, ei_np.shape[1], k, mode)
     finally:
         lib.pope_debug_set(_lib.KNOB_LIVE_MODE, -1)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_finalise_kernels_agree_on_random_shapes(seed):
+    """Every finalise kernel the library can pick (pipelined, shuffle, LDS-table in both batch orders, rounds 1-3) against the generic one
+    (POPE_KNOB_FINALIZE_VARIANT 0) on random planes of random shapes: node counts that leave ragged last batches, feature widths with
+    and without 16-byte rows, 1-8 shards of 4 to 2 048 anchors, 0 to 4 hop bits, a column offset and spare columns behind the
+    embedding; NaN-poisoned outputs, so a missed or a doubly-claimed element shows (utils.py:73, 129-135: out = x (+) 1 / (hops + 1))."""
+    from graphpope_amd import _lib, engine
+    dev = engine.require_gpu()
+    lib = _lib.load()
+    rs = np.random.RandomState(7000 + seed)
+    g = torch.Generator().manual_seed(seed)
+    try:
+        for case in range(14):
+            n = int(rs.choice([1, 5, 63, 64, 65, 257, 1000, 4099, 12345]))
+            shards = int(rs.choice([1, 1, 2, 3, 4, 8]))
+            k = int(rs.choice([4, 7, 60, 64, 100, 128, 192, 256, 320, 512, 1024, 2048]))
+            if shards > 1 and k * shards > 4096:
+                k = 256
+            f = int(rs.choice([0, 0, 3, 16, 100, 500, 1028]))
+            bits = int(rs.choice([0, 1, 3, 4]))
+            spare = int(rs.choice([0, 0, 4, 5])) if shards == 1 else 0
+            c0 = int(rs.choice([0, 0, 4, 64])) if shards == 1 else 0
+            w = lib.pope_words(k)
+            planes = torch.randint(-2**62, 2**62, (shards, 5, n, w), generator=g, dtype=torch.int64).to(dev)
+            x = torch.rand((n, f), generator=g).to(dev) if f else None
+            outs = []
+            for variant in (0, 8, 9, 10, 12, 7):
+                lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 9 if variant == 12 else variant)
+                lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 12 if variant == 12 else 11)
+                out = torch.full((n, f + c0 + shards * k + spare), float("nan"), device=dev)
+                if shards == 1:
+                    engine.finalize(planes[0], bits, n, k, x, f, out, c0)
+                else:
+                    engine.finalize_shards(planes, bits, n, k, x, f, out)
+                outs.append(out)
+            ref = outs[0]
+            written = torch.ones_like(ref, dtype=torch.bool)
+            written[:, f:f + c0] = False
+            if spare:
+                written[:, -spare:] = False
+            assert not torch.isnan(ref[written]).any() and torch.isnan(ref[~written]).all(), (seed, case)
+            for o in outs[1:]:
+                assert torch.equal(torch.nan_to_num(o, nan=-7.0), torch.nan_to_num(ref, nan=-7.0)), (seed, case, n, shards, k, f, bits, c0, spare)
+    finally:
+        lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 8)
+        lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 11)

@@ -474,7 +474,7 @@ def config4_leg(dev, steps=3):
                         "traffic": pmc.get("k_bfs_level_hbm_bytes_densest_launch"), "traffic_source": pmc_src,
                         "level": dense_level, "launch_ms": level_ms[dense_level],
                         "algorithmic_bytes_per_launch": dense_bytes, "gather_roof_ms": e / 56.0e9 * 1e3,
-                        "level_ms": {str(l): round(v, 4) for l, v in level_ms.items()},
+                        "level_ms": {str(l): round(v, 3) for l, v in level_ms.items()},
                         "every_launch": {"avg_launch_ms": avg_ms, "launches_per_step": launches, "traffic": traffic_avg,
                                          "traffic_rate": None if not traffic_avg else traffic_avg / (avg_ms * 1e-3) / 1e9},
                         "note": "W = 8 words per node, the whole row in one gather; every neighbour row is a random 64-byte gather that "
@@ -487,7 +487,6 @@ def config4_leg(dev, steps=3):
                                  "store_roof_ms": 1.49,
                                  "note": "8.59 GB of columns written + 1.34 GB of planes read; a kernel that only stores the columns (no loads, no "
                                          "arithmetic: tools/micro/column_fill.hip) takes 1.49 ms = 5.8 TB/s on this part (store_roof_ms)"},
-           "per_source_model_gbs": 512 * (4.0 * e + 8.0 * n) / dt / 1e9,
            "cpu_baseline": {"value": n * 8 / cpu, "unit": "embeddings/s", "cores": 1, "kind": "port",
                             "sample": f"8 of the 512 anchor columns (RandomState(0)), full N, oracle/pope_oracle.c one BFS per anchor, {cpu:.1f} s"}}
     del out, hp, ei, planes

@@ -18,6 +18,7 @@ KNOB_PAIRWISE_KERNEL, KNOB_COPY_BATCHES, KNOB_FAIL_HOST_REGISTER = 4, 5, 7
 KNOB_SAGE_FORWARD_OVERLAP, KNOB_GEMM_SMALL_TILE16 = 14, 15
 KNOB_GEMM_TILE16_BUFFERS = 18
 KNOB_PREPARE_MERGE = 19
+KNOB_STREAMK_XCD = 20
 
 # name -> (restype, argtypes); exactly the symbols include/graphpope_hip.h declares
 SIGNATURES = {

@@ -39,7 +39,39 @@ struct SkTnArgs {
     const float *cs_part;
     float *cs_out;
     int cs_splits, cs_C;
+    // 1 = XCD-aware deal (round 5, POPE_KNOB_STREAMK_XCD): physical block p sits on XCD p % 8.  The tiles_m tiles of one (product, column
+    // panel) "group" share their B rows; the blocks that work on the same depth range of such a group are made neighbours IN ONE XCD
+    // (slots 4 j .. 4 j + 3 of it), so the 32 KB B slice of a stage crosses the fabric once per XCD instead of once per block.  Units
+    // are then (group, stage) pairs dealt to grid / tiles_m quads; a quad's blocks each take their own m-tile of the quad's span.
+    int xcd;
 };
+
+// The span of units block `block` of `grid` owns, and how a unit maps to a tile.
+struct SkTnSpan { long long u, u_end; int tm; };          // tm < 0: unit = tile * S + stage; else unit = group * S + stage, tile = group * tiles_m + tm
+__device__ __forceinline__ void sk_tn_quads(const SkTnArgs &a, int grid, int &per, long long &Tq, int &Q) {
+    per = (grid >> 3) / a.tiles_m;                         // quads per XCD
+    Tq = (long long)a.tiles_nb * 2 * a.S;
+    Q = grid / a.tiles_m;
+}
+__device__ __forceinline__ SkTnSpan sk_tn_span(const SkTnArgs &a, int block, int grid) {
+    SkTnSpan w;
+    if (!a.xcd) {
+        const long long T = (long long)a.tiles_m * a.tiles_nb * 2 * a.S;
+        w.u = sk_lo(block, T, grid);
+        w.u_end = sk_lo(block + 1, T, grid);
+        w.tm = -1;
+    } else {
+        int per, Q;
+        long long Tq;
+        sk_tn_quads(a, grid, per, Tq, Q);
+        const int xcd = block & 7, slot = block >> 3;
+        const int quad = xcd * per + slot / a.tiles_m;
+        w.tm = slot % a.tiles_m;
+        w.u = sk_lo(quad, Tq, Q);
+        w.u_end = sk_lo(quad + 1, Tq, Q);
+    }
+    return w;
+}
 
 template <int GK>
 __device__ __forceinline__ void sk_tn_resolve(SkTnArgs &a) {
@@ -70,17 +102,18 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem);
     const int S = a.S;
-    const long long T = (long long)a.tiles_m * a.tiles_nb * 2 * S, G = gridDim.x;
-    long long u = sk_lo(blockIdx.x, T, G);
-    const long long u_end = sk_lo(blockIdx.x + 1, T, G);
+    const SkTnSpan span = sk_tn_span(a, (int)blockIdx.x, (int)gridDim.x);
+    long long u = span.u;
+    const long long u_end = span.u_end;
 
     if (wave >= SKL_CONSUMERS) {
         // ---------------- loader waves ----------------
         __builtin_amdgcn_s_setprio(3);
         const int lw = wave - SKL_CONSUMERS;
         while (u < u_end) {
-            const int tile = (int)(u / S);
-            const int s_begin = (int)(u - (long long)tile * S);
+            const int base = (int)(u / S);
+            const int s_begin = (int)(u - (long long)base * S);
+            const int tile = span.tm < 0 ? base : base * a.tiles_m + span.tm;
             const long long left = u_end - u;
             const int s_end = (long long)(S - s_begin) <= left ? S : s_begin + (int)left;
             int q, m0, n0;
@@ -178,8 +211,9 @@ __global__ __launch_bounds__(SKL_THREADS) void k_gemm_streamk_tn(SkTnArgs a) {
     const int wm = wave & 1, wn = wave >> 1;
     const int g = lane >> 5, l31 = lane & 31;
     while (u < u_end) {
-        const int tile = (int)(u / S);
-        const int s_begin = (int)(u - (long long)tile * S);
+        const int base = (int)(u / S);
+        const int s_begin = (int)(u - (long long)base * S);
+        const int tile = span.tm < 0 ? base : base * a.tiles_m + span.tm;
         const long long left = u_end - u;
         const int s_end = (long long)(S - s_begin) <= left ? S : s_begin + (int)left;
         int q, m0, n0;
@@ -288,9 +322,20 @@ __global__ __launch_bounds__(256) void k_streamk_tn_fixup(SkTnArgs a, int G) {
         return;
     }
     if (T <= 0) return;                                                                   // (a device extent of 0 rows: nothing was computed)
-    const long long u0 = (long long)tile * S, u1 = u0 + S;
-    const int b_lo = (int)(((u0 + 1) * G - 1) / T), b_hi = (int)((u1 * G - 1) / T);
+    // the contributors of this tile, in depth order: blocks b_lo .. b_hi of the plain deal, or -- XCD-aware deal -- the quads b_lo .. b_hi
+    // of the tile's group, of each the block that takes this tile's m (its physical index: slab_of)
+    int per = 1, Q = G, tm = 0;
+    long long Td = T;
+    long long u0 = (long long)tile * S;
+    if (a.xcd) {
+        sk_tn_quads(a, G, per, Td, Q);
+        tm = tile % a.tiles_m;
+        u0 = (long long)(tile / a.tiles_m) * S;
+    }
+    const long long u1 = u0 + S;
+    const int b_lo = (int)(((u0 + 1) * Q - 1) / Td), b_hi = (int)((u1 * Q - 1) / Td);
     if (b_lo == b_hi) return;
+    auto slab_of = [&](int b) { return a.xcd ? (b / per) + 8 * ((b % per) * a.tiles_m + tm) : b; };
     int q, m0, n0;
     sk_tn_tile(a, tile, q, m0, n0);
     float *C = q ? a.C[1] : a.C[0];
@@ -310,10 +355,10 @@ __global__ __launch_bounds__(256) void k_streamk_tn_fixup(SkTnArgs a, int G) {
 #pragma unroll
             for (int i = 0; i < INFLIGHT; ++i) {
                 const int b = b0 + i;
-                const long long lo = sk_lo(b, T, G), hi = sk_lo(b + 1, T, G);
+                const long long lo = sk_lo(b, Td, Q), hi = sk_lo(b + 1, Td, Q);
                 const long long sb = lo > u0 ? lo : u0, se = hi < u1 ? hi : u1;
                 const bool has = b <= b_hi && sb < se;
-                v[i] = has ? *reinterpret_cast<const float4 *>(a.slab + ((size_t)b * 2 + (sb > u0 ? 0 : 1)) * SK_SLAB_FLOATS + off)
+                v[i] = has ? *reinterpret_cast<const float4 *>(a.slab + ((size_t)slab_of(b) * 2 + (sb > u0 ? 0 : 1)) * SK_SLAB_FLOATS + off)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll

@@ -1764,7 +1764,7 @@ static bool g_finalize_blocks_set = false;   // POPE_KNOB_FINALIZE_BLOCKS given:
 static int g_finalize_shard_batches = 1;   // k_finalize_lut over several short-rowed shards: 1 = a batch per (shard, block of rows), 0 = the flat order (POPE_KNOB_FINALIZE_VARIANT 11 / 12)
 static int g_finalize_lut = 1;           // wide rows: 1 (default) k_finalize_lut for rows without features, k_finalize_wide with them (copy kernel + table kernel measured slower: Flickr / 1 024 anchors 0.619 against 0.562 ms); 2 always; 0 never -- POPE_KNOB_FINALIZE_VARIANT 8 / 9 / 10
 static int g_prepare_merge = 1;          // POPE_KNOB_PREPARE_MERGE: 1 (default) = pope_geodesic_run clears, seeds and builds the CSR in ONE launch (k_prepare); 0 = two launches
-namespace pope { int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0, g_sage_forward_overlap = 1, g_gemm_small_tile16 = 1, g_gemm_tile16_buffers = 4; }
+namespace pope { int g_streamk_xcd = 1; int g_gemm_force_tile = 0, g_pairwise_kernel = 0, g_fail_host_register = 0, g_sage_forward_overlap = 1, g_gemm_small_tile16 = 1, g_gemm_tile16_buffers = 4; }
 
 extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     clear_error();
@@ -1784,6 +1784,7 @@ extern "C" int pope_debug_set(int32_t knob, int32_t value) {
     case POPE_KNOB_GEMM_TILE16_BUFFERS: pope::g_gemm_tile16_buffers = value == 4 ? 4 : 3; break;
     case POPE_KNOB_GEMM_SMALL_TILE16: pope::g_gemm_small_tile16 = value; break;
     case POPE_KNOB_PREPARE_MERGE:    g_prepare_merge = value; break;
+    case POPE_KNOB_STREAMK_XCD:      pope::g_streamk_xcd = value != 0; break;
     default: set_error("pope_debug_set: unknown knob %d", knob); return POPE_ERR_INVALID;
     }
     return POPE_OK;

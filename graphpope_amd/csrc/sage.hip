@@ -459,6 +459,7 @@ static int launch_gemm(const Operand &A0, const Operand &B0, int K0, const Opera
 extern int g_gemm_force_tile;          // pope_debug_set(POPE_KNOB_GEMM_TILE, ...) in geodesic.hip: 0 = automatic choice
 extern int g_gemm_small_tile16;        // POPE_KNOB_GEMM_SMALL_TILE16: 1 (default) = forward products too small for stream-K take 16 / 32-row whole tiles (layer 1: 14.4 us against 21)
 extern int g_sage_forward_overlap;     // pope_debug_set(POPE_KNOB_SAGE_FORWARD_OVERLAP, ...): 1 (default) gather beside half of the projection, 0 one after the other
+extern int g_streamk_xcd;            // POPE_KNOB_STREAMK_XCD
 extern int g_gemm_tile16_buffers;     // pope_debug_set(POPE_KNOB_GEMM_TILE16_BUFFERS, ...)
 
 static long long tiles(int M, int N, int tm, int tn) { return (long long)((M + tm - 1) / tm) * ((N + tn - 1) / tn); }
@@ -906,6 +907,7 @@ static int gemm_streamk_tn(const float *G, const float *B0, const float *B1, int
     long long grid = cus < SK_MAX_GRID ? cus : SK_MAX_GRID;
     if (grid > T) grid = T;
     if (!slab || slab_bytes < sk_slab_bytes((int)grid)) return POPE_OK;
+    a.xcd = g_streamk_xcd && grid % 8 == 0 && (grid / 8) % a.tiles_m == 0 && grid / a.tiles_m <= 2ll * a.tiles_nb * a.S;
     static LdsOptIn opt_in;
     static const float *zero_page[64];
     int dev = 0;

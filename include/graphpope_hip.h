@@ -88,6 +88,7 @@ int pope_require_device(int32_t *cu_count_host);
 #define POPE_KNOB_GEMM_SMALL_TILE16 15  /* SAGE forward products too small for stream-K: 1 (default) = whole tiles of 16 or 32 rows (gemm_tile16.h), 0 = the 64 x 64 tile kernel */
 #define POPE_KNOB_GEMM_TILE16_BUFFERS 18 /* whole-tile forward GEMM: 4 (default) or 3 LDS stage buffers (two or one stage times to hide a request; same bits) */
 #define POPE_KNOB_PREPARE_MERGE     19  /* pope_geodesic_run: 1 (default) = the clear + seed of the BFS state and the speculative CSR build as two roles of ONE launch (k_prepare; at most 256 anchors per call); 0 = two launches */
+#define POPE_KNOB_STREAMK_XCD       20  /* SAGE weight-gradient GEMM (stream-K): 0 units dealt to the blocks in block order; 1 (default) = XCD-aware: the blocks that work on the same depth range of the tiles sharing their B rows are neighbours in one XCD (csrc/gemm_streamk_tn.h) -- the partial sums of a tile are cut at other depths, so the last bits may differ; deterministic either way */
 /* (Knob numbers 6, 8-13, 16 and 17 belonged to experiments that were measured slower and removed in round 5 -- a copy role and block caps
  * in the level launches, the last levels inside the finalise launch, side streams in the SAGE backward pass, split-bf16 products, the
  * one-launch SAGE layer, the registered result mode: DESIGN.md keeps their figures.) */

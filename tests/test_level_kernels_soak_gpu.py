@@ -6,11 +6,14 @@ POPE_KNOB_LIVE_MODE forces them on small graphs: random directed multigraphs wit
 and hubs (rows spanning many 256-slot chunks), anchors drawn with repeats, 1 to 1 100 anchors (1 to 18 words per node), on workspaces
 that hold the previous case's bytes.  utils.py:64-81 (nx.shortest_path per node and anchor) is what the hop counts must equal.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+SEEDS = int(os.environ.get("GRAPHPOPE_SOAK_SEEDS", "6"))        # a long soak: GRAPHPOPE_SOAK_SEEDS=200 pytest tests/test_level_kernels_soak_gpu.py
 
 
 def _graph(rs, kind):
@@ -40,7 +43,7 @@ def _graph(rs, kind):
     return ei.astype(np.int64), n
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(SEEDS))
 def test_forced_live_modes_and_tilings_on_random_graphs(seed, oracle):
     from graphpope_amd import _lib, engine
     dev = engine.require_gpu()
@@ -63,7 +66,7 @@ def test_forced_live_modes_and_tilings_on_random_graphs(seed, oracle):
         lib.pope_debug_set(_lib.KNOB_LIVE_MODE, -1)
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(max(4, SEEDS // 2)))
 def test_finalise_kernels_agree_on_random_shapes(seed):
     """Every finalise kernel the library can pick (pipelined, shuffle, LDS-table in both batch orders, rounds 1-3) against the generic one
     (POPE_KNOB_FINALIZE_VARIANT 0) on random planes of random shapes: node counts that leave ragged last batches, feature widths with

@@ -157,6 +157,51 @@ def forward_order(request):
 
 
 @pytest.mark.parametrize("indexed", [False, True], ids=["materialised", "indexed"])
+def test_weight_gradients_with_the_xcd_aware_deal(indexed, config2_block, dev, oracle):
+    """POPE_KNOB_STREAMK_XCD = 1 (the default): the stream-K weight-gradient kernel deals (group, stage) units to quads of blocks that sit in one XCD
+    (csrc/gemm_streamk_tn.h); the fix-up finds each tile's partial slabs through the same mapping.  Both weight gradients against
+    oracle.sage_conv_torch at bench.py's layer-0 shape and against the plain deal (the partial sums are cut at other depths: close, not
+    equal), twice (deterministic), with the destination rows as a matrix and read through n_id."""
+    from graphpope_amd import _lib
+    from graphpope_amd.sage import SAGEConv, IndexedFeatures
+    lib = _lib.load()
+    n, n_id, a0 = config2_block
+    c_in, c_out = 756, 256
+    torch.manual_seed(0)
+    feats = torch.rand(n, c_in)
+    conv = SAGEConv(c_in, c_out).to(dev)
+    g = torch.randn(a0.n_dst, c_out)
+    adj = a0.to(dev)
+    fd, nd, gd = feats.to(dev), n_id.to(dev), g.to(dev)
+    grads = {}
+    try:
+        for order in (0, 1, 1):
+            lib.pope_debug_set(_lib.KNOB_STREAMK_XCD, order)
+            for p in conv.parameters():
+                p.grad = None
+            if indexed:
+                out = conv(IndexedFeatures(fd, nd), adj)
+            else:
+                x = fd[nd]
+                out = conv((x, x[:a0.n_dst]), adj)
+            out.backward(gd)
+            got = (conv.lin_l.weight.grad.clone(), conv.lin_r.weight.grad.clone())
+            if order in grads:
+                assert torch.equal(got[0], grads[order][0]) and torch.equal(got[1], grads[order][1])
+            grads[order] = got
+    finally:
+        lib.pope_debug_set(_lib.KNOB_STREAMK_XCD, 1)
+    xr = feats[n_id]
+    wl, bl, wr = (p.detach().cpu().clone().requires_grad_(True) for p in (conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight))
+    oracle.sage_conv_torch(xr, a0.rowptr, a0.col, wl, bl, wr).backward(g)
+    for order in (0, 1):
+        _close(grads[order][0].cpu(), wl.grad, 1e-3)
+        _close(grads[order][1].cpu(), wr.grad, 1e-3)
+    _close(grads[1][0].cpu(), grads[0][0].cpu(), 1e-5)
+    _close(grads[1][1].cpu(), grads[0][1].cpu(), 1e-5)
+
+
+@pytest.mark.parametrize("indexed", [False, True], ids=["materialised", "indexed"])
 def test_config2_block_shape_matches_torch(indexed, forward_order, config2_block, dev, oracle):
     """Layer 0 at the shape bench.py times (9 988 x 37 799, 756 -> 256): forward and every gradient against
     oracle.sage_conv_torch, for the plain call and for IndexedFeatures (neighbours read through n_id, no x[n_id] copy),

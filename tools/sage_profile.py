@@ -28,6 +28,9 @@ torch.manual_seed(0)
 model = SAGE(756, 7, 256, 3).to(dev)
 opt = Adam(model.parameters(), lr=1e-3)
 torch.autograd.set_multithreading_enabled(False)
+if os.environ.get("GRAPHPOPE_STREAMK_XCD"):                    # A/B of the weight-gradient kernel's unit deal (POPE_KNOB_STREAMK_XCD)
+    from graphpope_amd import _lib
+    _lib.check(_lib.load().pope_debug_set(_lib.KNOB_STREAMK_XCD, int(os.environ["GRAPHPOPE_STREAMK_XCD"])))
 if mode == "eager":
     from graphpope_amd.sage import IndexedFeatures, cross_entropy
     rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei_np[0], minlength=n))])

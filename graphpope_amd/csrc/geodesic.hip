@@ -338,1217 +338,9 @@ __global__ void k_bfs_seed(const long long *__restrict__ anchors, int K, int Wp,
     if (j < K) seed_anchor(anchors[j], j, Wp, seen, front, live);
 }
 
-#ifdef POPE_STAMP
-// Diagnostic build only (make stamp): per-wave phase timestamps of k_bfs_level in 100 MHz real-time ticks.
-__device__ unsigned long long g_stamps[16384 * 8];
-__device__ int g_stamp_level;
-#define STAMP(slot)                                                                         \
-    do {                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        if (lane == 0 && wave < 16384 && level == g_stamp_level) g_stamps[wave * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-    } while (0)
-#else
-#define STAMP(slot) do { } while (0)
-#endif
+#include "geodesic_level.h"        // Words, DPP moves, live tables, k_live_summary, k_bfs_level
 
-template <int WT> struct Words { u64 w[WT]; };
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: what the non-temporal builtins accept
-
-// Cross-lane moves on the vector ALUs (DPP) instead of the LDS crossbar (ds_bpermute, which sixteen waves of a CU share): shifts
-// inside rows of 16 lanes, the row broadcasts (lane 15 of a row to the next row, lane 31 to rows 2 and 3) and whole-wave shifts by
-// one lane.  A lane without a source reads 0 (bound_ctrl).
-constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142,
-              DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
-template <int CTRL>
-__device__ __forceinline__ int dpp_mov(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
-template <int CTRL>
-__device__ __forceinline__ u64 dpp_mov64(u64 x) {
-    const unsigned lo = (unsigned)dpp_mov<CTRL>((int)(unsigned)x), hi = (unsigned)dpp_mov<CTRL>((int)(unsigned)(x >> 32));
-    return ((u64)hi << 32) | lo;
-}
-
-template <int WT>
-__device__ __forceinline__ Words<WT> load_words(const u64 *__restrict__ p) {
-    Words<WT> r;
-    if constexpr (WT == 1) {
-        r.w[0] = p[0];
-    } else {
-#pragma unroll
-        for (int i = 0; i < WT; i += 2) {                      // 16-byte loads (rows of 16 / 32 bytes, aligned)
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p + i);
-            r.w[i] = v.x;
-            r.w[i + 1] = v.y;
-        }
-    }
-    return r;
-}
-
-// Frontier gathers go through L1 like any load: reading them with the non-temporal hint was measured 57 % slower
-// (BFS 349 us against 223 us, tools/ab_lib.py) -- the rows of hubs are gathered again and again and L1 serves them.
-// The same accesses with the non-temporal hint: streams that are read or written once per level and should not displace the frontier
-// rows (the gathers' table) from L2 and the Infinity Cache on graphs whose frontier does not fit beside them.
-typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
-typedef int i32x4v __attribute__((ext_vector_type(4)));
-template <int WT, bool NT>
-__device__ __forceinline__ Words<WT> load_words_hint(const u64 *__restrict__ p) {
-    if constexpr (!NT) return load_words<WT>(p);
-    Words<WT> r;
-    if constexpr (WT == 1) {
-        r.w[0] = __builtin_nontemporal_load(p);
-    } else {
-#pragma unroll
-        for (int i = 0; i < WT; i += 2) {
-            const u64x2v v = __builtin_nontemporal_load(reinterpret_cast<const u64x2v *>(p + i));
-            r.w[i] = v.x;
-            r.w[i + 1] = v.y;
-        }
-    }
-    return r;
-}
-
-template <int WT>
-__device__ __forceinline__ Words<WT> gather_words(const u64 *__restrict__ p) { return load_words<WT>(p); }
-
-template <int WT>
-__device__ __forceinline__ void store_words(u64 *__restrict__ p, const Words<WT> &r) {
-    if constexpr (WT == 1) {
-        p[0] = r.w[0];
-    } else {
-#pragma unroll
-        for (int i = 0; i < WT; i += 2) *reinterpret_cast<ulonglong2 *>(p + i) = make_ulonglong2(r.w[i], r.w[i + 1]);
-    }
-}
-
-template <int WT, bool NT>
-__device__ __forceinline__ void store_words_hint(u64 *__restrict__ p, const Words<WT> &r) {
-    if constexpr (!NT) {
-        store_words<WT>(p, r);
-    } else if constexpr (WT == 1) {
-        __builtin_nontemporal_store(r.w[0], p);
-    } else {
-#pragma unroll
-        for (int i = 0; i < WT; i += 2) {
-            const u64x2v v = {r.w[i], r.w[i + 1]};
-            __builtin_nontemporal_store(v, reinterpret_cast<u64x2v *>(p + i));
-        }
-    }
-}
-
-template <int WT>
-__device__ __forceinline__ u64 any_bits(const Words<WT> &r) {
-    u64 a = 0;
-#pragma unroll
-    for (int i = 0; i < WT; ++i) a |= r.w[i];
-    return a;
-}
-
-// Newly reached anchors of node slot idx at `level`: reachability plane and hop-bit planes (bit-sliced count).
-// All plane loads are issued before the first store, so the read-modify-writes cost ONE memory round trip
-// instead of one per set bit of the level.
-template <int WT, bool NT = false>
-__device__ __forceinline__ void commit_words(const Words<WT> &fresh, const Words<WT> &seen_old, size_t idx,
-                                             u64 *__restrict__ seen, u64 *__restrict__ hop_planes,
-                                             size_t plane_elems, int level) {
-    Words<WT> s;
-#pragma unroll
-    for (int i = 0; i < WT; ++i) s.w[i] = seen_old.w[i] | fresh.w[i];
-    store_words_hint<WT, NT>(seen + idx, s);
-    Words<WT> h[5];
-#pragma unroll
-    for (int b = 0; b < 5; ++b) {
-        h[b] = fresh;
-        if ((level >> b) & 1) h[b] = load_words_hint<WT, NT>(hop_planes + (size_t)b * plane_elems + idx);
-    }
-#pragma unroll
-    for (int b = 0; b < 5; ++b)
-        if ((level >> b) & 1) {
-#pragma unroll
-            for (int i = 0; i < WT; ++i) h[b].w[i] |= fresh.w[i];
-            store_words_hint<WT, NT>(hop_planes + (size_t)b * plane_elems + idx, h[b]);
-        }
-    for (int b = 5, l = level >> 5; l; ++b, l >>= 1)              // levels >= 32: rare, one at a time
-        if (l & 1) {
-            u64 *p = hop_planes + (size_t)b * plane_elems + idx;
-            Words<WT> g = load_words_hint<WT, NT>(p);
-#pragma unroll
-            for (int i = 0; i < WT; ++i) g.w[i] |= fresh.w[i];
-            store_words_hint<WT, NT>(p, g);
-        }
-}
-
-// One BFS level, bottom-up and EDGE-parallel: a lane owns SLOTS = 4 consecutive CSR slots e = (v -> u), a wave
-// pass covers a chunk of 256 slots.
-//   cand = front[u] & ~seen[v]           anchors that reach v through u and had not reached v before
-// Slots are sorted by v, so a row is a run of consecutive slots.  Runs are combined in two steps: serially
-// inside the lane, then ONE 6-step segmented OR-scan across the 64 lanes on each lane's last run (a lane whose
-// four slots share one row is "transparent" and passes the carry on).  Work per wave is 256 edges whatever the
-// degree distribution (no long rows, no dependent pointer chase: erow/col are coalesced 16-byte streams).
-//   * A row that lies inside this chunk is complete: its words are stored to acc[v] (the next frontier, zeros
-//     included unless the live table makes them unnecessary, so acc needs no clearing).
-//   * A row that spans chunks ("multi-chunk": every hub) receives one piece per chunk, OR-ed into acc[v] with a
-//     device-scope atomic (a few thousand per level, distinct addresses); the housekeeping blocks clear those words
-//     in the idle third buffer, which launch l+1 will accumulate into.
-//   * Nobody commits level l inside launch l.  The COMMIT (reachability plane, bit-sliced hop planes) of level l-1 is
-//     done by the housekeeping blocks of launch l, one thread per node with a non-zero frontier row, beside the expand
-//     waves; every row masks its candidates with seen[v] | front[v] -- front[v] is exactly what level l-1 added -- so a
-//     commit that has or has not landed yet gives the same result.  The expand waves' dependent chain therefore ends at
-//     the frontier store (round 1 ended it with a plane read-modify-write: ~2.7 of a wave's ~13 us).  The launch after
-//     the last productive level finds nothing and commits that level: the BFS always runs it (it also proves the end).
-//     One launch per level, no second pass, no inter-block hand-off inside a launch.
-// Three frontier buffers rotate: front = level l-1 (read), acc = level l (written), idle = level l+1 (cleared).
-// Beside each goes a "live" table, one BIT per node: set when the node's frontier row is not all zero.  It is N/8
-// bytes (11 KB for Flickr) and every block copies it into LDS first (LIVE = 1; graphs up to LIVE_MAX_NODES), so a lane looks
-// its four neighbours up there and gathers the 8*W-byte frontier row -- a random 128-byte line from L2 -- only for
-// live ones.  The first and the last levels of a BFS have few live nodes: their launches skip most gathers, and a
-// chunk with no live neighbour skips its mask loads too.  (Looking the bits up in global memory instead was measured
-// slower than no table at all FOR FLICKR: each chunk's 256 gathered lines flush the 32 KB L1, so the lookups went to L2
-// as well.  Beyond LIVE_MAX_NODES the table is read from global memory (LIVE = 2): there the frontier rows come from the
-// Infinity Cache or HBM while the table still sits in L2 -- R-MAT scale 22 runs 20 % faster with it than without.)
-// WT = words per tile (1, 2 or 4); a node with more words (K > 256) has several tiles (TILES, see level_expand).
-// The live table (one bit per node, at most LIVE_MAX_NODES / 8 = 32 KB) into LDS: every load of a thread is requested before its
-// first write (round 4: as `for (i ...) lds[i] = src[i]` the loop compiled to load - s_waitcnt vmcnt(0) - ds_write per trip, three
-// serial round trips for Flickr's 11 KB in front of the barrier every expand wave waits at).
-__device__ __forceinline__ void stage_live_table(const unsigned *__restrict__ live, int live_words, uint4 *live_lds4) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(live);                       // tables are padded to 256 bytes
-    const int n4 = (live_words + 3) / 4;
-    for (int base = 0; base < n4; base += 4 * 256) {                                // one trip up to 131 072 nodes
-        // Branch-free on purpose: indices past the table are clamped to its last piece (loaded and written again by several threads,
-        // the same 16 bytes).  A load under an `if` is waited for at the join, and loads whose only use sits under an `if` are sunk
-        // into it by the optimiser -- either way one load in flight.
-        uint4 t[4];
-        int idx[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) idx[j] = min(base + (int)threadIdx.x + 256 * j, n4 - 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = src[idx[j]];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) live_lds4[idx[j]] = t[j];
-    }
-}
-
-// The summary of a live table for LIVE = 3: bit w of it says that table word w is non-zero (one bit per 32 nodes: 16 KB for the 4.2 M
-// nodes of R-MAT scale 22, where the table itself is 512 KB and cannot be staged).  A launch of its own between two level launches
-// (~4 us against levels of 0.3-2.5 ms): the table of the level just finished is complete, nobody else writes the summary.
-// Tables are padded to 256 bytes with zeros, so a wave may read its 64 words unconditionally.
-__global__ __launch_bounds__(256) void k_live_summary(const unsigned *__restrict__ live, int padded_words, unsigned *__restrict__ sum) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned v = w < padded_words ? live[w] : 0u;
-    const unsigned long long b = __ballot(v != 0u);
-    if ((threadIdx.x & 63) == 0 && w < padded_words) {
-        sum[(w >> 5)] = (unsigned)b;
-        sum[(w >> 5) + 1] = (unsigned)(b >> 32);
-    }
-}
-
-// Housekeeping share of one level (see k_bfs_level): thread t0 of tstride threads.  (1) clears two levels ahead -- the live
-// table and the accumulator words of the rows that span chunks; (2) commits level - 1 for every node whose
-// frontier row is non-zero.  A node's W = tiles * WT words are walked tile by tile.
-template <int WT, int LIVE, int TILES>
-__device__ __forceinline__ void level_housekeeping(int E, int N, int Wp, int tiles_arg, const u64 *__restrict__ front, u64 *__restrict__ seen,
-                                                   u64 *__restrict__ idle, u64 *__restrict__ hop_planes, size_t plane_elems, int level,
-                                                   const int *aux, const unsigned *__restrict__ live, unsigned *__restrict__ live_idle,
-                                                   int live_words, int t0, int tstride) {
-    const int tiles = TILES ? tiles_arg : 1;
-    const int n = (E + CHUNK - 1) >> CHUNK_SHIFT;              // one slot per chunk, -1 = no row continues into it
-    const int *mrows = aux + AUX_HEADER;
-    for (int i = t0; i < live_words; i += tstride) live_idle[i] = 0u;
-    Words<WT> zero;
-#pragma unroll
-    for (int i = 0; i < WT; ++i) zero.w[i] = 0;
-    for (int i = t0; i < n; i += tstride) {
-        const int mv = mrows[i];
-        if (mv >= 0)
-            for (int t = 0; t < tiles; ++t) store_words<WT>(idle + (size_t)mv * Wp + t * WT, zero);
-    }
-    if (level > 1) {
-        for (int v = t0; v < N; v += tstride) {
-            if (!((live[v >> 5] >> (v & 31)) & 1u)) continue;                      // frontier row all zero: nothing gained
-            constexpr bool NT = LIVE >= 2 && POPE_NT_PLANES != 0;
-            for (int t = 0; t < tiles; ++t) {
-                const size_t idx = (size_t)v * Wp + t * WT;
-                const Words<WT> fresh = load_words<WT>(front + idx);
-                if (any_bits<WT>(fresh))
-                    commit_words<WT, NT>(fresh, load_words_hint<WT, NT>(seen + idx), idx, seen, hop_planes, plane_elems, level - 1);
-            }
-        }
-    }
-}
-
-// erow of the slot in front of chunk `chunk` (.x, -1: none) and of the slot behind it (.y, -2: none).
-__device__ __forceinline__ int2 chunk_edge_rows(const int *__restrict__ erow, int chunk, int E) {
-    int2 r = make_int2(-1, -2);
-    if (chunk > 0 && chunk * CHUNK - 1 < E) r.x = erow[chunk * CHUNK - 1];
-    if ((chunk + 1) * CHUNK < E) r.y = erow[(chunk + 1) * CHUNK];
-    return r;
-}
-
-// Expand share of one level (see k_bfs_level): this wave walks chunks wave, wave + nwaves, ...; (vr, ur) hold the first chunk's
-// slots, loaded by the caller before it staged the live table.  Returns whether this lane emitted a non-zero row.
-// A node with more than 256 anchors has several WT-word tiles (TILES != 0).  Two ways to walk them, chosen by the size of the graph:
-//  TILES = 1 (round 5, graphs whose frontier lives in HBM: LIVE >= 2): INSIDE the wave -- the chunk's index loads, live look-ups and row
-//    structure (which slots end a run, which rows span chunks, who connects to whom in the scan) are computed once and the gather /
-//    mask / scan / store part runs once per tile, the next tile's gathers requested behind this tile's mask loads.  R-MAT scale 22 with
-//    512 anchors: 11.95 -> 9.3 ms for the nine levels (one pass over the 522 MB index stream and over the live look-ups instead of two).
-//  TILES = 2 (rounds 2-4, graphs that live in L2: LIVE = 1): every tile of a chunk is a wave of its own, adjacent waves of one block, so
-//    the 128-byte frontier line they all gather from is fetched from L2 once.  These levels are latency-bound and want the waves: with
-//    the tiles inside the wave the Flickr-shaped graph with 1 024 anchors ran 0.616 ms instead of 0.565.
-template <int WT, int LIVE, int TILES>
-__device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const int *__restrict__ col, int E, int Wp, int tile_begin, int tile_end,
-                                             const u64 *__restrict__ front, u64 *__restrict__ seen, u64 *__restrict__ acc,
-                                             const unsigned *__restrict__ live, unsigned *__restrict__ live_acc,
-                                             const unsigned *live_lds, int level, int lane, int wave, int nwaves, int nchunks,
-                                             int4 vr, int4 ur, unsigned *wave_words) {
-    auto load_idx = [&](const int *p) {
-        if constexpr (LIVE >= 2 && POPE_NT_INDEX != 0) {
-            const i32x4v t = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(p));
-            return make_int4(t.x, t.y, t.z, t.w);
-        } else {
-            return *reinterpret_cast<const int4 *>(p);
-        }
-    };
-    constexpr bool LOOP = TILES == 1;                          // only then a wave sees more than one tile
-    constexpr int TILE_AHEAD = LOOP ? (WT == 8 ? POPE_WT8_PREFETCH : POPE_TILE_PREFETCH) : 0;   // ... and carries the prefetch registers
-    if (!TILES) { tile_begin = 0; tile_end = 1; }
-    bool found = false;
-    STAMP(0);
-    // One bit per node: is the frontier row of node u non-zero?  LIVE = 3: a two-level table -- the summary in LDS says whether the
-    // node's table word holds any bit at all, and only then the word itself matters (from L2); lanes whose summary bit is clear read
-    // word 0 instead (one address, served by a broadcast), so the four look-ups of a lane are four loads in flight at once and a
-    // sparse level's waves stream the indices and touch little else.  (As `if (!summary) return false; return word` every look-up was
-    // a branch with a load inside: four serial L2 round trips per chunk, 4.2 us of a chunk's 21.8 on R-MAT scale 22.)
-    auto live4 = [&](int u0, int u1, int u2, int u3, bool &q0, bool &q1, bool &q2, bool &q3) {
-        if constexpr (LIVE == 3) {
-            const bool s0 = (live_lds[u0 >> 10] >> ((u0 >> 5) & 31)) & 1u, s1 = (live_lds[u1 >> 10] >> ((u1 >> 5) & 31)) & 1u,
-                       s2 = (live_lds[u2 >> 10] >> ((u2 >> 5) & 31)) & 1u, s3 = (live_lds[u3 >> 10] >> ((u3 >> 5) & 31)) & 1u;
-            const unsigned w0 = live[s0 ? u0 >> 5 : 0], w1 = live[s1 ? u1 >> 5 : 0], w2 = live[s2 ? u2 >> 5 : 0], w3 = live[s3 ? u3 >> 5 : 0];
-            q0 = s0 & ((w0 >> (u0 & 31)) & 1u); q1 = s1 & ((w1 >> (u1 & 31)) & 1u);
-            q2 = s2 & ((w2 >> (u2 & 31)) & 1u); q3 = s3 & ((w3 >> (u3 & 31)) & 1u);
-        } else {
-            const unsigned *t = LIVE == 1 ? live_lds : live;
-            const unsigned w0 = t[u0 >> 5], w1 = t[u1 >> 5], w2 = t[u2 >> 5], w3 = t[u3 >> 5];
-            q0 = (w0 >> (u0 & 31)) & 1u; q1 = (w1 >> (u1 & 31)) & 1u; q2 = (w2 >> (u2 & 31)) & 1u; q3 = (w3 >> (u3 & 31)) & 1u;
-        }
-    };
-    // Graphs whose waves walk many chunks (LIVE >= 2): the NEXT chunk's indices are requested before this chunk is worked on and its
-    // live look-ups go out behind this chunk's gathers -- memory instructions retire in order, so neither waits for the gathers -- and
-    // the chain index load -> live look-up -> gather of a chunk no longer starts from nothing (round 5: 4 of a chunk's ~22 us).
-    constexpr bool AHEAD = LIVE >= 2 && POPE_AHEAD != 0;
-    constexpr bool AHEAD_LIVE = AHEAD && POPE_AHEAD == 1;
-    auto slots_of = [&](int chunk, const int4 &vr_, const int4 &ur_, int &v0, int &v1, int &v2, int &v3, int &u0, int &u1, int &u2, int &u3) {
-        const int base = chunk * CHUNK + lane * SLOTS;
-        v0 = v1 = v2 = v3 = -1;
-        u0 = u1 = u2 = u3 = 0;
-        if (base < E) {                       // arrays are padded to a multiple of 4 entries: the 16-byte load is in bounds
-            v0 = vr_.x; u0 = ur_.x;
-            if (base + 1 < E) { v1 = vr_.y; u1 = ur_.y; }
-            if (base + 2 < E) { v2 = vr_.z; u2 = ur_.z; }
-            if (base + 3 < E) { v3 = vr_.w; u3 = ur_.w; }
-        }
-    };
-    bool q0 = false, q1 = false, q2 = false, q3 = false;       // AHEAD_LIVE: the live bits of the chunk about to be worked on
-    if (AHEAD_LIVE && wave < nchunks) {
-        int a0, a1, a2, a3, b0, b1, b2, b3;
-        slots_of(wave, vr, ur, a0, a1, a2, a3, b0, b1, b2, b3);
-        live4(b0, b1, b2, b3, q0, q1, q2, q3);
-    }
-    for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
-        STAMP(7);                                              // (slots 1-5 and 7 hold the wave's LAST chunk; 2-4 its first tile)
-        if (!AHEAD && chunk != wave && chunk * CHUNK + lane * SLOTS < E) {
-            vr = load_idx(erow + chunk * CHUNK + lane * SLOTS);
-            ur = load_idx(col + chunk * CHUNK + lane * SLOTS);
-        }
-        int v0, v1, v2, v3, u0, u1, u2, u3;
-        slots_of(chunk, vr, ur, v0, v1, v2, v3, u0, u1, u2, u3);
-        // the next chunk's indices: requested now, looked at behind this chunk's gathers (next_live)
-        int4 vr_n = make_int4(-1, -1, -1, -1), ur_n = make_int4(0, 0, 0, 0);
-        bool qn0 = false, qn1 = false, qn2 = false, qn3 = false;
-        const int chunk_n = chunk + nwaves;
-        if (AHEAD && chunk_n < nchunks && chunk_n * CHUNK + lane * SLOTS < E) {
-            vr_n = load_idx(erow + chunk_n * CHUNK + lane * SLOTS);
-            ur_n = load_idx(col + chunk_n * CHUNK + lane * SLOTS);
-        }
-        auto next_live = [&]() {
-            if constexpr (AHEAD_LIVE) {
-                if (chunk_n < nchunks) {
-                    int a0, a1, a2, a3, b0, b1, b2, b3;
-                    slots_of(chunk_n, vr_n, ur_n, a0, a1, a2, a3, b0, b1, b2, b3);
-                    live4(b0, b1, b2, b3, qn0, qn1, qn2, qn3);
-                }
-            }
-        };
-        auto advance = [&]() {
-            if constexpr (AHEAD) { vr = vr_n; ur = ur_n; }
-            if constexpr (AHEAD_LIVE) { q0 = qn0; q1 = qn1; q2 = qn2; q3 = qn3; }
-        };
-        // the four look-ups first, unconditionally (u = 0 for an empty slot), then the tests: as `v >= 0 && is_live(u)` each look-up sat
-        // behind a branch and was waited for on its own
-        if constexpr (!AHEAD_LIVE) live4(u0, u1, u2, u3, q0, q1, q2, q3);
-        const bool g0 = (v0 >= 0) & q0, g1 = (v1 >= 0) & q1, g2 = (v2 >= 0) & q2, g3 = (v3 >= 0) & q3;
-        const int vc = __builtin_amdgcn_readlane(v0, 0);                               // row of the chunk's first slot
-        const int vl = __builtin_amdgcn_readlane(v3, 63);                              // row of its last slot (-1: short chunk)
-        STAMP(1);
-        const bool work = __any(g0 || g1 || g2 || g3);                 // else: no live neighbour behind these 256 slots
-        if (!work) {                                                   // nothing to gather, nothing to store (nobody gathers a row whose live bit is clear), nothing to mark
-            next_live();
-            advance();
-            continue;
-        }
-        // the rows of the slots just outside the chunk: does its first row begin earlier, does its last row run on?
-        const int2 er = chunk_edge_rows(erow, __builtin_amdgcn_readfirstlane(chunk), E);     // wave-uniform: scalar loads
-        const bool head_multi = chunk > 0 && er.x == vc;                               // first row began in an earlier chunk
-        const bool tail_multi = vl >= 0 && (chunk + 1) * CHUNK < E && er.y == vl;     // last row runs on
-        // slots of a row that spans chunks (only the chunk's first and last row can)
-        const bool x0 = (head_multi && v0 == vc) || (tail_multi && v0 == vl);
-        const bool x1 = (head_multi && v1 == vc) || (tail_multi && v1 == vl);
-        const bool x2 = (head_multi && v2 == vc) || (tail_multi && v2 == vl);
-        const bool x3 = (head_multi && v3 == vc) || (tail_multi && v3 == vl);
-        // a run ends in this lane where the slot after it belongs to another row, or the chunk ends
-        const int nv0 = dpp_mov<DPP_WAVE_SHL1>(v0);
-        const int after3 = lane == 63 ? -3 : nv0;
-        const bool e0 = v0 >= 0 && v0 != v1, e1 = v1 >= 0 && v1 != v2, e2 = v2 >= 0 && v2 != v3, e3 = v3 >= 0 && v3 != after3;
-        // across lanes: segmented scan over each lane's LAST run (row v3); a lane starts a new segment unless all
-        // its slots share one row and that row is also the previous lane's last row
-        const int pv3 = dpp_mov<DPP_WAVE_SHR1>(v3);
-        const bool connects = lane > 0 && pv3 == v0 && v0 >= 0;
-        const bool head0 = !(connects && v0 == v3);
-        // the live bits of the rows themselves: row v's mask includes front[v] only when v is live
-        bool lv0, lv1, lv2, lv3;                                       // (only used for v >= 0)
-        live4(max(v0, 0), max(v1, 0), max(v2, 0), max(v3, 0), lv0, lv1, lv2, lv3);
-        bool m0 = false, m1 = false, m2 = false, m3 = false;           // run ends here with something new, in any tile
-        // With the live table an all-zero row need not be written: nobody gathers a row whose live bit is clear.
-        // (Several tiles share one live bit per node: then zeros are written too, so a live row is exact in every tile.)
-        const bool dense = TILES != 0;
-
-        auto gather4 = [&](int woff, Words<WT> &c0, Words<WT> &c1, Words<WT> &c2, Words<WT> &c3) {
-#pragma unroll
-            for (int i = 0; i < WT; ++i) c0.w[i] = c1.w[i] = c2.w[i] = c3.w[i] = 0;
-            if (g0) c0 = gather_words<WT>(front + (size_t)u0 * Wp + woff);
-            if (g1) c1 = gather_words<WT>(front + (size_t)u1 * Wp + woff);
-            if (g2) c2 = gather_words<WT>(front + (size_t)u2 * Wp + woff);
-            if (g3) c3 = gather_words<WT>(front + (size_t)u3 * Wp + woff);
-        };
-        Words<WT> c0, c1, c2, c3, d0, d1, d2, d3;
-        gather4(tile_begin * WT, c0, c1, c2, c3);
-        // Tiles in pairs (TILE_AHEAD = 2): the two tiles' pieces of a node's row lie in one 128-byte line.  Requested a tile apart, the
-        // second request came 1-3 us after the first, behind a tile's mask loads and their waits -- by then the ~8 MB of lines the waves
-        // of one XCD have in flight had pushed the line out of its 4 MB L2 again: 103 raw bytes fetched per edge on the dense levels of
-        // R-MAT scale 22 / 512 anchors where one line per edge and the streams make 75 (profiles/r05_config4_pmc.json).
-        if (TILE_AHEAD == 2 && tile_begin + 1 < tile_end) gather4((tile_begin + 1) * WT, d0, d1, d2, d3);
-        next_live();                                                   // behind the gathers: its loads wait for the NEXT chunk's indices only
-        for (int tile = tile_begin; tile < tile_end; ++tile) {
-            const int woff = tile * WT;
-            // mask of row v: what reached it before this level = seen[v] | front[v].  front[v] (level - 1's gain) is committed to
-            // seen by the housekeeping blocks of THIS launch: either order gives the same mask.  Rows whose live bit is clear
-            // have an all-zero (possibly never written) frontier row: not loaded.
-            // (Round 4, after the finalise kernel's lesson: this chain compiles to up to four serial load - wait rounds behind the gathers.
-            //  Requesting the first and last row's masks with the gathers and the interior rows' in a second batch was built and
-            //  A/B-ed as separate library builds, tools/ab_lib.py: BFS 205-212 us against 193-197 us for this chain; all four rows at
-            //  once needs 142 registers, three waves per SIMD, every level 3-6 us slower.  Requesting the rows of the slots next to
-            //  the chunk with the index loads made no measurable difference either.  profiles/r04_level_ab_libs.txt)
-            {
-                auto row_mask = [&](int v, bool lv) {
-                    Words<WT> m = load_words_hint<WT, LIVE >= 2 && POPE_NT_PLANES != 0>(seen + (size_t)v * Wp + woff);
-                    if (lv) {
-                        const Words<WT> f = load_words<WT>(front + (size_t)v * Wp + woff);
-#pragma unroll
-                        for (int i = 0; i < WT; ++i) m.w[i] |= f.w[i];
-                    }
-                    return m;
-                };
-                Words<WT> s0, s1, s2, s3;
-#pragma unroll
-                for (int i = 0; i < WT; ++i) s0.w[i] = s1.w[i] = s2.w[i] = s3.w[i] = 0;
-                if (v0 >= 0) s0 = row_mask(v0, lv0);
-                if (v3 >= 0) s3 = v3 == v0 ? s0 : row_mask(v3, lv3);
-                // an interior row (neither the lane's first nor last row)
-                if (v1 >= 0) s1 = v1 == v0 ? s0 : (v1 == v3 ? s3 : row_mask(v1, lv1));
-                if (v2 >= 0) s2 = v2 == v1 ? s1 : (v2 == v3 ? s3 : row_mask(v2, lv2));
-#pragma unroll
-                for (int i = 0; i < WT; ++i) {
-                    c0.w[i] &= ~s0.w[i];
-                    c1.w[i] &= ~s1.w[i];
-                    c2.w[i] &= ~s2.w[i];
-                    c3.w[i] &= ~s3.w[i];
-                }
-            }
-            // the next tile's gathers go out behind this tile's mask loads (memory instructions retire in order: requested in front of
-            // them they would be waited for first), and fly while this tile is scanned and stored
-            if (TILE_AHEAD == 1 && tile + 1 < tile_end) gather4(woff + WT, d0, d1, d2, d3);
-            const u64 any = any_bits<WT>(c0) | any_bits<WT>(c1) | any_bits<WT>(c2) | any_bits<WT>(c3);
-            if (tile == tile_begin) STAMP(2);
-            if (__any(any != 0)) {                                         // else: nothing new through these 256 edges
-                // inclusive OR along the lane's own slots, restarting where the row changes
-#pragma unroll
-                for (int i = 0; i < WT; ++i) {
-                    if (v1 == v0) c1.w[i] |= c0.w[i];
-                    if (v2 == v1) c2.w[i] |= c1.w[i];
-                    if (v3 == v2) c3.w[i] |= c2.w[i];
-                }
-                Words<WT> t = c3;
-                bool head = head0;
-                // Round 4: the scan network runs on DPP moves -- four shifts inside the rows of 16 lanes, then lane 15 of rows 0 / 2 to
-                // rows 1 / 3 and lane 31 to rows 2 / 3 -- where rounds 1-3 shuffled through the LDS crossbar (9 ds_bpermute per step and
-                // wave, sixteen waves of a CU queueing for it: 1.9 us of a wave's 13.8, tools/stamp_expand.py).  The operator on
-                // (value, head) pairs is the same, so is the result.  A step nobody would take anything in is skipped: rows average ten
-                // slots, so chunks without a hub row need two or three of the six.
-                auto scan_step = [&](auto ctrl, bool valid) {
-                    constexpr int CTRL = decltype(ctrl)::value;
-                    if (!__any(valid && !head)) return;
-                    const bool ph = dpp_mov<CTRL>((int)head) != 0;
-                    const bool take = valid && !head;
-#pragma unroll
-                    for (int i = 0; i < WT; ++i) {
-                        const u64 pt = dpp_mov64<CTRL>(t.w[i]);
-                        if (take) t.w[i] |= pt;
-                    }
-                    if (take) head = ph;
-                };
-                const int in_row = lane & 15;
-                scan_step(std::integral_constant<int, DPP_ROW_SHR1>{}, in_row >= 1);
-                scan_step(std::integral_constant<int, DPP_ROW_SHR2>{}, in_row >= 2);
-                scan_step(std::integral_constant<int, DPP_ROW_SHR4>{}, in_row >= 4);
-                scan_step(std::integral_constant<int, DPP_ROW_SHR8>{}, in_row >= 8);
-                scan_step(std::integral_constant<int, DPP_ROW_BCAST15>{}, ((lane >> 4) & 1) != 0);
-                scan_step(std::integral_constant<int, DPP_ROW_BCAST31>{}, lane >= 32);
-                // carry into this lane's first run = accumulated value of the previous lane's last run
-#pragma unroll
-                for (int i = 0; i < WT; ++i) {
-                    u64 ci = dpp_mov64<DPP_WAVE_SHR1>(t.w[i]);
-                    if (!connects) ci = 0;
-                    c0.w[i] |= ci;
-                    if (v1 == v0) c1.w[i] |= ci;
-                    if (v2 == v0) c2.w[i] |= ci;
-                    if (v3 == v0) c3.w[i] |= ci;
-                }
-            }
-            if (tile == tile_begin) STAMP(3);
-            // Emit every run that ends in this lane.
-            const size_t i0 = (size_t)v0 * Wp + woff, i1 = (size_t)v1 * Wp + woff, i2 = (size_t)v2 * Wp + woff,
-                         i3 = (size_t)v3 * Wp + woff;
-            const bool n0 = e0 && any_bits<WT>(c0) != 0, n1 = e1 && any_bits<WT>(c1) != 0, n2 = e2 && any_bits<WT>(c2) != 0,
-                       n3 = e3 && any_bits<WT>(c3) != 0;
-            // rows that lie inside the chunk: plain stores
-            if (e0 && !x0 && (n0 || dense)) store_words<WT>(acc + i0, c0);
-            if (e1 && !x1 && (n1 || dense)) store_words<WT>(acc + i1, c1);
-            if (e2 && !x2 && (n2 || dense)) store_words<WT>(acc + i2, c2);
-            if (e3 && !x3 && (n3 || dense)) store_words<WT>(acc + i3, c3);
-            // pieces of the (at most two) rows that span chunks: OR them in (their words were cleared two launches ago), commit later.
-            // Wave-uniform guard, and no branch per word (round 4: ~28 divergent branch regions in this phase before).
-            if (head_multi || tail_multi) {
-                auto piece = [&](size_t idx, const Words<WT> &c) {
-#pragma unroll
-                    for (int i = 0; i < WT; ++i) atomicOr(&acc[idx + i], c.w[i]);
-                };
-                if (n0 && x0) piece(i0, c0);
-                if (n1 && x1) piece(i1, c1);
-                if (n2 && x2) piece(i2, c2);
-                if (n3 && x3) piece(i3, c3);
-            }
-            if (tile == tile_begin) STAMP(4);
-            m0 |= n0; m1 |= n1; m2 |= n2; m3 |= n3;
-            if (TILE_AHEAD == 1 && tile + 1 < tile_end) { c0 = d0; c1 = d1; c2 = d2; c3 = d3; }
-            else if (TILE_AHEAD == 2 && tile + 1 < tile_end) {
-                if (!((tile - tile_begin) & 1)) { c0 = d0; c1 = d1; c2 = d2; c3 = d3; }          // second tile of the pair: already here
-                else {                                                                         // the next pair
-                    gather4(woff + WT, c0, c1, c2, c3);
-                    if (tile + 2 < tile_end) gather4(woff + 2 * WT, d0, d1, d2, d3);
-                }
-            } else if (LOOP && tile + 1 < tile_end) gather4(woff + WT, c0, c1, c2, c3);
-        }
-        found |= m0 || m1 || m2 || m3;
-        // Mark the rows that received something.  The chunk's rows are a short ascending run of node ids: build each
-        // 32-bit table word with a wave-wide OR and let one lane publish it (per-row atomics -- ~30 to every word
-        // from a few waves -- cost 14 us per dense level).
-        if (__any(m0 || m1 || m2 || m3)) {
-            const int wfirst = vc >> 5;
-            // the row of the chunk's last slot: lane 63's last slot, except in the one short chunk at the end of the edge list
-            const int last_row = vl >= 0 ? vl : erow[min((chunk + 1) * CHUNK, E) - 1];
-            const int kmax = (last_row >> 5) - wfirst;
-            if (kmax < 8) {
-                // Round 4: every row of the chunk has exactly one emitting slot (the end of its run), so the set bits are distinct:
-                // the emitting lanes OR them into eight LDS words of the wave (one ds_or each, no return), and lanes 0 .. kmax publish
-                // the words.  (Rounds 2-3 built each word with a six-step wave-wide OR per word and read the last row from memory:
-                // 1.36 us of a wave's 13.8, tools/stamp_expand.py.)  A wave's LDS instructions execute in order: no barrier.
-                if (lane < 8) wave_words[lane] = 0u;
-                if (m0) atomicOr(&wave_words[(v0 >> 5) - wfirst], 1u << (v0 & 31));
-                if (m1) atomicOr(&wave_words[(v1 >> 5) - wfirst], 1u << (v1 & 31));
-                if (m2) atomicOr(&wave_words[(v2 >> 5) - wfirst], 1u << (v2 & 31));
-                if (m3) atomicOr(&wave_words[(v3 >> 5) - wfirst], 1u << (v3 & 31));
-                __builtin_amdgcn_wave_barrier();
-                if (lane <= kmax) {
-                    const unsigned m = wave_words[lane];
-                    if (m) atomicOr(&live_acc[wfirst + lane], m);
-                }
-            } else {                                       // a run with wide gaps (isolated nodes in between)
-                if (m0) atomicOr(&live_acc[v0 >> 5], 1u << (v0 & 31));
-                if (m1) atomicOr(&live_acc[v1 >> 5], 1u << (v1 & 31));
-                if (m2) atomicOr(&live_acc[v2 >> 5], 1u << (v2 & 31));
-                if (m3) atomicOr(&live_acc[v3 >> 5], 1u << (v3 & 31));
-            }
-        }
-        STAMP(5);
-        advance();
-    }
-    STAMP(6);
-    return found;
-}
-
-// LIVE: 1 live table staged in LDS; 2 live table read from global memory (graphs beyond LIVE_MAX_NODES); 3 the same behind a summary
-// in LDS (one bit per table word, built by k_live_summary between the launches).  TILES: 0 one WT-word tile per node; several tiles
-// walked inside the wave (1) or dealt to adjacent waves (2), see level_expand.
-template <int WT, int LIVE, int TILES>
-__global__ __launch_bounds__(256, WT == 8 ? (TILES == 1 ? POPE_WT8_LOOP_WAVES : POPE_WT8_WAVES) : 1) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
-                                                   int E, int N, int Wp, int tiles, const u64 *__restrict__ front,
-                                                   u64 *__restrict__ seen, u64 *__restrict__ acc,
-                                                   u64 *__restrict__ idle, u64 *__restrict__ hop_planes,
-                                                   size_t plane_elems, int level, BfsCtl *ctl, const int *aux,
-                                                   int expand_blocks, const unsigned *__restrict__ live,
-                                                   unsigned *__restrict__ live_acc, unsigned *__restrict__ live_idle,
-                                                   int live_words, const unsigned *__restrict__ live_sum, int sum_words) {
-    if (bfs_over(ctl, aux, level)) return;
-    const int lane = threadIdx.x & 63;
-    if ((int)blockIdx.x >= expand_blocks) {
-        // Housekeeping blocks (beside the expand waves, not on their critical path):
-        //  (1) clear, two levels ahead: the live table and the accumulator words of the rows that span chunks;
-        //  (2) COMMIT level - 1 for every node: a node whose frontier row is non-zero gained those anchors at level - 1
-        //      -> reachability plane and hop-bit planes.  The expand waves never commit: they mask with seen[v] | front[v],
-        //      which is the same whether this commit has landed or not (OR is idempotent), and their chain ends at the store
-        //      of the next frontier instead of a plane read-modify-write behind it.
-        const int hb = (int)gridDim.x - expand_blocks;
-        level_housekeeping<WT, LIVE, TILES>(E, N, Wp, tiles, front, seen, idle, hop_planes, plane_elems, level, aux, live, live_idle, live_words,
-                                     ((int)blockIdx.x - expand_blocks) * blockDim.x + threadIdx.x, hb * blockDim.x);
-        return;
-    }
-    // which stream of chunks this wave walks, and which tiles of a node's words
-    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (expand_blocks * blockDim.x) >> 6, tile_begin = 0, tile_end = tiles;
-    if constexpr (TILES == 2) {                                    // the tiles of one chunk go to adjacent waves of the same block
-        const int wid = wave;
-        wave = wid / tiles;
-        tile_begin = wid - wave * tiles;
-        tile_end = tile_begin + 1;
-        nwaves /= tiles;
-    }
-    const int nchunks = (E + CHUNK - 1) >> CHUNK_SHIFT;
-    // The first chunk's slot loads are issued before the live table is staged: they fly while LDS fills.
-    int4 vr = make_int4(-1, -1, -1, -1), ur = make_int4(0, 0, 0, 0);
-    if (wave < nchunks && wave * CHUNK + lane * SLOTS < E) {
-        if constexpr (LIVE >= 2 && POPE_NT_INDEX != 0) {
-            const i32x4v a = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(erow + wave * CHUNK + lane * SLOTS));
-            const i32x4v b = __builtin_nontemporal_load(reinterpret_cast<const i32x4v *>(col + wave * CHUNK + lane * SLOTS));
-            vr = make_int4(a.x, a.y, a.z, a.w);
-            ur = make_int4(b.x, b.y, b.z, b.w);
-        } else {
-            vr = *reinterpret_cast<const int4 *>(erow + wave * CHUNK + lane * SLOTS);
-            ur = *reinterpret_cast<const int4 *>(col + wave * CHUNK + lane * SLOTS);
-        }
-    }
-    extern __shared__ uint4 live_lds4[];
-    const unsigned *live_lds = reinterpret_cast<const unsigned *>(live_lds4);
-    if constexpr (LIVE == 1) {
-        stage_live_table(live, live_words, live_lds4);
-        __syncthreads();
-    } else if constexpr (LIVE == 3) {
-        stage_live_table(live_sum, sum_words, live_lds4);
-        __syncthreads();
-    }
-    __shared__ unsigned wave_live_words[4][8];                     // per wave: the live-table words its chunk's rows fall into
-    const bool found = level_expand<WT, LIVE, TILES>(erow, col, E, Wp, tile_begin, tile_end, front, seen, acc, live, live_acc, live_lds, level, lane, wave, nwaves,
-                                              nchunks, vr, ur, wave_live_words[threadIdx.x >> 6]);
-    if (__any(found) && lane == 0) raise_level(ctl, level);
-}
-
-// pope_geodesic_run: the finalise kernel doubles as the report (deepest active level, CSR flags) into pinned,
-// device-mapped host memory, which the host reads after its one stream synchronisation.
-// The ticket is stored last (system-scope release): a host thread spinning on it sees the verdict as soon as the
-// kernel STARTS, i.e. when the BFS levels before it in the stream are done, not when the 100 us expansion ends.
-__device__ __forceinline__ void write_report(const int *max_hop_dev, const int *aux, int *report, int ticket) {
-    if (report && blockIdx.x == 0 && threadIdx.x == 0) {
-        report[0] = *max_hop_dev;
-        report[1] = csr_flags(reinterpret_cast<const BfsCtl *>(max_hop_dev), aux);        // (&ctl->last_active: the block's first word)
-        __hip_atomic_store(&report[2], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Finalise: hop planes -> 1/(h+1) float32 written next to the features (utils.py:73,125,129-135)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float hop_value(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
-                                           size_t widx, int bit) {
-    if (!((planes[widx] >> bit) & 1ull)) return 0.0f;             // unreachable (utils.py:75-76)
-    int h = 0;
-    for (int b = 0; b < n_hop_bits; ++b)
-        h |= (int)((planes[(size_t)(b + 1) * plane_elems + widx] >> bit) & 1ull) << b;
-    return 1.0f / (float)(h + 1);                                  // IEEE division, == f32(1.0 / (h + 1))
-}
-
-// One wave per row at a time.  VEC: 16-byte accesses (F, K, c0, out_cols multiples of 4, bases aligned).
-template <bool VEC>
-__global__ __launch_bounds__(256) void k_finalize(const u64 *__restrict__ planes, size_t plane_elems,
-                                                  int n_hop_bits, const int *__restrict__ max_hop_dev, int N, int K,
-                                                  int Wp, const float *__restrict__ x, int F,
-                                                  float *__restrict__ out, long long out_cols, int c0,
-                                                  const int *__restrict__ aux, int *report, int ticket) {
-    if (max_hop_dev) {                        // enqueued before the host knew the depth: read it from the BFS control block
-        const int m = *max_hop_dev;
-        n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
-        write_report(max_hop_dev, aux, report, ticket);
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int v = wave; v < N; v += nwaves) {
-        float *orow = out + (size_t)v * out_cols;
-        if (x) {
-            const float *xrow = x + (size_t)v * F;
-            if (VEC) {
-                const float4 *xs = reinterpret_cast<const float4 *>(xrow);
-                float4 *os = reinterpret_cast<float4 *>(orow);
-                for (int q = lane; q < F / 4; q += 64) os[q] = xs[q];
-            } else {
-                for (int c = lane; c < F; c += 64) orow[c] = xrow[c];
-            }
-        }
-        float *erow = orow + F + c0;
-        const size_t wbase = (size_t)v * Wp;
-        if (VEC) {
-            for (int q = lane; q < K / 4; q += 64) {
-                const int j = q * 4;                       // four anchors of one word: one load per plane
-                const size_t widx = wbase + (j >> 6);
-                const int bit = j & 63;
-                const unsigned reach = (unsigned)(planes[widx] >> bit) & 15u;
-                int h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-                for (int b = 0; b < n_hop_bits; ++b) {
-                    const unsigned p = (unsigned)(planes[(size_t)(b + 1) * plane_elems + widx] >> bit) & 15u;
-                    h0 |= (int)(p & 1u) << b;
-                    h1 |= (int)((p >> 1) & 1u) << b;
-                    h2 |= (int)((p >> 2) & 1u) << b;
-                    h3 |= (int)((p >> 3) & 1u) << b;
-                }
-                float4 r;
-                r.x = (reach & 1u) ? 1.0f / (float)(h0 + 1) : 0.0f;
-                r.y = (reach & 2u) ? 1.0f / (float)(h1 + 1) : 0.0f;
-                r.z = (reach & 4u) ? 1.0f / (float)(h2 + 1) : 0.0f;
-                r.w = (reach & 8u) ? 1.0f / (float)(h3 + 1) : 0.0f;
-                reinterpret_cast<float4 *>(erow)[q] = r;
-            }
-        } else {
-            for (int j = lane; j < K; j += 64)
-                erow[j] = hop_value(planes, plane_elems, n_hop_bits, wbase + (j >> 6), j & 63);
-        }
-    }
-}
-
-// Fast path of the finalise kernel: 16-byte accesses, at most 4 hop-bit planes (hops < 16: any small-world graph).
-//  * every wave owns a CONTIGUOUS block of rows, so the cache lines that straddle two rows (row pitch 4*(F+K) bytes is
-//    not a multiple of 128) are completed by the same wave;
-//  * 1/(h+1) comes from a 16-entry table built once per block with the same IEEE division (bit-identical);
-//  * the four hop counts of a lane are pulled out of the packed plane nibbles with one multiply each;
-//  * x is read with non-temporal loads (read once); stores are plain -- non-temporal stores measured 23 % slower.
-// Since round 4 the fallback of k_finalize_pipe / k_finalize_wide for shapes they have no instance for (F > 1024).
-// n_shards > 1 (multi-GPU): `planes` holds the all-gathered shards back to back (shard_elems words apart, K anchors
-// each); a row's columns of ALL shards are written in one pass, so the [N, F + shards*K] matrix is streamed once.
-__global__ __launch_bounds__(256) void k_finalize_fast(const u64 *__restrict__ planes, size_t plane_elems,
-                                                       int n_hop_bits, const int *__restrict__ max_hop_dev, int N, int K,
-                                                       int Wp, const float *__restrict__ x, int F,
-                                                       float *__restrict__ out, long long out_cols, int c0,
-                                                       int n_shards, size_t shard_elems, const int *__restrict__ aux,
-                                                       int *report, int ticket) {
-    if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
-    __shared__ float inv[16];
-    if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
-    __syncthreads();
-    if (max_hop_dev) {
-        const int m = *max_hop_dev;
-        n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int per = (N + nwaves - 1) / nwaves;
-    const int v_begin = wave * per, v_end = min(N, v_begin + per);
-    const int F4 = F >> 2, K4 = K >> 2;
-    for (int v = v_begin; v < v_end; ++v) {
-        f32x4 *orow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols);
-        if (x) {
-            const f32x4 *xs = reinterpret_cast<const f32x4 *>(x + (size_t)v * F);
-            for (int q = lane; q < F4; q += 64) {
-                const f32x4 t = __builtin_nontemporal_load(xs + q);
-                orow[q] = t;
-            }
-        }
-        f32x4 *erow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols + F + c0);
-        const size_t wbase = (size_t)v * Wp;
-        for (int q = lane; q < K4 * n_shards; q += 64) {
-            const int shard = q / K4;
-            const int j = (q - shard * K4) * 4;                // four anchors of one word of that shard
-            const size_t widx = (size_t)shard * shard_elems + wbase + (j >> 6);
-            const int bit = j & 63;
-            const unsigned reach = (unsigned)(planes[widx] >> bit) & 15u;
-            unsigned t = 0;                                    // nibble b = the four anchors' hop bit b
-            for (int b = 0; b < n_hop_bits; ++b)
-                t |= ((unsigned)(planes[(size_t)(b + 1) * plane_elems + widx] >> bit) & 15u) << (4 * b);
-            // bits 0,4,8,12 of (t >> i) are anchor i's hop bits 0..3: the multiply gathers them into bits 12..15
-            const unsigned h0 = (((t) & 0x1111u) * 0x1248u >> 12) & 15u;
-            const unsigned h1 = (((t >> 1) & 0x1111u) * 0x1248u >> 12) & 15u;
-            const unsigned h2 = (((t >> 2) & 0x1111u) * 0x1248u >> 12) & 15u;
-            const unsigned h3 = (((t >> 3) & 0x1111u) * 0x1248u >> 12) & 15u;
-            f32x4 r;
-            r.x = (reach & 1u) ? inv[h0] : 0.0f;
-            r.y = (reach & 2u) ? inv[h1] : 0.0f;
-            r.z = (reach & 4u) ? inv[h2] : 0.0f;
-            r.w = (reach & 8u) ? inv[h3] : 0.0f;
-            erow[q] = r;
-        }
-    }
-}
-
-// k_finalize_fast with every load of a row in flight at once, the NEXT row's loads issued before this row's stores, and the rows
-// dealt to the waves round-robin (round 4).  The ISA of k_finalize_fast shows why it runs at 4.6 TB/s: its loops compile to
-// load - s_waitcnt vmcnt(0) - store per 16-byte piece and to one plane load per s_waitcnt in the hop-bit loop -- seven serial round
-// trips per row and ONE load in flight per lane, the chip's 32 waves per CU being all that hides them.  Here a row's XP feature
-// pieces and the 5 plane words of its EP embedding pieces are independent loads (no loops), held in registers for one
-// iteration while the next row's are requested: 0.263 -> 0.254 ms per configs[1] step.  Row v goes to wave v mod nwaves, so
-// the waves that run at the same time stream through ONE moving window of consecutive rows instead of 8 192 separate places
-// (0.254 -> 0.247; with the old kernel's serial loops contiguous row blocks per wave were the faster choice), and the grid is one
-// row per wave (22 313 blocks for Flickr: 0.2395 ms; profiles/r04_finalize_pipe*.txt): 463 MB in ~74 us = 6.25 TB/s, the measured
-// copy rate of the part.  Shapes: F <= 256 XP (XP <= 4), any K * shards (rows wider than 1 024 columns are cut into segments, one
-// work item each), at most four hop bits (others: k_finalize_fast).
-template <int XP, int EP>
-struct FinRow {
-    f32x4 x[XP > 0 ? XP : 1];
-    u64 w[EP][5];
-};
-
-template <int XP, int EP>
-__device__ __forceinline__ FinRow<XP, EP> fin_load(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits, int Wp, const float *__restrict__ x,
-                                                   int F4, int v, int lane, bool copy_x, int K4, int n_emb, size_t shard_elems, int q0) {
-    FinRow<XP, EP> r;
-#pragma unroll
-    for (int i = 0; i < (XP > 0 ? XP : 1); ++i) r.x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (XP > 0 && copy_x) {
-        const f32x4 *xs = reinterpret_cast<const f32x4 *>(x) + (size_t)v * F4;
-#pragma unroll
-        for (int i = 0; i < XP; ++i)
-            if (lane + 64 * i < F4) r.x[i] = __builtin_nontemporal_load(xs + lane + 64 * i);
-    }
-#pragma unroll
-    for (int e = 0; e < EP; ++e) {
-#pragma unroll
-        for (int b = 0; b < 5; ++b) r.w[e][b] = 0;
-        const int q = q0 + lane + 64 * e;
-        if (q < n_emb) {
-            const int shard = q / K4, j = (q - shard * K4) * 4;
-            const size_t widx = (size_t)shard * shard_elems + (size_t)v * Wp + (j >> 6);
-            r.w[e][0] = planes[widx];
-            if (n_hop_bits > 0) r.w[e][1] = planes[plane_elems + widx];
-            if (n_hop_bits > 1) r.w[e][2] = planes[2 * plane_elems + widx];
-            if (n_hop_bits > 2) r.w[e][3] = planes[3 * plane_elems + widx];
-            if (n_hop_bits > 3) r.w[e][4] = planes[4 * plane_elems + widx];
-        }
-    }
-    return r;
-}
-
-template <int XP, int EP>
-__global__ __launch_bounds__(256) void k_finalize_pipe(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
-                                                       const int *__restrict__ max_hop_dev, int N, int K, int Wp,
-                                                       const float *__restrict__ x, int F, float *__restrict__ out, long long out_cols,
-                                                       int c0, int n_shards, size_t shard_elems, const int *__restrict__ aux, int *report,
-                                                       int ticket) {
-    if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
-    __shared__ float inv[16];
-    if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
-    __syncthreads();
-    if (max_hop_dev) {
-        const int m = *max_hop_dev;
-        n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    // A work item is (row, segment): a row wider than 256 EP embedding columns (many shards) is cut into segments of 64 EP pieces,
-    // each a work item of its own; segment 0 also copies the row's features.  Items are dealt to the waves round-robin
-    const int F4 = F >> 2, K4 = K >> 2, n_emb = K4 * n_shards;
-    const int n_seg = (n_emb + 64 * EP - 1) / (64 * EP);
-    const int items = N * n_seg;                                         // < 2^31: checked on the host
-    const int i_begin = wave, i_end = items, i_step = nwaves;
-    if (i_begin >= i_end) return;
-    auto row_of = [&](int i, int &seg) { const int v = (int)((unsigned)i / (unsigned)n_seg); seg = i - v * n_seg; return v; };
-    int seg = 0, v = row_of(i_begin, seg);
-    FinRow<XP, EP> cur = fin_load<XP, EP>(planes, plane_elems, n_hop_bits, Wp, x, F4, v, lane, x && seg == 0, K4, n_emb, shard_elems, seg * 64 * EP);
-    for (int i = i_begin; i < i_end; i += i_step) {
-        FinRow<XP, EP> nxt = cur;
-        int seg_n = 0, v_n = 0;
-        if (i + i_step < i_end) {
-            v_n = row_of(i + i_step, seg_n);
-            nxt = fin_load<XP, EP>(planes, plane_elems, n_hop_bits, Wp, x, F4, v_n, lane, x && seg_n == 0, K4, n_emb, shard_elems, seg_n * 64 * EP);
-        }
-        f32x4 *orow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols);
-        if (XP > 0 && x && seg == 0) {
-#pragma unroll
-            for (int p = 0; p < XP; ++p)
-                if (lane + 64 * p < F4) orow[lane + 64 * p] = cur.x[p];
-        }
-        f32x4 *erow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols + F + c0);
-#pragma unroll
-        for (int e = 0; e < EP; ++e) {
-            const int q = seg * 64 * EP + lane + 64 * e;
-            if (q < n_emb) {
-                const int shard = q / K4, j = (q - shard * K4) * 4, bit = j & 63;
-                const unsigned reach = (unsigned)(cur.w[e][0] >> bit) & 15u;
-                unsigned t = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) t |= ((unsigned)(cur.w[e][b + 1] >> bit) & 15u) << (4 * b);      // planes past n_hop_bits were loaded as 0
-                const unsigned h0 = (((t) & 0x1111u) * 0x1248u >> 12) & 15u;
-                const unsigned h1 = (((t >> 1) & 0x1111u) * 0x1248u >> 12) & 15u;
-                const unsigned h2 = (((t >> 2) & 0x1111u) * 0x1248u >> 12) & 15u;
-                const unsigned h3 = (((t >> 3) & 0x1111u) * 0x1248u >> 12) & 15u;
-                f32x4 r;
-                r.x = (reach & 1u) ? inv[h0] : 0.0f;
-                r.y = (reach & 2u) ? inv[h1] : 0.0f;
-                r.z = (reach & 4u) ? inv[h2] : 0.0f;
-                r.w = (reach & 8u) ? inv[h3] : 0.0f;
-                erow[q] = r;
-            }
-        }
-        cur = nxt;
-        v = v_n;
-        seg = seg_n;
-    }
-}
-
-// Wide rows (more than 256 embedding columns: several shards after the all-gather, or K > 256 on one GPU), K a multiple of 64.
-// In k_finalize_pipe sixteen lanes load the same plane word, and an item of 256 pieces costs twenty narrow loads and ~100
-// registers: at 8 x 256 anchors the plane loads alone took 162 us for 114 MB and the stores another 150 (profiles/
-// r04_finalize_shards.txt).  Here a work item is (row, 16 words): lane l < 32 loads one 32-bit HALF of a word of each of the five
-// planes -- five loads per item -- and every lane fetches the half-word of its four anchors from lane (piece >> 3) with ONE
-// 32-bit shuffle per plane; five registers per item instead of forty, so the next item's loads fit beside this one's stores at full occupancy: 220 us against 382 at 8 x 256
-// anchors.  (Four lanes per word and no shuffles -- each lane expanding pieces (l & 3) + 4 e of its own word -- makes every store
-// instruction write sixteen 64-byte runs instead of whole lines: 285 us.)
-template <int XP>
-__global__ __launch_bounds__(256) void k_finalize_wide(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
-                                                       const int *__restrict__ max_hop_dev, int N, int K, int Wp,
-                                                       const float *__restrict__ x, int F, float *__restrict__ out, long long out_cols,
-                                                       int c0, int n_shards, size_t shard_elems, const int *__restrict__ aux, int *report,
-                                                       int ticket) {
-    if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
-    __shared__ float inv[16];
-    if (threadIdx.x < 16) inv[threadIdx.x] = 1.0f / (float)(threadIdx.x + 1);
-    __syncthreads();
-    if (max_hop_dev) {
-        const int m = *max_hop_dev;
-        n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int F4 = F >> 2, K4 = K >> 2, n_emb = K4 * n_shards;          // K4 is a multiple of 16: a word never spans two shards
-    const int wps = K4 >> 4;                                             // words per shard and node (not Wp: that one is padded to the tile width)
-    const int n_words = n_emb >> 4, n_seg = (n_words + 15) >> 4;
-    const int items = N * n_seg;                                         // < 2^31: checked on the host
-    if (wave >= items) return;
-    struct Item { f32x4 x[XP > 0 ? XP : 1]; unsigned w[5]; };      // w: one 32-bit HALF of a plane word per lane (lanes 0 .. 31)
-    auto load = [&](int i, int &v, int &seg) {
-        v = (int)((unsigned)i / (unsigned)n_seg);
-        seg = i - v * n_seg;
-        Item r;
-#pragma unroll
-        for (int p = 0; p < (XP > 0 ? XP : 1); ++p) r.x[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < 5; ++b) r.w[b] = 0;
-        if (XP > 0 && x && seg == 0) {
-            const f32x4 *xs = reinterpret_cast<const f32x4 *>(x) + (size_t)v * F4;
-#pragma unroll
-            for (int p = 0; p < XP; ++p)
-                if (lane + 64 * p < F4) r.x[p] = __builtin_nontemporal_load(xs + lane + 64 * p);
-        }
-        const int word = seg * 16 + (lane >> 1);                         // lanes 0 .. 31: half (lane & 1) of word lane >> 1 of the item
-        if (lane < 32 && word < n_words) {
-            const int shard = word / wps;
-            const unsigned *p = reinterpret_cast<const unsigned *>(planes + ((size_t)shard * shard_elems + (size_t)v * Wp + (word - shard * wps))) + (lane & 1);
-            r.w[0] = p[0];
-            if (n_hop_bits > 0) r.w[1] = p[2 * plane_elems];
-            if (n_hop_bits > 1) r.w[2] = p[4 * plane_elems];
-            if (n_hop_bits > 2) r.w[3] = p[6 * plane_elems];
-            if (n_hop_bits > 3) r.w[4] = p[8 * plane_elems];
-        }
-        return r;
-    };
-    int v = 0, seg = 0;
-    Item cur = load(wave, v, seg);
-    for (int i = wave; i < items; i += nwaves) {
-        Item nxt = cur;
-        int v_n = 0, seg_n = 0;
-        if (i + nwaves < items) nxt = load(i + nwaves, v_n, seg_n);
-        if (XP > 0 && x && seg == 0) {
-            f32x4 *orow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols);
-#pragma unroll
-            for (int p = 0; p < XP; ++p)
-                if (lane + 64 * p < F4) orow[lane + 64 * p] = cur.x[p];
-        }
-        f32x4 *erow = reinterpret_cast<f32x4 *>(out + (size_t)v * out_cols + F + c0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int q = seg * 256 + lane + 64 * e;                     // piece: four anchors of half-word q >> 3, held by lane (q >> 3) - 32 seg
-            const int src = (lane >> 3) + 8 * e, bit = (q & 7) * 4;
-            unsigned nib[5];
-#pragma unroll
-            for (int b = 0; b < 5; ++b) nib[b] = ((unsigned)__shfl((int)cur.w[b], src) >> bit) & 15u;
-            if (q < n_emb) {
-                const unsigned reach = nib[0];
-                const unsigned t = nib[1] | (nib[2] << 4) | (nib[3] << 8) | (nib[4] << 12);
-                const unsigned h0 = (((t) & 0x1111u) * 0x1248u >> 12) & 15u;
-                const unsigned h1 = (((t >> 1) & 0x1111u) * 0x1248u >> 12) & 15u;
-                const unsigned h2 = (((t >> 2) & 0x1111u) * 0x1248u >> 12) & 15u;
-                const unsigned h3 = (((t >> 3) & 0x1111u) * 0x1248u >> 12) & 15u;
-                f32x4 r;
-                r.x = (reach & 1u) ? inv[h0] : 0.0f;
-                r.y = (reach & 2u) ? inv[h1] : 0.0f;
-                r.z = (reach & 4u) ? inv[h2] : 0.0f;
-                r.w = (reach & 8u) ? inv[h3] : 0.0f;
-                erow[q] = r;
-            }
-        }
-        cur = nxt;
-        v = v_n;
-        seg = seg_n;
-    }
-}
-
-// Wide rows without shuffles and with a tenth of the bit arithmetic (round 5).  k_finalize_wide spends ~50 vector instructions and
-// five ds_bpermute per 16-byte store pulling nibbles out of bit-sliced planes (8.6 GB of [N, 512] columns for R-MAT scale 22 at
-// 4.0 TB/s; 3.8 TB/s at 8 x 256 anchors).  Here a lane owns one 32-bit HALF of a plane word -- 32 anchors, 128 bytes of output -- and
-// turns it into floats byte by byte through two tables in LDS:
-//   spread[b][byte]   the byte's 8 bits moved to bit b of 8 nibbles (u32), so the OR over the four hop-bit planes is the 8 anchors'
-//                     4-bit hop counts side by side;
-//   pair[code]        code = two neighbouring hop nibbles + their two reachability bits (10 bits) -> float2{1 / (h + 1) or 0}, built
-//                     per block with the same IEEE division as every other finalise kernel (bit-identical to f32(1.0 / (h + 1))).
-// Per 8 anchors: four spread look-ups, three ORs, and per pair one field extract for the code, one for the reachability bits, one
-// OR and one 8-byte look-up.  A wave takes 64 consecutive half-words of the flat (row, half-word) sequence (rows with few words do
-// not leave lanes idle), prefetches the next batch's five plane dwords before it stores, and transposes its 8 KB through LDS so that
-// every store instruction writes 1 KB of whole lines (a lane's own 128 bytes are 64 partial lines per instruction).  Shapes: K a
-// multiple of 64, words per shard and number of shards powers of two (the half-words per row then are one: shifts, no divisions).
-constexpr int FIN_LUT_LDS = 4 * 256 * 4 + 1024 * 8 + 4 * 8192;      // spread tables, pair table, one 8 KB transpose image per wave
-
-__global__ __launch_bounds__(256) void k_finalize_lut(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
-                                                      const int *__restrict__ max_hop_dev, int N, int Wp, float *__restrict__ out,
-                                                      long long out_cols, int col0, int hpr_shift, int wps_shift, int rows_shift, size_t shard_elems,
-                                                      const int *__restrict__ aux, int *report, int ticket) {
-    if (max_hop_dev) write_report(max_hop_dev, aux, report, ticket);
-    extern __shared__ __attribute__((aligned(16))) char fin_lds[];
-    unsigned *spread = reinterpret_cast<unsigned *>(fin_lds);                       // [4][256]
-    float2 *pair = reinterpret_cast<float2 *>(fin_lds + 4 * 256 * 4);               // [1024]
-    char *image = fin_lds + 4 * 256 * 4 + 1024 * 8 + (threadIdx.x >> 6) * 8192;     // this wave's transpose image
-    for (int i = threadIdx.x; i < 1024; i += 256) {
-        const int b = i >> 8, x = i & 255;
-        unsigned y = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) y |= ((unsigned)(x >> k) & 1u) << (4 * k + b);
-        spread[i] = y;
-        const int h0 = i & 15, h1 = (i >> 4) & 15;
-        pair[i] = make_float2((i & 256) ? 1.0f / (float)(h0 + 1) : 0.0f, (i & 512) ? 1.0f / (float)(h1 + 1) : 0.0f);
-    }
-    __syncthreads();
-    if (max_hop_dev) {
-        const int m = *max_hop_dev;
-        n_hop_bits = m > 0 ? 32 - __clz(m) : 0;
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    const unsigned hpr_mask = (1u << hpr_shift) - 1u;
-    const long long total = (long long)N << hpr_shift;                              // half-words in all (< 2^31: checked on the host)
-    // Which half-word slot o (0 .. 63) of batch `batch` is: node v, half-word hw of the output row, and where its plane dwords lie.
-    //  rows_shift < 0: the flat (row, half-word) sequence, 64 consecutive half-words a batch.
-    //  rows_shift >= 0 (several shards whose rows are shorter than a batch): a batch is ONE shard's half-words of 2^rows_shift consecutive
-    //    nodes -- 256 contiguous bytes of each plane, where the flat order reads eight 32-byte pieces from eight shards (R-MAT scale 22,
-    //    8 shards x 64 anchors: 2.79 -> 1.94 ms; Flickr-shaped, 8 x 256: 196-211 -> 170 us); the batches of a row block in the other shards are the neighbouring waves'.
-    const int hps_shift = wps_shift + 1, shards_shift = hpr_shift - hps_shift;
-    const int batches = rows_shift < 0 ? (int)((total + 63) >> 6) : (((N + (1 << rows_shift) - 1) >> rows_shift) << shards_shift);
-    const unsigned *planes32 = reinterpret_cast<const unsigned *>(planes);
-    struct Slot { unsigned v, hw; size_t off; bool ok; };
-    auto slot_of = [&](int batch, int o) {
-        Slot t;
-        if (rows_shift < 0) {
-            const long long g = (long long)batch * 64 + o;
-            t.ok = g < total;
-            t.v = (unsigned)(g >> hpr_shift);
-            t.hw = (unsigned)g & hpr_mask;
-        } else {
-            const unsigned shard = (unsigned)batch & ((1u << shards_shift) - 1u), rb = (unsigned)batch >> shards_shift;
-            t.v = (rb << rows_shift) + ((unsigned)o >> hps_shift);
-            t.hw = (shard << hps_shift) | ((unsigned)o & ((1u << hps_shift) - 1u));
-            t.ok = t.v < (unsigned)N;
-        }
-        const unsigned word = t.hw >> 1, shard = word >> wps_shift, wl = word & ((1u << wps_shift) - 1u);
-        t.off = (((size_t)shard * shard_elems + (size_t)t.v * Wp + wl) << 1) + (t.hw & 1u);
-        return t;
-    };
-    struct Halves { unsigned w[5]; };
-    auto load = [&](int batch) {
-        Halves r;
-#pragma unroll
-        for (int b = 0; b < 5; ++b) r.w[b] = 0;
-        const Slot t = slot_of(batch, lane);
-        if (t.ok) {
-            const unsigned *p = planes32 + t.off;
-            r.w[0] = p[0];
-            if (n_hop_bits > 0) r.w[1] = p[2 * plane_elems];
-            if (n_hop_bits > 1) r.w[2] = p[4 * plane_elems];
-            if (n_hop_bits > 2) r.w[3] = p[6 * plane_elems];
-            if (n_hop_bits > 3) r.w[4] = p[8 * plane_elems];
-        }
-        return r;
-    };
-    if (wave >= batches) return;
-    Halves cur = load(wave);
-    for (int batch = wave; batch < batches; batch += nwaves) {
-        Halves nxt = cur;
-        if (batch + nwaves < batches) nxt = load(batch + nwaves);
-        // this lane's 32 floats, as 8 pieces of 16 bytes, into the wave's image: piece j of lane l at l * 128 + ((j ^ (l & 7)) * 16)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned code = spread[(cur.w[1] >> (8 * k)) & 255u] | spread[256 + ((cur.w[2] >> (8 * k)) & 255u)] |
-                                  spread[512 + ((cur.w[3] >> (8 * k)) & 255u)] | spread[768 + ((cur.w[4] >> (8 * k)) & 255u)];
-            const unsigned reach = (cur.w[0] >> (8 * k)) & 255u;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {                                            // two pairs = one 16-byte piece
-                const float2 a = pair[((code >> (16 * q)) & 255u) | (((reach >> (4 * q)) & 3u) << 8)];
-                const float2 b = pair[((code >> (16 * q + 8)) & 255u) | (((reach >> (4 * q + 2)) & 3u) << 8)];
-                const int j = 2 * k + q;
-                *reinterpret_cast<float4 *>(image + lane * 128 + ((j ^ (lane & 7)) << 4)) = make_float4(a.x, a.y, b.x, b.y);
-            }
-        }
-        // store instruction e writes bytes [1024 e, 1024 e + 1024) of the batch's 8 KB: lane l takes piece l & 7 of owner 8 e + (l >> 3)
-        // (a wave's LDS instructions execute in order: no barrier between the writes above and these reads)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int o = 8 * e + (lane >> 3), pc = lane & 7;
-            const float4 val = *reinterpret_cast<const float4 *>(image + o * 128 + ((pc ^ (o & 7)) << 4));
-            const Slot t = slot_of(batch, o);
-            if (t.ok) *reinterpret_cast<float4 *>(out + (size_t)t.v * out_cols + col0 + t.hw * 32 + pc * 4) = val;
-        }
-        cur = nxt;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_hops(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
-                                              int N, int K, int Wp, int *__restrict__ hops) {
-    const size_t total = (size_t)N * K;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int v = (int)(i / K), j = (int)(i % K);
-        const size_t widx = (size_t)v * Wp + (j >> 6);
-        const int bit = j & 63;
-        int h = -1;
-        if ((planes[widx] >> bit) & 1ull) {
-            h = 0;
-            for (int b = 0; b < n_hop_bits; ++b)
-                h |= (int)((planes[(size_t)(b + 1) * plane_elems + widx] >> bit) & 1ull) << b;
-        }
-        hops[i] = h;
-    }
-}
-
-// Transport form of the embedding for the host -> host boundary: one byte per (node, anchor), 0 = no path, c = hops + 1
-// otherwise (the caller has checked max hop <= 254), plus the 256 floats the bytes stand for -- lut[c] = 1 / c computed
-// HERE with the finalise kernel's own expression, so the host only looks values up.  A quarter of the float matrix's bytes
-// cross PCIe.  Wave-per-row-block like k_finalize_fast; a lane turns four anchors of one plane word into one 32-bit store.
-__global__ __launch_bounds__(256) void k_hop_codes(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits, int N, int K, int Wp,
-                                                   unsigned char *__restrict__ codes, long long pitch, float *__restrict__ lut) {
-    if (blockIdx.x == 0) lut[threadIdx.x] = threadIdx.x ? 1.0f / (float)threadIdx.x : 0.0f;
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int per = (N + nwaves - 1) / nwaves;
-    const int v_begin = wave * per, v_end = min(N, v_begin + per);
-    const int K4 = (K + 3) >> 2;
-    const bool words = (K & 3) == 0 && (pitch & 3) == 0;
-    for (int v = v_begin; v < v_end; ++v) {
-        unsigned char *row = codes + (size_t)v * pitch;
-        const size_t wbase = (size_t)v * Wp;
-        for (int q = lane; q < K4; q += 64) {
-            const int j = q * 4;
-            const size_t widx = wbase + (j >> 6);
-            const int bit = j & 63;
-            const unsigned reach = (unsigned)(planes[widx] >> bit) & 15u;
-            unsigned c[4] = {0, 0, 0, 0};
-            for (int b = 0; b < n_hop_bits; ++b) {
-                const unsigned t = (unsigned)(planes[(size_t)(b + 1) * plane_elems + widx] >> bit) & 15u;
-                c[0] |= (t & 1u) << b; c[1] |= ((t >> 1) & 1u) << b; c[2] |= ((t >> 2) & 1u) << b; c[3] |= ((t >> 3) & 1u) << b;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c[i] = ((reach >> i) & 1u) ? c[i] + 1u : 0u;
-            if (words) {
-                reinterpret_cast<unsigned *>(row)[q] = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (j + i < K) row[j + i] = (unsigned char)c[i];
-            }
-        }
-    }
-}
-
-// Per-anchor column statistics of the hop matrix straight from the planes: how many nodes reach anchor j and the sum of
-// their hop counts (closeness centrality = inward distances, utils.py:50-54).  Thread t of a block owns anchor column
-// tile * 256 + t and walks a slice of the rows; 64 threads share each plane word (one L1 line).  Two deterministic stages.
-__global__ __launch_bounds__(256) void k_column_stats_partial(const u64 *__restrict__ planes, size_t plane_elems, int n_hop_bits,
-                                                              int N, int K, int Wp, long long *__restrict__ part_sum,
-                                                              long long *__restrict__ part_cnt) {
-    const int j = blockIdx.y * 256 + threadIdx.x;
-    const int per = (N + gridDim.x - 1) / gridDim.x;
-    const int v0 = blockIdx.x * per, v1 = min(N, v0 + per);
-    long long sum = 0, cnt = 0;
-    if (j < K) {
-        const int w = j >> 6, bit = j & 63;
-        for (int v = v0; v < v1; ++v) {
-            const size_t widx = (size_t)v * Wp + w;
-            if ((planes[widx] >> bit) & 1ull) {
-                int h = 0;
-                for (int b = 0; b < n_hop_bits; ++b) h |= (int)((planes[(size_t)(b + 1) * plane_elems + widx] >> bit) & 1ull) << b;
-                sum += h;
-                ++cnt;
-            }
-        }
-        part_sum[(size_t)blockIdx.x * K + j] = sum;
-        part_cnt[(size_t)blockIdx.x * K + j] = cnt;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_column_stats_final(const long long *__restrict__ part_sum, const long long *__restrict__ part_cnt,
-                                                            int parts, int K, long long *__restrict__ hop_sum, long long *__restrict__ reach) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= K) return;
-    long long s = 0, c = 0;
-    for (int p = 0; p < parts; ++p) {
-        s += part_sum[(size_t)p * K + j];
-        c += part_cnt[(size_t)p * K + j];
-    }
-    hop_sum[j] = s;
-    reach[j] = c;
-}
-
-// out[v, 0:F] = x[v, :].  Every wave owns a contiguous block of rows (see k_finalize_fast).
-__global__ __launch_bounds__(256) void k_concat(const float *__restrict__ x, int N, int F, float *__restrict__ out,
-                                                long long out_cols, bool vec) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int per = (N + nwaves - 1) / nwaves;
-    const int v_begin = wave * per, v_end = min(N, v_begin + per);
-    for (int v = v_begin; v < v_end; ++v) {
-        const float *xrow = x + (size_t)v * F;
-        float *orow = out + (size_t)v * out_cols;
-        if (vec) {
-            const f32x4 *xs = reinterpret_cast<const f32x4 *>(xrow);
-            f32x4 *os = reinterpret_cast<f32x4 *>(orow);
-            for (int q = lane; q < F / 4; q += 64) os[q] = __builtin_nontemporal_load(xs + q);
-        } else {
-            for (int c = lane; c < F; c += 64) orow[c] = xrow[c];
-        }
-    }
-}
+#include "geodesic_expand.h"       // write_report, k_finalize*, k_hops, k_hop_codes, k_column_stats_*, k_concat
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -1,4 +1,5 @@
-"""Every instantiation of the level kernel against the oracle on small random graphs (GPU).
+"""Randomised soaks (GPU): the level kernel's instantiations against the oracle on small random graphs, every finalise kernel against
+the generic one on random shapes, the host -> host result assembly through every transport.  GRAPHPOPE_SOAK_SEEDS scales all three.
 
 The large-graph forms of k_bfs_level (live table read from global memory, with or without its LDS summary; 8-word tiles; tiles walked
 inside the wave, in pairs) only run by themselves on graphs of more than 256 Ki nodes, where the oracle needs seconds per case.
@@ -112,3 +113,43 @@ def test_finalise_kernels_agree_on_random_shapes(seed):
     finally:
         lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 8)
         lib.pope_debug_set(_lib.KNOB_FINALIZE_VARIANT, 11)
+
+
+@pytest.mark.parametrize("seed", range(max(3, SEEDS // 4)))
+def test_host_results_assemble_on_random_shapes(seed):
+    """The host -> host boundary's last step (utils.py:129-135 on the host: features (+) embedding into a pageable tensor) on random
+    shapes through every transport round 5 left -- pinned ring, bounce buffer (ring refused), blocking copies (both refused) -- as
+    floats and as byte codes, into heap tensors and page-aligned mappings, with strided sources, 1-7 copy threads and 0-9 chunks; the
+    result is poisoned first and must equal the sources bit for bit."""
+    from graphpope_amd import _lib, engine
+    dev = engine.require_gpu()
+    lib = _lib.load()
+    rs = np.random.RandomState(9000 + seed)
+    g = torch.Generator().manual_seed(seed)
+    lut = torch.rand(256, generator=g).to(dev)
+    try:
+        for case in range(8):
+            n = int(rs.choice([1, 3, 17, 1000, 4097, 30011, 120001]))
+            f = int(rs.choice([0, 1, 3, 40, 500]))
+            k = int(rs.choice([1, 5, 36, 64, 255, 256, 1000]))
+            refuse = int(rs.choice([0, 0, 2, 6]))
+            threads, chunks = int(rs.randint(1, 8)), int(rs.randint(0, 10))
+            coded = bool(rs.randint(2)) and refuse == 0           # the byte transport needs the pinned ring (utils.py falls back to floats without it)
+            lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, refuse)
+            pad = int(rs.choice([0, 3]))
+            x = torch.rand(n, f + pad, generator=g)[:, :f] if f else None
+            out = engine.host_result_tensor(n, f + k) if rs.randint(2) else torch.empty((n, f + k))
+            out.fill_(-1.0)
+            if coded:
+                codes = torch.randint(0, 256, (n, k + pad), generator=g, dtype=torch.uint8).to(dev)[:, :k]
+                with engine.HostAssembly(x, out, f, threads=threads) as asm:
+                    asm.finish_codes(codes, lut)
+                want = lut.cpu()[codes.cpu().long()]
+            else:
+                emb = torch.rand(n, k + pad, generator=g).to(dev)[:, :k]
+                engine.assemble_host_result(x, emb, out, f, threads=threads, chunks=chunks)
+                want = emb.cpu()
+            assert (f == 0 or torch.equal(out[:, :f], x)) and torch.equal(out[:, f:], want), (seed, case, n, f, k, refuse, threads, chunks, coded)
+            del out
+    finally:
+        lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, 0)

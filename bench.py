@@ -342,7 +342,7 @@ def pairwise_leg(n, anchors, x, dev, steps):
                       "note": "table in, features in and out, embedding out, each once; the call also re-reads and re-writes the embedding "
                               "in the min-max pass (+8NK bytes): with the feature copy running beside the MFMA kernel the whole call "
                               "is HBM-bound, the embedding alone is MFMA-bound"},
-        "roofline": {"kernel": "pope_pairwise_minmax (all its launches: persistent MFMA tile kernel k_pairwise_persistent, min-max fold, scaling pass)", "bound": "mfma",
+        "roofline": {"kernel": "k_pairwise_persistent + min-max fold + scaling pass", "bound": "mfma",
                      "achieved": flops / (emb_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / (emb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": tile_traffic, "traffic_source": tile_traffic_src,
                      "algorithmic_flops": flops,
@@ -787,6 +787,24 @@ def sage_leg(feats, ei_np, n, dev, steps, warmup):
                    "note": "fan-out [25, 10] sampled on the GPU inside the replayed step (device-extent sampler, no host synchronisation), "
                            "seeds taken from the epoch's shuffled order through a device cursor and their labels gathered by the sampler's first "
                            "kernel (SageTrainStep.set_epoch / step_epoch), features gathered from the HBM-resident matrix"}
+        # the same step (epoch mode, device extents, no host synchronisation) with eager launches instead of a replayed graph: on a host
+        # that keeps the queue full the ~23 launches pipeline better than the graph's nodes do
+        etrainer = SageTrainStep(model, opt, feats, BATCH, sampler=sampler, graph=False)
+        etrainer.set_epoch(perm, labels)
+        for i in range(max(warmup, 4)):
+            etrainer.step_epoch()
+        assert etrainer.batches_left() >= steps
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            etrainer.step_epoch()
+        torch.cuda.synchronize()
+        sampled["eager_launches_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
+        sampled["graph_replay_ms_per_step"] = sampled["ms_per_step"]
+        if sampled["eager_launches_ms_per_step"] < sampled["ms_per_step"]:
+            sampled["ms_per_step"] = sampled["eager_launches_ms_per_step"]
+            sampled["nodes_per_s"] = BATCH / (sampled["ms_per_step"] * 1e-3)
+        sampled["mode"] = "graph replay" if sampled["ms_per_step"] == sampled["graph_replay_ms_per_step"] else "eager launches"
         # and as rounds 1-2 ran it: eager launches, sizes read back by the host every hop
         model.dropout_seed_dev = None
         opt.use_device_step(None)

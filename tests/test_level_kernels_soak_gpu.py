@@ -14,7 +14,8 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-SEEDS = int(os.environ.get("GRAPHPOPE_SOAK_SEEDS", "6"))        # a long soak: GRAPHPOPE_SOAK_SEEDS=200 pytest tests/test_level_kernels_soak_gpu.py
+SEEDS = int(os.environ.get("GRAPHPOPE_SOAK_SEEDS", "6"))
+BASE = int(os.environ.get("GRAPHPOPE_SOAK_BASE", "0"))         # first seed (a later soak continues where an earlier one stopped)        # a long soak: GRAPHPOPE_SOAK_SEEDS=200 pytest tests/test_level_kernels_soak_gpu.py
 
 
 def _graph(rs, kind):
@@ -49,7 +50,7 @@ def test_forced_live_modes_and_tilings_on_random_graphs(seed, oracle):
     from graphpope_amd import _lib, engine
     dev = engine.require_gpu()
     lib = _lib.load()
-    rs = np.random.RandomState(1000 + seed)
+    rs = np.random.RandomState(1000 + BASE + seed)
     ks = [1, 64, 65, 128, 200, 256, 257, 300, 511, 512, 513, 600, 768, 1000, 1024, 1100]
     try:
         for case in range(10):
@@ -76,8 +77,8 @@ def test_finalise_kernels_agree_on_random_shapes(seed):
     from graphpope_amd import _lib, engine
     dev = engine.require_gpu()
     lib = _lib.load()
-    rs = np.random.RandomState(7000 + seed)
-    g = torch.Generator().manual_seed(seed)
+    rs = np.random.RandomState(7000 + BASE + seed)
+    g = torch.Generator().manual_seed(BASE + seed)
     try:
         for case in range(14):
             n = int(rs.choice([1, 5, 63, 64, 65, 257, 1000, 4099, 12345]))
@@ -124,8 +125,8 @@ def test_host_results_assemble_on_random_shapes(seed):
     from graphpope_amd import _lib, engine
     dev = engine.require_gpu()
     lib = _lib.load()
-    rs = np.random.RandomState(9000 + seed)
-    g = torch.Generator().manual_seed(seed)
+    rs = np.random.RandomState(9000 + BASE + seed)
+    g = torch.Generator().manual_seed(BASE + seed)
     lut = torch.rand(256, generator=g).to(dev)
     try:
         for case in range(8):

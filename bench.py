@@ -386,18 +386,33 @@ def config3_leg(x, ei, n, steps):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     del out
+    # the level kernel of this shape (16 words per node as two 8-word tiles, a wave each), timed like the headline's; the byte model
+    # E (8 + 8 W) + N 16 W per level that works.  The 11.4 MB frontier does not fit one XCD's L2: rows come across the fabric.
+    e = int(ei.shape[1])
+    lvl_ms, launches, active, hp = level_kernel_times(ei, n, anchors, reps=10)
+    wp = hp.planes.shape[2]
+    lvl_bytes = (e * (8.0 + 8.0 * wp) + n * 16.0 * wp) * active / launches
+    f = 0 if x is None else x.shape[1]
+    fin_bytes = 4.0 * n * f + 4.0 * n * (f + 1024) + 8.0 * n * wp * (1 + hp.n_hop_bits)
+    pmc, pmc_src = config4_pmc(3)
+    pmc = pmc or {}
     return {"workload": "configs[3] on ONE GPU: flickr-shaped graph, 1024 anchors (np seed 42, 1020 distinct), x resident -> [N, 1524] f32",
             "ms_per_step": dt * 1e3, "embeddings_per_s": n * 1024 / dt,
+            "roofline": {"kernel": level_kernel_name(n, 1024), "bound": "hbm", "achieved": lvl_bytes / (lvl_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": lvl_bytes / (lvl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get("k_bfs_level_hbm_bytes_per_launch"),
+                         "traffic_source": pmc_src, "algorithmic_bytes_per_launch": lvl_bytes, "avg_launch_ms": lvl_ms, "launches_per_step": launches},
+            "finalize": {"kernel": finalize_kernel_name(n, 1024, f, f > 0, 1), "algorithmic_bytes_per_launch": fin_bytes,
+                         "traffic": pmc.get("k_finalize_hbm_bytes_per_launch")},
             "note": "the 8-GPU form shards 128 anchors per rank (tests/test_configs_gpu.py runs it sharded over 2 ranks)"}
 
 
-def config4_pmc():
-    """HBM-side bytes per launch of configs[4]'s kernels from the committed rocprofv3 --pmc passes (profiles/r05_config4_pmc.json, a
-    separate run of tools/r05_config4_profile.sh: not measured live)."""
-    path = os.path.join(ROOT, "profiles", "r05_config4_pmc.json")
+def config4_pmc(cfg=4):
+    """HBM-side bytes per launch of configs[4]'s (or configs[3]'s) kernels from the committed rocprofv3 --pmc passes
+    (profiles/r05_config4_pmc.json / r05_config3_pmc.json, separate runs of tools/r05_config{4,3}_profile.sh: not measured live)."""
+    name = "r05_config%d_pmc.json" % cfg
     try:
-        with open(path) as fh:
-            return json.load(fh), "profiles/r05_config4_pmc.json"
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            return json.load(fh), "profiles/" + name
     except (OSError, ValueError):
         return None, None
 

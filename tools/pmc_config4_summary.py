@@ -9,12 +9,14 @@ tallies 64 bytes raw = one 128-byte line (profiles/r05_micro_gather_rows_pmc.jso
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-src = os.path.join(ROOT, "gpurun_out", f"r05_c4_{tag}")
+# `config3`: the run of tools/r05_config3_profile.sh (gpurun_out/r05_c3/) into profiles/r05_config3_*
+cfg = "config3" if tag == "config3" else "config4"
+src = os.path.join(ROOT, "gpurun_out", "r05_c3" if cfg == "config3" else f"r05_c4_{tag}")
 dst = os.path.join(ROOT, "profiles")
-shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "r05_config4_kernel_stats.csv"))
+shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, f"r05_{cfg}_kernel_stats.csv"))
 for name in ("levels.jsonl", "runs.jsonl", "kstats.txt"):
     if os.path.exists(os.path.join(src, name)):
-        shutil.copy(os.path.join(src, name), os.path.join(dst, "r05_config4_" + name))
+        shutil.copy(os.path.join(src, name), os.path.join(dst, f"r05_{cfg}_" + name))
 
 
 def per_kernel(kind):
@@ -25,8 +27,8 @@ def per_kernel(kind):
 
 
 fetch, write = per_kernel("fetch"), per_kernel("write")
-out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, the program right behind --) on `python3 tools/big_graph_run.py rmat22 512 2 run` "
-                 f"= BASELINE configs[4] on one GPU, tag {tag}",
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, the program right behind --) on `python3 tools/big_graph_run.py "
+                 + ("flickr 1024 2 run` = BASELINE configs[3] on one GPU" if cfg == "config3" else f"rmat22 512 2 run` = BASELINE configs[4] on one GPU, tag {tag}"),
        "units": "bytes per launch; hbm = FETCH_SIZE x 2 (gfx950 half-count, calibrated for this access pattern by tools/micro/gather_rows.hip) + WRITE_SIZE",
        "kernels": {}}
 for name, f in fetch.items():
@@ -42,6 +44,6 @@ for name, f in fetch.items():
         out["kernels"][name] = {"fetch_raw": f[-1], "write": w[-1], "hbm": 2 * f[-1] + w[-1], "launches": len(f)}
         if name.startswith("k_finalize"):
             out["k_finalize_hbm_bytes_per_launch"] = 2 * f[-1] + w[-1]
-with open(os.path.join(dst, "r05_config4_pmc.json"), "w") as fh:
+with open(os.path.join(dst, f"r05_{cfg}_pmc.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps({k: v for k, v in out.items() if not isinstance(v, dict)}, indent=1))

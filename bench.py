@@ -923,7 +923,16 @@ def compact(obj, depth=0):
     """The JSON line without its explanatory strings (--verbose keeps them; DESIGN.md says what every figure is): the driver's
     record keeps only the tail of stdout, so the line has to stay well under 8 KB."""
     if isinstance(obj, dict):
-        return {k: compact(v, depth + 1) for k, v in obj.items() if k not in PROSE_KEYS}
+        out = {k: compact(v, depth + 1) for k, v in obj.items() if k not in PROSE_KEYS}
+        # the side legs (everything but the headline's own cpu_baseline and config): what was timed, in brief
+        for key, cap, from_depth in (("sample", 72, 2), ("workload", 120, 1)):
+            if depth >= from_depth and "baseline_config" not in out and isinstance(out.get(key), str) and len(out[key]) > cap:
+                out[key] = out[key][:cap - 3] + "..."
+        if depth == 0:
+            for leg in ("cpu_baseline_all_cores", "cpu_baseline_bfs"):
+                if isinstance(out.get(leg), dict) and isinstance(out[leg].get("sample"), str) and len(out[leg]["sample"]) > 72:
+                    out[leg]["sample"] = out[leg]["sample"][:69] + "..."
+        return out
     if isinstance(obj, list):
         return [compact(v, depth + 1) for v in obj]
     if isinstance(obj, float):

@@ -145,8 +145,19 @@ __global__ __launch_bounds__(256) void k_csr_sorted(const long long *__restrict_
                                                     int *__restrict__ erow, int *aux,
                                                     const long long *__restrict__ anchors, int K, int Wp, u64 *seen,
                                                     u64 *front, unsigned *live) {
-    if (K > 0 && blockIdx.x == gridDim.x - 1)
+    // The seeds: the anchors are read in place from the call's pinned host slot -- a PCIe round trip per load -- so the last
+    // ceil(K / 256) blocks take 256 anchors each, one load per thread (one block looping over 1 024 anchors made four serial
+    // round trips: 18.6 us for this launch at configs[3]'s shape where the CSR pass itself needs 8).
+    const int seed_blocks = (K + (int)blockDim.x - 1) / (int)blockDim.x;
+    if (K > 0 && (int)gridDim.x >= seed_blocks) {
+        const int sb = (int)blockIdx.x - ((int)gridDim.x - seed_blocks);
+        if (sb >= 0) {
+            const int j = sb * (int)blockDim.x + (int)threadIdx.x;
+            if (j < K) seed_anchor(anchors[j], j, Wp, seen, front, live);
+        }
+    } else if (K > 0 && blockIdx.x == gridDim.x - 1) {
         for (int j = threadIdx.x; j < K; j += blockDim.x) seed_anchor(anchors[j], j, Wp, seen, front, live);
+    }
     const int flags = csr_sorted_role<PAIRS>(src, dst, E, N, rowptr, col, erow, aux, (int)blockIdx.x, (int)gridDim.x);
     if (flags) atomicOr(&aux[AUX_FLAGS], flags);
 }

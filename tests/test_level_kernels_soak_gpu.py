@@ -154,3 +154,58 @@ def test_host_results_assemble_on_random_shapes(seed):
             del out
     finally:
         lib.pope_debug_set(_lib.KNOB_FAIL_HOST_REGISTER, 0)
+
+
+def test_graphpope_calls_in_a_row_leak_nothing_and_stay_exact(oracle):
+    """The host -> host boundary as a process uses it (utils.py:182-210): Graphpope() calls over three graph sizes and both
+    transports (ring / staged), results released and re-allocated in between, ordinary pageable torch transfers of recycled host
+    buffers interleaved (the kind of transfer that died behind an assembly in rounds 3-4) -- every eighth result bit for bit
+    against the oracle; resident memory, device memory and open files must not grow.  24 calls by default, GRAPHPOPE_SOAK_SEEDS x 4."""
+    import contextlib
+    import gc
+    import sys
+    import psutil
+    from graphpope_amd import engine, synth, utils as gp
+    dev = engine.require_gpu()
+    proc = psutil.Process()
+    cases = []
+    for scale, f, k in ((12, 20, 96), (14, 64, 128), (15, 100, 256)):
+        ei, n = synth.rmat(scale, edge_factor=8, seed=scale)
+        cases.append((ei, n, np.random.RandomState(scale).rand(n, f).astype(np.float32), k))
+
+    class Data:
+        pass
+
+    calls = max(24, 4 * SEEDS)
+    marks = []
+    old = os.environ.get("GRAPHPOPE_HOST_RESULT")
+    try:
+        for it in range(calls):
+            ei, n, x, k = cases[it % 3]
+            os.environ["GRAPHPOPE_HOST_RESULT"] = ("ring", "staged")[(it // 3) % 2]
+            d = Data()
+            d.x, d.edge_index, d.num_nodes = torch.as_tensor(x), torch.as_tensor(ei), n
+            gp.clear_cache()
+            np.random.seed(BASE + it)
+            with contextlib.redirect_stdout(sys.stderr):
+                out = gp.Graphpope(d, "flickr", "geodesic", "stochastic", k, None, 2)
+            if it % 8 == 0:
+                want = oracle.geodesic_features(x, ei, n, d.anchor_nodes)
+                assert np.array_equal(out.numpy().view(np.uint32), want.view(np.uint32)), it
+            junk = torch.rand(1 << 22)
+            assert torch.equal(junk.to(dev).cpu(), junk)
+            del out, junk, d
+            if it % 7 == 0:
+                gc.collect()
+            if it in (calls // 3, calls - 1):
+                gc.collect()
+                torch.cuda.synchronize()
+                marks.append((proc.memory_info().rss, torch.cuda.memory_allocated(), proc.num_fds()))
+    finally:
+        if old is None:
+            os.environ.pop("GRAPHPOPE_HOST_RESULT", None)
+        else:
+            os.environ["GRAPHPOPE_HOST_RESULT"] = old
+        gp.clear_cache()
+    (rss0, cuda0, fds0), (rss1, cuda1, fds1) = marks
+    assert rss1 - rss0 < 256 << 20 and cuda1 - cuda0 < 64 << 20 and fds1 <= fds0 + 2, marks

@@ -1254,7 +1254,7 @@ extern "C" int pope_geodesic_run(const int64_t *edge_index, int64_t E, int64_t N
         // offsets, chunk rows of another graph's CSR, or -1 (tag 0x1fffffff, never handed out) -- cannot carry it.  (Round 4 counted
         // 1, 2, 3, ...: the word (7 << 3) | 1 = 57 is also a node id, and a workspace reused across graphs of different sizes, or
         // fresh from an allocator that had held index arrays, reported "node id outside [0, N)" for a clean edge list --
-        // tests/test_level_kernels_soak_gpu.py hit it on its fourth call; random and 0xFF fills, which round 4 soaked, could not.)
+        // tests/test_soak_gpu.py hit it on its fourth call; random and 0xFF fills, which round 4 soaked, could not.)
         static std::atomic<unsigned> epochs{0};
         unsigned epoch;
         do epoch = 0x10000000u | ((++epochs * 0x9E3779B1u) & 0x0fffffffu); while (epoch == 0x1fffffffu);

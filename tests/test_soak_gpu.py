@@ -1,5 +1,6 @@
 """Randomised soaks (GPU): the level kernel's instantiations against the oracle on small random graphs, every finalise kernel against
-the generic one on random shapes, the host -> host result assembly through every transport.  GRAPHPOPE_SOAK_SEEDS scales all three.
+the generic one on random shapes, the host -> host result assembly through every transport, Graphpope() calls in a row, the fan-out
+sampler against its CPU restatement, the node2vec embedding against the oracle.  GRAPHPOPE_SOAK_SEEDS scales all of them.
 
 The large-graph forms of k_bfs_level (live table read from global memory, with or without its LDS summary; 8-word tiles; tiles walked
 inside the wave, in pairs) only run by themselves on graphs of more than 256 Ki nodes, where the oracle needs seconds per case.
@@ -15,7 +16,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 SEEDS = int(os.environ.get("GRAPHPOPE_SOAK_SEEDS", "6"))
-BASE = int(os.environ.get("GRAPHPOPE_SOAK_BASE", "0"))         # first seed (a later soak continues where an earlier one stopped)        # a long soak: GRAPHPOPE_SOAK_SEEDS=200 pytest tests/test_level_kernels_soak_gpu.py
+BASE = int(os.environ.get("GRAPHPOPE_SOAK_BASE", "0"))         # first seed (a later soak continues where an earlier one stopped)        # a long soak: GRAPHPOPE_SOAK_SEEDS=200 pytest tests/test_soak_gpu.py
 
 
 def _graph(rs, kind):
@@ -209,3 +210,72 @@ def test_graphpope_calls_in_a_row_leak_nothing_and_stay_exact(oracle):
         gp.clear_cache()
     (rss0, cuda0, fds0), (rss1, cuda1, fds1) = marks
     assert rss1 - rss0 < 256 << 20 and cuda1 - cuda0 < 64 << 20 and fds1 <= fds0 + 2, marks
+
+
+@pytest.mark.parametrize("seed", range(max(3, SEEDS // 2)))
+def test_fan_out_sampler_on_random_graphs(seed, oracle):
+    """The fan-out sampler (main.py:100-116, NeighborSampler(sizes)) on random graphs, seed sets and fan-outs -- host-sized and
+    device-extent forms (a reused DeviceBatch: the buffers hold the previous batch) -- against its CPU restatement, bit for bit."""
+    from graphpope_amd import engine
+    from graphpope_amd.sampler import DeviceBatch, NeighborSampler
+    dev = engine.require_gpu()
+    rs = np.random.RandomState(11000 + BASE + seed)
+    n = int(rs.randint(30, 5000))
+    e = int(n * rs.uniform(0.5, 12.0))
+    ei = rs.randint(0, n, (2, e)).astype(np.int64)
+    if rs.rand() < 0.5:                                               # a few hubs
+        ei[0, : e // 5] = rs.randint(0, max(n // 50, 1), e // 5)
+    csr = engine.build_csr(torch.as_tensor(ei, device=dev), n)
+    rowptr, col = csr.rowptr.cpu().numpy(), csr.col.cpu().numpy()[: csr.num_edges]
+    batch = None
+    for case in range(4):
+        hops = int(rs.randint(1, 4))
+        sizes = tuple(int(rs.choice([1, 2, 3, 10, 25])) for _ in range(hops))
+        b = int(rs.choice([1, 7, 64, 257, min(n, 1550)]))
+        b = min(b, n)
+        seeds = rs.choice(n, b, replace=False).astype(np.int64)
+        sd = int(rs.randint(0, 2**31)) + (int(rs.randint(0, 2**20)) << 32)
+        want_n_id, want = seeds, []
+        for hop, size in enumerate(sizes):
+            rp, cl, want_n_id = oracle.sample_hop(rowptr, col, want_n_id, size, sd, hop)
+            want.append((rp, cl, len(want_n_id)))
+        sampler = NeighborSampler(csr.rowptr, csr.col, n, sizes)
+        seeds_dev = torch.as_tensor(seeds, device=dev)
+        n_id, adjs = sampler.sample(seeds_dev, seed=sd)
+        assert np.array_equal(n_id.cpu().numpy(), want_n_id), (seed, case)
+        for adj, (rp, cl, n_src) in zip(adjs, want[::-1]):
+            assert adj.n_src == n_src and np.array_equal(adj.rowptr.cpu().numpy(), rp) and np.array_equal(adj.col.cpu().numpy(), cl), (seed, case)
+        if batch is None or batch.n_seeds != b or batch.sizes != list(sizes):
+            batch = DeviceBatch(b, sizes, dev)
+        for _ in range(2):                                            # the second fill meets the first one's contents
+            sampler.sample_device(seeds_dev, seed=sd, out=batch)
+            dims = batch.dims.cpu().numpy()
+            assert np.array_equal(batch.n_id.cpu().numpy()[: dims[-1, 1]], want_n_id), (seed, case)
+            for h, (rp, cl, n_src) in enumerate(want):
+                assert dims[h, 1] == n_src and dims[h, 2] == len(cl) and dims[h, 0] == len(rp) - 1
+                assert np.array_equal(batch.rowptrs[h].cpu().numpy()[: len(rp)], rp) and np.array_equal(batch.cols[h].cpu().numpy()[: len(cl)], cl), (seed, case, h)
+
+
+@pytest.mark.parametrize("seed", range(max(3, SEEDS // 2)))
+def test_node2vec_embedding_on_random_shapes(seed, oracle):
+    """The node2vec-space embedding (utils.py:149-180: distance to the anchors' rows + per-column min-max) on random shapes -- depths on
+    both sides of the anchor-resident kernel's limit, anchor counts that leave ragged column groups, feature widths 0 .. 1 028, repeated
+    anchors and coincident rows -- against the oracle at the path's stated tolerance (1e-5 absolute on the scaled values)."""
+    from graphpope_amd import engine
+    dev = engine.require_gpu()
+    rs = np.random.RandomState(13000 + BASE + seed)
+    for case in range(3):
+        n = int(rs.choice([2, 40, 257, 1000, 4099, 20011]))
+        d = int(rs.choice([1, 4, 7, 36, 64, 100, 128, 129, 200]))
+        k = int(rs.choice([1, 2, 33, 64, 200, 256, 300, 513]))
+        f = int(rs.choice([0, 3, 8, 500, 1028]))
+        fn = ["distance", "similarity", "euclidean"][int(rs.randint(3))]
+        emb = rs.randn(n, d).astype(np.float32)
+        if n > 12:
+            emb[5] = emb[9]
+        anchors = rs.choice(n, k)
+        x = rs.rand(n, f).astype(np.float32)
+        out = engine.pairwise_features(torch.as_tensor(x, device=dev), torch.as_tensor(emb, device=dev), anchors, fn).cpu().numpy()
+        want = oracle.node2vec_features(x, emb, anchors, fn)
+        assert out.shape == want.shape and np.array_equal(out[:, :f], x), (seed, case)
+        np.testing.assert_allclose(out[:, f:], want[:, f:], rtol=0, atol=1e-5, err_msg=str((seed, case, n, d, k, f, fn)))

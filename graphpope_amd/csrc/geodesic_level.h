@@ -300,7 +300,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
     // Graphs whose waves walk many chunks (LIVE >= 2): the NEXT chunk's indices are requested before this chunk is worked on and its
     // live look-ups go out behind this chunk's gathers -- memory instructions retire in order, so neither waits for the gathers -- and
     // the chain index load -> live look-up -> gather of a chunk no longer starts from nothing (round 5: 4 of a chunk's ~22 us).
-    constexpr bool AHEAD = LIVE >= 2 && POPE_AHEAD != 0;
+    constexpr bool AHEAD = (LIVE >= 2 || (WT == 8 && POPE_L2_LOOP != 0)) && POPE_AHEAD != 0;
     constexpr bool AHEAD_LIVE = AHEAD && POPE_AHEAD == 1;
     auto slots_of = [&](int chunk, const int4 &vr_, const int4 &ur_, int &v0, int &v1, int &v2, int &v3, int &u0, int &u1, int &u2, int &u3) {
         const int base = chunk * CHUNK + lane * SLOTS;

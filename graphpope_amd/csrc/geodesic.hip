@@ -37,8 +37,14 @@
 #ifndef POPE_WT8
 #define POPE_WT8 1                    // 1 = tiles of 8 words (a node's whole 64-byte row in one gather) where the frontier comes from HBM
 #endif
+#ifndef POPE_HBM_BLOCKS
+#define POPE_HBM_BLOCKS 0             // A/B: cap of the expand blocks of the 8-word kernel on HBM-resident graphs (0: 2 048)
+#endif
 #ifndef POPE_L2_LOOP
-#define POPE_L2_LOOP (256 * 3)        // cap of the expand blocks of the 8-word, wave-per-tile kernel (graphs with the LDS live table): what is resident at once; 0 = no cap
+#define POPE_L2_LOOP (256 * 2)        // cap of the expand blocks of the 8-word, wave-per-tile kernel (graphs with the LDS live table): what is resident at once; 0 = no cap
+#endif
+#ifndef POPE_WT8_L2_WAVES
+#define POPE_WT8_L2_WAVES 1           // waves per SIMD that kernel must fit (1: the compiler's own 178 registers = 2 waves, no scratch)
 #endif
 #ifndef POPE_WT8_L2
 #define POPE_WT8_L2 1                 // 1 = 8-word tiles (a wave each) on graphs that live in L2 too
@@ -604,11 +610,14 @@ static void launch_level(int E, int N, int Wp, const int *col, const int *erow, 
     const int tiles = Wp / WT;
     int expand_blocks = (nchunks + 3) / 4;                           // one wave per chunk ...
     if (expand_blocks > 256 * 8) expand_blocks = 256 * 8;            // ... up to 8 blocks per CU, then waves loop
+    if (POPE_HBM_BLOCKS != 0 && WT == 8 && TILES != 2 && expand_blocks > POPE_HBM_BLOCKS) expand_blocks = POPE_HBM_BLOCKS;   // (A/B: only what is resident)
     if (TILES == 2) expand_blocks *= tiles;                          // ... and per tile (4 waves per block: the tiles of a chunk share a block for 1, 2 or 4 tiles)
-    // The 8-word kernel holds three blocks per CU (168 registers): more blocks than that queue behind them and their waves START late --
-    // the 1 024-anchor levels of the Flickr-shaped graph were 2.3 such rounds.  Only what is resident is launched; its waves walk
-    // their chunks in a loop, the next chunk's indices requested a chunk ahead (as the HBM-resident graphs' waves do): BFS at 512 / 1 024
-    // anchors 0.276 / 0.425 -> 0.257 / 0.413 ms (profiles/r05_ab_flickr_loop.txt; 512 and 1 024 blocks: 0.272 / 0.419, 0.273 / 0.412).
+    // The 8-word kernel holds two blocks per CU (178 registers; three when held to 168): more blocks than that queue behind them and
+    // their waves START late -- the 1 024-anchor levels of the Flickr-shaped graph were 2.3 such rounds.  Only what is resident is
+    // launched; its waves walk their chunks in a loop, the next chunk's indices requested a chunk ahead (as the HBM-resident graphs'
+    // waves do).  BFS at 512 / 1 024 anchors: every block launched 0.276 / 0.425 ms; 768 blocks at 3 waves per SIMD 0.257 / 0.413 (512
+    // and 1 024 blocks: 0.272 / 0.419, 0.273 / 0.412); 512 blocks at the compiler's own 2 waves, no scratch: 0.250 / 0.388 (640:
+    // 0.252 / 0.398) -- profiles/r05_ab_flickr_loop.txt.
     if (POPE_L2_LOOP != 0 && WT == 8 && TILES == 2 && expand_blocks > POPE_L2_LOOP) expand_blocks = POPE_L2_LOOP / tiles * tiles;
     int house_blocks = (N + 255) / 256;                              // the commit of the previous level: one thread per node
     if (house_blocks > 1024) house_blocks = 1024;                    // (+ the clears: rows that span chunks, the live table)

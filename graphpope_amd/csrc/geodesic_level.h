@@ -565,7 +565,7 @@ __device__ __forceinline__ bool level_expand(const int *__restrict__ erow, const
 // in LDS (one bit per table word, built by k_live_summary between the launches).  TILES: 0 one WT-word tile per node; several tiles
 // walked inside the wave (1) or dealt to adjacent waves (2), see level_expand.
 template <int WT, int LIVE, int TILES>
-__global__ __launch_bounds__(256, WT == 8 ? (TILES == 1 ? POPE_WT8_LOOP_WAVES : POPE_WT8_WAVES) : 1) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
+__global__ __launch_bounds__(256, WT == 8 ? (TILES == 1 ? POPE_WT8_LOOP_WAVES : (LIVE == 1 ? POPE_WT8_L2_WAVES : POPE_WT8_WAVES)) : 1) void k_bfs_level(const int *__restrict__ erow, const int *__restrict__ col,
                                                    int E, int N, int Wp, int tiles, const u64 *__restrict__ front,
                                                    u64 *__restrict__ seen, u64 *__restrict__ acc,
                                                    u64 *__restrict__ idle, u64 *__restrict__ hop_planes,

@@ -110,3 +110,29 @@ def test_result_tensor_pool_reuses_the_pages_of_a_freed_result(monkeypatch):
     del t5
     assert not engine._RESULT_POOL
     assert engine.host_result_tensor(3, 5).shape == (3, 5)
+
+
+def test_kernel_name_queries_follow_the_shapes():
+    """pope_level_kernel_name / pope_finalize_kernel_name are host logic (which instantiation a shape gets: bench.py and the profiles label
+    their roofline entries with them): the shapes of BASELINE configs[1], [3], [4] and of their per-rank shards, no GPU needed."""
+    import ctypes
+    from graphpope_amd import _lib
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(64)
+
+    def level(n, k):
+        _lib.check(lib.pope_level_kernel_name(n, k, buf, 64))
+        return buf.value.decode()
+
+    def fin(n, k, f, shards):
+        _lib.check(lib.pope_finalize_kernel_name(n, k, f, 1 if f else 0, shards, buf, 64))
+        return buf.value.decode()
+
+    flickr, rmat = 89250, 1 << 22
+    assert level(flickr, 256) == "k_bfs_level<4, 1, 0>" and level(flickr, 128) == "k_bfs_level<2, 1, 0>"
+    assert level(flickr, 1024) == "k_bfs_level<8, 1, 2>" and level(flickr, 768) == "k_bfs_level<4, 1, 2>"
+    assert level(rmat, 512) == "k_bfs_level<8, 3, 0>" and level(rmat, 64) == "k_bfs_level<1, 3, 0>"
+    assert level(rmat, 1024) == "k_bfs_level<8, 3, 1>" and level(rmat, 768) == "k_bfs_level<4, 3, 1>"
+    assert fin(flickr, 256, 500, 1) == "k_finalize_pipe<2, 1>" and fin(flickr, 1024, 500, 1) == "k_finalize_wide<2>"
+    assert fin(rmat, 512, 0, 1) == "k_finalize_lut" and fin(flickr, 256, 500, 8) == "k_finalize_wide<2>" and fin(rmat, 64, 0, 8) == "k_finalize_lut"
+    assert lib.pope_level_kernel_name(0, 256, buf, 64) != 0 and lib.pope_finalize_kernel_name(flickr, 0, 0, 0, 1, buf, 64) != 0
